@@ -1,0 +1,471 @@
+/*
+ * fmx_oracle.c -- CPU restatement of findex's FM-index hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker / the timed CPU baseline.
+ * The product (findex_amd/, libfmx.so) never links, imports or calls it.
+ *
+ * Parity status: PINNED BY FIXTURES.  The reference is Scala 2.10 on the JVM
+ * and cannot be compiled or run in this image (no java/scala/sbt), so there is
+ * no oracle/_ref build.  This restatement is pinned instead against every
+ * known-answer and golden file the reference's own tests hold for this path
+ * (see tests/test_oracle_kat.py, tests/golden/).  One thing stays unpinned:
+ * the dequeue order among equal keys of scala.collection.mutable.PriorityQueue
+ * (Scala 2.10.0), restated below from the published library source; no
+ * reference test pins an outcome that depends on it.
+ *
+ * Every function cites the reference file:line it follows.  Paths are relative
+ * to /root/reference:  F = src/main/scala/org/fmindex
+ *
+ * Positions are 64-bit here (the reference is Int/32-bit, F/findex.scala:10-13);
+ * values are identical for n < 2^31.  The inverted list holds uint32 entries, so
+ * this oracle supports n <= 2^32.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_ERR_IO -1
+#define ORC_ERR_FORMAT -2
+#define ORC_ERR_INDEX -3   /* the reference would throw ArrayIndexOutOfBounds */
+#define ORC_ERR_NOMEM -4
+#define ORC_ERR_RANGE -5
+
+#define ALPHA_SIZE 256     /* F/bwtmerger.scala BWTMerger2.ALPHA_SIZE, F/util.scala:91 */
+
+typedef struct orc_index {
+  uint64_t n;              /* rows incl. the EOF row = fm.size, F/bwtmerger.scala:339 */
+  uint64_t eof;            /* BWT slot holding the EOF symbol, F/bwtmerger.scala:151 */
+  uint8_t *bwt;            /* raw bytes as stored (slot eof is a filler byte) */
+  int64_t aux[ALPHA_SIZE]; /* .aux counts, F/bwtmerger.scala:130-142 */
+  uint64_t bs[ALPHA_SIZE];  /* bucketStarts : c2bs(aux with c(0):=1), F/bwtmerger.scala:346-350 */
+  uint64_t bs0[ALPHA_SIZE]; /* bucketStarts0: c2bs(aux) untouched,    F/bwtmerger.scala:341-345 */
+  uint32_t *fm;            /* inverted list = the .fm payload, F/bwtmerger.scala:424-533 */
+} orc_index;
+
+/* ---------------------------------------------------------------- formats */
+
+static uint64_t rd_u64(const uint8_t *p, int big_endian) {
+  uint64_t v = 0;
+  if (big_endian) for (int i = 0; i < 8; i++) v = (v << 8) | p[i];
+  else for (int i = 7; i >= 0; i--) v = (v << 8) | p[i];
+  return v;
+}
+
+/* BWTLoader, F/bwtmerger.scala:144-174: int64 size, int64 eof, then size bytes;
+ * size + 16 must equal the file length (:153). */
+int orc_load_bwt(const char *path, int big_endian, uint8_t **bwt_out,
+                 uint64_t *n_out, uint64_t *eof_out) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return ORC_ERR_IO;
+  uint8_t hdr[16];
+  if (fread(hdr, 1, 16, f) != 16) { fclose(f); return ORC_ERR_FORMAT; }
+  uint64_t size = rd_u64(hdr, big_endian), eof = rd_u64(hdr + 8, big_endian);
+  fseek(f, 0, SEEK_END);
+  uint64_t flen = (uint64_t)ftell(f);
+  if (size + 16 != flen) { fclose(f); return ORC_ERR_FORMAT; }
+  fseek(f, 16, SEEK_SET);
+  uint8_t *b = (uint8_t *)malloc(size ? size : 1);
+  if (!b) { fclose(f); return ORC_ERR_NOMEM; }
+  if (fread(b, 1, size, f) != size) { free(b); fclose(f); return ORC_ERR_IO; }
+  fclose(f);
+  *bwt_out = b; *n_out = size; *eof_out = eof;
+  return ORC_OK;
+}
+
+/* AUXLoader, F/bwtmerger.scala:130-142: exactly 256 int64 counts. */
+int orc_load_aux(const char *path, int big_endian, int64_t aux[ALPHA_SIZE]) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return ORC_ERR_IO;
+  uint8_t buf[ALPHA_SIZE * 8];
+  size_t got = fread(buf, 1, sizeof buf, f);
+  fclose(f);
+  if (got != sizeof buf) return ORC_ERR_FORMAT;
+  for (int i = 0; i < ALPHA_SIZE; i++) aux[i] = (int64_t)rd_u64(buf + 8 * i, big_endian);
+  return ORC_OK;
+}
+
+void orc_free_buf(void *p) { free(p); }
+
+/* ------------------------------------------------------------ construction */
+
+/* c2bs, F/util.scala:109-119 */
+static void c2bs(const int64_t c[ALPHA_SIZE], uint64_t bs[ALPHA_SIZE]) {
+  uint64_t tot = 0;
+  for (int i = 0; i < ALPHA_SIZE; i++) { bs[i] = tot; tot += (uint64_t)c[i]; }
+}
+
+/* FMCreator.create, F/bwtmerger.scala:452-532, in memory: a stable bucket sort
+ * of BWT positions by symbol.  The byte at stream index eofNum is replaced by 0
+ * (:493); bucket starts are bs(0)=0, bs(c)=1+sum_{1<=j<c} aux(j) (:440-450), i.e.
+ * aux(0) is ignored and symbol 0 owns exactly the one EOF slot. */
+static int build_fm(orc_index *ix) {
+  uint64_t bkt[ALPHA_SIZE];
+  uint64_t tot = 1;
+  bkt[0] = 0;
+  for (int i = 1; i < ALPHA_SIZE; i++) { bkt[i] = tot; tot += (uint64_t)ix->aux[i]; }
+  ix->fm = (uint32_t *)malloc((ix->n ? ix->n : 1) * sizeof(uint32_t));
+  if (!ix->fm) return ORC_ERR_NOMEM;
+  uint64_t lim[ALPHA_SIZE];                       /* one past each bucket's last slot */
+  for (int i = 0; i + 1 < ALPHA_SIZE; i++) lim[i] = bkt[i + 1];
+  lim[ALPHA_SIZE - 1] = ix->n;
+  for (uint64_t i = 0; i < ix->n; i++) {
+    int c = (i == ix->eof) ? 0 : ix->bwt[i];
+    /* a bucket overflow means .aux does not describe this .bwt; the reference
+     * would silently write into the next bucket's file region */
+    if (bkt[c] >= lim[c] || bkt[c] >= ix->n) return ORC_ERR_FORMAT;
+    ix->fm[bkt[c]++] = (uint32_t)i;
+  }
+  return ORC_OK;
+}
+
+/* NaiveFMSearcher constructor, F/bwtmerger.scala:335-353 */
+orc_index *orc_open_mem(const uint8_t *bwt, uint64_t n, uint64_t eof,
+                        const int64_t aux[ALPHA_SIZE], int *err) {
+  int e = ORC_OK;
+  orc_index *ix = NULL;
+  if (n > (1ull << 32) || eof >= (n ? n : 1)) { e = ORC_ERR_RANGE; goto done; }
+  ix = (orc_index *)calloc(1, sizeof *ix);
+  if (!ix) { e = ORC_ERR_NOMEM; goto done; }
+  ix->n = n; ix->eof = eof;
+  ix->bwt = (uint8_t *)malloc(n ? n : 1);
+  if (!ix->bwt) { e = ORC_ERR_NOMEM; goto done; }
+  memcpy(ix->bwt, bwt, n);
+  memcpy(ix->aux, aux, sizeof ix->aux);
+  int64_t c1[ALPHA_SIZE];
+  memcpy(c1, aux, sizeof c1);
+  c2bs(c1, ix->bs0);          /* :341-345 */
+  c1[0] = 1;                  /* :348 */
+  c2bs(c1, ix->bs);           /* :349 */
+  e = build_fm(ix);
+done:
+  if (e != ORC_OK && ix) { free(ix->bwt); free(ix->fm); free(ix); ix = NULL; }
+  if (err) *err = e;
+  return ix;
+}
+
+orc_index *orc_open_files(const char *bwt_path, const char *aux_path, int big_endian, int *err) {
+  uint8_t *bwt = NULL; uint64_t n = 0, eof = 0; int64_t aux[ALPHA_SIZE];
+  int e = orc_load_bwt(bwt_path, big_endian, &bwt, &n, &eof);
+  if (e == ORC_OK) e = orc_load_aux(aux_path, big_endian, aux);
+  orc_index *ix = NULL;
+  if (e == ORC_OK) ix = orc_open_mem(bwt, n, eof, aux, &e);
+  free(bwt);
+  if (err) *err = e;
+  return ix;
+}
+
+void orc_close(orc_index *ix) {
+  if (!ix) return;
+  free(ix->bwt); free(ix->fm); free(ix);
+}
+
+uint64_t orc_n(const orc_index *ix) { return ix->n; }
+uint64_t orc_eof(const orc_index *ix) { return ix->eof; }
+const uint32_t *orc_fm_ptr(const orc_index *ix) { return ix->fm; }
+const uint8_t *orc_bwt_ptr(const orc_index *ix) { return ix->bwt; }
+
+/* .fm wire format, F/bwtmerger.scala:483-485,476-481: byte elSize(=4), int64 BE
+ * size, then size x int32 BE. */
+int orc_write_fm(const orc_index *ix, const char *path) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return ORC_ERR_IO;
+  uint8_t hdr[9];
+  hdr[0] = 4;
+  for (int i = 0; i < 8; i++) hdr[1 + i] = (uint8_t)(ix->n >> (56 - 8 * i));
+  fwrite(hdr, 1, 9, f);
+  for (uint64_t i = 0; i < ix->n; i++) {
+    uint32_t v = ix->fm[i];
+    uint8_t b[4] = {(uint8_t)(v >> 24), (uint8_t)(v >> 16), (uint8_t)(v >> 8), (uint8_t)v};
+    fwrite(b, 1, 4, f);
+  }
+  fclose(f);
+  return ORC_OK;
+}
+
+/* --------------------------------------------------------------- rank / LF */
+
+/* NaiveFMSearcher.cf, F/bwtmerger.scala:352 */
+int64_t orc_cf(const orc_index *ix, int c) {
+  if (c < 0 || c >= ALPHA_SIZE) return ORC_ERR_INDEX;
+  return (int64_t)ix->bs[c];
+}
+
+/* NaiveFMSearcher.occ, F/bwtmerger.scala:354-375: binary search for `key` in
+ * fm[bs(c) .. bs(c+1)-1] (last bucket ends at n-1); number of entries <= key. */
+int64_t orc_occ(const orc_index *ix, int c, int64_t key) {
+  if (c < 0 || c >= ALPHA_SIZE) return ORC_ERR_INDEX;
+  int64_t istart = (int64_t)ix->bs[c];
+  int64_t imin = istart;
+  int64_t imax = (c == ALPHA_SIZE - 1) ? (int64_t)ix->n - 1 : (int64_t)ix->bs[c + 1] - 1;
+  if (imin <= imax) {
+    int found = 0;
+    int64_t imid = 0, ival = 0;
+    while (!found && imax >= imin) {
+      imid = (imax + imin) / 2;
+      ival = (int64_t)ix->fm[imid];
+      if (ival < key) imin = imid + 1;
+      else if (ival > key) imax = imid - 1;
+      else found = 1;
+    }
+    return (ival <= key) ? (imid - istart + 1) : (imid - istart);
+  }
+  return 0;
+}
+
+/* SuffixAlgo.search, F/findex.scala:15-31.  Returns 1 for Some((sp,ep)), 0 for
+ * None; sp/ep always receive the loop's final values.  The reference indexes
+ * cf/occ with a signed Byte, so bytes >= 0x80 throw (F/findex.scala:21,26):
+ * strict_signed=1 reports that as ORC_ERR_INDEX; 0 reads the byte unsigned
+ * (the product's documented superset).  *steps = loop iterations executed. */
+int orc_search(const orc_index *ix, const uint8_t *in, uint64_t len, int strict_signed,
+               uint64_t *sp_out, uint64_t *ep_out, uint32_t *steps) {
+  int64_t sp = 0, ep = (int64_t)ix->n;
+  int64_t i = (int64_t)len - 1;
+  uint32_t st = 0;
+  while (sp < ep && i >= 0) {
+    int c = in[i];
+    if (strict_signed && c >= 0x80) return ORC_ERR_INDEX;
+    i -= 1;
+    int64_t nsp = orc_cf(ix, c) + orc_occ(ix, c, sp - 1);
+    int64_t nep = orc_cf(ix, c) + orc_occ(ix, c, ep - 1);
+    sp = nsp; ep = nep;
+    st++;
+  }
+  *sp_out = (uint64_t)sp; *ep_out = (uint64_t)ep;
+  if (steps) *steps = st;
+  return sp < ep ? 1 : 0;
+}
+
+/* SuffixAlgo.getPrevRange, F/findex.scala:32-36 */
+int orc_get_prev_range(const orc_index *ix, int64_t sp, int64_t ep, int c,
+                       uint64_t *sp1, uint64_t *ep1) {
+  if (c < 0 || c >= ALPHA_SIZE) return ORC_ERR_INDEX;
+  int64_t a = orc_cf(ix, c) + orc_occ(ix, c, sp - 1);
+  int64_t b = orc_cf(ix, c) + orc_occ(ix, c, ep - 1);
+  *sp1 = (uint64_t)a; *ep1 = (uint64_t)b;
+  return a < b ? 1 : 0;
+}
+
+/* SuffixAlgo.getIntervalPrevRange, F/findex.scala:37-51: every c in
+ * [cstart,cend] inclusive; non-empty ranges only; the Scala list is built by
+ * prepending, so it comes back in DESCENDING c.  out arrays need room for
+ * cend-cstart+1 entries.  Returns the number of ranges or ORC_ERR_INDEX. */
+int orc_get_interval_prev_range(const orc_index *ix, int64_t sp, int64_t ep, int cstart, int cend,
+                                uint64_t *out_sp, uint64_t *out_ep, int *out_c) {
+  if (cstart < 0 || (cstart <= cend && cend >= ALPHA_SIZE)) return ORC_ERR_INDEX;
+  int k = 0;
+  for (int c = cstart; c <= cend; c++) {
+    int64_t occ1 = orc_occ(ix, c, sp - 1), occ2 = orc_occ(ix, c, ep - 1);
+    if (occ1 < occ2) {
+      out_sp[k] = (uint64_t)(orc_cf(ix, c) + occ1);
+      out_ep[k] = (uint64_t)(orc_cf(ix, c) + occ2);
+      if (out_c) out_c[k] = c;
+      k++;
+    }
+  }
+  for (int a = 0, b = k - 1; a < b; a++, b--) {   /* prepend order */
+    uint64_t t = out_sp[a]; out_sp[a] = out_sp[b]; out_sp[b] = t;
+    t = out_ep[a]; out_ep[a] = out_ep[b]; out_ep[b] = t;
+    if (out_c) { int tc = out_c[a]; out_c[a] = out_c[b]; out_c[b] = tc; }
+  }
+  return k;
+}
+
+/* BWTLoader.read, F/bwtmerger.scala:155-162: 0 at i == eof */
+static int bwt_read(const orc_index *ix, uint64_t i) { return i == ix->eof ? 0 : ix->bwt[i]; }
+int orc_bwt_read(const orc_index *ix, uint64_t i) { return i < ix->n ? bwt_read(ix, i) : ORC_ERR_INDEX; }
+
+/* NaiveFMSearcher.pos2char, F/bwtmerger.scala:376-385 (uses bucketStarts0) */
+int orc_pos2char(const orc_index *ix, int64_t key) {
+  int i = ALPHA_SIZE - 1;
+  if ((int64_t)ix->bs0[i] > key) {
+    while ((int64_t)ix->bs0[i] > key && i > 0) i -= 1;
+  } else {
+    while (ix->bs0[i - 1] == ix->bs0[i] && i > 1) i -= 1;
+    i -= 1;
+  }
+  return i;
+}
+
+/* NaiveFMSearcher.getPrevI (LF step), F/bwtmerger.scala:386-389 */
+int64_t orc_get_prev_i(const orc_index *ix, int64_t i) {
+  if (i < 0 || (uint64_t)i >= ix->n) return ORC_ERR_INDEX;
+  int c = bwt_read(ix, (uint64_t)i);
+  return orc_cf(ix, c) + orc_occ(ix, c, i - 1);
+}
+
+/* NaiveFMSearcher.getNextI (Psi step), F/bwtmerger.scala:390-392 */
+int64_t orc_get_next_i(const orc_index *ix, int64_t i) {
+  if (i < 0 || (uint64_t)i >= ix->n) return ORC_ERR_INDEX;
+  return (int64_t)ix->fm[i];
+}
+
+/* NaiveFMSearcher.nextSubstr, F/bwtmerger.scala:394-405: walk Psi, stop after
+ * appending a 0 byte, then reverse.  Returns the number of bytes written. */
+int64_t orc_next_substr(const orc_index *ix, int64_t sp, int64_t len, uint8_t *out) {
+  if (sp < 0 || (uint64_t)sp >= ix->n) return ORC_ERR_INDEX;
+  int64_t cp = orc_get_next_i(ix, sp), k = 0;
+  int eof = 0;
+  for (int64_t i = 0; i < len && !eof; i++) {
+    int b = bwt_read(ix, (uint64_t)cp);
+    eof = (b == 0);
+    out[k++] = (uint8_t)b;
+    cp = orc_get_next_i(ix, cp);
+  }
+  for (int64_t a = 0, b = k - 1; a < b; a++, b--) { uint8_t t = out[a]; out[a] = out[b]; out[b] = t; }
+  return k;
+}
+
+/* NaiveFMSearcher.prevSubstr, F/bwtmerger.scala:409-419: walk LF; `eof` is
+ * never set there, so the walk runs through the EOF row for all len steps. */
+int64_t orc_prev_substr(const orc_index *ix, int64_t sp, int64_t len, uint8_t *out) {
+  if (sp < 0 || (uint64_t)sp >= ix->n) return ORC_ERR_INDEX;
+  int64_t cp = sp;
+  for (int64_t i = 0; i < len; i++) {
+    out[i] = (uint8_t)bwt_read(ix, (uint64_t)cp);
+    cp = orc_get_prev_i(ix, cp);
+  }
+  return len;
+}
+
+/* ----------------------------------------------------------------- batches */
+/* Plain loops over the functions above; `threads` > 1 uses OpenMP when built
+ * with -fopenmp (bench.py's cpu_baseline leg). */
+
+int orc_occ_batch(const orc_index *ix, const uint8_t *c, const int64_t *i, int64_t *out, uint64_t k) {
+  for (uint64_t q = 0; q < k; q++) out[q] = orc_occ(ix, c[q], i[q]);
+  return ORC_OK;
+}
+
+int orc_search_batch(const orc_index *ix, const uint8_t *pat, const uint64_t *off, uint64_t k,
+                     uint64_t *sp, uint64_t *ep, uint32_t *steps, int threads) {
+  int bad = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads > 0 ? threads : 1)
+#endif
+  for (int64_t q = 0; q < (int64_t)k; q++) {
+    uint32_t st = 0;
+    int r = orc_search(ix, pat + off[q], off[q + 1] - off[q], 0, &sp[q], &ep[q], &st);
+    if (steps) steps[q] = st;
+    if (r < 0) bad = 1;
+  }
+  (void)threads;
+  return bad ? ORC_ERR_INDEX : ORC_OK;
+}
+
+int orc_prev_range_batch(const orc_index *ix, const uint64_t *sp, const uint64_t *ep, const uint8_t *c,
+                         uint64_t *sp1, uint64_t *ep1, uint64_t k) {
+  for (uint64_t q = 0; q < k; q++) orc_get_prev_range(ix, (int64_t)sp[q], (int64_t)ep[q], c[q], &sp1[q], &ep1[q]);
+  return ORC_OK;
+}
+
+/* -------------------------------------------------- Glushkov frontier search */
+/* ReTree._matchSA, F/re2/retree.scala:618-653, over tables produced by the
+ * Python restatement of ReTree (oracle/retree.py): per CharNode its byte `c`,
+ * `num` (F/re2/retree.scala:393-423), `isLast` (:40-50) and `follows` (:14-38)
+ * as a CSR list that keeps the reference's order and multiplicity. */
+
+typedef struct { int64_t len; int64_t sp, ep; int32_t state; } orc_sp;   /* StatePoint :562 */
+
+typedef struct { orc_sp *a; int64_t size0, cap; const int32_t *num; } orc_pq;
+
+/* StatePoint.compare, F/re2/retree.scala:564: this < that  <=>  this.num > that.num */
+static int pq_lt(const orc_pq *q, const orc_sp *x, const orc_sp *y) { return q->num[x->state] > q->num[y->state]; }
+
+/* scala.collection.mutable.PriorityQueue (Scala 2.10.0): a 1-based binary heap
+ * in a resizable array; `+=` appends then fixUp, `dequeue` swaps the root with
+ * the last slot and fixDown-s.  Restated from the library source. */
+static int pq_push(orc_pq *q, orc_sp e) {
+  if (q->size0 + 1 > q->cap) {
+    int64_t nc = q->cap ? q->cap * 2 : 64;
+    orc_sp *na = (orc_sp *)realloc(q->a, (size_t)nc * sizeof(orc_sp));
+    if (!na) return ORC_ERR_NOMEM;
+    q->a = na; q->cap = nc;
+  }
+  q->a[q->size0] = e;
+  int64_t k = q->size0;                          /* fixUp(as, size0) */
+  while (k > 1 && pq_lt(q, &q->a[k / 2], &q->a[k])) {
+    orc_sp t = q->a[k]; q->a[k] = q->a[k / 2]; q->a[k / 2] = t;
+    k = k / 2;
+  }
+  q->size0 += 1;
+  return ORC_OK;
+}
+
+static orc_sp pq_pop(orc_pq *q) {
+  q->size0 -= 1;
+  orc_sp t = q->a[1]; q->a[1] = q->a[q->size0]; q->a[q->size0] = t;
+  int64_t n = q->size0 - 1, k = 1;               /* fixDown(as, 1, size0-1) */
+  while (n >= 2 * k) {
+    int64_t j = 2 * k;
+    if (j < n && pq_lt(q, &q->a[j], &q->a[j + 1])) j += 1;
+    if (!pq_lt(q, &q->a[k], &q->a[j])) break;    /* as(k) >= as(j) */
+    orc_sp h = q->a[k]; q->a[k] = q->a[j]; q->a[j] = h;
+    k = j;
+  }
+  return q->a[q->size0];
+}
+
+/* Returns the number of results (written newest-first, i.e. in the reference's
+ * `ret ::= ...` list order, up to cap) or a negative error.  *front_left = size
+ * of the leftover frontier, *pops = getPrevRange calls made.
+ * matchSA itself (F/re2/retree.scala:570-617) returns this first-pass `ret`
+ * whatever the exploratory restarts at :578-614 find, so they are not restated. */
+int64_t orc_match_sa(const orc_index *ix, int32_t nstates, const uint8_t *st_c, const int32_t *st_num,
+                     const uint8_t *st_last, const int32_t *fol_off, const int32_t *fol,
+                     const int32_t *firsts, int32_t nfirsts, int64_t max_branching, int64_t max_iterations,
+                     int64_t *res_len, uint64_t *res_sp, uint64_t *res_ep, int64_t cap,
+                     int64_t *front_left, int64_t *pops) {
+  (void)nstates;
+  orc_pq q = {0};
+  q.num = st_num;
+  q.size0 = 1;                                   /* array(0) is unused */
+  q.cap = 0;
+  /* discovery-ordered scratch; reversed into the output at the end */
+  int64_t nres = 0, rcap = 1024;
+  int64_t *rl = (int64_t *)malloc((size_t)rcap * sizeof(int64_t));
+  uint64_t *rs = (uint64_t *)malloc((size_t)rcap * sizeof(uint64_t));
+  uint64_t *re = (uint64_t *)malloc((size_t)rcap * sizeof(uint64_t));
+  int64_t rc = ORC_OK;
+  for (int32_t f = 0; f < nfirsts; f++) {        /* pqFront ++= inputStates, :624 */
+    orc_sp e = {0, 0, (int64_t)ix->n, firsts[f]};
+    if (pq_push(&q, e) != ORC_OK) { rc = ORC_ERR_NOMEM; goto out; }
+  }
+  int64_t i = 1, npop = 0;
+  while (q.size0 >= 2 && (q.size0 - 1) < max_branching && (max_iterations == 0 || i < max_iterations)) {  /* :628 */
+    orc_sp s = pq_pop(&q);
+    uint64_t sp1, ep1;
+    npop++;
+    if (orc_get_prev_range(ix, s.sp, s.ep, st_c[s.state], &sp1, &ep1) == 1) {   /* :633 */
+      if (st_last[s.state]) {                                                  /* :636-638 */
+        if (nres == rcap) {
+          rcap *= 2;
+          rl = (int64_t *)realloc(rl, (size_t)rcap * sizeof(int64_t));
+          rs = (uint64_t *)realloc(rs, (size_t)rcap * sizeof(uint64_t));
+          re = (uint64_t *)realloc(re, (size_t)rcap * sizeof(uint64_t));
+          if (!rl || !rs || !re) { rc = ORC_ERR_NOMEM; goto out; }
+        }
+        rl[nres] = s.len + 1; rs[nres] = sp1; re[nres] = ep1; nres++;
+      } else {                                                                 /* :641 */
+        for (int32_t j = fol_off[s.state]; j < fol_off[s.state + 1]; j++) {
+          orc_sp e = {s.len + 1, (int64_t)sp1, (int64_t)ep1, fol[j]};
+          if (pq_push(&q, e) != ORC_OK) { rc = ORC_ERR_NOMEM; goto out; }
+        }
+      }
+    }
+    i += 1;
+  }
+  if (front_left) *front_left = q.size0 - 1;
+  if (pops) *pops = npop;
+  for (int64_t k = 0; k < nres && k < cap; k++) {          /* newest first */
+    res_len[k] = rl[nres - 1 - k]; res_sp[k] = rs[nres - 1 - k]; res_ep[k] = re[nres - 1 - k];
+  }
+  rc = nres;
+out:
+  free(q.a); free(rl); free(rs); free(re);
+  return rc;
+}

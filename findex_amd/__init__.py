@@ -1,0 +1,20 @@
+"""findex_amd -- MI355X-native FM-index backward search behind findex's SuffixAlgo API.
+
+The compute lives in libfmx.so (hand-written HIP for gfx950, C ABI in include/fmx.h); this
+package is the thin host-side mirror of the reference's Scala interface for that path:
+
+    reference (Scala)                              here
+    NaiveFMSearcher(filename, bigEndian)           HipFMSearcher(filename, bigEndian=True)
+      .n .cf .occ .search .getPrevRange ...          same names, same meaning
+    REParser.re2post(str, lineOnly)                REParser.re2post(str, lineOnly=False)
+    ReTree(postfix).matchSA(sa)                    ReTree(postfix).matchSA(sa)
+    SAResult(sa,len,sp,ep)                         SAResult
+
+There is no CPU fallback: importing works anywhere, but every compute call needs the built
+library and a HIP device and fails loudly otherwise.
+"""
+from ._lib import FmxError, MatchError, Re2PostSyntax, LIB_PATH, load  # noqa: F401
+from .searcher import HipFMSearcher  # noqa: F401
+from .regex import REParser, ReTree, SAResult  # noqa: F401
+
+__all__ = ["HipFMSearcher", "REParser", "ReTree", "SAResult", "FmxError", "MatchError", "Re2PostSyntax"]

@@ -1,0 +1,116 @@
+"""ctypes binding of libfmx.so (include/fmx.h).  Fails loudly when the HIP library is missing:
+there is no CPU fallback in this package."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfmx.so")
+
+FMX_OK = 0
+ERR_NAMES = {1: "FMX_ERR_IO", 2: "FMX_ERR_FORMAT", 3: "FMX_ERR_ARG", 4: "FMX_ERR_NOMEM", 5: "FMX_ERR_HIP",
+             6: "FMX_ERR_UNSUPPORTED", 7: "FMX_ERR_SYNTAX", 8: "FMX_ERR_MATCH", 9: "FMX_ERR_OVERFLOW"}
+
+
+class FmxError(Exception):
+    """A non-zero status from libfmx (the Scala adapter would rethrow it as Exception)."""
+
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, code), msg))
+        self.code = code
+
+
+class Re2PostSyntax(FmxError):
+    """`throw new Exception("re2post syntax")`, re2/re2.scala"""
+
+
+class MatchError(FmxError):
+    """scala.MatchError from ReTree.apply, re2/retree.scala:235-238,291-294"""
+
+
+class fmx_limits(ctypes.Structure):
+    _fields_ = [("max_steps", ctypes.c_uint32), ("max_frontier", ctypes.c_uint64)]
+
+
+class fmx_result(ctypes.Structure):
+    _fields_ = [("regex", ctypes.c_uint32), ("len", ctypes.c_uint32), ("sp", ctypes.c_uint64),
+                ("ep", ctypes.c_uint64)]
+
+
+class fmx_stats_t(ctypes.Structure):
+    _fields_ = [("rank_queries", ctypes.c_uint64), ("backward_steps", ctypes.c_uint64),
+                ("launches", ctypes.c_uint64), ("last_kernel_ms", ctypes.c_double),
+                ("index_bytes", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("n_symbols", ctypes.c_uint32),
+                ("block_bytes", ctypes.c_uint32), ("build_ms", ctypes.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/fmx.h declares
+_vp, _u64, _i32, _u32, _sz, _cp = (ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t,
+                                   ctypes.c_char_p)
+_P = ctypes.POINTER
+SYMBOLS = {
+    "fmx_last_error": (_cp, []),
+    "fmx_abi_version": (_i32, []),
+    "fmx_device_count": (_i32, [_P(_i32)]),
+    "fmx_open": (_i32, [_cp, _cp, _i32, _i32, _P(_vp)]),
+    "fmx_open_mem": (_i32, [_vp, _u64, _u64, _vp, _i32, _P(_vp)]),
+    "fmx_open_dev": (_i32, [_vp, _u64, _u64, _vp, _i32, _vp, _P(_vp)]),
+    "fmx_close": (_i32, [_vp]),
+    "fmx_n": (_i32, [_vp, _P(_u64)]),
+    "fmx_eof": (_i32, [_vp, _P(_u64)]),
+    "fmx_cf": (_i32, [_vp, _i32, _P(_u64)]),
+    "fmx_counts": (_i32, [_vp, _vp]),
+    "fmx_device": (_i32, [_vp, _P(_i32)]),
+    "fmx_occ_batch": (_i32, [_vp, _vp, _vp, _vp, _sz]),
+    "fmx_occ_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "fmx_search_batch": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz]),
+    "fmx_search_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fmx_prev_range_batch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "fmx_prev_range_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fmx_interval_prev_range": (_i32, [_vp, _u64, _u64, _i32, _i32, _vp, _vp, _vp, _P(_sz)]),
+    "fmx_lf_walk_batch": (_i32, [_vp, _vp, _sz, _u32, _vp, _vp]),
+    "fmx_lf_walk_batch_dev": (_i32, [_vp, _vp, _sz, _u32, _vp, _vp, _vp]),
+    "fmx_psi_batch": (_i32, [_vp, _vp, _vp, _sz]),
+    "fmx_next_substr": (_i32, [_vp, _u64, _u32, _vp, _P(_u32)]),
+    "fmx_prev_substr": (_i32, [_vp, _u64, _u32, _vp]),
+    "fmx_regex_compile": (_i32, [_cp, _i32, _P(_vp)]),
+    "fmx_regex_free": (_i32, [_vp]),
+    "fmx_regex_tables": (_i32, [_vp, _P(_u32), _vp, _vp, _vp, _vp, _P(_u32), _vp, _P(_u32), _vp]),
+    "fmx_regex_post_string": (_i32, [_cp, _i32, _vp, _sz]),
+    "fmx_regex_match_batch": (_i32, [_vp, _vp, _sz, _vp, _vp, _sz, _P(_sz), _vp]),
+    "fmx_stats": (_i32, [_vp, _P(fmx_stats_t)]),
+    "fmx_stats_reset": (_i32, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libfmx.so once.  torch (if installed) is imported first so that both share the one
+    HIP runtime torch ships; raises ImportError when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("findex_amd: %s is missing -- run `python -m findex_amd.build` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != FMX_OK:
+        msg = (load().fmx_last_error() or b"").decode("utf-8", "replace")
+        if rc == 7:
+            raise Re2PostSyntax(rc, msg)
+        if rc == 8:
+            raise MatchError(rc, msg)
+        raise FmxError(rc, msg)

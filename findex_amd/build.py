@@ -1,0 +1,65 @@
+"""Builds libfmx.so (HIP kernels + C ABI) for gfx950, in-tree.
+
+    python -m findex_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the .so lands in findex_amd/lib/ (git-ignored,
+but shipped to the GPU box with the tree).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+OUT = os.path.join(OUT_DIR, "libfmx.so")
+SOURCES = ["fmx_api.cpp", "fmx_regex.cpp", "fmx_build.hip", "fmx_kernels.hip", "fmx_frontier.hip"]
+HEADERS = ["fmx_device.h", "fmx_host.h", "fmx_regex.h"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "fmx.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    objs = []
+    flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),
+             "-I" + CSRC, "-Wall", "-Wno-unused-result"]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(OUT_DIR, src + ".o")
+        objs.append(obj)
+        cmd = [_hipcc()] + flags + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    tmp = OUT + ".%d.tmp" % os.getpid()
+    cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,211 @@
+// fmx_build.hip -- K1: build the rank dictionary in HBM from the raw BWT bytes.
+//
+// This is the device analogue of the reference's rank-structure build, FMCreator.create
+// (bwtmerger.scala:452-532: one pass over the BWT with the byte at stream index eof replaced by
+// 0, positions bucketed by symbol).  Instead of inverted position lists it emits, per symbol,
+// one-hot bit-vector blocks with a running count in each block header (layout: fmx_device.h).
+//
+// Three launches over "superchunks" of kSuper blocks (= kSuper*960 BWT positions):
+//   k_hist : per-superchunk symbol histogram            (reads n bytes)
+//   k_scan : exclusive scan of the histograms per symbol (tiny)
+//   k_fill : per superchunk, block by block: bits via LDS atomicOr, headers from the running
+//            counts, whole 128-byte blocks written with coalesced dword stores
+//            (reads n bytes, writes nslots * nblocks * 128 bytes)
+#include "fmx_device.h"
+#include "fmx_host.h"
+
+#include <string>
+
+namespace fmx {
+
+constexpr int kBuildThreads = 256;
+constexpr uint32_t kSuper = 256;                    // blocks per superchunk
+constexpr uint32_t kWordsPerBlock = kBlockBits / 32;  // 30 payload dwords
+
+__global__ __launch_bounds__(kBuildThreads) void k_hist(const uint8_t *__restrict__ bwt, uint64_t n, uint64_t eof,
+                                                         uint64_t *__restrict__ hist /* [nsuper][256] */) {
+  __shared__ uint32_t h[4][256];
+  const int wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const uint64_t lo = (uint64_t)blockIdx.x * kSuper * kBlockBits;
+  uint64_t hi = lo + (uint64_t)kSuper * kBlockBits;
+  if (hi > n) hi = n;
+  for (uint64_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+    if (p != eof) atomicAdd(&h[wave][bwt[p]], 1u);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 256; c += blockDim.x)
+    hist[(uint64_t)blockIdx.x * 256 + c] = (uint64_t)h[0][c] + h[1][c] + h[2][c] + h[3][c];
+}
+
+// One thread per symbol walks the superchunks: hist becomes the exclusive prefix, totals[c] the sum.
+__global__ __launch_bounds__(256) void k_scan(uint64_t *__restrict__ hist, uint64_t nsuper,
+                                               uint64_t *__restrict__ totals) {
+  const int c = threadIdx.x;
+  uint64_t run = 0;
+  for (uint64_t s = 0; s < nsuper; s++) {
+    uint64_t v = hist[s * 256 + c];
+    hist[s * 256 + c] = run;
+    run += v;
+  }
+  totals[c] = run;
+}
+
+__global__ __launch_bounds__(kBuildThreads) void k_fill(const uint8_t *__restrict__ bwt, uint64_t n, uint64_t eof,
+                                                         uint64_t nblocks, uint32_t nslots,
+                                                         const uint16_t *__restrict__ slot_of /* [256] */,
+                                                         const uint16_t *__restrict__ sym_of /* [nslots] */,
+                                                         const uint64_t *__restrict__ base /* [nsuper][256] */,
+                                                         uint32_t *__restrict__ bv) {
+  extern __shared__ uint32_t lds[];
+  uint32_t *bits = lds;                                      // [nslots][30]
+  uint64_t *run = reinterpret_cast<uint64_t *>(lds + ((nslots * kWordsPerBlock + 1) & ~1u));   // [nslots]
+  uint16_t *s_slot = reinterpret_cast<uint16_t *>(run + nslots);                               // [256]
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) s_slot[c] = slot_of[c];
+  for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x) run[s] = base[(uint64_t)blockIdx.x * 256 + sym_of[s]];
+  const uint64_t b0 = (uint64_t)blockIdx.x * kSuper;
+  uint64_t b1 = b0 + kSuper;
+  if (b1 > nblocks) b1 = nblocks;
+  const uint32_t nwords = nslots * kWordsPerBlock;
+  for (uint64_t b = b0; b < b1; b++) {
+    for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) bits[i] = 0;
+    __syncthreads();
+    const uint64_t p0 = b * kBlockBits;
+    for (uint32_t r = threadIdx.x; r < kBlockBits; r += blockDim.x) {
+      const uint64_t p = p0 + r;
+      if (p < n && p != eof) {
+        const uint16_t s = s_slot[bwt[p]];
+        if (s < kSlotEof) atomicOr(&bits[s * kWordsPerBlock + (r >> 5)], 1u << (r & 31));
+      }
+    }
+    __syncthreads();
+    // write nslots blocks of 32 dwords: [hdr lo, hdr hi, 30 payload dwords]
+    for (uint32_t i = threadIdx.x; i < nslots * 32; i += blockDim.x) {
+      const uint32_t s = i >> 5, w = i & 31;
+      uint32_t v;
+      if (w == 0) v = (uint32_t)run[s];
+      else if (w == 1) v = (uint32_t)(run[s] >> 32);
+      else v = bits[s * kWordsPerBlock + w - 2];
+      bv[((uint64_t)s * nblocks + b) * 32 + w] = v;
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x) {
+      uint32_t pc = 0;
+      for (uint32_t w = 0; w < kWordsPerBlock; w++) pc += __builtin_popcount(bits[s * kWordsPerBlock + w]);
+      run[s] += pc;
+    }
+    __syncthreads();
+  }
+}
+
+// Builds the whole device side of an index from h->d_bwt / h->n / h->eof:
+//   1. symbol histogram on the device (authoritative; EOF slot excluded),
+//   2. validation against the caller's .aux counts when given,
+//   3. symbol->slot map, C[] (NaiveFMSearcher.cf, bwtmerger.scala:346-352: counts(0):=1 then
+//      exclusive prefix sums), table upload, rank dictionary allocation,
+//   4. the fill pass.
+// Returns an FMX_* status.
+int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
+  const uint64_t nsuper = (h->nblocks + kSuper - 1) / kSuper;
+  uint64_t *d_hist = nullptr, *d_tot = nullptr;
+  uint16_t *d_sym = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int rc = 0;
+  hipError_t e = hipSuccess;
+  uint64_t tot[256];
+  uint16_t sym_of[256] = {0};
+#define FMX_TRY(call, what)                       \
+  if ((e = (call)) != hipSuccess) {               \
+    rc = hip_fail(e, what);                       \
+    break;                                        \
+  }
+  do {
+    FMX_TRY(hipEventCreate(&ev0), "hipEventCreate");
+    FMX_TRY(hipEventCreate(&ev1), "hipEventCreate");
+    FMX_TRY(hipMalloc(&d_hist, nsuper * 256 * sizeof(uint64_t)), "hipMalloc(hist)");
+    FMX_TRY(hipMalloc(&d_tot, 256 * sizeof(uint64_t)), "hipMalloc(totals)");
+    FMX_TRY(hipMalloc(&d_sym, 256 * sizeof(uint16_t)), "hipMalloc(sym)");
+    FMX_TRY(hipEventRecord(ev0, st), "hipEventRecord");
+    k_hist<<<(int)nsuper, kBuildThreads, 0, st>>>((const uint8_t *)h->d_bwt, h->n, h->eof, d_hist);
+    FMX_TRY(hipGetLastError(), "k_hist");
+    k_scan<<<1, 256, 0, st>>>(d_hist, nsuper, d_tot);
+    FMX_TRY(hipGetLastError(), "k_scan");
+    FMX_TRY(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st), "copy totals");
+    FMX_TRY(hipStreamSynchronize(st), "sync(hist)");
+
+    if (tot[0] != 0) {
+      set_error("BWT holds byte 0 outside the EOF slot: findex escapes 0 on input (bwtreader.scala:136-155) and its "
+                "FMCreator gives symbol 0 exactly one slot (bwtmerger.scala:440-450)");
+      rc = 6 /* FMX_ERR_UNSUPPORTED */;
+      break;
+    }
+    if (given_counts) {
+      bool ok = given_counts[0] == 0;
+      for (int c = 1; c < 256 && ok; c++) ok = (uint64_t)given_counts[c] == tot[c];
+      if (!ok) {
+        set_error("symbol counts (.aux) do not describe this BWT");
+        rc = 2 /* FMX_ERR_FORMAT */;
+        break;
+      }
+    }
+    h->nslots = 0;
+    uint64_t run = 1;                       // counts(0) := 1, bwtmerger.scala:348
+    h->cf[0] = 0;
+    h->counts[0] = 0;
+    h->slot[0] = kSlotEof;
+    for (int c = 1; c < 256; c++) {
+      h->counts[c] = (int64_t)tot[c];
+      h->cf[c] = run;
+      run += tot[c];
+      if (tot[c]) { sym_of[h->nslots] = (uint16_t)c; h->slot[c] = (uint16_t)h->nslots++; }
+      else h->slot[c] = kSlotNone;
+    }
+    const uint64_t bv_bytes = (uint64_t)h->nslots * h->nblocks * kBlockBytes;
+    size_t free_b = 0, total_b = 0;
+    FMX_TRY(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
+    if (bv_bytes + (64ull << 20) > free_b) {
+      set_error("rank dictionary needs " + std::to_string(bv_bytes >> 20) + " MiB of device memory, " +
+                std::to_string(free_b >> 20) + " MiB free");
+      rc = 4 /* FMX_ERR_NOMEM */;
+      break;
+    }
+    FMX_TRY(hipMalloc(&h->d_bv, bv_bytes ? bv_bytes : 16), "hipMalloc(rank dictionary)");
+    FMX_TRY(hipMalloc(&h->d_cf, sizeof h->cf), "hipMalloc(cf)");
+    FMX_TRY(hipMalloc(&h->d_slot, sizeof h->slot), "hipMalloc(slot)");
+    FMX_TRY(hipMalloc((void **)&h->d_counters, 4 * sizeof(unsigned long long)), "hipMalloc(counters)");
+    FMX_TRY(hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), st), "memset(counters)");
+    FMX_TRY(hipMemcpyAsync(h->d_cf, h->cf, sizeof h->cf, hipMemcpyHostToDevice, st), "copy cf");
+    FMX_TRY(hipMemcpyAsync(h->d_slot, h->slot, sizeof h->slot, hipMemcpyHostToDevice, st), "copy slot");
+    FMX_TRY(hipMemcpyAsync(d_sym, sym_of, sizeof sym_of, hipMemcpyHostToDevice, st), "copy sym");
+    if (h->nslots) {
+      size_t lds = (size_t)((h->nslots * kWordsPerBlock + 1) & ~1u) * 4 + (size_t)h->nslots * 8 + 256 * 2;
+      k_fill<<<(int)nsuper, kBuildThreads, lds, st>>>((const uint8_t *)h->d_bwt, h->n, h->eof, h->nblocks, h->nslots,
+                                                       (const uint16_t *)h->d_slot, d_sym, d_hist,
+                                                       (uint32_t *)h->d_bv);
+      FMX_TRY(hipGetLastError(), "k_fill");
+    }
+    FMX_TRY(hipEventRecord(ev1, st), "hipEventRecord");
+    FMX_TRY(hipStreamSynchronize(st), "sync(fill)");
+    float ms = 0;
+    FMX_TRY(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
+    h->build_ms = ms;
+    h->index_bytes = bv_bytes + h->n + sizeof h->cf + sizeof h->slot;
+    h->dev.bv = (const uint4 *)h->d_bv;
+    h->dev.bwt = (const uint8_t *)h->d_bwt;
+    h->dev.cf = (const uint64_t *)h->d_cf;
+    h->dev.slot = (const uint16_t *)h->d_slot;
+    h->dev.n = h->n;
+    h->dev.eof = h->eof;
+    h->dev.nblocks = h->nblocks;
+  } while (0);
+#undef FMX_TRY
+  if (d_hist) (void)hipFree(d_hist);
+  if (d_tot) (void)hipFree(d_tot);
+  if (d_sym) (void)hipFree(d_sym);
+  if (ev0) (void)hipEventDestroy(ev0);
+  if (ev1) (void)hipEventDestroy(ev1);
+  return rc;
+}
+
+}  // namespace fmx

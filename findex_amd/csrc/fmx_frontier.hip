@@ -1,0 +1,370 @@
+// fmx_frontier.hip -- K5: Glushkov SA-interval frontier expansion for a batch of regexes.
+//
+// Reference: ReTree._matchSA, re2/retree.scala:618-653.  There one priority queue of
+// StatePoint(len, sp, ep, state) is popped serially; each pop is one getPrevRange; a non-empty
+// range either emits SAResult (isLast) or pushes one StatePoint per entry of state.follows.
+// Every frontier element is independent of the others, so the device keeps the whole batch's
+// frontier in two HBM work queues (SoA) and expands it level by level (level = len):
+//   - one frontier element per octet of lanes, stepped with the same one-line rank primitive
+//     as the literal search;
+//   - survivors are compacted into the next queue: per-octet push counts are prefix-summed
+//     across the wave, one atomicAdd per wave reserves the slots, and the octet's lanes write
+//     the follows in parallel; results are compacted the same way with __ballot.
+// The set of getPrevRange calls, and so the result multiset, equals the reference's whenever
+// its maxBranching / maxIterations limits do not bind.
+#include <fmx.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "fmx_device.h"
+#include "fmx_host.h"
+#include "fmx_regex.h"
+
+namespace fmx {
+
+constexpr int kFThreads = 256;
+
+struct Queue {           // SoA frontier queue in HBM
+  uint32_t *state;       // global CharNode id
+  uint32_t *len;
+  uint64_t *sp;
+  uint64_t *ep;
+};
+
+struct NfaTables {       // all regexes of the batch, concatenated; state ids are global
+  const uint8_t *st_c;
+  const uint8_t *st_last;
+  const uint32_t *st_regex;
+  const uint32_t *fol_off;   // n_states + 1
+  const uint32_t *fol;
+};
+
+struct FrontierCtl {     // device-resident counters
+  unsigned long long next_count;
+  unsigned long long res_count;
+  unsigned long long overflow;     // bit 0: queue, bit 1: results
+  unsigned long long steps;
+};
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
+  // inclusive Hillis-Steele over the 64 lanes, then shift
+  const uint32_t lane = __lane_id();
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+__global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, uint64_t cur_count,
+                                                         Queue nxt, uint64_t nxt_cap, fmx_result *__restrict__ res,
+                                                         uint64_t res_cap, FrontierCtl *__restrict__ ctl) {
+  __shared__ uint64_t s_cf[256];
+  __shared__ uint16_t s_slot[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  __syncthreads();
+  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const uint64_t noct = (uint64_t)gridDim.x * (kFThreads / kOctet);
+  const uint64_t first = ((uint64_t)blockIdx.x * kFThreads + threadIdx.x) >> 3;
+  uint32_t stepped = 0;
+  // all octets of a wave run the same number of rounds so that the wave-wide scans stay convergent
+  const uint64_t rounds = (cur_count + noct - 1) / noct;
+  for (uint64_t rd = 0; rd < rounds; rd++) {
+    const uint64_t q = first + rd * noct;
+    const bool have = q < cur_count;
+    uint32_t s = 0, ln = 0, nf = 0, f0 = 0;
+    uint64_t sp = 0, ep = 0;
+    bool emit = false;
+    if (have) {
+      s = cur.state[q];
+      ln = cur.len[q];
+      sp = cur.sp[q];
+      ep = cur.ep[q];
+      const uint32_t c = nfa.st_c[s];
+      const uint16_t slot = s_slot[c];
+      const uint64_t cfc = s_cf[c];
+      uint64_t r1 = 0, r2 = 0;
+      if (slot < kSlotEof) {
+        uint64_t b1, b2;
+        uint32_t m1, m2;
+        split960(sp, b1, m1);
+        split960(ep, b2, m2);
+        const uint4 w1 = *block_ptr(ix, slot, b1, t);
+        const uint4 w2 = *block_ptr(ix, slot, b2, t);
+        r1 = rank_finish(w1, m1, t);
+        r2 = rank_finish(w2, m2, t);
+      } else if (slot == kSlotEof) {
+        r1 = sp > ix.eof ? 1 : 0;
+        r2 = ep > ix.eof ? 1 : 0;
+      }
+      sp = cfc + r1;
+      ep = cfc + r2;
+      stepped++;
+      if (sp < ep) {                                   // Some((sp1,ep1)), retree.scala:634
+        if (nfa.st_last[s]) emit = true;               // :636-638
+        else { f0 = nfa.fol_off[s]; nf = nfa.fol_off[s + 1] - f0; }   // :641
+      }
+    }
+    // ---- compaction: results by ballot, pushes by wave prefix sum
+    const bool lead = t == 0;
+    const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
+    uint32_t push_total = 0;
+    const uint32_t push_off = wave_excl_scan(lead ? nf : 0u, push_total);
+    const uint32_t lane = __lane_id();
+    unsigned long long rbase = 0, qbase = 0;
+    if (lane == 0) {
+      if (em) rbase = atomicAdd(&ctl->res_count, (unsigned long long)__builtin_popcountll(em));
+      if (push_total) qbase = atomicAdd(&ctl->next_count, (unsigned long long)push_total);
+    }
+    rbase = __shfl(rbase, 0, 64);
+    qbase = __shfl(qbase, 0, 64);
+    if (lead && emit) {
+      const unsigned long long at = rbase + __builtin_popcountll(em & ((1ull << lane) - 1ull));
+      if (at < res_cap) {
+        fmx_result r;
+        r.regex = nfa.st_regex[s];
+        r.len = ln + 1;
+        r.sp = sp;
+        r.ep = ep;
+        res[at] = r;
+      } else {
+        atomicOr(&ctl->overflow, 2ull);
+      }
+    }
+    // the octet's leader holds its offset; share it with the octet and write follows in parallel
+    const uint32_t my_off = __shfl(push_off, lane & ~7u, 64);
+    for (uint32_t j = t; j < nf; j += kOctet) {
+      const unsigned long long at = qbase + my_off + j;
+      if (at < nxt_cap) {
+        nxt.state[at] = nfa.fol[f0 + j];
+        nxt.len[at] = ln + 1;
+        nxt.sp[at] = sp;
+        nxt.ep[at] = ep;
+      } else {
+        atomicOr(&ctl->overflow, 1ull);
+      }
+    }
+  }
+  if (t == 0 && stepped) atomicAdd(&ctl->steps, (unsigned long long)stepped);
+}
+
+namespace {
+
+struct DevMem {
+  std::vector<void *> ptrs;
+  ~DevMem() { for (void *p : ptrs) (void)hipFree(p); }
+  template <class T>
+  hipError_t alloc(T **out, size_t count) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+    if (e == hipSuccess) { ptrs.push_back(p); *out = (T *)p; }
+    return e;
+  }
+};
+
+}  // namespace
+
+#define HIP_TRY(call, what)                            \
+  do {                                                 \
+    hipError_t e__ = (call);                           \
+    if (e__ != hipSuccess) return hip_fail(e__, what); \
+  } while (0)
+
+int regex_match_batch(const Index *h, const Regex *const *res, size_t k, const fmx_limits *lim, fmx_result *out,
+                      size_t cap, size_t *n_out, uint32_t *per_regex_count) {
+  const uint32_t max_steps = (lim && lim->max_steps) ? lim->max_steps : 4096u;
+  const uint64_t qcap = (lim && lim->max_frontier) ? lim->max_frontier : (1ull << 22);
+  // concatenate the batch's tables
+  std::vector<uint8_t> st_c, st_last;
+  std::vector<uint32_t> st_regex, fol_off, fol;
+  std::vector<uint32_t> q_state;
+  fol_off.push_back(0);
+  for (size_t r = 0; r < k; r++) {
+    const Regex &re = *res[r];
+    const uint32_t base = (uint32_t)st_c.size();
+    for (size_t s = 0; s < re.st_c.size(); s++) {
+      st_c.push_back(re.st_c[s]);
+      st_last.push_back(re.st_last[s]);
+      st_regex.push_back((uint32_t)r);
+      for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol.push_back(base + (uint32_t)re.fol[j]);
+      fol_off.push_back((uint32_t)fol.size());
+    }
+    for (int32_t f : re.firsts) q_state.push_back(base + (uint32_t)f);   // root.firsts x (0, 0, n), :576
+  }
+  if (per_regex_count) std::fill(per_regex_count, per_regex_count + k, 0u);
+  *n_out = 0;
+  if (q_state.empty()) return FMX_OK;
+  if (q_state.size() > qcap) { set_error("initial frontier exceeds max_frontier"); return FMX_ERR_OVERFLOW; }
+
+  HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+  DevMem mem;
+  uint8_t *d_c = nullptr, *d_last = nullptr;
+  uint32_t *d_regex = nullptr, *d_foff = nullptr, *d_fol = nullptr;
+  Queue qa{}, qb{};
+  fmx_result *d_res = nullptr;
+  FrontierCtl *d_ctl = nullptr;
+  const size_t rcap = cap ? cap : 1;
+  HIP_TRY(mem.alloc(&d_c, st_c.size()), "hipMalloc");
+  HIP_TRY(mem.alloc(&d_last, st_last.size()), "hipMalloc");
+  HIP_TRY(mem.alloc(&d_regex, st_regex.size()), "hipMalloc");
+  HIP_TRY(mem.alloc(&d_foff, fol_off.size()), "hipMalloc");
+  HIP_TRY(mem.alloc(&d_fol, fol.size()), "hipMalloc");
+  for (Queue *q : {&qa, &qb}) {
+    HIP_TRY(mem.alloc(&q->state, qcap), "hipMalloc(queue)");
+    HIP_TRY(mem.alloc(&q->len, qcap), "hipMalloc(queue)");
+    HIP_TRY(mem.alloc(&q->sp, qcap), "hipMalloc(queue)");
+    HIP_TRY(mem.alloc(&q->ep, qcap), "hipMalloc(queue)");
+  }
+  HIP_TRY(mem.alloc(&d_res, rcap), "hipMalloc(results)");
+  HIP_TRY(mem.alloc(&d_ctl, 1), "hipMalloc(ctl)");
+  hipStream_t st = nullptr;
+  HIP_TRY(hipStreamCreate(&st), "hipStreamCreate");
+  struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{st};
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0), "hipEventCreate");
+  HIP_TRY(hipEventCreate(&e1), "hipEventCreate");
+  struct EG { hipEvent_t a, b; ~EG() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
+
+  HIP_TRY(hipMemcpyAsync(d_c, st_c.data(), st_c.size(), hipMemcpyHostToDevice, st), "H2D");
+  HIP_TRY(hipMemcpyAsync(d_last, st_last.data(), st_last.size(), hipMemcpyHostToDevice, st), "H2D");
+  HIP_TRY(hipMemcpyAsync(d_regex, st_regex.data(), st_regex.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+  HIP_TRY(hipMemcpyAsync(d_foff, fol_off.data(), fol_off.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+  if (!fol.empty()) HIP_TRY(hipMemcpyAsync(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+  // level 0 frontier
+  const size_t f0 = q_state.size();
+  std::vector<uint32_t> zlen(f0, 0u);
+  std::vector<uint64_t> zsp(f0, 0ull), zep(f0, h->n);
+  HIP_TRY(hipMemcpyAsync(qa.state, q_state.data(), f0 * 4, hipMemcpyHostToDevice, st), "H2D");
+  HIP_TRY(hipMemcpyAsync(qa.len, zlen.data(), f0 * 4, hipMemcpyHostToDevice, st), "H2D");
+  HIP_TRY(hipMemcpyAsync(qa.sp, zsp.data(), f0 * 8, hipMemcpyHostToDevice, st), "H2D");
+  HIP_TRY(hipMemcpyAsync(qa.ep, zep.data(), f0 * 8, hipMemcpyHostToDevice, st), "H2D");
+  HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(FrontierCtl), st), "memset(ctl)");
+
+  NfaTables nfa{d_c, d_last, d_regex, d_foff, d_fol};
+  uint64_t count = f0;
+  FrontierCtl ctl{};
+  Queue *cur = &qa, *nxt = &qb;
+  uint32_t level = 0;
+  uint64_t launches = 0;
+  HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
+  while (count) {
+    if (level >= max_steps) { set_error("frontier still alive after max_steps levels"); return FMX_ERR_OVERFLOW; }
+    uint64_t want = (count + (kFThreads / kOctet) - 1) / (kFThreads / kOctet);
+    uint64_t gcap = (uint64_t)h->cu_count * 8;
+    int grid = (int)(want < gcap ? want : gcap);
+    k_frontier<<<grid, kFThreads, 0, st>>>(h->dev, nfa, *cur, count, *nxt, qcap, d_res, (uint64_t)cap, d_ctl);
+    HIP_TRY(hipGetLastError(), "k_frontier");
+    launches++;
+    HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
+    HIP_TRY(hipStreamSynchronize(st), "sync(level)");
+    if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
+    count = ctl.next_count;
+    // reset next_count for the following level (res_count and steps keep accumulating)
+    HIP_TRY(hipMemsetAsync(&d_ctl->next_count, 0, sizeof(unsigned long long), st), "memset(next_count)");
+    std::swap(cur, nxt);
+    level++;
+  }
+  HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
+  HIP_TRY(hipStreamSynchronize(st), "sync");
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->last_kernel_ms = ms;
+    h->launches += launches;
+  }
+  // fold this call's steps into the handle's counters
+  if (ctl.steps) {
+    unsigned long long add[2] = {2ull * ctl.steps, ctl.steps}, cur_cnt[2];
+    HIP_TRY(hipMemcpy(cur_cnt, h->d_counters, sizeof cur_cnt, hipMemcpyDeviceToHost), "D2H(counters)");
+    cur_cnt[0] += add[0];
+    cur_cnt[1] += add[1];
+    HIP_TRY(hipMemcpy(h->d_counters, cur_cnt, sizeof cur_cnt, hipMemcpyHostToDevice), "H2D(counters)");
+  }
+  *n_out = (size_t)ctl.res_count;
+  if (ctl.res_count > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
+  if (ctl.res_count) {
+    HIP_TRY(hipMemcpy(out, d_res, (size_t)ctl.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost), "D2H(results)");
+    std::sort(out, out + ctl.res_count, [](const fmx_result &a, const fmx_result &b) {
+      if (a.regex != b.regex) return a.regex < b.regex;
+      if (a.len != b.len) return a.len < b.len;
+      if (a.sp != b.sp) return a.sp < b.sp;
+      return a.ep < b.ep;
+    });
+    if (per_regex_count)
+      for (size_t j = 0; j < ctl.res_count; j++) per_regex_count[out[j].regex]++;
+  }
+  return FMX_OK;
+}
+
+}  // namespace fmx
+
+using namespace fmx;
+
+extern "C" {
+
+int fmx_regex_compile(const char *re, int line_only, fmx_regex **out) {
+  if (!re || !out) { set_error("null argument"); return FMX_ERR_ARG; }
+  *out = nullptr;
+  try {
+    Regex *r = new Regex(compile_regex(re, line_only != 0));
+    *out = reinterpret_cast<fmx_regex *>(r);
+    return FMX_OK;
+  } catch (const RegexError &e) {
+    set_error(e.msg);
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return FMX_ERR_NOMEM;
+  }
+}
+
+int fmx_regex_free(fmx_regex *re) {
+  delete reinterpret_cast<Regex *>(re);
+  return FMX_OK;
+}
+
+int fmx_regex_post_string(const char *re, int line_only, char *out, size_t cap) {
+  if (!re || !out || !cap) { set_error("null argument"); return FMX_ERR_ARG; }
+  try {
+    std::string s = re2poststr(re, line_only != 0);
+    if (s.size() + 1 > cap) { set_error("output buffer too small"); return FMX_ERR_OVERFLOW; }
+    std::copy(s.begin(), s.end(), out);
+    out[s.size()] = 0;
+    return FMX_OK;
+  } catch (const RegexError &e) {
+    set_error(e.msg);
+    return e.code;
+  }
+}
+
+int fmx_regex_tables(const fmx_regex *re, uint32_t *n_states, uint8_t *st_c, int32_t *st_num, uint8_t *st_last,
+                     int32_t *fol_off, uint32_t *n_follows, int32_t *fol, uint32_t *n_firsts, int32_t *firsts) {
+  if (!re) { set_error("null argument"); return FMX_ERR_ARG; }
+  const Regex *r = reinterpret_cast<const Regex *>(re);
+  if (n_states) *n_states = (uint32_t)r->st_c.size();
+  if (n_follows) *n_follows = (uint32_t)r->fol.size();
+  if (n_firsts) *n_firsts = (uint32_t)r->firsts.size();
+  if (st_c) std::copy(r->st_c.begin(), r->st_c.end(), st_c);
+  if (st_num) std::copy(r->st_num.begin(), r->st_num.end(), st_num);
+  if (st_last) std::copy(r->st_last.begin(), r->st_last.end(), st_last);
+  if (fol_off) std::copy(r->fol_off.begin(), r->fol_off.end(), fol_off);
+  if (fol) std::copy(r->fol.begin(), r->fol.end(), fol);
+  if (firsts) std::copy(r->firsts.begin(), r->firsts.end(), firsts);
+  return FMX_OK;
+}
+
+int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,
+                          fmx_result *out, size_t cap, size_t *n_out, uint32_t *per_regex_count) {
+  if (!idx || !n_out || (k && !res) || (cap && !out)) { set_error("null argument"); return FMX_ERR_ARG; }
+  for (size_t r = 0; r < k; r++)
+    if (!res[r]) { set_error("null regex handle"); return FMX_ERR_ARG; }
+  return regex_match_batch(reinterpret_cast<const Index *>(idx), reinterpret_cast<const Regex *const *>(res), k, lim,
+                           out, cap, n_out, per_regex_count);
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// fmx_host.h -- host-side handle and the launch entry points shared by the .hip/.cpp units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+
+#include "fmx_device.h"
+
+namespace fmx {
+
+struct Index {
+  int device = 0;
+  int cu_count = 256;
+  uint64_t n = 0, eof = 0, nblocks = 0;
+  uint32_t nslots = 0;
+  int64_t counts[256] = {0};
+  uint64_t cf[256] = {0};
+  uint16_t slot[256] = {0};
+  // device memory owned by the handle
+  void *d_bv = nullptr;
+  void *d_bwt = nullptr;
+  void *d_cf = nullptr;
+  void *d_slot = nullptr;
+  unsigned long long *d_counters = nullptr;   // [0] rank queries, [1] backward steps
+  DevIndex dev{};
+  uint64_t index_bytes = 0;
+  double build_ms = 0.0;
+  // host-call bookkeeping
+  mutable std::mutex mu;
+  mutable uint64_t launches = 0;
+  mutable double last_kernel_ms = 0.0;
+};
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP
+
+// fmx_build.hip
+int build_index(Index *h, hipStream_t st, const int64_t *given_counts);   // returns an FMX_* status
+
+// fmx_kernels.hip
+hipError_t launch_occ(const Index *h, const void *d_c, const void *d_i, void *d_out, uint64_t k, hipStream_t st);
+hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep, const void *d_c, void *d_sp1,
+                             void *d_ep1, uint64_t k, hipStream_t st);
+hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
+                         hipStream_t st);
+hipError_t launch_lf_walk(const Index *h, const void *d_rows, uint64_t k, uint32_t len, void *d_out, void *d_end,
+                          hipStream_t st);
+hipError_t launch_psi(const Index *h, const void *d_rows, void *d_out, uint64_t k, hipStream_t st);
+hipError_t launch_next_substr(const Index *h, const void *d_sps, uint64_t k, uint32_t len, void *d_out,
+                              void *d_out_len, hipStream_t st);
+
+}  // namespace fmx

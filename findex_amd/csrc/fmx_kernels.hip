@@ -1,0 +1,286 @@
+// fmx_kernels.hip -- query kernels over the rank dictionary (gfx950, wave64).
+//
+// K2 occ_batch, K3 literal backward search, K4 prev_range_batch, LF / Psi walks.
+// All are HBM-bound integer work: one 128-byte line per rank query, fetched whole by an octet
+// of lanes (fmx_device.h); C[] and the symbol->slot map are staged in LDS per workgroup.
+// Reference semantics: SuffixAlgo (findex.scala:9-52), NaiveFMSearcher (bwtmerger.scala:335-421).
+#include "fmx_device.h"
+#include "fmx_host.h"
+
+namespace fmx {
+
+constexpr int kThreads = 256;                       // 4 waves, 32 octets per workgroup
+constexpr int kOctetsPerBlock = kThreads / kOctet;
+
+struct Tables {
+  uint64_t cf[256];
+  uint16_t slot[256];
+};
+
+__device__ __forceinline__ void stage_tables(const DevIndex &ix, Tables &tb) {
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) {
+    tb.cf[c] = ix.cf[c];
+    tb.slot[c] = ix.slot[c];
+  }
+  __syncthreads();
+}
+
+// One backward step for the whole octet: (sp, ep) -> (cf(c)+rank(c,sp), cf(c)+rank(c,ep)).
+// Both lines are requested before either is consumed.
+__device__ __forceinline__ void step(const DevIndex &ix, const Tables &tb, uint32_t c, uint32_t t, uint64_t &sp,
+                                     uint64_t &ep) {
+  const uint16_t slot = tb.slot[c];
+  const uint64_t cfc = tb.cf[c];
+  uint64_t r1 = 0, r2 = 0;
+  if (slot < kSlotEof) {
+    uint64_t b1, b2;
+    uint32_t m1, m2;
+    split960(sp, b1, m1);
+    split960(ep, b2, m2);
+    const uint4 w1 = *block_ptr(ix, slot, b1, t);
+    const uint4 w2 = *block_ptr(ix, slot, b2, t);
+    r1 = rank_finish(w1, m1, t);
+    r2 = rank_finish(w2, m2, t);
+  } else if (slot == kSlotEof) {
+    r1 = sp > ix.eof ? 1 : 0;
+    r2 = ep > ix.eof ? 1 : 0;
+  }
+  sp = cfc + r1;
+  ep = cfc + r2;
+}
+
+// ---------------------------------------------------------------- K2: occ_batch
+// SuffixAlgo.occ(c,i) = rank_excl(c, i+1); i < 0 -> 0; i >= n clamps to n-1.
+__global__ __launch_bounds__(kThreads) void k_occ(DevIndex ix, const uint8_t *__restrict__ c,
+                                                   const int64_t *__restrict__ i, uint64_t *__restrict__ out,
+                                                   uint64_t k, unsigned long long *__restrict__ counters) {
+  __shared__ Tables tb;
+  stage_tables(ix, tb);
+  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
+  uint32_t done = 0;
+  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
+    int64_t key = i[q];
+    uint64_t x = key < 0 ? 0 : ((uint64_t)key >= ix.n ? ix.n : (uint64_t)key + 1);
+    uint64_t r = rank_excl(ix, tb.slot[c[q]], x, t);
+    if (t == 0) out[q] = r;
+    done++;
+  }
+  if (t == 0 && done) atomicAdd(&counters[0], (unsigned long long)done);
+}
+
+// ---------------------------------------------------------------- K4: prev_range_batch
+__global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint64_t *__restrict__ sp_in,
+                                                          const uint64_t *__restrict__ ep_in,
+                                                          const uint8_t *__restrict__ c, uint64_t *__restrict__ sp1,
+                                                          uint64_t *__restrict__ ep1, uint64_t k,
+                                                          unsigned long long *__restrict__ counters) {
+  __shared__ Tables tb;
+  stage_tables(ix, tb);
+  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
+  uint32_t done = 0;
+  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
+    uint64_t sp = sp_in[q], ep = ep_in[q];
+    step(ix, tb, c[q], t, sp, ep);
+    if (t == 0) { sp1[q] = sp; ep1[q] = ep; }
+    done++;
+  }
+  if (t == 0 && done) { atomicAdd(&counters[0], 2ull * done); atomicAdd(&counters[1], (unsigned long long)done); }
+}
+
+// ---------------------------------------------------------------- K3: literal backward search
+// SuffixAlgo.search (findex.scala:15-31): one pattern per octet, octets walk the batch with a
+// grid stride and pick up their next pattern as soon as the current one ends (last byte consumed
+// or interval empty), so early exits do not idle lanes.  The next pattern's offsets and the next
+// pattern byte are requested a step early; only the two rank lines are on the dependent chain.
+__global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t *__restrict__ pat,
+                                                      const uint64_t *__restrict__ off, uint64_t *__restrict__ sp_out,
+                                                      uint64_t *__restrict__ ep_out, uint64_t k,
+                                                      unsigned long long *__restrict__ counters) {
+  __shared__ Tables tb;
+  stage_tables(ix, tb);
+  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
+  uint64_t p = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3;
+  bool active = p < k;
+  uint64_t base = 0, sp = 0, ep = ix.n;
+  int64_t i = -1;          // index of the byte to consume next
+  uint32_t c = 0;
+  uint64_t nb = 0, ne = 0; // offsets of the pattern this octet takes next
+  uint32_t steps = 0;
+  if (active) {
+    base = off[p];
+    i = (int64_t)(off[p + 1] - base) - 1;
+    if (i >= 0) c = pat[base + i];
+    if (p + noct < k) { nb = off[p + noct]; ne = off[p + noct + 1]; }
+  }
+  while (__builtin_amdgcn_ballot_w64(active)) {
+    if (active) {
+      if (i >= 0 && sp < ep) {
+        const uint32_t cn = i > 0 ? pat[base + i - 1] : 0;   // next byte, off the critical path
+        step(ix, tb, c, t, sp, ep);
+        c = cn;
+        i--;
+        steps++;
+      } else {
+        if (t == 0) { sp_out[p] = sp; ep_out[p] = ep; }
+        p += noct;
+        active = p < k;
+        if (active) {
+          base = nb;
+          i = (int64_t)(ne - nb) - 1;
+          sp = 0;
+          ep = ix.n;
+          if (i >= 0) c = pat[base + i];
+          if (p + noct < k) { nb = off[p + noct]; ne = off[p + noct + 1]; }
+        }
+      }
+    }
+  }
+  if (t == 0 && steps) { atomicAdd(&counters[0], 2ull * steps); atomicAdd(&counters[1], (unsigned long long)steps); }
+}
+
+// ---------------------------------------------------------------- LF walk (prevSubstr / getPrevI)
+// NaiveFMSearcher.prevSubstr (bwtmerger.scala:409-419): emit BWT'[row], row = cf(b)+occ(b,row-1).
+__global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_t *__restrict__ rows, uint64_t k,
+                                                       uint32_t len, uint8_t *__restrict__ out_bytes,
+                                                       uint64_t *__restrict__ end_rows,
+                                                       unsigned long long *__restrict__ counters) {
+  __shared__ Tables tb;
+  stage_tables(ix, tb);
+  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
+  uint32_t done = 0;
+  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
+    uint64_t r = rows[q];
+    for (uint32_t s = 0; s < len; s++) {
+      const uint32_t b = r == ix.eof ? 0u : ix.bwt[r];
+      if (out_bytes && t == 0) out_bytes[q * len + s] = (uint8_t)b;
+      r = tb.cf[b] + rank_excl(ix, tb.slot[b], r, t);
+    }
+    if (end_rows && t == 0) end_rows[q] = r;
+    done += len;
+  }
+  if (t == 0 && done) atomicAdd(&counters[0], (unsigned long long)done);
+}
+
+// ---------------------------------------------------------------- Psi (getNextI = fm[row])
+// fm[row] is the BWT position of the (row - cf(c))-th occurrence of the symbol c whose bucket
+// holds `row` (FMCreator, bwtmerger.scala:424-533): a select on c's bit-vector.  One lane per
+// query: binary search over block headers, then a scan of the block.  Not on the hot path.
+__device__ uint64_t psi_one(const DevIndex &ix, const uint64_t *cf, const uint16_t *slot, uint64_t row) {
+  if (row == 0) return ix.eof;                 // bucket 0 = the EOF row
+  int lo = 1, hi = 255;                        // last c with cf[c] <= row (cf is non-decreasing)
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (cf[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  // symbols without occurrences share their start with the next present symbol, so the LAST c
+  // with cf[c] <= row is the one that owns the row
+  const int c = lo;
+  const uint16_t s = slot[c];
+  if (s >= kSlotEof) return ix.n;              // unreachable for row < n
+  const uint64_t j = row - cf[c];              // 0-based occurrence wanted
+  const uint64_t *hdr = reinterpret_cast<const uint64_t *>(ix.bv + (uint64_t)s * ix.nblocks * (kBlockBytes / 16));
+  uint64_t a = 0, b = ix.nblocks - 1;          // last block with header <= j
+  while (a < b) {
+    uint64_t mid = (a + b + 1) >> 1;
+    if (hdr[mid * (kBlockBytes / 8)] <= j) a = mid; else b = mid - 1;
+  }
+  uint64_t need = j - hdr[a * (kBlockBytes / 8)];
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(hdr + a * (kBlockBytes / 8)) + 2;
+  for (uint32_t d = 0; d < 30; d++) {
+    uint32_t v = w[d];
+    uint32_t pc = __builtin_popcount(v);
+    if (need < pc) {
+      for (uint32_t z = 0; z < need; z++) v &= v - 1;       // drop `need` lowest set bits
+      return a * kBlockBits + d * 32 + (uint32_t)__builtin_ctz(v);
+    }
+    need -= pc;
+  }
+  return ix.n;   // unreachable for row < n
+}
+
+__global__ __launch_bounds__(kThreads) void k_psi(DevIndex ix, const uint64_t *__restrict__ rows,
+                                                   uint64_t *__restrict__ out, uint64_t k) {
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < k; q += (uint64_t)gridDim.x * blockDim.x)
+    out[q] = psi_one(ix, ix.cf, ix.slot, rows[q]);
+}
+
+// NaiveFMSearcher.nextSubstr (bwtmerger.scala:394-405) for k independent (sp) starts: walk Psi,
+// stop after a 0 byte; bytes are written in walk order (the host reverses, :404).
+__global__ __launch_bounds__(kThreads) void k_next_substr(DevIndex ix, const uint64_t *__restrict__ sps, uint64_t k,
+                                                           uint32_t len, uint8_t *__restrict__ out,
+                                                           uint32_t *__restrict__ out_len) {
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < k; q += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t cp = psi_one(ix, ix.cf, ix.slot, sps[q]);
+    uint32_t w = 0;
+    bool eof = false;
+    for (uint32_t s = 0; s < len && !eof; s++) {
+      const uint32_t b = cp == ix.eof ? 0u : ix.bwt[cp];
+      eof = b == 0;
+      out[q * len + w++] = (uint8_t)b;
+      cp = psi_one(ix, ix.cf, ix.slot, cp);
+    }
+    out_len[q] = w;
+  }
+}
+
+// ---------------------------------------------------------------- launchers
+static inline int grid_for(const Index *h, uint64_t k, int per_block) {
+  uint64_t want = (k + per_block - 1) / per_block;
+  uint64_t cap = (uint64_t)h->cu_count * 8;   // 8 x 256 threads fill a CU's 32 wave slots
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+hipError_t launch_occ(const Index *h, const void *d_c, const void *d_i, void *d_out, uint64_t k, hipStream_t st) {
+  if (!k) return hipSuccess;
+  k_occ<<<grid_for(h, k, kOctetsPerBlock), kThreads, 0, st>>>(h->dev, (const uint8_t *)d_c, (const int64_t *)d_i,
+                                                                 (uint64_t *)d_out, k, h->d_counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep, const void *d_c, void *d_sp1,
+                             void *d_ep1, uint64_t k, hipStream_t st) {
+  if (!k) return hipSuccess;
+  k_prev_range<<<grid_for(h, k, kOctetsPerBlock), kThreads, 0, st>>>(
+      h->dev, (const uint64_t *)d_sp, (const uint64_t *)d_ep, (const uint8_t *)d_c, (uint64_t *)d_sp1,
+      (uint64_t *)d_ep1, k, h->d_counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
+                         hipStream_t st) {
+  if (!k) return hipSuccess;
+  k_search<<<grid_for(h, k, kOctetsPerBlock), kThreads, 0, st>>>(h->dev, (const uint8_t *)d_pat,
+                                                                    (const uint64_t *)d_off, (uint64_t *)d_sp,
+                                                                    (uint64_t *)d_ep, k, h->d_counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_lf_walk(const Index *h, const void *d_rows, uint64_t k, uint32_t len, void *d_out, void *d_end,
+                          hipStream_t st) {
+  if (!k) return hipSuccess;
+  k_lf_walk<<<grid_for(h, k, kOctetsPerBlock), kThreads, 0, st>>>(h->dev, (const uint64_t *)d_rows, k, len,
+                                                                     (uint8_t *)d_out, (uint64_t *)d_end,
+                                                                     h->d_counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_psi(const Index *h, const void *d_rows, void *d_out, uint64_t k, hipStream_t st) {
+  if (!k) return hipSuccess;
+  k_psi<<<grid_for(h, k, kThreads), kThreads, 0, st>>>(h->dev, (const uint64_t *)d_rows, (uint64_t *)d_out, k);
+  return hipGetLastError();
+}
+
+hipError_t launch_next_substr(const Index *h, const void *d_sps, uint64_t k, uint32_t len, void *d_out,
+                              void *d_out_len, hipStream_t st) {
+  if (!k) return hipSuccess;
+  k_next_substr<<<grid_for(h, k, kThreads), kThreads, 0, st>>>(h->dev, (const uint64_t *)d_sps, k, len,
+                                                                 (uint8_t *)d_out, (uint32_t *)d_out_len);
+  return hipGetLastError();
+}
+
+}  // namespace fmx

@@ -1,0 +1,520 @@
+// fmx_regex.cpp -- REParser.re2post and ReTree, host side (see fmx_regex.h).
+//
+// The reference keeps its trees in Scala immutable Lists that are built by prepending; here a
+// list is a std::vector whose element 0 is the head, `xs ::= x` is insert-at-front and
+// `xs :::= ys` is "ys then xs".  Node identity is the arena index.
+#include "fmx_regex.h"
+
+#include <fmx.h>
+
+#include <algorithm>
+
+namespace fmx {
+namespace {
+
+constexpr int MIN_CHAR = 2;     // re2.scala:22
+constexpr int MAX_CHAR = 255;   // re2.scala:23
+
+[[noreturn]] void syntax() { throw RegexError{FMX_ERR_SYNTAX, "re2post syntax"}; }
+
+struct Paren { int nalt, natom; };
+
+}  // namespace
+
+// REParser.re2post, re2.scala:50-185
+std::vector<PostPoint> re2post(const std::string &s, bool line_only) {
+  const int l = (int)s.size();
+  int natom = 0, nalt = 0;
+  std::vector<PostPoint> dst;          // appended in emission order (the Scala code prepends, then reverses)
+  std::vector<Paren> stack;
+  auto emit = [&](PostPoint::Kind k) { PostPoint p; p.kind = k; dst.push_back(p); };
+  auto concat_if = [&]() {
+    if (natom > 1) { natom -= 1; emit(PostPoint::Concat); }
+  };
+  auto process_char = [&](int c, bool quoted) {          // :60-75
+    concat_if();
+    PostPoint p;
+    p.kind = PostPoint::Char;
+    p.c = c;
+    if (quoted) {
+      if (c == 'w') { p.kind = PostPoint::Interval; p.start = 'A'; p.end = 'z'; }
+      else if (c == 'd') { p.kind = PostPoint::Interval; p.start = '0'; p.end = '9'; }
+    } else if (c == '.') {
+      p.kind = PostPoint::Interval;
+      p.start = line_only ? 0x20 : MIN_CHAR;
+      p.end = MAX_CHAR;
+    }
+    dst.push_back(p);
+    natom += 1;
+  };
+  auto process_alt = [&](int i) -> int {                  // :76-119
+    std::vector<int> alts;                               // newest first
+    bool quoted = false, end = false, interval = false;
+    auto pc = [&](int c) {
+      if (interval) {
+        if (alts.empty()) syntax();
+        int cAlt = alts.front() + 1;
+        const int eAlt = c;
+        if (cAlt > eAlt) syntax();
+        while (cAlt <= eAlt) { alts.insert(alts.begin(), cAlt); cAlt += 1; }
+        interval = false;
+      } else {
+        alts.insert(alts.begin(), c);
+      }
+    };
+    while (i < l && !end) {
+      const int c = (unsigned char)s[i];
+      if (quoted) { pc(c); quoted = false; }
+      else if (c == '\\') quoted = true;
+      else if (c == '-') interval = true;
+      else if (c == ']') end = true;
+      else pc(c);
+      i += 1;
+    }
+    if (!end || interval) syntax();
+    concat_if();
+    PostPoint p;
+    p.kind = PostPoint::Alt;
+    p.alts = alts;
+    dst.push_back(p);
+    natom += 1;
+    return i;
+  };
+
+  int i = 0;
+  bool quoted = false;
+  while (i < l) {
+    const int c = (unsigned char)s[i];
+    if (!quoted) {
+      switch (c) {
+        case '(':                                         // :124-131
+          concat_if();
+          stack.push_back({nalt, natom});
+          nalt = 0;
+          natom = 0;
+          break;
+        case '|':                                         // :132-139
+          if (natom == 0) syntax();
+          natom -= 1;
+          while (natom > 0) { emit(PostPoint::Concat); natom -= 1; }
+          nalt += 1;
+          break;
+        case ')': {                                       // :140-153
+          if (natom == 0) syntax();
+          natom -= 1;
+          while (natom > 0) { emit(PostPoint::Concat); natom -= 1; }
+          while (nalt > 0) { emit(PostPoint::Or); nalt -= 1; }
+          if (stack.empty()) syntax();                    // Stack.pop on empty: NoSuchElementException there
+          const Paren t = stack.back();
+          stack.pop_back();
+          nalt = t.nalt;
+          natom = t.natom + 1;
+          break;
+        }
+        case '[':                                         // :154-155
+          i = process_alt(i + 1) - 1;
+          break;
+        case '\\':
+          quoted = true;
+          break;
+        case '*': case '+': case '?':                     // :158-164
+          if (natom == 0) syntax();
+          emit(c == '*' ? PostPoint::Star : c == '+' ? PostPoint::Plus : PostPoint::Question);
+          break;
+        default:
+          process_char(c, false);
+      }
+    } else {
+      process_char(c, true);
+      quoted = false;
+    }
+    i += 1;
+  }
+  if (!stack.empty()) syntax();
+  natom -= 1;
+  while (natom > 0) { emit(PostPoint::Concat); natom -= 1; }
+  while (nalt > 0) { emit(PostPoint::Or); nalt -= 1; }
+  return dst;
+}
+
+static void put_utf8(std::string &o, int c) {
+  if (c < 0x80) o.push_back((char)c);
+  else { o.push_back((char)(0xC0 | (c >> 6))); o.push_back((char)(0x80 | (c & 0x3F))); }
+}
+
+// PostPoint.toString, re2.scala:25-48
+std::string re2poststr(const std::string &re, bool line_only) {
+  std::string o;
+  for (const PostPoint &p : re2post(re, line_only)) {
+    switch (p.kind) {
+      case PostPoint::Char: put_utf8(o, p.c); break;
+      case PostPoint::Interval:
+        if (p.start == MIN_CHAR && p.end == MAX_CHAR) o += ".";
+        else { o += "["; put_utf8(o, p.start); o += "-"; put_utf8(o, p.end); o += "]"; }
+        break;
+      case PostPoint::Alt:
+        o += "[";
+        for (auto it = p.alts.rbegin(); it != p.alts.rend(); ++it) put_utf8(o, *it);
+        o += "]";
+        break;
+      case PostPoint::Concat: o += "\xC2\xB7"; break;     // U+00B7
+      case PostPoint::Star: o += "*"; break;
+      case PostPoint::Question: o += "?"; break;
+      case PostPoint::Plus: o += "+"; break;
+      case PostPoint::Or: o += "|"; break;
+    }
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------ ReTree
+namespace {
+
+enum NodeKind { N_CHAR, N_STAR, N_QUESTION, N_PLUS, N_OR, N_FOLLOW };
+constexpr int ROOT = -1;
+
+struct Node {
+  NodeKind kind;
+  int c = 0;
+  int num = 0;
+  int parent = ROOT;
+  std::vector<int> childs;    // head first
+};
+
+struct Tree {
+  std::vector<Node> a;
+
+  int make(NodeKind k, int c = 0) {
+    Node n;
+    n.kind = k;
+    n.c = c;
+    a.push_back(n);
+    return (int)a.size() - 1;
+  }
+  static bool unar(NodeKind k) { return k == N_STAR || k == N_QUESTION || k == N_PLUS; }
+
+  // Node.append of each class: UnarOp :73-77, Or :99-110, Follow :130-133
+  void append(int self, int n) {
+    Node &s = a[self];
+    if (s.kind == N_OR && a[n].kind == N_OR) {
+      for (int ch : a[n].childs) a[ch].parent = self;
+      std::vector<int> merged = a[n].childs;
+      merged.insert(merged.end(), s.childs.begin(), s.childs.end());
+      s.childs.swap(merged);
+    } else {
+      a[n].parent = self;
+      s.childs.insert(s.childs.begin(), n);
+    }
+  }
+
+  bool is_null(int x) const {
+    const Node &n = a[x];
+    switch (n.kind) {
+      case N_CHAR: return false;
+      case N_STAR: case N_QUESTION: return true;
+      case N_PLUS: case N_FOLLOW:
+        for (int ch : n.childs) if (!is_null(ch)) return false;
+        return true;
+      case N_OR:
+        for (int ch : n.childs) if (is_null(ch)) return true;
+        return false;
+    }
+    return false;
+  }
+
+  std::vector<int> firsts(int x) const {
+    const Node &n = a[x];
+    std::vector<int> ret;
+    if (n.kind == N_CHAR) { ret.push_back(x); return ret; }
+    if (n.kind == N_FOLLOW) {                              // :117-127
+      size_t p = 0;
+      auto prepend = [&](int ch) {
+        std::vector<int> f = firsts(ch);
+        f.insert(f.end(), ret.begin(), ret.end());
+        ret.swap(f);
+      };
+      while (p < n.childs.size() && is_null(n.childs[p])) { prepend(n.childs[p]); p++; }
+      if (p < n.childs.size()) prepend(n.childs[p]);
+      return ret;
+    }
+    for (int ch : n.childs) {                              // flatMap, :78,97
+      std::vector<int> f = firsts(ch);
+      ret.insert(ret.end(), f.begin(), f.end());
+    }
+    return ret;
+  }
+
+  std::vector<int> siblings_after(int parent, int me) const {   // childs.dropWhile(_ != this).tail
+    const std::vector<int> &ch = a[parent].childs;
+    size_t k = 0;
+    while (k < ch.size() && ch[k] != me) k++;
+    if (k >= ch.size()) return {};
+    return std::vector<int>(ch.begin() + k + 1, ch.end());
+  }
+
+  std::vector<int> follows(int x) const {                  // :14-38
+    const int p = a[x].parent;
+    if (p == ROOT) return {};
+    const Node &pn = a[p];
+    switch (pn.kind) {
+      case N_OR: return follows(p);
+      case N_FOLLOW: {
+        std::vector<int> last = siblings_after(p, x);
+        if (last.empty()) return follows(p);
+        std::vector<int> ret = firsts(last[0]);
+        auto prepend = [&](int ch) {
+          std::vector<int> f = firsts(ch);
+          f.insert(f.end(), ret.begin(), ret.end());
+          ret.swap(f);
+        };
+        if (is_null(last[0])) {
+          size_t k = 1;
+          while (k < last.size() && is_null(last[k])) { prepend(last[k]); k++; }
+          if (k < last.size()) prepend(last[k]);
+        }
+        return ret;
+      }
+      case N_STAR: {
+        std::vector<int> ret = firsts(x);
+        std::vector<int> pf = follows(p);
+        ret.insert(ret.end(), pf.begin(), pf.end());
+        return ret;
+      }
+      case N_QUESTION: return follows(p);
+      default: return {};                                  // PlusNode parent: List()
+    }
+  }
+
+  bool is_last(int x) const {                              // :40-50
+    const int p = a[x].parent;
+    if (p == ROOT) return true;
+    const Node &pn = a[p];
+    if (pn.kind == N_OR || unar(pn.kind)) return is_last(p);
+    if (pn.kind == N_FOLLOW) {
+      std::vector<int> last = siblings_after(p, x);
+      bool all_null = true;
+      for (int s : last) if (!is_null(s)) { all_null = false; break; }
+      return (last.empty() || all_null) ? is_last(p) : false;
+    }
+    return true;
+  }
+};
+
+char kind_letter(NodeKind k) {
+  switch (k) {
+    case N_CHAR: return 'C';
+    case N_OR: return 'O';
+    case N_FOLLOW: return 'F';
+    default: return 'U';
+  }
+}
+
+[[noreturn]] void match_error(const char *what) { throw RegexError{FMX_ERR_MATCH, what}; }
+
+int pop(std::vector<int> &args) {
+  if (args.empty()) throw RegexError{FMX_ERR_MATCH, "pop of an empty operand stack (NoSuchElementException)"};
+  int v = args.back();
+  args.pop_back();
+  return v;
+}
+
+// PlusPoint / StarPoint / QuestionPoint, retree.scala:296-337
+int unary(Tree &t, int a1, PostPoint::Kind op) {
+  const NodeKind k = t.a[a1].kind;
+  auto star_of_child = [&]() {
+    int el = t.make(N_STAR);
+    t.append(el, t.a[a1].childs.front());
+    return el;
+  };
+  if (op == PostPoint::Plus || op == PostPoint::Star) {
+    if (k == N_STAR) return a1;
+    if (k == N_QUESTION || k == N_PLUS) return star_of_child();
+    int el = t.make(op == PostPoint::Plus ? N_PLUS : N_STAR);
+    t.append(el, a1);
+    return el;
+  }
+  if (k == N_QUESTION) {
+    int el = t.make(N_QUESTION);
+    t.append(el, t.a[a1].childs.front());
+    return el;
+  }
+  if (k == N_STAR) return a1;
+  if (k == N_PLUS) return star_of_child();
+  int el = t.make(N_QUESTION);
+  t.append(el, a1);
+  return el;
+}
+
+// postProcess, retree.scala:439-482: rebuilds the tree (which undoes the prepend order of
+// `childs`) and rewrites x+ as x x*.
+int post_process(Tree &t, int r) {
+  const NodeKind k = t.a[r].kind;
+  if (k == N_CHAR) return t.make(N_CHAR, t.a[r].c);
+  if (k == N_PLUS) match_error("postProcess: PlusNode has no case");
+  const int nc = t.make(k);
+  const std::vector<int> old = t.a[r].childs;
+  for (int ch : old) {
+    if (t.a[ch].kind == N_PLUS) {
+      const int inner = t.a[ch].childs.front();
+      const int a1 = post_process(t, inner);
+      const int a2 = t.make(N_STAR);
+      t.append(a2, post_process(t, inner));
+      std::vector<int> &c = t.a[nc].childs;              // a1 :: a2 :: newL
+      c.insert(c.begin(), a2);
+      c.insert(c.begin(), a1);
+    } else {
+      const int pc = post_process(t, ch);
+      t.a[nc].childs.insert(t.a[nc].childs.begin(), pc);
+    }
+  }
+  return nc;
+}
+
+int remove_border_nulls(Tree &t, int a1) {                 // :371-385
+  const int n = t.make(N_FOLLOW);
+  std::vector<int> p = t.a[a1].childs;
+  size_t b = 0;
+  while (b < p.size() && t.is_null(p[b])) b++;
+  p.erase(p.begin(), p.begin() + b);
+  std::reverse(p.begin(), p.end());
+  b = 0;
+  while (b < p.size() && t.is_null(p[b])) b++;
+  p.erase(p.begin(), p.begin() + b);
+  for (int x : p) t.append(n, x);
+  return n;
+}
+
+void set_parents(Tree &t, int r, int parent) {             // :386-391
+  t.a[r].parent = parent;
+  for (int ch : t.a[r].childs) set_parents(t, ch, r);
+}
+
+int set_nums_scope(Tree &t, int r, int idx0);
+
+int set_nums_inner(Tree &t, int r, int &idx) {             // __setNums, :396-418
+  if (t.a[r].kind == N_OR) {
+    int nidx = idx;
+    for (int ch : t.a[r].childs) {
+      if (t.a[ch].kind == N_CHAR) {
+        t.a[ch].num = idx;
+        nidx = std::max(nidx, idx + 1);
+      } else {
+        nidx = std::max(nidx, set_nums_scope(t, ch, idx));
+      }
+    }
+    idx = nidx;
+  } else {
+    for (int ch : t.a[r].childs) {
+      if (t.a[ch].kind == N_CHAR) { t.a[ch].num = idx; idx += 1; }
+      else set_nums_inner(t, ch, idx);
+    }
+  }
+  return idx;
+}
+
+int set_nums_scope(Tree &t, int r, int idx0) {             // _setNums, :394-420
+  int idx = idx0;
+  return set_nums_inner(t, r, idx);
+}
+
+void collect_chars(const Tree &t, int r, std::vector<int> &out) {
+  if (t.a[r].kind == N_CHAR) out.push_back(r);
+  for (int ch : t.a[r].childs) collect_chars(t, ch, out);
+}
+
+}  // namespace
+
+// ReTree.apply, retree.scala:156-370, then the flattening the kernels use.
+Regex compile_regex(const std::string &re, bool line_only) {
+  const std::vector<PostPoint> post = re2post(re, line_only);
+  Tree t;
+  std::vector<int> args;                                   // mutable.Stack, top = back
+  for (const PostPoint &c : post) {
+    switch (c.kind) {
+      case PostPoint::Interval: {                          // :165-173, end exclusive
+        int el = t.make(N_OR);
+        for (int j = c.start; j < c.end; j++) t.append(el, t.make(N_CHAR, j));
+        args.push_back(el);
+        break;
+      }
+      case PostPoint::Alt: {                               // :174-179
+        int el = t.make(N_OR);
+        for (int ch : c.alts) t.append(el, t.make(N_CHAR, ch));
+        args.push_back(el);
+        break;
+      }
+      case PostPoint::Char:
+        args.push_back(t.make(N_CHAR, c.c));
+        break;
+      case PostPoint::Or: {                                // :181-239
+        const int a2 = pop(args), a1 = pop(args);
+        const char k1 = kind_letter(t.a[a1].kind), k2 = kind_letter(t.a[a2].kind);
+        if (k2 == 'O' && (k1 == 'C' || k1 == 'U' || k1 == 'F' || k1 == 'O')) {
+          t.append(a2, a1);
+          args.push_back(a2);
+        } else if ((k1 == 'F' && k2 == 'F') || (k1 == 'C' && k2 == 'C') || (k1 == 'U' && k2 == 'F') ||
+                   (k1 == 'C' && k2 == 'F') || (k1 == 'U' && k2 == 'C') || (k1 == 'F' && k2 == 'C') ||
+                   (k1 == 'U' && k2 == 'U')) {
+          int el = t.make(N_OR);
+          t.append(el, a1);
+          t.append(el, a2);
+          args.push_back(el);
+        } else {
+          match_error("OrPoint have no match for these operands");
+        }
+        break;
+      }
+      case PostPoint::Concat: {                            // :240-295
+        const int a2 = pop(args), a1 = pop(args);
+        const char k1 = kind_letter(t.a[a1].kind), k2 = kind_letter(t.a[a2].kind);
+        if ((k1 == 'O' && k2 == 'O') || (k1 == 'C' && k2 == 'O') || (k1 == 'C' && k2 == 'C') ||
+            (k1 == 'U' && k2 == 'C') || (k1 == 'U' && k2 == 'O') || (k1 == 'C' && k2 == 'U') ||
+            (k1 == 'U' && k2 == 'U')) {
+          int el = t.make(N_FOLLOW);
+          t.append(el, a1);
+          t.append(el, a2);
+          args.push_back(el);
+        } else if (k1 == 'F' && (k2 == 'C' || k2 == 'O' || k2 == 'U')) {
+          t.append(a1, a2);
+          args.push_back(a1);
+        } else {
+          match_error("ConcatPoint have no match for these operands");
+        }
+        break;
+      }
+      case PostPoint::Plus: case PostPoint::Star: case PostPoint::Question:
+        args.push_back(unary(t, pop(args), c.kind));
+        break;
+    }
+  }
+  const int a0 = pop(args);
+  int a2 = a0;                                             // :345-360
+  if (t.a[a0].kind != N_FOLLOW) {
+    a2 = t.make(N_FOLLOW);
+    t.append(a2, a0);
+  }
+  const int a1 = post_process(t, a2);
+  const int a3 = remove_border_nulls(t, a1);
+  set_parents(t, a3, ROOT);
+  set_nums_scope(t, a3, 1);
+
+  std::vector<int> chars;
+  collect_chars(t, a3, chars);
+  std::vector<int> index_of(t.a.size(), -1);
+  for (size_t k = 0; k < chars.size(); k++) index_of[chars[k]] = (int)k;
+  Regex out;
+  out.source = re;
+  out.fol_off.push_back(0);
+  for (int x : chars) {
+    if (t.a[x].c < 0 || t.a[x].c > 255) throw RegexError{FMX_ERR_SYNTAX, "character outside 0..255"};
+    out.st_c.push_back((uint8_t)t.a[x].c);
+    out.st_num.push_back(t.a[x].num);
+    out.st_last.push_back(t.is_last(x) ? 1 : 0);
+    for (int f : t.follows(x)) out.fol.push_back(index_of[f]);
+    out.fol_off.push_back((int32_t)out.fol.size());
+  }
+  for (int f : t.firsts(a3)) out.firsts.push_back(index_of[f]);
+  return out;
+}
+
+}  // namespace fmx

@@ -1,0 +1,127 @@
+"""REParser / ReTree / SAResult: the regex-search surface of findex (re2/re2.scala:9-205,
+re2/retree.scala) over libfmx.so.  Parsing and the Glushkov tables are built by the library's
+C++ host code; the SA-interval frontier is expanded on the GPU."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class PostfixRe:
+    """REParser.PostfixRe (re2.scala:49): the postfix token list, kept as the source string the
+    library re-parses; str() gives re2poststr."""
+
+    def __init__(self, src, lineOnly):
+        self.src = src
+        self.lineOnly = bool(lineOnly)
+        raw = src.encode("latin-1")
+        buf = ctypes.create_string_buffer(600 * len(raw) + 1024)     # '.' can print as 1 char, sets as many
+        _lib.check(_lib.load().fmx_regex_post_string(raw, 1 if lineOnly else 0, buf, len(buf)))
+        self.text = buf.value.decode("utf-8")
+
+    def __str__(self):
+        return self.text
+
+
+class REParser:
+    @staticmethod
+    def re2post(s, lineOnly=False):
+        """REParser.re2post, re2.scala:50-185 (raises Re2PostSyntax like the reference's Exception)."""
+        return PostfixRe(s, lineOnly)
+
+    @staticmethod
+    def re2poststr(s):
+        """re2.scala:187"""
+        return str(PostfixRe(s, False))
+
+
+class SAResult:
+    """SAResult(sa, len, sp, ep), re2.scala:9-19."""
+
+    def __init__(self, sa, length, sp, ep):
+        self.sa, self.len, self.sp, self.ep = sa, int(length), int(sp), int(ep)
+        self.cnt = self.ep - self.sp
+
+    @property
+    def strResult(self):
+        if self.cnt == 1:
+            return self.sa.nextSubstr(self.sp, self.len).decode("latin-1")
+        if self.cnt > 0:
+            return "[%d Results] %s" % (self.cnt, self.sa.nextSubstr(self.sp, self.len).decode("latin-1"))
+        return "[no results]"
+
+    def __str__(self):
+        return self.strResult
+
+    def __repr__(self):
+        return "SAResult(len=%d, sp=%d, ep=%d)" % (self.len, self.sp, self.ep)
+
+    def key(self):
+        return (self.len, self.sp, self.ep)
+
+
+class ReTree:
+    """ReTree(postfix) (retree.scala:156-370): raises MatchError for the operand shapes the
+    reference has no case for."""
+
+    def __init__(self, postfix):
+        if isinstance(postfix, str):
+            postfix = PostfixRe(postfix, False)
+        self._L = _lib.load()
+        self.postfix = postfix
+        self._h = ctypes.c_void_p()
+        _lib.check(self._L.fmx_regex_compile(postfix.src.encode("latin-1"), 1 if postfix.lineOnly else 0,
+                                             ctypes.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.fmx_regex_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def tables(self):
+        """The flat Glushkov tables (c, num, isLast, follows, firsts) as Python lists."""
+        ns, nf, nfi = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        _lib.check(self._L.fmx_regex_tables(self._h, ctypes.byref(ns), None, None, None, None, ctypes.byref(nf), None,
+                                            ctypes.byref(nfi), None))
+        c = np.zeros(max(ns.value, 1), dtype=np.uint8)
+        num = np.zeros(max(ns.value, 1), dtype=np.int32)
+        last = np.zeros(max(ns.value, 1), dtype=np.uint8)
+        off = np.zeros(ns.value + 1, dtype=np.int32)
+        fol = np.zeros(max(nf.value, 1), dtype=np.int32)
+        firsts = np.zeros(max(nfi.value, 1), dtype=np.int32)
+
+        def p(a):
+            return a.ctypes.data_as(ctypes.c_void_p)
+
+        _lib.check(self._L.fmx_regex_tables(self._h, None, p(c), p(num), p(last), p(off), None, p(fol), None,
+                                            p(firsts)))
+        n = ns.value
+        return {"c": c[:n].tolist(), "num": num[:n].tolist(), "isLast": [bool(x) for x in last[:n]],
+                "follows": [fol[off[k]:off[k + 1]].tolist() for k in range(n)],
+                "firsts": firsts[: nfi.value].tolist()}
+
+    def matchSA(self, sa, max_steps=0, max_frontier=0, cap=1 << 20):
+        """ReTree.matchSA (retree.scala:570-617) -> list of SAResult, sorted by (len, sp, ep).
+        Equals the reference's result multiset whenever its limits do not bind."""
+        return ReTree.matchSA_batch(sa, [self], max_steps, max_frontier, cap)[0]
+
+    @staticmethod
+    def matchSA_batch(sa, trees, max_steps=0, max_frontier=0, cap=1 << 20):
+        L = _lib.load()
+        k = len(trees)
+        arr = (ctypes.c_void_p * max(k, 1))(*[t._h for t in trees])
+        lim = _lib.fmx_limits(int(max_steps), int(max_frontier))
+        out = (_lib.fmx_result * cap)()
+        n_out = ctypes.c_size_t()
+        per = np.zeros(max(k, 1), dtype=np.uint32)
+        _lib.check(L.fmx_regex_match_batch(sa.handle, arr, k, ctypes.byref(lim), out, cap, ctypes.byref(n_out),
+                                           per.ctypes.data_as(ctypes.c_void_p)))
+        res = [[] for _ in range(k)]
+        for j in range(n_out.value):
+            r = out[j]
+            res[r.regex].append(SAResult(sa, r.len, r.sp, r.ep))
+        return res

@@ -1,0 +1,217 @@
+"""HipFMSearcher: the drop-in for findex's NaiveFMSearcher (bwtmerger.scala:335-421) and the
+SuffixAlgo / SuffixWalkingAlgo traits it implements (findex.scala:9-57), served by libfmx.so."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+def _swap_ext(filename, ext):
+    """BWTTempStorage.gen*Filename, bwtmerger.scala:17-48"""
+    return os.path.splitext(filename)[0] + ext
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None and a.size else None
+
+
+def _dp(x):
+    return ctypes.c_void_p(int(x) if x else 0)
+
+
+class HipFMSearcher:
+    """`new NaiveFMSearcher(filename, bigEndian)`: opens X.bwt and X.aux next to `filename` and
+    builds the rank dictionary in HBM (the reference's X.fm is not needed).
+
+    Scalar methods keep the reference's names and Option-like results (tuple or None); each
+    `*_batch` method is the batched form the kernels are built for.  Positions are Python ints /
+    uint64 arrays."""
+
+    def __init__(self, filename=None, bigEndian=True, device=0, _handle=None):
+        self._L = _lib.load()
+        self._h = ctypes.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _lib.check(self._L.fmx_open(_swap_ext(filename, ".bwt").encode(), _swap_ext(filename, ".aux").encode(),
+                                        1 if bigEndian else 0, int(device), ctypes.byref(self._h)))
+        v = ctypes.c_uint64()
+        _lib.check(self._L.fmx_n(self._h, ctypes.byref(v)))
+        self.n = int(v.value)
+        _lib.check(self._L.fmx_eof(self._h, ctypes.byref(v)))
+        self.eof = int(v.value)
+        self.K = 256
+        cf = np.zeros(256, dtype=np.uint64)
+        for c in range(256):
+            _lib.check(self._L.fmx_cf(self._h, c, ctypes.byref(v)))
+            cf[c] = v.value
+        self.bucketStarts = cf
+
+    # ---- alternative constructors
+    @classmethod
+    def from_mem(cls, bwt, eof, counts, device=0):
+        """fmx_open_mem: BWT bytes (filler at slot eof) + the .aux counts, from host memory."""
+        L = _lib.load()
+        bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        if counts.size != 256:
+            raise ValueError("counts must have 256 entries")
+        h = ctypes.c_void_p()
+        _lib.check(L.fmx_open_mem(_ptr(bwt), bwt.size, int(eof), _ptr(counts), int(device), ctypes.byref(h)))
+        return cls(_handle=h)
+
+    @classmethod
+    def from_device(cls, d_bwt_ptr, n, eof, counts=None, device=0, stream=0):
+        """fmx_open_dev: BWT bytes already resident in HBM (e.g. tensor.data_ptr())."""
+        L = _lib.load()
+        c = None if counts is None else np.ascontiguousarray(counts, dtype=np.int64)
+        h = ctypes.c_void_p()
+        _lib.check(L.fmx_open_dev(_dp(d_bwt_ptr), int(n), int(eof), _ptr(c), int(device), _dp(stream),
+                                  ctypes.byref(h)))
+        return cls(_handle=h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fmx_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- SuffixAlgo (findex.scala:9-52)
+    def cf(self, c):
+        if not 0 <= int(c) < 256:
+            raise IndexError("symbol %r (reference: ArrayIndexOutOfBoundsException)" % (c,))
+        return int(self.bucketStarts[int(c)])
+
+    def occ(self, c, i):
+        if not 0 <= int(c) < 256:
+            raise IndexError("symbol %r (reference: ArrayIndexOutOfBoundsException)" % (c,))
+        return int(self.occ_batch(np.array([c], dtype=np.uint8), np.array([i], dtype=np.int64))[0])
+
+    def search(self, pat):
+        pat = bytes(pat)
+        sp, ep = self.search_batch(np.frombuffer(pat, dtype=np.uint8), np.array([0, len(pat)], dtype=np.uint64))
+        return (int(sp[0]), int(ep[0])) if sp[0] < ep[0] else None
+
+    def getPrevRange(self, sp, ep, c):
+        if not 0 <= int(c) < 256:
+            raise IndexError("symbol %r (reference: ArrayIndexOutOfBoundsException)" % (c,))
+        a, b = self.prev_range_batch(np.array([sp], dtype=np.uint64), np.array([ep], dtype=np.uint64),
+                                     np.array([c], dtype=np.uint8))
+        return (int(a[0]), int(b[0])) if a[0] < b[0] else None
+
+    def getIntervalPrevRange(self, sp, ep, cstart, cend):
+        k = max(int(cend) - int(cstart) + 1, 1)
+        osp = np.zeros(k, dtype=np.uint64)
+        oep = np.zeros(k, dtype=np.uint64)
+        n_out = ctypes.c_size_t()
+        _lib.check(self._L.fmx_interval_prev_range(self._h, int(sp), int(ep), int(cstart), int(cend), _ptr(osp),
+                                                   _ptr(oep), None, ctypes.byref(n_out)))
+        return [(int(osp[j]), int(oep[j])) for j in range(n_out.value)]
+
+    # ---- NaiveFMSearcher walkers (bwtmerger.scala:376-419)
+    def getPrevI(self, i):
+        _, end = self.lf_walk_batch(np.array([i], dtype=np.uint64), 1, want_bytes=False)
+        return int(end[0])
+
+    def getNextI(self, i):
+        return int(self.psi_batch(np.array([i], dtype=np.uint64))[0])
+
+    def bwt_read(self, i):
+        """BWTLoader.read (bwtmerger.scala:155-162): 0 at the EOF slot."""
+        b, _ = self.lf_walk_batch(np.array([i], dtype=np.uint64), 1)
+        return int(b[0, 0])
+
+    def nextSubstr(self, sp, length):
+        out = np.zeros(max(int(length), 1), dtype=np.uint8)
+        w = ctypes.c_uint32()
+        _lib.check(self._L.fmx_next_substr(self._h, int(sp), int(length), _ptr(out), ctypes.byref(w)))
+        return bytes(out[: w.value])
+
+    def prevSubstr(self, sp, length):
+        out = np.zeros(max(int(length), 1), dtype=np.uint8)
+        _lib.check(self._L.fmx_prev_substr(self._h, int(sp), int(length), _ptr(out)))
+        return bytes(out[: int(length)])
+
+    # ---- batched forms (host arrays in, host arrays out)
+    def occ_batch(self, c, i):
+        c = np.ascontiguousarray(c, dtype=np.uint8)
+        i = np.ascontiguousarray(i, dtype=np.int64)
+        if c.size != i.size:
+            raise ValueError("c and i differ in length")
+        out = np.zeros(c.size, dtype=np.uint64)
+        _lib.check(self._L.fmx_occ_batch(self._h, _ptr(c), _ptr(i), _ptr(out), c.size))
+        return out
+
+    def search_batch(self, pat, off):
+        pat = np.ascontiguousarray(pat, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        k = off.size - 1
+        if k < 0:
+            raise ValueError("off needs k+1 entries")
+        if k and int(off[-1]) > pat.size:
+            raise ValueError("offsets run past the pattern buffer")
+        sp = np.zeros(k, dtype=np.uint64)
+        ep = np.zeros(k, dtype=np.uint64)
+        _lib.check(self._L.fmx_search_batch(self._h, _ptr(pat), _ptr(off), _ptr(sp), _ptr(ep), k))
+        return sp, ep
+
+    def prev_range_batch(self, sp, ep, c):
+        sp = np.ascontiguousarray(sp, dtype=np.uint64)
+        ep = np.ascontiguousarray(ep, dtype=np.uint64)
+        c = np.ascontiguousarray(c, dtype=np.uint8)
+        if not (sp.size == ep.size == c.size):
+            raise ValueError("sp, ep and c differ in length")
+        sp1 = np.zeros(sp.size, dtype=np.uint64)
+        ep1 = np.zeros(sp.size, dtype=np.uint64)
+        _lib.check(self._L.fmx_prev_range_batch(self._h, _ptr(sp), _ptr(ep), _ptr(c), _ptr(sp1), _ptr(ep1), sp.size))
+        return sp1, ep1
+
+    def lf_walk_batch(self, rows, length, want_bytes=True):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros((rows.size, int(length)), dtype=np.uint8) if want_bytes else None
+        end = np.zeros(rows.size, dtype=np.uint64)
+        _lib.check(self._L.fmx_lf_walk_batch(self._h, _ptr(rows), rows.size, int(length),
+                                             _ptr(out) if want_bytes else None, _ptr(end)))
+        return out, end
+
+    def psi_batch(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros(rows.size, dtype=np.uint64)
+        _lib.check(self._L.fmx_psi_batch(self._h, _ptr(rows), _ptr(out), rows.size))
+        return out
+
+    # ---- device-pointer forms (inputs resident in HBM; only enqueue on `stream`)
+    def search_batch_dev(self, d_pat, d_off, d_sp, d_ep, k, stream=0):
+        _lib.check(self._L.fmx_search_batch_dev(self._h, _dp(d_pat), _dp(d_off), _dp(d_sp), _dp(d_ep), int(k),
+                                                _dp(stream)))
+
+    def occ_batch_dev(self, d_c, d_i, d_out, k, stream=0):
+        _lib.check(self._L.fmx_occ_batch_dev(self._h, _dp(d_c), _dp(d_i), _dp(d_out), int(k), _dp(stream)))
+
+    def prev_range_batch_dev(self, d_sp, d_ep, d_c, d_sp1, d_ep1, k, stream=0):
+        _lib.check(self._L.fmx_prev_range_batch_dev(self._h, _dp(d_sp), _dp(d_ep), _dp(d_c), _dp(d_sp1), _dp(d_ep1),
+                                                    int(k), _dp(stream)))
+
+    def lf_walk_batch_dev(self, d_rows, k, length, d_out_bytes, d_end_rows, stream=0):
+        _lib.check(self._L.fmx_lf_walk_batch_dev(self._h, _dp(d_rows), int(k), int(length), _dp(d_out_bytes),
+                                                 _dp(d_end_rows), _dp(stream)))
+
+    # ---- statistics
+    def stats(self):
+        s = _lib.fmx_stats_t()
+        _lib.check(self._L.fmx_stats(self._h, ctypes.byref(s)))
+        return {f: getattr(s, f) for f, _ in s._fields_}
+
+    def stats_reset(self):
+        _lib.check(self._L.fmx_stats_reset(self._h))

@@ -1,0 +1,197 @@
+/*
+ * fmx.h -- C ABI of libfmx.so, the MI355X-native FM-index backward-search engine.
+ *
+ * This is the drop-in boundary for findex's search hot path.  The reference
+ * (martende/findex, Scala) has no FFI layer; its seam is the Scala trait
+ * SuffixAlgo / SuffixWalkingAlgo (src/main/scala/org/fmindex/findex.scala:9-57)
+ * that every search engine is written against.  Each entry point below names the
+ * reference member it replaces; INTEGRATION.md shows the JNI stub and the Scala
+ * adapter class (`HipFMSearcher extends SuffixWalkingAlgo`) a maintainer would
+ * add on the reference side.
+ *
+ * Conventions
+ *  - Every function returns an int status (FMX_OK == 0).  No exception crosses the
+ *    ABI; fmx_last_error() gives a thread-local message for the last failure.
+ *  - "No match" is a value, not an error: a miss is reported as sp == ep
+ *    (the Scala adapter maps that to None, findex.scala:30,35).
+ *  - Positions are uint64 (the reference's Int widened; identical for n < 2^31).
+ *  - Symbols are unsigned bytes.  The reference indexes with a signed Byte and
+ *    throws on bytes >= 0x80 (findex.scala:21,26); accepting them is a documented
+ *    superset.
+ *  - The caller owns every buffer it passes; the library keeps no caller pointer
+ *    after a call returns (fmx_open_dev copies the BWT).  Handles own their device
+ *    memory.  An index handle is immutable after open: concurrent calls on one
+ *    handle are allowed from different host threads.
+ *  - Plain entry points take HOST pointers and move data themselves.  The `_dev`
+ *    twins take DEVICE pointers plus a hipStream_t (as void*) and only enqueue
+ *    work: inputs already resident in HBM, outputs left in HBM.
+ *  - There is no CPU fallback anywhere: without a usable HIP device every compute
+ *    entry point fails with FMX_ERR_HIP.
+ */
+#ifndef FMX_H
+#define FMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMX_ABI_VERSION 1
+
+enum {
+  FMX_OK = 0,
+  FMX_ERR_IO = 1,          /* cannot open/read a file (reference: java.io exceptions) */
+  FMX_ERR_FORMAT = 2,      /* bad size/header ("File %s bad size", bwtmerger.scala:153,261-262) */
+  FMX_ERR_ARG = 3,         /* null handle / out-of-range argument (reference: ArrayIndexOutOfBounds) */
+  FMX_ERR_NOMEM = 4,       /* host or device allocation failed */
+  FMX_ERR_HIP = 5,         /* HIP runtime error / no device */
+  FMX_ERR_UNSUPPORTED = 6, /* valid input this build cannot serve */
+  FMX_ERR_SYNTAX = 7,      /* "re2post syntax" (re2/re2.scala:84,87,109,133,141,159,174) */
+  FMX_ERR_MATCH = 8,       /* scala.MatchError from ReTree.apply (re2/retree.scala:235-238,291-294) */
+  FMX_ERR_OVERFLOW = 9     /* a caller-sized output or a device work queue was too small */
+};
+
+typedef struct fmx_index fmx_index;   /* replaces class NaiveFMSearcher, bwtmerger.scala:335-421 */
+typedef struct fmx_regex fmx_regex;   /* replaces class ReTree, re2/retree.scala:485 */
+
+const char *fmx_last_error(void);
+int fmx_abi_version(void);
+/* Number of HIP devices visible (0 and FMX_OK when there is none). */
+int fmx_device_count(int *count);
+
+/* ---- open / close ------------------------------------------------------------
+ * fmx_open      : NaiveFMSearcher(filename, bigEndian) constructor, bwtmerger.scala:335-353,
+ *                 reading X.bwt (BWTLoader :144-174) and X.aux (AUXLoader :130-142).  The
+ *                 reference's third file, X.fm (FMLoader :252-290), is not read: its content
+ *                 is a function of the other two (FMCreator :424-533) and the device rank
+ *                 dictionary is built from them directly.
+ * fmx_open_mem  : the same from host memory (bwt[n] raw bytes incl. the filler at slot eof,
+ *                 counts[256] = the .aux array).
+ * fmx_open_dev  : the same with the BWT bytes already in device memory; counts may be NULL
+ *                 (then they are computed on the device).
+ * counts[0] must be 0 (the reference's readers escape byte 0, bwtreader.scala:136-155, and its
+ * FMCreator gives symbol 0 exactly the one EOF slot, bwtmerger.scala:440-450).  Unlike the
+ * reference, open verifies counts against the BWT and fails with FMX_ERR_FORMAT on mismatch. */
+int fmx_open(const char *bwt_path, const char *aux_path, int big_endian, int device, fmx_index **out);
+int fmx_open_mem(const uint8_t *bwt, uint64_t n, uint64_t eof, const int64_t counts[256], int device,
+                 fmx_index **out);
+int fmx_open_dev(const void *d_bwt, uint64_t n, uint64_t eof, const int64_t *counts_or_null, int device,
+                 void *stream, fmx_index **out);
+int fmx_close(fmx_index *idx);
+
+/* ---- scalars: SuffixAlgo.n / cf, findex.scala:10-12; NaiveFMSearcher.cf bwtmerger.scala:346-352 */
+int fmx_n(const fmx_index *idx, uint64_t *n);
+int fmx_eof(const fmx_index *idx, uint64_t *eof);
+int fmx_cf(const fmx_index *idx, int c, uint64_t *out);
+int fmx_counts(const fmx_index *idx, int64_t out[256]);
+int fmx_device(const fmx_index *idx, int *device);
+
+/* ---- batched rank: SuffixAlgo.occ(c,i), findex.scala:13; NaiveFMSearcher.occ bwtmerger.scala:354-375.
+ * out[q] = #{p <= i[q] : BWT'[p] == c[q]}, BWT' = BWT with slot eof read as symbol 0; i = -1 gives 0;
+ * i >= n is clamped to n-1 (what the binary search returns for any key past the last entry). */
+int fmx_occ_batch(const fmx_index *idx, const uint8_t *c, const int64_t *i, uint64_t *out, size_t k);
+int fmx_occ_batch_dev(const fmx_index *idx, const void *d_c, const void *d_i, void *d_out, size_t k, void *stream);
+
+/* ---- batched literal backward search: SuffixAlgo.search, findex.scala:15-31.
+ * Pattern q is pat[off[q] .. off[q+1]) (off has k+1 entries), matched last byte first from (0, n);
+ * sp[q], ep[q] receive the loop's final values: a hit iff sp < ep, a miss has sp == ep.
+ * An empty pattern yields (0, n). */
+int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
+                     size_t k);
+int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep,
+                         size_t k, void *stream);
+
+/* ---- batched single step: SuffixAlgo.getPrevRange(sp,ep,c), findex.scala:32-36.
+ * sp1 = cf(c)+occ(c,sp-1), ep1 = cf(c)+occ(c,ep-1); empty iff sp1 >= ep1.  Needs sp <= ep <= n. */
+int fmx_prev_range_batch(const fmx_index *idx, const uint64_t *sp, const uint64_t *ep, const uint8_t *c,
+                         uint64_t *sp1, uint64_t *ep1, size_t k);
+int fmx_prev_range_batch_dev(const fmx_index *idx, const void *d_sp, const void *d_ep, const void *d_c,
+                             void *d_sp1, void *d_ep1, size_t k, void *stream);
+
+/* ---- character-class step: SuffixAlgo.getIntervalPrevRange(sp,ep,cstart,cend), findex.scala:37-51.
+ * All c in [cstart, cend] (inclusive, 0 <= cstart, cend <= 255); only non-empty ranges are
+ * returned, in DESCENDING c like the reference's prepended list.  out arrays need cend-cstart+1
+ * slots; *n_out = number written. */
+int fmx_interval_prev_range(const fmx_index *idx, uint64_t sp, uint64_t ep, int cstart, int cend,
+                            uint64_t *out_sp, uint64_t *out_ep, uint8_t *out_c, size_t *n_out);
+
+/* ---- LF walks: NaiveFMSearcher.getPrevI / prevSubstr, bwtmerger.scala:386-389,409-419.
+ * For each start row: `len` times emit BWT'[row] (0 at the EOF row) and step row = LF(row).
+ * out_bytes is k*len bytes (walk q at q*len, in emission order = prevSubstr's string);
+ * end_rows (optional) receives the row after the last step. */
+int fmx_lf_walk_batch(const fmx_index *idx, const uint64_t *rows, size_t k, uint32_t len, uint8_t *out_bytes,
+                      uint64_t *end_rows);
+int fmx_lf_walk_batch_dev(const fmx_index *idx, const void *d_rows, size_t k, uint32_t len, void *d_out_bytes,
+                          void *d_end_rows, void *stream);
+
+/* ---- Psi walks: NaiveFMSearcher.getNextI / nextSubstr, bwtmerger.scala:390-405.
+ * fmx_psi_batch: out[q] = fm[rows[q]] (the inverted-list entry = select on the rank dictionary).
+ * fmx_next_substr: the reference's nextSubstr(sp,len): walk Psi, stop after a 0 byte, reversed;
+ * out needs len bytes, *out_len = bytes written. */
+int fmx_psi_batch(const fmx_index *idx, const uint64_t *rows, uint64_t *out, size_t k);
+int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out, uint32_t *out_len);
+int fmx_prev_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out);
+
+/* ---- regex: REParser.re2post (re2/re2.scala:50-185) + ReTree.apply (re2/retree.scala:156-370).
+ * Bytes of `re` are Latin-1 characters.  FMX_ERR_SYNTAX / FMX_ERR_MATCH mirror the reference's
+ * "re2post syntax" exception and scala.MatchError. */
+int fmx_regex_compile(const char *re, int line_only, fmx_regex **out);
+int fmx_regex_free(fmx_regex *re);
+/* Flat Glushkov tables (what ReTree._matchSA touches): per CharNode its byte, `num`
+ * (retree.scala:393-423), isLast (:40-50), and `follows` (:14-38) as a CSR list that keeps the
+ * reference's order and multiplicity; `firsts` = root.firsts.  Any output pointer may be NULL;
+ * sizes come back through the n_* pointers. */
+int fmx_regex_tables(const fmx_regex *re, uint32_t *n_states, uint8_t *st_c, int32_t *st_num, uint8_t *st_last,
+                     int32_t *fol_off /* n_states+1 */, uint32_t *n_follows, int32_t *fol, uint32_t *n_firsts,
+                     int32_t *firsts);
+/* re2poststr, re2/re2.scala:187 (UTF-8). */
+int fmx_regex_post_string(const char *re, int line_only, char *out, size_t cap);
+
+typedef struct fmx_limits {
+  /* ReTree.matchSA defaults: maxBranching=1024, maxIterations=1000 (re2/retree.scala:570).
+   * The frontier kernel expands every regex's frontier breadth-first, so results equal the
+   * reference's whenever its limits do not bind; here the limits are safety caps:
+   * max_steps   = maximum pattern length explored (levels), 0 = FMX default (4096)
+   * max_frontier= capacity of the device work queue in items, 0 = default (1<<22) */
+  uint32_t max_steps;
+  uint64_t max_frontier;
+} fmx_limits;
+
+typedef struct fmx_result {   /* SAResult(sa,len,sp,ep), re2/re2.scala:9-19, + which regex */
+  uint32_t regex;
+  uint32_t len;
+  uint64_t sp;
+  uint64_t ep;
+} fmx_result;
+
+/* ReTree.matchSA over a batch of compiled regexes (re2/retree.scala:570-653): frontier items
+ * (regex, CharNode, len, sp, ep) start at root.firsts x (0, 0, n); each is stepped with
+ * getPrevRange; isLast states emit a result, the others push their follows.  Results are written
+ * sorted by (regex, len, sp, ep) -- the reference's list order is its priority queue's discovery
+ * order, which is not part of this contract.  per_regex_count (optional, k entries) = results per
+ * regex.  FMX_ERR_OVERFLOW if out (cap entries) or the work queue was too small: *n_out then
+ * holds the number of results found so far / needed. */
+int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,
+                          fmx_result *out, size_t cap, size_t *n_out, uint32_t *per_regex_count);
+
+/* ---- statistics (since open or the last reset; device counters are read with a sync) */
+typedef struct fmx_stats_t {
+  uint64_t rank_queries;     /* occ evaluations actually executed on the device */
+  uint64_t backward_steps;   /* getPrevRange-equivalents executed (2 rank queries each) */
+  uint64_t launches;         /* kernels launched by this handle */
+  double last_kernel_ms;     /* device time of the last host-pointer call's kernel(s), HIP events */
+  uint64_t index_bytes;      /* device bytes held: rank dictionary + BWT + tables */
+  uint64_t n_blocks;         /* rank-dictionary blocks per symbol */
+  uint32_t n_symbols;        /* symbols that own a bit-vector */
+  uint32_t block_bytes;      /* bytes fetched per rank query = one block */
+  double build_ms;           /* device time to build the rank dictionary at open */
+} fmx_stats_t;
+int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
+int fmx_stats_reset(fmx_index *idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMX_H */

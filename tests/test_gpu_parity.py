@@ -1,0 +1,336 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes -> libfmx.so), against
+the CPU oracle on the same inputs, bit for bit.  Needs a real MI355X:  pytest -m gpu
+"""
+import os
+
+import numpy as np
+import pytest
+
+import findex_amd
+import oracle
+from oracle import retree as R
+from helpers import bwt_of_text, lf_walk_patterns, pack_patterns, synth_bwt
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = [("test1024.cmp", False), ("test2048.cmp", False), ("test2048-2.cmp", False), ("test3072.cmp", False),
+            ("test.cmp", False), ("test-part.cmp", False), ("words", True)]
+
+
+def pair_from_files(testdata, name, be):
+    p = os.path.join(testdata, name + ".bwt")
+    return findex_amd.HipFMSearcher(p, bigEndian=be), oracle.NaiveFMSearcher(p, bigEndian=be)
+
+
+def pair_from_mem(bwt, eof, counts):
+    return findex_amd.HipFMSearcher.from_mem(bwt, eof, counts), oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+
+
+def check_occ(hip, orc, rng, k, symbols):
+    c = rng.choice(np.asarray(symbols, dtype=np.uint8), size=k)
+    i = rng.integers(-1, orc.n + 2, size=k, dtype=np.int64)
+    i[:4] = [-1, 0, orc.n - 1, orc.n + 5]
+    want = orc.occ_batch(c, i)
+    got = hip.occ_batch(c, i)
+    assert np.array_equal(got.astype(np.int64), want)
+
+
+def check_search(hip, orc, pats):
+    buf, off = pack_patterns(pats)
+    wsp, wep, wsteps = orc.search_batch(buf, off)
+    hip.stats_reset()
+    gsp, gep = hip.search_batch(buf, off)
+    assert np.array_equal(gsp, wsp) and np.array_equal(gep, wep)
+    st = hip.stats()
+    assert st["backward_steps"] == int(wsteps.sum()) and st["rank_queries"] == 2 * int(wsteps.sum())
+    return int((wsp < wep).sum())
+
+
+# ---------------------------------------------------------------- reference fixtures
+@pytest.mark.parametrize("name,be", FIXTURES)
+def test_fixture_files_occ_search_step(testdata, name, be):
+    hip, orc = pair_from_files(testdata, name, be)
+    assert hip.n == orc.n and hip.eof == orc.eof
+    assert [hip.cf(c) for c in range(256)] == [orc.cf(c) for c in range(256)]
+    rng = np.random.default_rng(abs(hash(name)) % 2**32)
+    present = [c for c in range(256) if orc.occ(c, orc.n - 1) > 0]
+    check_occ(hip, orc, rng, 4000, present + [0, 1, 255, 200])
+    pats = lf_walk_patterns(orc, rng, 300, 8, 0.1, alphabet=present)
+    pats += lf_walk_patterns(orc, rng, 100, 40, 0.3, alphabet=present)
+    pats += [b"", b"a", bytes([present[0]]), b"\x00", b"zz\x00", b"\x80\xff", bytes(rng.integers(1, 256, 17, dtype=np.uint8))]
+    hits = check_search(hip, orc, pats)
+    assert hits > 200
+    # single steps on random valid intervals
+    sp = rng.integers(0, orc.n + 1, size=3000).astype(np.uint64)
+    ep = rng.integers(0, orc.n + 1, size=3000).astype(np.uint64)
+    sp, ep = np.minimum(sp, ep), np.maximum(sp, ep)
+    c = rng.choice(np.asarray(present + [0, 255], dtype=np.uint8), size=3000)
+    w1, w2 = orc.prev_range_batch(sp, ep, c)
+    g1, g2 = hip.prev_range_batch(sp, ep, c)
+    assert np.array_equal(g1, w1) and np.array_equal(g2, w2)
+    for a, b in ((0, orc.n), (5, 700), (int(sp[0]), int(ep[0]))):
+        assert hip.getIntervalPrevRange(a, b, 0, 255) == orc.getIntervalPrevRange(a, b, 0, 255)
+        assert hip.getIntervalPrevRange(a, b, 97, 122) == orc.getIntervalPrevRange(a, b, 97, 122)
+
+
+def test_words_c1_thousand_8char_literals(testdata):
+    """BASELINE config C1: 1k 8-char literals cut from words lines, reversed (the index is over
+    the reversed text); counts cross-checked against the text itself."""
+    hip, orc = pair_from_files(testdata, "words", True)
+    txt = open(os.path.join(testdata, "words.txt"), "rb").read()
+    rng = np.random.default_rng(1)
+    lines = [w for w in txt.split(b"\r\n") if len(w) >= 8]
+    pats = [bytes(lines[i][:8][::-1]) for i in rng.integers(0, len(lines), 1000)]
+    buf, off = pack_patterns(pats)
+    sp, ep = hip.search_batch(buf, off)
+    wsp, wep, _ = orc.search_batch(buf, off)
+    assert np.array_equal(sp, wsp) and np.array_equal(ep, wep) and (sp < ep).all()
+    for j in range(0, 1000, 50):
+        p = pats[j][::-1]
+        want, k = 0, txt.find(p)
+        while k >= 0:
+            want += 1
+            k = txt.find(p, k + 1)
+        assert int(ep[j] - sp[j]) == want
+    assert hip.search(b"aardvark"[::-1]) == (1044943, 1044945) and hip.search(b"aardvark") is None
+
+
+def test_reference_kats_through_the_product(testdata):
+    """The reference's own known answers (T/Indexer.scala:247-351,1076-1124, T/REParser.scala:236-291),
+    asked of the HIP path."""
+    hip = findex_amd.HipFMSearcher.from_mem(*bwt_of_text(b"abracadabra"))
+    assert hip.cf(0) == 0 and hip.cf(ord("a")) == 1 and hip.cf(ord("b")) == 6
+    rows = {0: [0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1], ord("a"): [1, 1, 1, 1, 1, 1, 2, 3, 4, 5, 5, 5],
+            ord("b"): [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2], ord("c"): [0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1],
+            ord("d"): [0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], ord("r"): [0, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2],
+            ord("x"): [0] * 12}
+    for c, want in rows.items():
+        assert [hip.occ(c, i) for i in range(12)] == want
+    assert hip.search(b"bra") == (6, 8)
+    assert hip.getPrevI(6) == 2 and hip.getNextI(6) == 10 and hip.getNextI(10) == 1
+    assert hip.psi_batch(np.arange(12, dtype=np.uint64)).tolist() == [3, 0, 6, 7, 8, 9, 10, 11, 5, 2, 1, 4]
+    hip = findex_amd.HipFMSearcher.from_mem(*bwt_of_text(b"mmabcacadabbbca"[::-1]))
+    assert hip.occ(ord("b"), 6) == 3
+    assert hip.getPrevRange(0, 16, ord("a")) == (1, 6) and hip.getPrevRange(1, 6, ord("b")) == (6, 8)
+    # file backed, little endian golden
+    hip = findex_amd.HipFMSearcher(os.path.join(testdata, "test1024.cmp.bwt"), bigEndian=False)
+    eof = hip.eof
+    assert eof == 462 and hip.bwt_read(0) == ord("u") and hip.bwt_read(eof) == 0
+    assert hip.getPrevI(eof) == 0 and hip.getNextI(eof) == 517 and hip.getPrevI(1) == 48 and hip.getPrevI(48) == 649
+    assert hip.nextSubstr(1, 3) == b"haa" and hip.prevSubstr(1, 5) == b"bqxxa"
+    assert hip.prevSubstr(eof, 5) == b"\0uexm" and hip.prevSubstr(hip.getPrevI(eof), 4) == b"uexm"
+    assert hip.nextSubstr(eof, 100) == (
+        b"ajrtzbeqwbxdfpwjflmmsseewuudgfbtzqenjqafwzcnfanycigwsflfvxojxpqhhzekjdkhgsptqveavquuoqujbezdkarayoml")
+    # small2.txt
+    hip = findex_amd.HipFMSearcher.from_mem(*bwt_of_text(b"ippisissim"[::-1]))
+    assert [hip.getNextI(i) for i in (0, 5, 4, 10, 9)] == [5, 4, 10, 9, 3]
+    assert [hip.getPrevI(i) for i in (3, 9, 10, 4, 5, 0)] == [9, 10, 4, 5, 0, 1]
+
+
+@pytest.mark.parametrize("name,be", [("test1024.cmp", False), ("test.cmp", False), ("words", True)])
+def test_walks_all_rows(testdata, name, be):
+    """Psi == the reference's .fm payload and LF == getPrevI, for every row (a sample on words)."""
+    hip, orc = pair_from_files(testdata, name, be)
+    rows = np.arange(orc.n, dtype=np.uint64)
+    if orc.n > 20000:
+        rows = np.random.default_rng(3).integers(0, orc.n, 20000).astype(np.uint64)
+        rows[:3] = [0, orc.eof, orc.n - 1]
+    fm = orc.fm()
+    assert np.array_equal(hip.psi_batch(rows), fm[rows.astype(np.int64)].astype(np.uint64))
+    b, end = hip.lf_walk_batch(rows, 6)
+    for j in range(min(300, rows.size)):
+        assert bytes(b[j]) == orc.prevSubstr(int(rows[j]), 6)
+    want_end = np.array([orc.getPrevI(int(r)) for r in rows[:2000]], dtype=np.uint64)
+    _, e1 = hip.lf_walk_batch(rows[:2000], 1, want_bytes=False)
+    assert np.array_equal(e1, want_end)
+    for sp, ln in ((1, 3), (int(orc.eof), 50), (int(orc.n - 1), 7), (0, 4)):
+        assert hip.nextSubstr(sp, ln) == orc.nextSubstr(sp, ln)
+        assert hip.prevSubstr(sp, ln) == orc.prevSubstr(sp, ln)
+
+
+# ---------------------------------------------------------------- synthetic indexes
+@pytest.mark.parametrize("n,lo,hi,seed", [
+    (1, 1, 1, 1), (2, 1, 2, 2), (959, 1, 4, 3), (960, 1, 4, 4), (961, 1, 4, 5), (1920, 1, 4, 6), (1921, 65, 68, 7),
+    (100_003, 1, 4, 8),            # DNA-like sigma=4 (C2 shape, small)
+    (300_007, 1, 128, 9),          # sigma=128 incl. byte 0x80 (C3 shape, small)
+    (200_000, 1, 255, 10),         # every byte value
+    (50_000, 200, 255, 11),        # only bytes >= 0x80: the reference would throw, the product must not
+])
+def test_synthetic_parity(n, lo, hi, seed):
+    rng = np.random.default_rng(seed)
+    for eof in sorted({0, n // 3, n - 1}):
+        bwt, eof, counts = synth_bwt(n, lo, hi, seed, eof=eof)
+        hip, orc = pair_from_mem(bwt, eof, counts)
+        syms = list(range(lo, hi + 1))
+        check_occ(hip, orc, rng, 3000, syms + [0, 255])
+        m = 1 if n < 10 else (16 if hi - lo < 8 else 6)
+        pats = lf_walk_patterns(orc, rng, 400, m, 0.1, alphabet=syms) + [b"", bytes([lo]), b"\x00"]
+        check_search(hip, orc, pats)
+        if n > 1000:
+            pats = lf_walk_patterns(orc, rng, 200, 33, 0.2, alphabet=syms)
+            check_search(hip, orc, pats)
+
+
+def test_many_patterns_ragged_lengths():
+    """More patterns than resident octets, lengths 0..70, so octets chain through several patterns."""
+    bwt, eof, counts = synth_bwt(400_000, 1, 4, 77)
+    hip, orc = pair_from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(5)
+    pats = []
+    for m in (0, 1, 2, 7, 19, 32, 70):
+        pats += lf_walk_patterns(orc, rng, 3000 if m else 50, m, 0.15, alphabet=[1, 2, 3, 4])
+    order = rng.permutation(len(pats))
+    pats = [pats[i] for i in order]
+    # ~130k patterns: replicate to exceed the 65536 resident octets
+    pats = pats * 8
+    hits = check_search(hip, orc, pats)
+    assert hits > 50_000
+
+
+def test_counts_must_describe_bwt():
+    bwt, eof, counts = synth_bwt(5000, 1, 4, 1)
+    bad = counts.copy()
+    bad[1] += 1
+    bad[2] -= 1
+    with pytest.raises(findex_amd.FmxError) as e:
+        findex_amd.HipFMSearcher.from_mem(bwt, eof, bad)
+    assert e.value.code == 2
+    zero = bwt.copy()
+    zero[17] = 0
+    c2 = np.bincount(zero, minlength=256).astype(np.int64)
+    c2[zero[eof]] -= 1
+    with pytest.raises(findex_amd.FmxError) as e:
+        findex_amd.HipFMSearcher.from_mem(zero, eof, c2)
+    assert e.value.code in (2, 6)
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    with pytest.raises(findex_amd.FmxError):
+        hip.prev_range_batch([5], [4], [1])            # sp > ep
+    with pytest.raises(findex_amd.FmxError):
+        hip.lf_walk_batch([5000], 1)                   # row out of range
+
+
+# ---------------------------------------------------------------- regex frontier (K5)
+REGEXES = ["ab", "abc", "a[bcd]e", "th(e|a)", "q[a-z]*k", "co(m|n)+e", "a[b-d]*e", "x?yz", "(ab)*c", "ing\r\n",
+           "ab(cd|ef)+gh", "a(cd|ef)*j", "s[aeiou]+t", "[a-c]", "(a|b|d|c)", "z(a|e)*b", "un[a-z][a-z]ed"]
+
+
+def oracle_results(orc, re, lineOnly=False):
+    t = R.ReTree(R.re2post(re, lineOnly))
+    res, left, pops = orc.match_tables(t.tables(), 1 << 40, 0, cap=1 << 22)
+    assert left == 0
+    return sorted(res), pops
+
+
+@pytest.mark.parametrize("name,be", [("test.cmp", False), ("words", True)])
+def test_regex_frontier_parity(testdata, name, be):
+    """ReTree.matchSA with limits that do not bind: same result multiset, same number of
+    getPrevRange calls."""
+    hip, orc = pair_from_files(testdata, name, be)
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re)) for re in REGEXES]
+    hip.stats_reset()
+    got = findex_amd.ReTree.matchSA_batch(hip, trees, cap=1 << 21)
+    total_pops = 0
+    for re, g in zip(REGEXES, got):
+        want, pops = oracle_results(orc, re)
+        total_pops += pops
+        assert [r.key() for r in g] == want, re
+    assert hip.stats()["backward_steps"] == total_pops
+    # single-regex entry point and SAResult rendering (re2.scala:9-19)
+    one = trees[1].matchSA(hip)
+    assert [r.key() for r in one] == oracle_results(orc, REGEXES[1])[0]
+    for r in one[:5]:
+        sub = orc.nextSubstr(r.sp, r.len).decode("latin-1")
+        assert str(r) == (sub if r.cnt == 1 else "[%d Results] %s" % (r.cnt, sub))
+
+
+def test_regex_reference_vectors():
+    """T/REParser.scala:591-605: '.*(a|b)ca' over reversed 'mmabcacamabbbca' -> 2 results."""
+    hip, orc = pair_from_mem(*bwt_of_text(b"mmabcacamabbbca"[::-1]))
+    got = findex_amd.ReTree(findex_amd.REParser.re2post(".*(a|b)ca")).matchSA(hip)
+    assert len(got) == 2
+    assert [r.key() for r in got] == oracle_results(orc, ".*(a|b)ca")[0]
+
+
+def test_regex_duplicate_follows_give_duplicate_results():
+    """The reference does not dedup frontier states: (a|a)b emits each hit twice."""
+    hip, orc = pair_from_mem(*bwt_of_text(b"xxabxxabyab"[::-1]))
+    for re in ("(a|a)b", "(a*b*)*c", "a(b|b|b)"):
+        want, _ = oracle_results(orc, re)
+        got = findex_amd.ReTree(findex_amd.REParser.re2post(re)).matchSA(hip)
+        assert [r.key() for r in got] == want, re
+    assert len(findex_amd.ReTree(findex_amd.REParser.re2post("(a|a)b")).matchSA(hip)) == 2
+
+
+def test_regex_overflow_is_reported():
+    bwt, eof, counts = synth_bwt(200_000, 97, 100, 3)
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    t = findex_amd.ReTree(findex_amd.REParser.re2post("a[a-d]*b"))
+    with pytest.raises(findex_amd.FmxError) as e:
+        t.matchSA(hip, max_frontier=64)
+    assert e.value.code == 9
+    with pytest.raises(findex_amd.FmxError) as e:
+        t.matchSA(hip, max_steps=3, max_frontier=1 << 22)
+    assert e.value.code == 9
+
+
+# ---------------------------------------------------------------- full-size properties (on device)
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("log2n,extra,sigma", [(28, 0, 4), (32, 12345, 16)])
+def test_full_size_properties(log2n, extra, sigma):
+    """BASELINE-size indexes (C2: 256 MB sigma=4; and n > 2^32 to cross the 32-bit line): no CPU
+    oracle can hold these, so check size-independent properties:
+      * occ(c, i) equals a brute-force count of the device BWT prefix (torch),
+      * occ(c, n-1) equals the symbol total, sum_c occ(c, i) == i + 1 - [i >= eof],
+      * LF-walk patterns hit, and the hit interval contains the row the walk ended on,
+      * the step partition: intervals of getIntervalPrevRange are disjoint and sum to ep - sp."""
+    torch = _torch()
+    n = (1 << log2n) + extra
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + log2n)
+    bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+    step = 1 << 28
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        bwt[a:b] = torch.randint(1, sigma + 1, (b - a,), generator=g, device="cuda", dtype=torch.uint8)
+    eof = n // 3
+    torch.cuda.synchronize()
+    hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None)
+    assert hip.n == n
+    rng = np.random.default_rng(9)
+    # brute-force rank on a few (c, i)
+    qs_i = np.concatenate([rng.integers(0, n, 6), [0, eof - 1, eof, eof + 1, n - 1]]).astype(np.int64)
+    qs_c = rng.integers(1, sigma + 1, qs_i.size).astype(np.uint8)
+    got = hip.occ_batch(qs_c, qs_i)
+    for c, i, gv in zip(qs_c, qs_i, got):
+        want = 0
+        for a in range(0, int(i) + 1, step):
+            b = min(int(i) + 1, a + step)
+            want += int((bwt[a:b] == int(c)).sum().item())
+        if eof <= i and int(bwt[eof].item()) == int(c):
+            want -= 1
+        assert int(gv) == want, (c, i)
+    # totals and the column sum
+    totals = hip.occ_batch(np.arange(1, sigma + 1, dtype=np.uint8), np.full(sigma, n - 1, dtype=np.int64))
+    assert int(totals.sum()) == n - 1
+    for i in (0, 12345, eof, n - 2):
+        col = hip.occ_batch(np.arange(0, sigma + 1, dtype=np.uint8), np.full(sigma + 1, i, dtype=np.int64))
+        assert int(col.sum()) == i + 1
+    # LF-walk patterns must hit and contain their end row
+    k, m = 20000, 16 if sigma == 4 else 12
+    rows = rng.integers(0, n, k).astype(np.uint64)
+    b, end = hip.lf_walk_batch(rows, m)
+    pats = np.ascontiguousarray(b[:, ::-1])
+    off = (np.arange(k + 1, dtype=np.uint64) * m)
+    sp, ep = hip.search_batch(pats.reshape(-1), off)
+    assert (sp < ep).all() and (sp <= end).all() and (end < ep).all()
+    # partition property of one step
+    for a, bnd in ((0, n), (int(sp[0]), int(ep[0])), (n // 2, n // 2 + 100000)):
+        parts = hip.getIntervalPrevRange(a, bnd, 0, 255)
+        assert sum(e - s for s, e in parts) == bnd - a
+        srt = sorted(parts)
+        assert all(srt[j][1] <= srt[j + 1][0] for j in range(len(srt) - 1))

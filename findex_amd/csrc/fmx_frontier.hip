@@ -176,7 +176,7 @@ struct DevMem {
 
 int regex_match_batch(const Index *h, const Regex *const *res, size_t k, const fmx_limits *lim, fmx_result *out,
                       size_t cap, size_t *n_out, uint32_t *per_regex_count) {
-  const uint32_t max_steps = (lim && lim->max_steps) ? lim->max_steps : 4096u;
+  const uint32_t max_steps = (lim && lim->max_steps) ? lim->max_steps : 0xFFFFFFFFu;   // 0 = no cap
   const uint64_t qcap = (lim && lim->max_frontier) ? lim->max_frontier : (1ull << 22);
   // concatenate the batch's tables
   std::vector<uint8_t> st_c, st_last;

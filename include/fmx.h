@@ -153,7 +153,8 @@ typedef struct fmx_limits {
   /* ReTree.matchSA defaults: maxBranching=1024, maxIterations=1000 (re2/retree.scala:570).
    * The frontier kernel expands every regex's frontier breadth-first, so results equal the
    * reference's whenever its limits do not bind; here the limits are safety caps:
-   * max_steps   = maximum pattern length explored (levels), 0 = FMX default (4096)
+   * max_steps   = maximum match length explored (levels), 0 = no cap (a frontier dies by itself:
+   *               no match is longer than the text)
    * max_frontier= capacity of the device work queue in items, 0 = default (1<<22) */
   uint32_t max_steps;
   uint64_t max_frontier;

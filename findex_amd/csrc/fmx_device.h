@@ -11,7 +11,15 @@
 //   Symbol 0 (the EOF row, BWT' only) needs no vector: rank0(x) = (x > eof).
 //
 // A query is served by 8 adjacent lanes ("octet"): lane t loads bytes 16t..16t+15 of the line
-// with one global_load_dwordx4, so every wave-level load instruction fetches 8 whole lines.
+// with one global_load_dwordx4, so every wave-level load instruction fetches 8 whole lines and
+// each line is requested exactly once.  (Measured on MI355X: the memory system delivers about
+// 46-48 G distinct-line requests/s whatever the granule size up to 128 B, and a second load
+// instruction to the same line is a second request -- tools/ubench/gather.hip -- so wider
+// per-lane loads or fewer lanes per query do not pay.)
+//
+// The popcount side is written for instruction count: the search kernels turned out to be bound
+// by vector-instruction issue, not by HBM (profiles/).  Per dword: saturating
+// subtract, bit-field extract, compare, select, popcount-accumulate.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,49 +64,77 @@ __device__ __forceinline__ uint32_t octet_or(uint32_t v) {
   return v;
 }
 
-// x / 960 and x % 960 for x < 2^38 without 64-bit division: 960 = 64 * 15.
-__device__ __forceinline__ void split960(uint64_t x, uint64_t &blk, uint32_t &rem) {
-  uint32_t y = (uint32_t)(x >> 6);
-  uint32_t q = y / 15u;
-  blk = q;
-  rem = ((y - q * 15u) << 6) | ((uint32_t)x & 63u);
+// popcount(x) + acc in one instruction (the compiler otherwise splits it into bcnt + add3)
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+  uint32_t d;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+  return d;
 }
 
-// Address of this lane's 16 bytes of block `blk` of slot `s`.
-__device__ __forceinline__ const uint4 *block_ptr(const DevIndex &ix, uint32_t s, uint64_t blk, uint32_t t) {
-  return ix.bv + ((uint64_t)s * ix.nblocks + blk) * (kBlockBytes / 16) + t;
+// Per-lane constants of the octet layout.
+struct LaneConst {
+  uint32_t k[4];      // first payload position of dword j of this lane (0xFFFFFFFF: header dword)
+  uint32_t t;         // lane index inside the octet
+};
+
+__device__ __forceinline__ LaneConst lane_const() {
+  LaneConst lc;
+  lc.t = threadIdx.x & (kOctet - 1);
+#pragma unroll
+  for (int j = 0; j < 4; j++) lc.k[j] = (lc.t == 0 && j < 2) ? 0xFFFFFFFFu : (128u * lc.t - 64u + 32u * j);
+  return lc;
 }
 
-// Number of set payload bits below position `rem` in this lane's 16 bytes, plus (lane 0 only)
-// the header: returns the octet-wide total = rank_excl for the block.
-__device__ __forceinline__ uint64_t rank_finish(uint4 w, uint32_t rem, uint32_t t) {
-  uint32_t hlo = 0, hhi = 0;
-  if (t == 0) { hlo = w.x; hhi = w.y; w.x = 0; w.y = 0; }
-  const int base = (int)rem - 32 * (4 * (int)t - 2);   // bits wanted from dword j: base - 32 j
-  uint32_t cnt = 0;
+// x / 960 and x % 960 for x < 2^38: one multiply (mul_hi) and shifts; 960 = 64 * 15.
+__device__ __forceinline__ void split960(uint64_t x, uint32_t &blk, uint32_t &rem) {
+  const uint32_t y = (uint32_t)(x >> 6);
+  blk = __umulhi(y, 0x88888889u) >> 3;                 // y / 15
+  rem = (uint32_t)x - (blk << 10) + (blk << 6);        // x - 960 * blk (mod 2^32, exact: rem < 960)
+}
+
+// The in-register half of a rank query: given this lane's 16 bytes `w` of the block and the
+// in-block boundary `rem`, returns (to every lane of the octet) header + #{set payload bits below
+// rem}.  WIDE = false when every count fits 32 bits (n <= 2^32): the header then rides in the
+// same 3-step DPP sum; WIDE = true carries the 64-bit header apart.
+template <bool WIDE>
+__device__ __forceinline__ uint64_t rank_finish(uint4 w, uint32_t rem, const LaneConst &lc) {
   const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+  const uint32_t hlo = lc.t == 0 ? w.x : 0u;
+  uint32_t cnt = WIDE ? 0u : hlo;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    int nb = base - 32 * j;
-    uint32_t m = nb >= 32 ? 0xFFFFFFFFu : ((1u << (nb > 0 ? nb : 0)) - 1u);
-    cnt += __builtin_popcount(ww[j] & m);
+    // bits of dword j below the boundary: nb = max(rem - first position of the dword, 0)
+    const uint32_t nb = __builtin_elementwise_sub_sat(rem, lc.k[j]);
+    uint32_t x = __builtin_amdgcn_ubfe(ww[j], 0u, nb);  // low nb bits (width taken mod 32)
+    x = nb > 31u ? ww[j] : x;                          // whole dword below the boundary
+    cnt = bcnt_acc(x, cnt);
   }
-  cnt = octet_sum(cnt);
-  hlo = octet_or(hlo);
-  hhi = octet_or(hhi);
-  return (((uint64_t)hhi << 32) | hlo) + cnt;
+  if (!WIDE) return octet_sum(cnt);
+  const uint32_t hhi = octet_or(lc.t == 0 ? w.y : 0u);
+  return (((uint64_t)hhi << 32) | octet_or(hlo)) + octet_sum(cnt);
+}
+
+// Loads in the global (not flat) address space from an integer address.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_line16(uint64_t addr) {
+  const u32x4 v = *(const u32x4 __attribute__((address_space(1))) *)addr;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// Byte address of this lane's 16 bytes of block `blk` of slot `s`.
+__device__ __forceinline__ uint64_t block_addr(const DevIndex &ix, uint32_t s, uint32_t blk, const LaneConst &lc) {
+  return (uint64_t)(uintptr_t)ix.bv + ((uint64_t)s * ix.nblocks + blk) * kBlockBytes + lc.t * 16u;
 }
 
 // rank_excl(c, x) = #{p < x : BWT'[p] == c}, 0 <= x <= n, evaluated by the whole octet.
 // occ(c, i) of the reference is rank_excl(c, i + 1).
-__device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint16_t slot, uint64_t x, uint32_t t) {
+template <bool WIDE>
+__device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint16_t slot, uint64_t x, const LaneConst &lc) {
   if (slot == kSlotNone) return 0;
   if (slot == kSlotEof) return x > ix.eof ? 1 : 0;
-  uint64_t blk;
-  uint32_t rem;
+  uint32_t blk, rem;
   split960(x, blk, rem);
-  uint4 w = *block_ptr(ix, slot, blk, t);
-  return rank_finish(w, rem, t);
+  return rank_finish<WIDE>(load_line16(block_addr(ix, slot, blk, lc)), rem, lc);
 }
 
 }  // namespace fmx

@@ -60,6 +60,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
   return x - v;
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, uint64_t cur_count,
                                                          Queue nxt, uint64_t nxt_cap, fmx_result *__restrict__ res,
                                                          uint64_t res_cap, FrontierCtl *__restrict__ ctl) {
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
   __syncthreads();
-  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const LaneConst lc = lane_const();
+  const uint32_t t = lc.t;
   const uint64_t noct = (uint64_t)gridDim.x * (kFThreads / kOctet);
   const uint64_t first = ((uint64_t)blockIdx.x * kFThreads + threadIdx.x) >> 3;
   uint32_t stepped = 0;
@@ -89,14 +91,13 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
       const uint64_t cfc = s_cf[c];
       uint64_t r1 = 0, r2 = 0;
       if (slot < kSlotEof) {
-        uint64_t b1, b2;
-        uint32_t m1, m2;
+        uint32_t b1, b2, m1, m2;
         split960(sp, b1, m1);
         split960(ep, b2, m2);
-        const uint4 w1 = *block_ptr(ix, slot, b1, t);
-        const uint4 w2 = *block_ptr(ix, slot, b2, t);
-        r1 = rank_finish(w1, m1, t);
-        r2 = rank_finish(w2, m2, t);
+        const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
+        const uint4 w2 = load_line16(block_addr(ix, slot, b2, lc));
+        r1 = rank_finish<WIDE>(w1, m1, lc);
+        r2 = rank_finish<WIDE>(w2, m2, lc);
       } else if (slot == kSlotEof) {
         r1 = sp > ix.eof ? 1 : 0;
         r2 = ep > ix.eof ? 1 : 0;
@@ -256,7 +257,10 @@ int regex_match_batch(const Index *h, const Regex *const *res, size_t k, const f
     uint64_t want = (count + (kFThreads / kOctet) - 1) / (kFThreads / kOctet);
     uint64_t gcap = (uint64_t)h->cu_count * 8;
     int grid = (int)(want < gcap ? want : gcap);
-    k_frontier<<<grid, kFThreads, 0, st>>>(h->dev, nfa, *cur, count, *nxt, qcap, d_res, (uint64_t)cap, d_ctl);
+    if (h->n > (1ull << 32))
+      k_frontier<true><<<grid, kFThreads, 0, st>>>(h->dev, nfa, *cur, count, *nxt, qcap, d_res, (uint64_t)cap, d_ctl);
+    else
+      k_frontier<false><<<grid, kFThreads, 0, st>>>(h->dev, nfa, *cur, count, *nxt, qcap, d_res, (uint64_t)cap, d_ctl);
     HIP_TRY(hipGetLastError(), "k_frontier");
     launches++;
     HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");

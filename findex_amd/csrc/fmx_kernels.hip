@@ -27,20 +27,20 @@ __device__ __forceinline__ void stage_tables(const DevIndex &ix, Tables &tb) {
 
 // One backward step for the whole octet: (sp, ep) -> (cf(c)+rank(c,sp), cf(c)+rank(c,ep)).
 // Both lines are requested before either is consumed.
-__device__ __forceinline__ void step(const DevIndex &ix, const Tables &tb, uint32_t c, uint32_t t, uint64_t &sp,
-                                     uint64_t &ep) {
+template <bool WIDE>
+__device__ __forceinline__ void step(const DevIndex &ix, const Tables &tb, uint32_t c, const LaneConst &lc,
+                                     uint64_t &sp, uint64_t &ep) {
   const uint16_t slot = tb.slot[c];
   const uint64_t cfc = tb.cf[c];
   uint64_t r1 = 0, r2 = 0;
   if (slot < kSlotEof) {
-    uint64_t b1, b2;
-    uint32_t m1, m2;
+    uint32_t b1, b2, m1, m2;
     split960(sp, b1, m1);
     split960(ep, b2, m2);
-    const uint4 w1 = *block_ptr(ix, slot, b1, t);
-    const uint4 w2 = *block_ptr(ix, slot, b2, t);
-    r1 = rank_finish(w1, m1, t);
-    r2 = rank_finish(w2, m2, t);
+    const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
+    const uint4 w2 = load_line16(block_addr(ix, slot, b2, lc));
+    r1 = rank_finish<WIDE>(w1, m1, lc);
+    r2 = rank_finish<WIDE>(w2, m2, lc);
   } else if (slot == kSlotEof) {
     r1 = sp > ix.eof ? 1 : 0;
     r2 = ep > ix.eof ? 1 : 0;
@@ -51,18 +51,20 @@ __device__ __forceinline__ void step(const DevIndex &ix, const Tables &tb, uint3
 
 // ---------------------------------------------------------------- K2: occ_batch
 // SuffixAlgo.occ(c,i) = rank_excl(c, i+1); i < 0 -> 0; i >= n clamps to n-1.
+template <bool WIDE>
 __global__ __launch_bounds__(kThreads) void k_occ(DevIndex ix, const uint8_t *__restrict__ c,
                                                    const int64_t *__restrict__ i, uint64_t *__restrict__ out,
                                                    uint64_t k, unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const LaneConst lc = lane_const();
+  const uint32_t t = lc.t;
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
   uint32_t done = 0;
   for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
     int64_t key = i[q];
     uint64_t x = key < 0 ? 0 : ((uint64_t)key >= ix.n ? ix.n : (uint64_t)key + 1);
-    uint64_t r = rank_excl(ix, tb.slot[c[q]], x, t);
+    uint64_t r = rank_excl<WIDE>(ix, tb.slot[c[q]], x, lc);
     if (t == 0) out[q] = r;
     done++;
   }
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(kThreads) void k_occ(DevIndex ix, const uint8_t *__
 }
 
 // ---------------------------------------------------------------- K4: prev_range_batch
+template <bool WIDE>
 __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint64_t *__restrict__ sp_in,
                                                           const uint64_t *__restrict__ ep_in,
                                                           const uint8_t *__restrict__ c, uint64_t *__restrict__ sp1,
@@ -77,12 +80,13 @@ __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint
                                                           unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const LaneConst lc = lane_const();
+  const uint32_t t = lc.t;
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
   uint32_t done = 0;
   for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
     uint64_t sp = sp_in[q], ep = ep_in[q];
-    step(ix, tb, c[q], t, sp, ep);
+    step<WIDE>(ix, tb, c[q], lc, sp, ep);
     if (t == 0) { sp1[q] = sp; ep1[q] = ep; }
     done++;
   }
@@ -94,13 +98,15 @@ __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint
 // grid stride and pick up their next pattern as soon as the current one ends (last byte consumed
 // or interval empty), so early exits do not idle lanes.  The next pattern's offsets and the next
 // pattern byte are requested a step early; only the two rank lines are on the dependent chain.
+template <bool WIDE>
 __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t *__restrict__ pat,
                                                       const uint64_t *__restrict__ off, uint64_t *__restrict__ sp_out,
                                                       uint64_t *__restrict__ ep_out, uint64_t k,
                                                       unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const LaneConst lc = lane_const();
+  const uint32_t t = lc.t;
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
   uint64_t p = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3;
   bool active = p < k;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t 
     if (active) {
       if (i >= 0 && sp < ep) {
         const uint32_t cn = i > 0 ? pat[base + i - 1] : 0;   // next byte, off the critical path
-        step(ix, tb, c, t, sp, ep);
+        step<WIDE>(ix, tb, c, lc, sp, ep);
         c = cn;
         i--;
         steps++;
@@ -143,13 +149,15 @@ __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t 
 
 // ---------------------------------------------------------------- LF walk (prevSubstr / getPrevI)
 // NaiveFMSearcher.prevSubstr (bwtmerger.scala:409-419): emit BWT'[row], row = cf(b)+occ(b,row-1).
+template <bool WIDE>
 __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_t *__restrict__ rows, uint64_t k,
                                                        uint32_t len, uint8_t *__restrict__ out_bytes,
                                                        uint64_t *__restrict__ end_rows,
                                                        unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const uint32_t t = threadIdx.x & (kOctet - 1);
+  const LaneConst lc = lane_const();
+  const uint32_t t = lc.t;
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
   uint32_t done = 0;
   for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_
     for (uint32_t s = 0; s < len; s++) {
       const uint32_t b = r == ix.eof ? 0u : ix.bwt[r];
       if (out_bytes && t == 0) out_bytes[q * len + s] = (uint8_t)b;
-      r = tb.cf[b] + rank_excl(ix, tb.slot[b], r, t);
+      r = tb.cf[b] + rank_excl<WIDE>(ix, tb.slot[b], r, lc);
     }
     if (end_rows && t == 0) end_rows[q] = r;
     done += len;
@@ -228,6 +236,13 @@ __global__ __launch_bounds__(kThreads) void k_next_substr(DevIndex ix, const uin
 }
 
 // ---------------------------------------------------------------- launchers
+// Counts fit 32 bits iff n <= 2^32; the kernels then reduce the block header with the popcounts.
+#define FMX_WIDE_DISPATCH(h, kern, grid, st, ...)                            \
+  do {                                                                       \
+    if ((h)->n > (1ull << 32)) kern<true><<<(grid), kThreads, 0, (st)>>>(__VA_ARGS__);  \
+    else kern<false><<<(grid), kThreads, 0, (st)>>>(__VA_ARGS__);            \
+  } while (0)
+
 static inline int grid_for(const Index *h, uint64_t k, int per_block) {
   uint64_t want = (k + per_block - 1) / per_block;
   uint64_t cap = (uint64_t)h->cu_count * 8;   // 8 x 256 threads fill a CU's 32 wave slots
@@ -237,35 +252,34 @@ static inline int grid_for(const Index *h, uint64_t k, int per_block) {
 
 hipError_t launch_occ(const Index *h, const void *d_c, const void *d_i, void *d_out, uint64_t k, hipStream_t st) {
   if (!k) return hipSuccess;
-  k_occ<<<grid_for(h, k, kOctetsPerBlock), kThreads, 0, st>>>(h->dev, (const uint8_t *)d_c, (const int64_t *)d_i,
-                                                                 (uint64_t *)d_out, k, h->d_counters);
+  FMX_WIDE_DISPATCH(h, k_occ, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint8_t *)d_c, (const int64_t *)d_i,
+                    (uint64_t *)d_out, k, h->d_counters);
   return hipGetLastError();
 }
 
 hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep, const void *d_c, void *d_sp1,
                              void *d_ep1, uint64_t k, hipStream_t st) {
   if (!k) return hipSuccess;
-  k_prev_range<<<grid_for(h, k, kOctetsPerBlock), kThreads, 0, st>>>(
-      h->dev, (const uint64_t *)d_sp, (const uint64_t *)d_ep, (const uint8_t *)d_c, (uint64_t *)d_sp1,
-      (uint64_t *)d_ep1, k, h->d_counters);
+  FMX_WIDE_DISPATCH(h, k_prev_range, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint64_t *)d_sp,
+                    (const uint64_t *)d_ep, (const uint8_t *)d_c, (uint64_t *)d_sp1, (uint64_t *)d_ep1, k,
+                    h->d_counters);
   return hipGetLastError();
 }
 
-hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
-                         hipStream_t st) {
+// v1: one pattern per octet, byte-at-a-time pattern reads (kept for A/B runs; FMX_SEARCH_VARIANT=1)
+hipError_t launch_search_v1(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
+                            hipStream_t st) {
   if (!k) return hipSuccess;
-  k_search<<<grid_for(h, k, kOctetsPerBlock), kThreads, 0, st>>>(h->dev, (const uint8_t *)d_pat,
-                                                                    (const uint64_t *)d_off, (uint64_t *)d_sp,
-                                                                    (uint64_t *)d_ep, k, h->d_counters);
+  FMX_WIDE_DISPATCH(h, k_search, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint8_t *)d_pat,
+                    (const uint64_t *)d_off, (uint64_t *)d_sp, (uint64_t *)d_ep, k, h->d_counters);
   return hipGetLastError();
 }
 
 hipError_t launch_lf_walk(const Index *h, const void *d_rows, uint64_t k, uint32_t len, void *d_out, void *d_end,
                           hipStream_t st) {
   if (!k) return hipSuccess;
-  k_lf_walk<<<grid_for(h, k, kOctetsPerBlock), kThreads, 0, st>>>(h->dev, (const uint64_t *)d_rows, k, len,
-                                                                     (uint8_t *)d_out, (uint64_t *)d_end,
-                                                                     h->d_counters);
+  FMX_WIDE_DISPATCH(h, k_lf_walk, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint64_t *)d_rows, k, len,
+                    (uint8_t *)d_out, (uint64_t *)d_end, h->d_counters);
   return hipGetLastError();
 }
 

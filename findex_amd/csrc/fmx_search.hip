@@ -1,0 +1,217 @@
+// fmx_search.hip -- K3: batched literal backward search (SuffixAlgo.search, findex.scala:15-31).
+//
+// The dominant kernel of the headline benchmark.  Per backward step an octet of lanes fetches the
+// two rank-dictionary lines of (c, sp) and (c, ep) and turns them into the next interval; the
+// only dependent chain is line -> popcount -> next line address.  What the kernel does to keep
+// the memory system busy while each chain waits:
+//   * U patterns per octet are stepped in the same loop trip: all 2U lines are requested before
+//     any is consumed (U x the lines in flight per wave at the same wave count);
+//   * nothing on the step path waits for a load issued in the same trip except those lines:
+//     pattern bytes are read 4 at a time, two dwords ahead; the descriptor of the pattern an
+//     octet takes next (offset, length, last 4 bytes; written by the k_prep pre-pass) is
+//     requested one whole pattern earlier;
+//   * C[] and each symbol's bit-vector base address sit in LDS as one 16-byte entry per symbol.
+// Octets pick up their next pattern as soon as one ends, so early exits do not idle lanes.
+#include "fmx_device.h"
+#include "fmx_host.h"
+
+namespace fmx {
+
+constexpr int kSThreads = 256;
+constexpr int kSOctets = kSThreads / kOctet;
+
+struct PatDesc {      // 16 bytes, one per pattern
+  uint64_t end;       // offset one past the pattern's last byte
+  uint32_t len;
+  uint32_t tail4;     // byte j = pat[end-1-j] (the first four bytes the search consumes)
+};
+
+// Bytes pat[pos-1], pat[pos-2], pat[pos-3], pat[pos-4] in byte lanes 0..3 (fewer when pos < 4).
+__device__ __forceinline__ uint32_t fetch4(const uint8_t *__restrict__ pat, uint64_t pos) {
+  if (pos >= 4) {
+    uint32_t d;
+    __builtin_memcpy(&d, pat + pos - 4, 4);          // unaligned dword load
+    return __builtin_bswap32(d);
+  }
+  uint32_t r = 0;
+  for (uint32_t j = 0; j < (uint32_t)pos; j++) r |= (uint32_t)pat[pos - 1 - j] << (8 * j);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_prep(const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
+                                               PatDesc *__restrict__ desc, uint32_t k) {
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < k; q += gridDim.x * blockDim.x) {
+    const uint64_t b = off[q], e = off[q + 1];
+    const uint64_t len = e - b;
+    PatDesc d;
+    d.end = e;
+    d.len = (uint32_t)len;
+    d.tail4 = len ? fetch4(pat, e) : 0;
+    desc[q] = d;
+  }
+}
+
+// ---------------------------------------------------------------- lean single-pattern-per-octet kernel
+// One pattern per octet, written for instruction count: the profile of the first version
+// (FMX_SEARCH_VARIANT=1, fmx_kernels.hip) showed the kernel bound by vector-instruction issue
+// (about 165 vector instructions per backward step and wave), not by HBM.  What this one does:
+//   * the rank primitive of fmx_device.h (5 instructions per payload dword);
+//   * C[] and each symbol's bit-vector base address in LDS as one 16-byte entry per symbol;
+//   * pattern bytes read 4 at a time, two dwords ahead; the descriptor of the pattern an octet
+//     takes next (offset, length, last 4 bytes; written by the k_prep pre-pass) is requested
+//     one whole pattern earlier, so nothing on the step path waits for a load issued in the
+//     same trip except the two rank lines;
+//   * the retire / refill block is skipped with one wave-uniform test when no octet ends.
+// Tried and dropped (slower, VALU-bound): 2 or 3 patterns per octet in one trip; skipping the
+// second line load when sp and ep share a block (the extra select costs more than the request).
+template <bool WIDE>
+__global__ __launch_bounds__(kSThreads) void k_search3(DevIndex ix, const uint8_t *__restrict__ pat,
+                                                        const PatDesc *__restrict__ desc,
+                                                        uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
+                                                        uint32_t k, unsigned long long *__restrict__ counters) {
+  __shared__ uint4 s_tab[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) {
+    const uint64_t cf = ix.cf[c];
+    const uint16_t s = ix.slot[c];
+    uint64_t vb = 0;
+    if (s < kSlotEof) vb = (uint64_t)(uintptr_t)ix.bv + (uint64_t)s * ix.nblocks * kBlockBytes;
+    else if (s == kSlotEof) vb = 1;
+    s_tab[c] = make_uint4((uint32_t)cf, (uint32_t)(cf >> 32), (uint32_t)vb, (uint32_t)(vb >> 32));
+  }
+  __syncthreads();
+  const LaneConst lc = lane_const();
+  const uint32_t t = lc.t;
+  const uint32_t lane_off = t * 16;
+  const uint32_t octet = (blockIdx.x * kSThreads + threadIdx.x) >> 3;
+  const uint32_t stride = gridDim.x * kSOctets;
+
+  uint32_t pid = octet;
+  bool act = pid < k;
+  uint32_t left = 0, ch = 0, nx = 0, nch = 0, steps = 0;
+  uint64_t cur = 0, sp = 0, ep = ix.n;
+  PatDesc nd;
+  nd.end = 0; nd.len = 0; nd.tail4 = 0;
+  if (act) {
+    const PatDesc d = desc[pid];
+    cur = d.end;
+    left = d.len;
+    ch = d.tail4;
+    nch = 4;
+    if (left > 4) nx = fetch4(pat, cur - 4);
+    if ((uint64_t)pid + stride < k) nd = desc[pid + stride];
+  }
+
+  while (__builtin_amdgcn_ballot_w64(act)) {
+    const bool stepping = act && left > 0 && sp < ep;
+    if (stepping) {
+      const uint4 e = s_tab[ch & 0xFFu];
+      const uint64_t cfc = ((uint64_t)e.y << 32) | e.x;
+      const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
+      // byte cursor bookkeeping (runs while the two lines are in flight on the common path)
+      auto next_char = [&]() {
+        ch >>= 8;
+        nch -= 1;
+        left -= 1;
+        cur -= 1;
+        if (nch == 0) {
+          ch = nx;
+          nch = 4;
+          if (left > 4) nx = fetch4(pat, cur - 4);
+        }
+      };
+      if (vb > 1) {
+        uint32_t b1, b2, m1, m2;
+        split960(sp, b1, m1);
+        split960(ep, b2, m2);
+        const uint64_t base = vb + lane_off;
+        const uint4 w1 = load_line16(base + (uint64_t)b1 * kBlockBytes);
+        const uint4 w2 = load_line16(base + (uint64_t)b2 * kBlockBytes);
+        next_char();
+        sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+        ep = cfc + rank_finish<WIDE>(w2, m2, lc);
+      } else {                       // symbol absent from the BWT, or the EOF symbol 0
+        next_char();
+        const uint64_t r1 = (vb == 1 && sp > ix.eof) ? 1 : 0;
+        const uint64_t r2 = (vb == 1 && ep > ix.eof) ? 1 : 0;
+        sp = cfc + r1;
+        ep = cfc + r2;
+      }
+      steps++;
+    }
+    // retire / refill: skipped by the whole wave when no octet ended this trip
+    if (__builtin_amdgcn_ballot_w64(act && !stepping)) {
+      if (act && !stepping) {
+        if (t == 0) { sp_out[pid] = sp; ep_out[pid] = ep; }
+        const uint64_t np = (uint64_t)pid + stride;
+        act = np < k;
+        if (act) {
+          pid = (uint32_t)np;
+          cur = nd.end;
+          left = nd.len;
+          ch = nd.tail4;
+          nch = 4;
+          sp = 0;
+          ep = ix.n;
+          if (left > 4) nx = fetch4(pat, cur - 4);
+          if (np + stride < k) nd = desc[np + stride];
+        }
+      }
+    }
+  }
+  if (t == 0 && steps) { atomicAdd(&counters[0], 2ull * steps); atomicAdd(&counters[1], (unsigned long long)steps); }
+}
+
+// v1 kernel (fmx_kernels.hip), kept for A/B runs
+hipError_t launch_search_v1(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
+                            hipStream_t st);
+
+static int search_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("FMX_SEARCH_VARIANT");
+    v = e ? atoi(e) : 2;
+  }
+  return v;
+}
+
+// Resident workgroups per CU for a kernel: the grid is sized to what is resident so that every
+// octet starts at once and the static pattern striding stays balanced.
+template <class K>
+static int blocks_per_cu(K kernel) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kSThreads, 0) != hipSuccess || nb < 1) nb = 1;
+  return nb > 8 ? 8 : nb;
+}
+
+template <bool WIDE>
+static hipError_t launch_v3w(const Index *h, const uint8_t *pat, const PatDesc *desc, uint64_t *sp, uint64_t *ep,
+                             uint32_t k, hipStream_t st) {
+  static const int per_cu = blocks_per_cu(k_search3<WIDE>);
+  uint64_t want = ((uint64_t)k + kSOctets - 1) / kSOctets;
+  uint64_t cap = (uint64_t)h->cu_count * per_cu;
+  int grid = (int)(want < cap ? (want ? want : 1) : cap);
+  k_search3<WIDE><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
+                         hipStream_t st) {
+  if (!k) return hipSuccess;
+  const int variant = search_variant();
+  if (variant == 1 || k > 0xFFFFFFF0ull) return launch_search_v1(h, d_pat, d_off, d_sp, d_ep, k, st);
+  PatDesc *desc = nullptr;
+  hipError_t e = hipMallocAsync((void **)&desc, k * sizeof(PatDesc), st);
+  if (e != hipSuccess) return e;
+  int pg = (int)((k + 255) / 256);
+  if (pg > h->cu_count * 8) pg = h->cu_count * 8;
+  k_prep<<<pg, 256, 0, st>>>((const uint8_t *)d_pat, (const uint64_t *)d_off, desc, (uint32_t)k);
+  e = hipGetLastError();
+  if (e == hipSuccess)
+    e = h->n > (1ull << 32)
+            ? launch_v3w<true>(h, (const uint8_t *)d_pat, desc, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st)
+            : launch_v3w<false>(h, (const uint8_t *)d_pat, desc, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st);
+  hipError_t e2 = hipFreeAsync(desc, st);
+  return e != hipSuccess ? e : e2;
+}
+
+}  // namespace fmx

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Workload for rocprofv3 passes: the C3 bench step (k_search) plus a calibration launch of
+k_occ whose HBM byte count is known -- 2^24 uniformly random (c, i) rank queries over the
+72 GiB rank dictionary touch 2^24 distinct 128-byte lines (collisions < 0.4 %), i.e. 2 GiB.
+FETCH_SIZE read for k_occ calibrates the counter for this access pattern
+(MI355X_MICROARCH.md, HBM: FETCH_SIZE halves wide reads on gfx950; other widths uncalibrated).
+
+    rocprofv3 --kernel-trace --stats ... -- python3 tools/prof_workload.py [--workload c3] [--steps 5]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import findex_amd  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="c3")
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--calib-queries", type=int, default=1 << 24)
+a = ap.parse_args()
+
+log2n, sigma, k, m, seed = bench.WORKLOADS[a.workload]
+n = 1 << log2n
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+stream = torch.cuda.current_stream().cuda_stream
+bwt, eof = bench.make_bwt(torch, n, sigma, seed, dev)
+torch.cuda.synchronize()
+hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=0, stream=stream)
+del bwt
+torch.cuda.empty_cache()
+pats, off = bench.make_patterns(torch, hip, n, sigma, k, m, seed * 1000, dev, stream)
+sp = torch.empty(k, dtype=torch.int64, device=dev)
+ep = torch.empty(k, dtype=torch.int64, device=dev)
+g = torch.Generator(device=dev)
+g.manual_seed(42)
+kc = a.calib_queries
+qc = torch.randint(1, sigma + 1, (kc,), generator=g, device=dev, dtype=torch.uint8)
+qi = torch.randint(0, n, (kc,), generator=g, device=dev, dtype=torch.int64)
+qo = torch.empty(kc, dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
+hip.stats_reset()
+for _ in range(a.steps):
+    hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
+torch.cuda.synchronize()
+st = hip.stats()
+print("k_search: %d launches, %d rank queries per launch, algorithmic bytes per launch %d"
+      % (a.steps, st["rank_queries"] // a.steps, st["rank_queries"] // a.steps * 128))
+for _ in range(3):
+    hip.occ_batch_dev(qc.data_ptr(), qi.data_ptr(), qo.data_ptr(), kc, stream)
+torch.cuda.synchronize()
+print("k_occ: 3 launches, %d rank queries per launch = %d known bytes of 128-B lines" % (kc, kc * 128))

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Condenses a tools/rocprof_passes.sh output directory into the files kept under profiles/:
+   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, fmx kernels only
+   <tag>_counters.csv       per kernel, per counter: dispatches, mean value
+   <tag>_summary.md         durations + HBM traffic with the gfx950 FETCH_SIZE correction
+Usage: tools/summarize_prof.py gpurun_out/prof_r1 profiles/r01_c3
+"""
+import collections
+import csv
+import glob
+import os
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+
+
+def short(name):
+    return name.split("(")[0].replace("fmx::", "")
+
+
+stats = []
+for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        if "fmx::" in r["Name"]:
+            stats.append(r)
+with open(dst + "_kernel_stats.csv", "w", newline="") as fo:
+    w = csv.writer(fo)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+    for r in stats:
+        w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"],
+                    r["StdDev"]])
+
+agg = collections.defaultdict(list)
+meta = {}
+for f in glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "fmx::" not in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"], r["Grid_Size"])
+with open(dst + "_counters.csv", "w", newline="") as fo:
+    w = csv.writer(fo)
+    w.writerow(["Kernel", "Counter", "Dispatches", "Mean"])
+    for (k, c), v in sorted(agg.items()):
+        w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
+
+
+def mean(k, c):
+    v = agg.get((k, c))
+    return sum(v) / len(v) if v else None
+
+
+with open(dst + "_summary.md", "w") as fo:
+    fo.write("# rocprofv3 summary (%s)\n\n" % os.path.basename(dst))
+    fo.write("Source: `tools/rocprof_passes.sh` (pass 0 `--kernel-trace --stats`; one `--pmc` group per further pass), "
+             "workload `tools/prof_workload.py`.\n\n")
+    fo.write("| kernel | calls | avg ms | min ms | max ms | VGPR | SGPR | LDS B |\n|---|---|---|---|---|---|---|---|\n")
+    for r in stats:
+        k = short(r["Name"])
+        m = meta.get(k, ("", "", "", "", ""))
+        fo.write("| %s | %s | %.4f | %.4f | %.4f | %s | %s | %s |\n" % (
+            k, r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6, m[0], m[1], m[2]))
+    fo.write("\nHBM traffic per dispatch.  FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE = "
+             "TCC_EA0_RDREQ x 64 B while these kernels' requests are 128-byte lines (TCC_EA0_RDREQ_32B = 0), so read "
+             "bytes = 2 x FETCH_SIZE x 1024 (MI355X_MICROARCH.md, HBM).  The k_occ row is the calibration: its "
+             "2^24 random rank queries are 2^24 distinct 128-B lines = 2.147 GB plus 0.15 GB of streamed inputs.\n\n")
+    fo.write("| kernel | FETCH_SIZE KiB | read GB (x2 corrected) | WRITE_SIZE KiB | write GB | RDREQ | RDREQ_32B | L2 hit rate |\n"
+             "|---|---|---|---|---|---|---|---|\n")
+    for k in sorted({k for k, _ in agg}):
+        fs, ws = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
+        hit, miss = mean(k, "TCC_HIT_sum"), mean(k, "TCC_MISS_sum")
+        rq, rq32 = mean(k, "TCC_EA0_RDREQ_sum"), mean(k, "TCC_EA0_RDREQ_32B_sum")
+        fo.write("| %s | %s | %s | %s | %s | %s | %s | %s |\n" % (
+            k, "%.0f" % fs if fs else "", "%.3f" % (2 * fs * 1024 / 1e9) if fs else "",
+            "%.0f" % ws if ws else "", "%.3f" % (ws * 1024 / 1e9) if ws else "",
+            "%.4g" % rq if rq else "", "%.4g" % rq32 if rq32 is not None else "",
+            "%.3f" % (hit / (hit + miss)) if hit is not None and miss else ""))
+    fo.write("\nSQ counters (quad-cycles, summed over waves): see `%s_counters.csv`.\n" % os.path.basename(dst))
+    for k in sorted({k for k, _ in agg}):
+        wc = mean(k, "SQ_WAVE_CYCLES")
+        if wc:
+            fo.write("- %s: WAIT_ANY %.0f%%, WAIT_INST_ANY %.0f%%, ACTIVE_INST_ANY %.0f%% of SQ_WAVE_CYCLES; "
+                     "VALU insts %.4g, VMEM reads %.4g, waves %d\n" % (
+                         k, 100 * mean(k, "SQ_WAIT_ANY") / wc, 100 * mean(k, "SQ_WAIT_INST_ANY") / wc,
+                         100 * mean(k, "SQ_ACTIVE_INST_ANY") / wc, mean(k, "SQ_INSTS_VALU"),
+                         mean(k, "SQ_INSTS_VMEM_RD"), mean(k, "SQ_WAVES")))
+print("wrote", dst + "_{kernel_stats.csv,counters.csv,summary.md}")

@@ -159,15 +159,12 @@ def main():
     pats, off = make_patterns(torch, hip, n, sigma, k, m, seed * 1000 + rank, device, stream)
     sp = torch.empty(k, dtype=torch.int64, device=device)
     ep = torch.empty(k, dtype=torch.int64, device=device)
-    gathered = torch.empty((world, 2, k), dtype=torch.int64, device=device) if world > 1 else None
-    mine = torch.empty((2, k), dtype=torch.int64, device=device) if world > 1 else None
+    from findex_amd.distributed import gather_intervals_dev
 
     def step():
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
         if world > 1:       # the path's one exchange: gather the hit intervals over RCCL/xGMI
-            mine[0].copy_(sp)
-            mine[1].copy_(ep)
-            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
+            return gather_intervals_dev(sp, ep)
 
     # rank queries one step executes (device counter; identical every step)
     hip.stats_reset()
@@ -190,9 +187,7 @@ def main():
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
         b.record()
         if world > 1:
-            mine[0].copy_(sp)
-            mine[1].copy_(ep)
-            dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1))
+            gather_intervals_dev(sp, ep)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

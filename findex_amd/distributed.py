@@ -1,0 +1,132 @@
+"""Multi-GPU form of the search path: one process per GPU, every rank holds a full replica of the
+index (each LF step jumps to an arbitrary row, so the BWT itself cannot be split), the pattern /
+regex batch is cut into contiguous shards, each rank searches its shard with no data-path
+collective, and ONE gather of the result intervals (16 bytes per pattern) closes the call --
+`torch.distributed` all_gather: RCCL over xGMI with the "nccl" backend, gloo on CPU.
+
+The reference has no distributed layer at all; this module is the host logic the
+BASELINE config C5 asks for.  It is backend-agnostic: `searcher` is anything with the
+HipFMSearcher batch methods, so the CPU tests drive it with gloo.
+"""
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover - torch is plumbing; importing this module needs it
+    torch = None
+    dist = None
+
+
+def shard_bounds(off, world):
+    """Cut k patterns (offsets `off`, k+1 entries) into `world` contiguous slices balanced by
+    total pattern bytes.  Returns world+1 pattern indices; slice r is [b[r], b[r+1])."""
+    off = np.asarray(off, dtype=np.uint64)
+    k = off.size - 1
+    if k <= 0:
+        return [0] * (world + 1)
+    total = int(off[-1] - off[0])
+    if total == 0:                       # all patterns empty: balance by count
+        return [(k * r) // world for r in range(world + 1)]
+    rel = (off - off[0]).astype(np.float64)
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(rel, total * r / world, side="left")))
+    cuts.append(k)
+    for r in range(1, world + 1):        # keep monotone
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return cuts
+
+
+def _group_info(group):
+    if dist is None or not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def all_gather_varlen(t, group=None):
+    """all_gather of 1-D tensors whose lengths differ per rank: sizes first, then the payload
+    padded to the longest shard (one collective each).  Returns the list of per-rank tensors."""
+    rank, world = _group_info(group)
+    if world == 1:
+        return [t]
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes + [1])
+    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return [o[:s] for o, s in zip(out, sizes)]
+
+
+def search_batch_sharded(searcher, pat, off, group=None):
+    """SuffixAlgo.search over a pattern batch sharded across the ranks of `group`.
+    Every rank passes the same (pat, off); every rank gets the full (sp, ep) back."""
+    rank, world = _group_info(group)
+    pat = np.ascontiguousarray(pat, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    cuts = shard_bounds(off, world)
+    a, b = cuts[rank], cuts[rank + 1]
+    sp, ep = searcher.search_batch(pat, off[a:b + 1])
+    if world == 1:
+        return sp, ep
+    both = torch.from_numpy(np.concatenate([sp, ep]).astype(np.int64))      # same bits as uint64
+    dev = None
+    if dist.get_backend(group) == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device())
+        both = both.to(dev)
+    parts = all_gather_varlen(both, group)
+    sps, eps = [], []
+    for p in parts:
+        h = p.numel() // 2
+        q = p.cpu().numpy().astype(np.uint64)
+        sps.append(q[:h])
+        eps.append(q[h:])
+    return np.concatenate(sps), np.concatenate(eps)
+
+
+def match_batch_sharded(sa, trees, group=None, match_fn=None, **kw):
+    """ReTree.matchSA over a regex batch sharded by regex index; results come back per regex, as
+    (len, sp, ep) tuples, on every rank.  `match_fn(sa, trees_slice)` defaults to the GPU frontier
+    search (ReTree.matchSA_batch); it returns, per regex, objects with .len/.sp/.ep or tuples."""
+    if match_fn is None:
+        from .regex import ReTree
+
+        def match_fn(sa_, ts):
+            return ReTree.matchSA_batch(sa_, ts, **kw)
+    rank, world = _group_info(group)
+    k = len(trees)
+    cuts = [(k * r) // world for r in range(world + 1)]
+    mine = match_fn(sa, trees[cuts[rank]:cuts[rank + 1]])
+    flat = []
+    for j, res in enumerate(mine):
+        for r in res:
+            ln, a, b = (r.len, r.sp, r.ep) if hasattr(r, "len") else r
+            flat += [cuts[rank] + j, ln, a if a < 2**63 else a - 2**64, b if b < 2**63 else b - 2**64]
+    if world == 1:
+        parts = [np.asarray(flat, dtype=np.int64)]
+    else:
+        t = torch.tensor(flat, dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        parts = [p.cpu().numpy() for p in all_gather_varlen(t, group)]
+    out = [[] for _ in range(k)]
+    for p in parts:
+        for q in p.reshape(-1, 4):
+            out[int(q[0])].append((int(q[1]), int(q[2]) & (2**64 - 1), int(q[3]) & (2**64 - 1)))
+    return out
+
+
+def gather_intervals_dev(sp, ep, group=None):
+    """Device form used by bench.py: equal-sized int64 device tensors sp, ep (k each) ->
+    one all_gather_into_tensor of 16 B per pattern; returns a (world, 2, k) tensor."""
+    rank, world = _group_info(group)
+    mine = torch.stack([sp, ep])
+    if world == 1:
+        return mine.unsqueeze(0)
+    out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)
+    return out

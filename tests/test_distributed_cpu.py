@@ -1,0 +1,133 @@
+"""The N > 1 host path (pattern sharding + the one gather of result intervals) on CPU: two gloo
+ranks, the oracle standing in for the per-rank searcher so that no GPU is needed."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+from findex_amd import distributed as D  # noqa: E402
+from helpers import lf_walk_patterns, pack_patterns, synth_bwt  # noqa: E402
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleSearcher:
+    """search_batch / regex matching through the CPU oracle (test stand-in for HipFMSearcher)."""
+
+    def __init__(self, bwt, eof, counts):
+        import oracle
+        self.o = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+        self.n = self.o.n
+
+    def search_batch(self, pat, off):
+        off = np.asarray(off, dtype=np.uint64)
+        base = int(off[0]) if off.size else 0
+        sp, ep, _ = self.o.search_batch(np.asarray(pat, dtype=np.uint8)[base:], off - np.uint64(base))
+        return sp, ep
+
+
+def workload():
+    bwt, eof, counts = synth_bwt(60_000, 97, 100, 11)
+    rng = np.random.default_rng(4)
+    s = OracleSearcher(bwt, eof, counts)
+    pats = []
+    for m in (0, 1, 3, 9, 17):
+        pats += lf_walk_patterns(s.o, rng, 60, m, 0.2, alphabet=[97, 98, 99, 100])
+    order = rng.permutation(len(pats))
+    pats = [pats[i] for i in order]
+    buf, off = pack_patterns(pats)
+    return (bwt, eof, counts), buf, off
+
+
+REGEXES = ["ab", "a[bc]d", "b(a|c)+d", "dd?a", "c[ab]*d"]     # no star over the whole alphabet: that never runs dry
+
+
+def oracle_match(sa, res):
+    from oracle import retree as R
+    out = []
+    for re in res:
+        r, left, _ = sa.o.match_tables(R.ReTree(R.re2post(re)).tables(), 1 << 40, 0)
+        assert left == 0
+        out.append(sorted(r))
+    return out
+
+
+def _rank_main(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        idx, buf, off = workload()
+        s = OracleSearcher(*idx)
+        sp, ep = D.search_batch_sharded(s, buf, off)
+        res = D.match_batch_sharded(s, REGEXES, match_fn=oracle_match)
+        cuts = D.shard_bounds(off, world)
+        t = torch.arange(3 + 2 * rank, dtype=torch.int64) + 100 * rank
+        parts = D.all_gather_varlen(t)
+        q.put((rank, sp, ep, res, cuts, [p.tolist() for p in parts]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_single_process():
+    world = 2
+    port = free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=120) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    idx, buf, off = workload()
+    s = OracleSearcher(*idx)
+    wsp, wep = s.search_batch(buf, off)
+    wres = oracle_match(s, REGEXES)
+    for rank, sp, ep, res, cuts, parts in got:
+        assert np.array_equal(sp, wsp) and np.array_equal(ep, wep)
+        assert [sorted(r) for r in res] == wres
+        assert cuts[0] == 0 and cuts[-1] == off.size - 1 and cuts == sorted(cuts)
+        assert parts == [[0, 1, 2], [100, 101, 102, 103, 104]]
+    # byte balance of the shards
+    cuts = got[0][4]
+    b0 = int(off[cuts[1]] - off[cuts[0]])
+    b1 = int(off[cuts[2]] - off[cuts[1]])
+    assert abs(b0 - b1) <= 20
+
+
+def test_shard_bounds_edge_cases():
+    assert D.shard_bounds(np.array([0], dtype=np.uint64), 4) == [0, 0, 0, 0, 0]
+    assert D.shard_bounds(np.zeros(9, dtype=np.uint64), 4) == [0, 2, 4, 6, 8]          # all empty patterns
+    off = np.array([0, 100, 101, 102, 103], dtype=np.uint64)                             # one huge pattern
+    c = D.shard_bounds(off, 2)
+    assert c[0] == 0 and c[-1] == 4 and c == sorted(c)
+    off = np.arange(0, 8 * 33, 8, dtype=np.uint64)
+    assert D.shard_bounds(off, 8) == [0, 4, 8, 12, 16, 20, 24, 28, 32]
+
+
+def test_single_process_path_needs_no_process_group():
+    idx, buf, off = workload()
+    s = OracleSearcher(*idx)
+    sp, ep = D.search_batch_sharded(s, buf, off)
+    wsp, wep = s.search_batch(buf, off)
+    assert np.array_equal(sp, wsp) and np.array_equal(ep, wep)

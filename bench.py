@@ -39,6 +39,25 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(workload, kernel="k_search3"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/<tag>_<workload>_counters.csv, written by tools/summarize_prof.py from separate
+    `--pmc` runs of tools/prof_workload.py -- the same step): reads = 2 x FETCH_SIZE KiB (gfx950
+    tallies these kernels' 128-byte requests at 64 B; calibrated on k_occ, see the summary file)
+    plus WRITE_SIZE KiB.  None when no profile of this workload is in the tree."""
+    import csv
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters.csv" % workload))):
+        vals = {}
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel"]:
+                vals[r["Counter"]] = float(r["Mean"])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            best = (int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.basename(f))
+    return best
+
+
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
@@ -236,7 +255,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "k_search",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": (pmc_traffic(args.workload) or (None, None))[0],
+                "traffic_source": (pmc_traffic(args.workload) or (None, "no PMC profile of this workload committed"))[1],
                 "bytes_per_rank_query": BYTES_PER_RANK, "rank_queries_per_launch": ranks_per_step,
                 "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
             },

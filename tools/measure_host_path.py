@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-pointer entry point (fmx_search_batch: H2D of patterns and
+offsets, k_prep + k_search, D2H of the intervals) on the C3 workload -- the figure DESIGN.md
+quotes beside the HBM-resident `value`; never the bench value."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import findex_amd  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+log2n, sigma, k, m, seed = bench.WORKLOADS[wl]
+n = 1 << log2n
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream().cuda_stream
+bwt, eof = bench.make_bwt(torch, n, sigma, seed, dev)
+torch.cuda.synchronize()
+hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=0, stream=stream)
+del bwt
+pats, off = bench.make_patterns(torch, hip, n, sigma, k, m, seed * 1000, dev, stream)
+h_p = pats.cpu().numpy()
+h_o = off.cpu().numpy().astype(np.uint64)
+hip.search_batch(h_p, h_o)
+hip.stats_reset()
+t0 = time.perf_counter()
+reps = 5
+for _ in range(reps):
+    sp, ep = hip.search_batch(h_p, h_o)
+dt = (time.perf_counter() - t0) / reps
+st = hip.stats()
+ranks = st["rank_queries"] / reps
+print("host-pointer path %s: %.3f ms per call (kernel part %.3f ms), %.0f M rank-queries/s, %.1f M patterns/s "
+      "PCIe-inclusive" % (wl, dt * 1e3, st["last_kernel_ms"], ranks / dt / 1e6, k / dt / 1e6))

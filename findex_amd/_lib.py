@@ -77,6 +77,9 @@ SYMBOLS = {
     "fmx_regex_tables": (_i32, [_vp, _P(_u32), _vp, _vp, _vp, _vp, _P(_u32), _vp, _P(_u32), _vp]),
     "fmx_regex_post_string": (_i32, [_cp, _i32, _vp, _sz]),
     "fmx_regex_match_batch": (_i32, [_vp, _vp, _sz, _vp, _vp, _sz, _P(_sz), _vp]),
+    "fmx_regex_batch_create": (_i32, [_vp, _vp, _sz, _P(_vp)]),
+    "fmx_regex_batch_free": (_i32, [_vp]),
+    "fmx_regex_batch_match": (_i32, [_vp, _vp, _vp, _vp, _sz, _P(_sz), _vp]),
     "fmx_stats": (_i32, [_vp, _P(fmx_stats_t)]),
     "fmx_stats_reset": (_i32, [_vp]),
 }
@@ -106,7 +109,13 @@ def load():
     return L
 
 
+FMX_TRUNCATED = 10
+
+
 def check(rc):
+    """Raises for error statuses; returns the status otherwise (FMX_OK or FMX_TRUNCATED)."""
+    if rc == FMX_TRUNCATED:
+        return rc
     if rc != FMX_OK:
         msg = (load().fmx_last_error() or b"").decode("utf-8", "replace")
         if rc == 7:
@@ -114,3 +123,4 @@ def check(rc):
         if rc == 8:
             raise MatchError(rc, msg)
         raise FmxError(rc, msg)
+    return rc

@@ -15,6 +15,9 @@
 #include <fmx.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "fmx_device.h"
@@ -41,7 +44,9 @@ struct NfaTables {       // all regexes of the batch, concatenated; state ids ar
 };
 
 struct FrontierCtl {     // device-resident counters
-  unsigned long long next_count;
+  // Level L reads count[L % 3] elements, appends to count[(L+1) % 3] and clears count[(L+2) % 3]
+  // (its predecessor's input), so a chain of level launches needs no host round trip in between.
+  unsigned long long count[3];
   unsigned long long res_count;
   unsigned long long overflow;     // bit 0: queue, bit 1: results
   unsigned long long steps;
@@ -61,9 +66,17 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
 }
 
 template <bool WIDE>
-__global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, uint64_t cur_count,
-                                                         Queue nxt, uint64_t nxt_cap, fmx_result *__restrict__ res,
+__global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, Queue nxt, uint32_t level,
+                                                         uint64_t nxt_cap, fmx_result *__restrict__ res,
                                                          uint64_t res_cap, FrontierCtl *__restrict__ ctl) {
+  // After a queue overflow the appended count exceeds what was stored: later levels of the chain
+  // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
+  if (ctl->overflow & 1ull) return;
+  uint64_t cur_count = ctl->count[level % 3];
+  if (cur_count > nxt_cap) cur_count = nxt_cap;          // both queues have nxt_cap entries
+  unsigned long long *next_count = &ctl->count[(level + 1) % 3];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->count[(level + 2) % 3] = 0;
+  if (cur_count == 0) return;
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
     unsigned long long rbase = 0, qbase = 0;
     if (lane == 0) {
       if (em) rbase = atomicAdd(&ctl->res_count, (unsigned long long)__builtin_popcountll(em));
-      if (push_total) qbase = atomicAdd(&ctl->next_count, (unsigned long long)push_total);
+      if (push_total) qbase = atomicAdd(next_count, (unsigned long long)push_total);
     }
     rbase = __shfl(rbase, 0, 64);
     qbase = __shfl(qbase, 0, 64);
@@ -175,14 +188,21 @@ struct DevMem {
     if (e__ != hipSuccess) return hip_fail(e__, what); \
   } while (0)
 
-int regex_match_batch(const Index *h, const Regex *const *res, size_t k, const fmx_limits *lim, fmx_result *out,
-                      size_t cap, size_t *n_out, uint32_t *per_regex_count) {
-  const uint32_t max_steps = (lim && lim->max_steps) ? lim->max_steps : 0xFFFFFFFFu;   // 0 = no cap
-  const uint64_t qcap = (lim && lim->max_frontier) ? lim->max_frontier : (1ull << 22);
-  // concatenate the batch's tables
+// A batch of compiled regexes made resident on one device: concatenated Glushkov tables plus
+// the level-0 frontier (root.firsts x (0, 0, n), retree.scala:576).  Reusable across calls.
+struct RegexBatch {
+  int device = 0;
+  size_t k = 0;
+  uint64_t n_index = 0;
+  size_t n_first = 0;
+  DevMem mem;
+  NfaTables nfa{};
+  uint32_t *d_first_state = nullptr;
+};
+
+int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexBatch **out) {
   std::vector<uint8_t> st_c, st_last;
-  std::vector<uint32_t> st_regex, fol_off, fol;
-  std::vector<uint32_t> q_state;
+  std::vector<uint32_t> st_regex, fol_off, fol, q_state;
   fol_off.push_back(0);
   for (size_t r = 0; r < k; r++) {
     const Regex &re = *res[r];
@@ -194,33 +214,67 @@ int regex_match_batch(const Index *h, const Regex *const *res, size_t k, const f
       for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol.push_back(base + (uint32_t)re.fol[j]);
       fol_off.push_back((uint32_t)fol.size());
     }
-    for (int32_t f : re.firsts) q_state.push_back(base + (uint32_t)f);   // root.firsts x (0, 0, n), :576
+    for (int32_t f : re.firsts) q_state.push_back(base + (uint32_t)f);
   }
-  if (per_regex_count) std::fill(per_regex_count, per_regex_count + k, 0u);
-  *n_out = 0;
-  if (q_state.empty()) return FMX_OK;
-  if (q_state.size() > qcap) { set_error("initial frontier exceeds max_frontier"); return FMX_ERR_OVERFLOW; }
-
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
-  DevMem mem;
+  std::unique_ptr<RegexBatch> b(new RegexBatch());
+  b->device = h->device;
+  b->k = k;
+  b->n_index = h->n;
+  b->n_first = q_state.size();
   uint8_t *d_c = nullptr, *d_last = nullptr;
   uint32_t *d_regex = nullptr, *d_foff = nullptr, *d_fol = nullptr;
+  HIP_TRY(b->mem.alloc(&d_c, st_c.size()), "hipMalloc");
+  HIP_TRY(b->mem.alloc(&d_last, st_last.size()), "hipMalloc");
+  HIP_TRY(b->mem.alloc(&d_regex, st_regex.size()), "hipMalloc");
+  HIP_TRY(b->mem.alloc(&d_foff, fol_off.size()), "hipMalloc");
+  HIP_TRY(b->mem.alloc(&d_fol, fol.size()), "hipMalloc");
+  HIP_TRY(b->mem.alloc(&b->d_first_state, q_state.size()), "hipMalloc");
+  if (!st_c.empty()) {
+    HIP_TRY(hipMemcpy(d_c, st_c.data(), st_c.size(), hipMemcpyHostToDevice), "H2D");
+    HIP_TRY(hipMemcpy(d_last, st_last.data(), st_last.size(), hipMemcpyHostToDevice), "H2D");
+    HIP_TRY(hipMemcpy(d_regex, st_regex.data(), st_regex.size() * 4, hipMemcpyHostToDevice), "H2D");
+  }
+  HIP_TRY(hipMemcpy(d_foff, fol_off.data(), fol_off.size() * 4, hipMemcpyHostToDevice), "H2D");
+  if (!fol.empty()) HIP_TRY(hipMemcpy(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice), "H2D");
+  if (!q_state.empty()) HIP_TRY(hipMemcpy(b->d_first_state, q_state.data(), q_state.size() * 4, hipMemcpyHostToDevice), "H2D");
+  b->nfa = NfaTables{d_c, d_last, d_regex, d_foff, d_fol};
+  *out = b.release();
+  return FMX_OK;
+}
+
+// Level-0 queue: states = firsts, len = 0, sp = 0, ep = n.
+__global__ void k_frontier_init(Queue q, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n,
+                                FrontierCtl *__restrict__ ctl) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    ctl->count[0] = count; ctl->count[1] = 0; ctl->count[2] = 0;
+    ctl->res_count = 0; ctl->overflow = 0; ctl->steps = 0;
+  }
+  if (i < count) { q.state[i] = first_state[i]; q.len[i] = 0; q.sp[i] = 0; q.ep[i] = n; }
+}
+
+int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_result *out, size_t cap,
+                      size_t *n_out, uint32_t *per_regex_count) {
+  const uint32_t max_steps = (lim && lim->max_steps) ? lim->max_steps : 4096u;
+  const uint64_t qcap = (lim && lim->max_frontier) ? lim->max_frontier : (1ull << 22);
+  if (b->device != h->device || b->n_index != h->n) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
+  if (per_regex_count) std::fill(per_regex_count, per_regex_count + b->k, 0u);
+  *n_out = 0;
+  if (b->n_first == 0) return FMX_OK;
+  if (b->n_first > qcap) { set_error("initial frontier exceeds max_frontier"); return FMX_ERR_OVERFLOW; }
+  HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+  DevMem mem;
   Queue qa{}, qb{};
   fmx_result *d_res = nullptr;
   FrontierCtl *d_ctl = nullptr;
-  const size_t rcap = cap ? cap : 1;
-  HIP_TRY(mem.alloc(&d_c, st_c.size()), "hipMalloc");
-  HIP_TRY(mem.alloc(&d_last, st_last.size()), "hipMalloc");
-  HIP_TRY(mem.alloc(&d_regex, st_regex.size()), "hipMalloc");
-  HIP_TRY(mem.alloc(&d_foff, fol_off.size()), "hipMalloc");
-  HIP_TRY(mem.alloc(&d_fol, fol.size()), "hipMalloc");
   for (Queue *q : {&qa, &qb}) {
     HIP_TRY(mem.alloc(&q->state, qcap), "hipMalloc(queue)");
     HIP_TRY(mem.alloc(&q->len, qcap), "hipMalloc(queue)");
     HIP_TRY(mem.alloc(&q->sp, qcap), "hipMalloc(queue)");
     HIP_TRY(mem.alloc(&q->ep, qcap), "hipMalloc(queue)");
   }
-  HIP_TRY(mem.alloc(&d_res, rcap), "hipMalloc(results)");
+  HIP_TRY(mem.alloc(&d_res, cap ? cap : 1), "hipMalloc(results)");
   HIP_TRY(mem.alloc(&d_ctl, 1), "hipMalloc(ctl)");
   hipStream_t st = nullptr;
   HIP_TRY(hipStreamCreate(&st), "hipStreamCreate");
@@ -230,47 +284,36 @@ int regex_match_batch(const Index *h, const Regex *const *res, size_t k, const f
   HIP_TRY(hipEventCreate(&e1), "hipEventCreate");
   struct EG { hipEvent_t a, b; ~EG() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
 
-  HIP_TRY(hipMemcpyAsync(d_c, st_c.data(), st_c.size(), hipMemcpyHostToDevice, st), "H2D");
-  HIP_TRY(hipMemcpyAsync(d_last, st_last.data(), st_last.size(), hipMemcpyHostToDevice, st), "H2D");
-  HIP_TRY(hipMemcpyAsync(d_regex, st_regex.data(), st_regex.size() * 4, hipMemcpyHostToDevice, st), "H2D");
-  HIP_TRY(hipMemcpyAsync(d_foff, fol_off.data(), fol_off.size() * 4, hipMemcpyHostToDevice, st), "H2D");
-  if (!fol.empty()) HIP_TRY(hipMemcpyAsync(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice, st), "H2D");
-  // level 0 frontier
-  const size_t f0 = q_state.size();
-  std::vector<uint32_t> zlen(f0, 0u);
-  std::vector<uint64_t> zsp(f0, 0ull), zep(f0, h->n);
-  HIP_TRY(hipMemcpyAsync(qa.state, q_state.data(), f0 * 4, hipMemcpyHostToDevice, st), "H2D");
-  HIP_TRY(hipMemcpyAsync(qa.len, zlen.data(), f0 * 4, hipMemcpyHostToDevice, st), "H2D");
-  HIP_TRY(hipMemcpyAsync(qa.sp, zsp.data(), f0 * 8, hipMemcpyHostToDevice, st), "H2D");
-  HIP_TRY(hipMemcpyAsync(qa.ep, zep.data(), f0 * 8, hipMemcpyHostToDevice, st), "H2D");
-  HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(FrontierCtl), st), "memset(ctl)");
-
-  NfaTables nfa{d_c, d_last, d_regex, d_foff, d_fol};
-  uint64_t count = f0;
-  FrontierCtl ctl{};
-  Queue *cur = &qa, *nxt = &qb;
-  uint32_t level = 0;
-  uint64_t launches = 0;
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
-  while (count) {
-    if (level >= max_steps) { set_error("frontier still alive after max_steps levels"); return FMX_ERR_OVERFLOW; }
-    uint64_t want = (count + (kFThreads / kOctet) - 1) / (kFThreads / kOctet);
-    uint64_t gcap = (uint64_t)h->cu_count * 8;
-    int grid = (int)(want < gcap ? want : gcap);
-    if (h->n > (1ull << 32))
-      k_frontier<true><<<grid, kFThreads, 0, st>>>(h->dev, nfa, *cur, count, *nxt, qcap, d_res, (uint64_t)cap, d_ctl);
-    else
-      k_frontier<false><<<grid, kFThreads, 0, st>>>(h->dev, nfa, *cur, count, *nxt, qcap, d_res, (uint64_t)cap, d_ctl);
-    HIP_TRY(hipGetLastError(), "k_frontier");
-    launches++;
+  k_frontier_init<<<(int)((b->n_first + 255) / 256), 256, 0, st>>>(qa, b->d_first_state, b->n_first, h->n, d_ctl);
+  HIP_TRY(hipGetLastError(), "k_frontier_init");
+  // Levels are chained on the stream without host round trips; the host looks at the counters
+  // every kChain levels.  A level with an empty queue returns at once.
+  constexpr uint32_t kChain = 8;
+  const int grid = h->cu_count * 8;
+  FrontierCtl ctl{};
+  uint32_t level = 0;
+  uint64_t launches = 1;
+  bool alive = true, truncated = false;
+  while (alive) {
+    for (uint32_t j = 0; j < kChain && level < max_steps; j++, level++) {
+      const Queue &cur = (level & 1) ? qb : qa;
+      const Queue &nxt = (level & 1) ? qa : qb;
+      if (h->n > (1ull << 32))
+        k_frontier<true><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, qcap, d_res, (uint64_t)cap, d_ctl);
+      else
+        k_frontier<false><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, qcap, d_res, (uint64_t)cap, d_ctl);
+      HIP_TRY(hipGetLastError(), "k_frontier");
+      launches++;
+    }
     HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
-    HIP_TRY(hipStreamSynchronize(st), "sync(level)");
+    HIP_TRY(hipStreamSynchronize(st), "sync(levels)");
     if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
-    count = ctl.next_count;
-    // reset next_count for the following level (res_count and steps keep accumulating)
-    HIP_TRY(hipMemsetAsync(&d_ctl->next_count, 0, sizeof(unsigned long long), st), "memset(next_count)");
-    std::swap(cur, nxt);
-    level++;
+    alive = ctl.count[level % 3] != 0;
+    if (getenv("FMX_TRACE"))
+      fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, steps %llu, overflow %llu\n", level,
+              ctl.count[level % 3], ctl.res_count, ctl.steps, ctl.overflow);
+    if (alive && level >= max_steps) { truncated = true; alive = false; }
   }
   HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
   HIP_TRY(hipStreamSynchronize(st), "sync");
@@ -281,12 +324,11 @@ int regex_match_batch(const Index *h, const Regex *const *res, size_t k, const f
     h->last_kernel_ms = ms;
     h->launches += launches;
   }
-  // fold this call's steps into the handle's counters
-  if (ctl.steps) {
-    unsigned long long add[2] = {2ull * ctl.steps, ctl.steps}, cur_cnt[2];
+  if (ctl.steps) {   // fold this call's steps into the handle's counters
+    unsigned long long cur_cnt[2];
     HIP_TRY(hipMemcpy(cur_cnt, h->d_counters, sizeof cur_cnt, hipMemcpyDeviceToHost), "D2H(counters)");
-    cur_cnt[0] += add[0];
-    cur_cnt[1] += add[1];
+    cur_cnt[0] += 2ull * ctl.steps;
+    cur_cnt[1] += ctl.steps;
     HIP_TRY(hipMemcpy(h->d_counters, cur_cnt, sizeof cur_cnt, hipMemcpyHostToDevice), "H2D(counters)");
   }
   *n_out = (size_t)ctl.res_count;
@@ -301,6 +343,10 @@ int regex_match_batch(const Index *h, const Regex *const *res, size_t k, const f
     });
     if (per_regex_count)
       for (size_t j = 0; j < ctl.res_count; j++) per_regex_count[out[j].regex]++;
+  }
+  if (truncated) {
+    set_error("frontier still alive after max_steps levels: results hold every match of length <= max_steps");
+    return FMX_TRUNCATED;
   }
   return FMX_OK;
 }
@@ -362,13 +408,39 @@ int fmx_regex_tables(const fmx_regex *re, uint32_t *n_states, uint8_t *st_c, int
   return FMX_OK;
 }
 
-int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,
-                          fmx_result *out, size_t cap, size_t *n_out, uint32_t *per_regex_count) {
-  if (!idx || !n_out || (k && !res) || (cap && !out)) { set_error("null argument"); return FMX_ERR_ARG; }
+int fmx_regex_batch_create(const fmx_index *idx, fmx_regex *const *res, size_t k, fmx_regex_batch **out) {
+  if (!idx || !out || (k && !res)) { set_error("null argument"); return FMX_ERR_ARG; }
+  *out = nullptr;
   for (size_t r = 0; r < k; r++)
     if (!res[r]) { set_error("null regex handle"); return FMX_ERR_ARG; }
-  return regex_match_batch(reinterpret_cast<const Index *>(idx), reinterpret_cast<const Regex *const *>(res), k, lim,
-                           out, cap, n_out, per_regex_count);
+  RegexBatch *b = nullptr;
+  int rc = regex_batch_create(reinterpret_cast<const Index *>(idx), reinterpret_cast<const Regex *const *>(res), k, &b);
+  if (rc == FMX_OK) *out = reinterpret_cast<fmx_regex_batch *>(b);
+  return rc;
+}
+
+int fmx_regex_batch_free(fmx_regex_batch *b) {
+  RegexBatch *rb = reinterpret_cast<RegexBatch *>(b);
+  if (rb) { (void)hipSetDevice(rb->device); delete rb; }
+  return FMX_OK;
+}
+
+int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *b, const fmx_limits *lim, fmx_result *out,
+                          size_t cap, size_t *n_out, uint32_t *per_regex_count) {
+  if (!idx || !b || !n_out || (cap && !out)) { set_error("null argument"); return FMX_ERR_ARG; }
+  return regex_batch_match(reinterpret_cast<const Index *>(idx), reinterpret_cast<RegexBatch *>(b), lim, out, cap, n_out,
+                           per_regex_count);
+}
+
+int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,
+                          fmx_result *out, size_t cap, size_t *n_out, uint32_t *per_regex_count) {
+  if (!n_out) { set_error("null argument"); return FMX_ERR_ARG; }
+  fmx_regex_batch *b = nullptr;
+  int rc = fmx_regex_batch_create(idx, res, k, &b);
+  if (rc != FMX_OK) return rc;
+  rc = fmx_regex_batch_match(idx, b, lim, out, cap, n_out, per_regex_count);
+  fmx_regex_batch_free(b);
+  return rc;
 }
 
 }  // extern "C"

@@ -104,10 +104,17 @@ class ReTree:
                 "follows": [fol[off[k]:off[k + 1]].tolist() for k in range(n)],
                 "firsts": firsts[: nfi.value].tolist()}
 
+    last_truncated = False      # True when the last matchSA* call stopped at max_steps (FMX_TRUNCATED)
+
     def matchSA(self, sa, max_steps=0, max_frontier=0, cap=1 << 20):
         """ReTree.matchSA (retree.scala:570-617) -> list of SAResult, sorted by (len, sp, ep).
         Equals the reference's result multiset whenever its limits do not bind."""
         return ReTree.matchSA_batch(sa, [self], max_steps, max_frontier, cap)[0]
+
+    @staticmethod
+    def prepare_batch(sa, trees):
+        """Make a batch of compiled regexes resident on sa's device (fmx_regex_batch_create)."""
+        return RegexBatch(sa, trees)
 
     @staticmethod
     def matchSA_batch(sa, trees, max_steps=0, max_frontier=0, cap=1 << 20):
@@ -118,10 +125,48 @@ class ReTree:
         out = (_lib.fmx_result * cap)()
         n_out = ctypes.c_size_t()
         per = np.zeros(max(k, 1), dtype=np.uint32)
-        _lib.check(L.fmx_regex_match_batch(sa.handle, arr, k, ctypes.byref(lim), out, cap, ctypes.byref(n_out),
-                                           per.ctypes.data_as(ctypes.c_void_p)))
+        rc = _lib.check(L.fmx_regex_match_batch(sa.handle, arr, k, ctypes.byref(lim), out, cap, ctypes.byref(n_out),
+                                                per.ctypes.data_as(ctypes.c_void_p)))
+        ReTree.last_truncated = rc == _lib.FMX_TRUNCATED
         res = [[] for _ in range(k)]
         for j in range(n_out.value):
             r = out[j]
             res[r.regex].append(SAResult(sa, r.len, r.sp, r.ep))
         return res
+
+
+RESULT_DTYPE = np.dtype([("regex", np.uint32), ("len", np.uint32), ("sp", np.uint64), ("ep", np.uint64)])
+
+
+class RegexBatch:
+    """A regex batch resident on the device: build once, match many times (serving shape of
+    ReTree.matchSA over many regexes)."""
+
+    def __init__(self, sa, trees):
+        self._L = _lib.load()
+        self.sa = sa
+        self.k = len(trees)
+        self._trees = list(trees)            # keep the handles alive
+        arr = (ctypes.c_void_p * max(self.k, 1))(*[t._h for t in trees])
+        self._h = ctypes.c_void_p()
+        _lib.check(self._L.fmx_regex_batch_create(sa.handle, arr, self.k, ctypes.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.fmx_regex_batch_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22):
+        """-> (results as a structured array sorted by (regex, len, sp, ep), per-regex counts)"""
+        lim = _lib.fmx_limits(int(max_steps), int(max_frontier))
+        out = np.zeros(cap, dtype=RESULT_DTYPE)
+        per = np.zeros(max(self.k, 1), dtype=np.uint32)
+        n_out = ctypes.c_size_t()
+        rc = _lib.check(self._L.fmx_regex_batch_match(self.sa.handle, self._h, ctypes.byref(lim),
+                                                      out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n_out),
+                                                      per.ctypes.data_as(ctypes.c_void_p)))
+        self.truncated = rc == _lib.FMX_TRUNCATED
+        return out[: n_out.value], per[: self.k]

@@ -50,11 +50,13 @@ enum {
   FMX_ERR_UNSUPPORTED = 6, /* valid input this build cannot serve */
   FMX_ERR_SYNTAX = 7,      /* "re2post syntax" (re2/re2.scala:84,87,109,133,141,159,174) */
   FMX_ERR_MATCH = 8,       /* scala.MatchError from ReTree.apply (re2/retree.scala:235-238,291-294) */
-  FMX_ERR_OVERFLOW = 9     /* a caller-sized output or a device work queue was too small */
+  FMX_ERR_OVERFLOW = 9,    /* a caller-sized output or a device work queue was too small */
+  FMX_TRUNCATED = 10       /* not an error: outputs are valid but a search was cut at a limit (regex max_steps) */
 };
 
 typedef struct fmx_index fmx_index;   /* replaces class NaiveFMSearcher, bwtmerger.scala:335-421 */
 typedef struct fmx_regex fmx_regex;   /* replaces class ReTree, re2/retree.scala:485 */
+typedef struct fmx_regex_batch fmx_regex_batch;   /* a set of compiled regexes made resident on a device */
 
 const char *fmx_last_error(void);
 int fmx_abi_version(void);
@@ -150,12 +152,16 @@ int fmx_regex_tables(const fmx_regex *re, uint32_t *n_states, uint8_t *st_c, int
 int fmx_regex_post_string(const char *re, int line_only, char *out, size_t cap);
 
 typedef struct fmx_limits {
-  /* ReTree.matchSA defaults: maxBranching=1024, maxIterations=1000 (re2/retree.scala:570).
-   * The frontier kernel expands every regex's frontier breadth-first, so results equal the
-   * reference's whenever its limits do not bind; here the limits are safety caps:
-   * max_steps   = maximum match length explored (levels), 0 = no cap (a frontier dies by itself:
-   *               no match is longer than the text)
-   * max_frontier= capacity of the device work queue in items, 0 = default (1<<22) */
+  /* ReTree.matchSA defaults: maxBranching=1024, maxIterations=1000 (re2/retree.scala:570); with them
+   * no reference result is longer than 999.  The frontier kernel expands every regex's frontier
+   * breadth-first, so results equal the reference's whenever its limits do not bind; here:
+   * max_steps   = longest match explored (levels); 0 = default 4096.  When the frontier is still alive
+   *               there, the call returns FMX_TRUNCATED with every match of length <= max_steps.  (On
+   *               the BWT of a real text a frontier always dies -- no match is longer than the text --
+   *               but on a synthetic "BWT" that is just a random string, LF has short cycles and x* can
+   *               run forever.)
+   * max_frontier= capacity of the device work queue in elements, 0 = default (1<<22); FMX_ERR_OVERFLOW
+   *               when exceeded. */
   uint32_t max_steps;
   uint64_t max_frontier;
 } fmx_limits;
@@ -173,9 +179,16 @@ typedef struct fmx_result {   /* SAResult(sa,len,sp,ep), re2/re2.scala:9-19, + w
  * sorted by (regex, len, sp, ep) -- the reference's list order is its priority queue's discovery
  * order, which is not part of this contract.  per_regex_count (optional, k entries) = results per
  * regex.  FMX_ERR_OVERFLOW if out (cap entries) or the work queue was too small: *n_out then
- * holds the number of results found so far / needed. */
+ * holds the number of results found so far / needed.  FMX_TRUNCATED: see fmx_limits.max_steps. */
 int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,
                           fmx_result *out, size_t cap, size_t *n_out, uint32_t *per_regex_count);
+
+/* The same in two stages for serving: make a batch of compiled regexes resident on idx's device
+ * once (concatenated tables + the level-0 frontier), then match it any number of times. */
+int fmx_regex_batch_create(const fmx_index *idx, fmx_regex *const *res, size_t k, fmx_regex_batch **out);
+int fmx_regex_batch_free(fmx_regex_batch *batch);
+int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *batch, const fmx_limits *lim, fmx_result *out,
+                          size_t cap, size_t *n_out, uint32_t *per_regex_count);
 
 /* ---- statistics (since open or the last reset; device counters are read with a sync) */
 typedef struct fmx_stats_t {

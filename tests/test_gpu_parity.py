@@ -228,7 +228,8 @@ def test_regex_frontier_parity(testdata, name, be):
     hip, orc = pair_from_files(testdata, name, be)
     trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re)) for re in REGEXES]
     hip.stats_reset()
-    got = findex_amd.ReTree.matchSA_batch(hip, trees, cap=1 << 21)
+    got = findex_amd.ReTree.matchSA_batch(hip, trees, max_steps=1 << 20, cap=1 << 21)   # test.txt is one 10 KB word
+    assert not findex_amd.ReTree.last_truncated
     total_pops = 0
     for re, g in zip(REGEXES, got):
         want, pops = oracle_results(orc, re)
@@ -236,7 +237,7 @@ def test_regex_frontier_parity(testdata, name, be):
         assert [r.key() for r in g] == want, re
     assert hip.stats()["backward_steps"] == total_pops
     # single-regex entry point and SAResult rendering (re2.scala:9-19)
-    one = trees[1].matchSA(hip)
+    one = trees[1].matchSA(hip, max_steps=1 << 20)
     assert [r.key() for r in one] == oracle_results(orc, REGEXES[1])[0]
     for r in one[:5]:
         sub = orc.nextSubstr(r.sp, r.len).decode("latin-1")
@@ -263,6 +264,26 @@ def test_regex_duplicate_follows_give_duplicate_results():
     assert keys and all(keys.count(k) == 2 for k in keys)
 
 
+def oracle_results_capped(bwt, eof, counts, re, max_len):
+    """All matches of length <= max_len: breadth-first over the oracle's getPrevRange."""
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+    t = R.ReTree(R.re2post(re)).tables()
+    front = [(0, 0, orc.n, s) for s in t["firsts"]]
+    out = []
+    while front:
+        nxt = []
+        for ln, sp, ep, s in front:
+            r = orc.getPrevRange(sp, ep, t["c"][s])
+            if r is None:
+                continue
+            if t["isLast"][s]:
+                out.append((ln + 1, r[0], r[1]))
+            elif ln + 1 < max_len:
+                nxt += [(ln + 1, r[0], r[1], f) for f in t["follows"][s]]
+        front = nxt
+    return out
+
+
 def test_regex_overflow_is_reported():
     bwt, eof, counts = synth_bwt(200_000, 97, 100, 3)
     hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
@@ -270,9 +291,10 @@ def test_regex_overflow_is_reported():
     with pytest.raises(findex_amd.FmxError) as e:
         t.matchSA(hip, max_frontier=64)
     assert e.value.code == 9
-    with pytest.raises(findex_amd.FmxError) as e:
-        t.matchSA(hip, max_steps=3, max_frontier=1 << 22)
-    assert e.value.code == 9
+    # a level cap is not an error: every match of length <= 3 comes back and the call says so
+    part = t.matchSA(hip, max_steps=3, max_frontier=1 << 22)
+    assert findex_amd.ReTree.last_truncated and part and all(r.len <= 3 for r in part)
+    assert {r.key() for r in part} == {k for k in oracle_results_capped(bwt, eof, counts, "a[a-d]*b", 3)}
 
 
 # ---------------------------------------------------------------- full-size properties (on device)

@@ -27,8 +27,12 @@ class MatchError(FmxError):
     """scala.MatchError from ReTree.apply, re2/retree.scala:235-238,291-294"""
 
 
+FMX_MATCH_FRONTIER, FMX_MATCH_REFERENCE = 0, 1
+
+
 class fmx_limits(ctypes.Structure):
-    _fields_ = [("max_steps", ctypes.c_uint32), ("max_frontier", ctypes.c_uint64)]
+    _fields_ = [("max_steps", ctypes.c_uint32), ("mode", ctypes.c_uint32), ("max_frontier", ctypes.c_uint64),
+                ("max_branching", ctypes.c_uint32), ("max_iterations", ctypes.c_uint32)]
 
 
 class fmx_result(ctypes.Structure):
@@ -72,6 +76,7 @@ SYMBOLS = {
     "fmx_psi_batch": (_i32, [_vp, _vp, _vp, _sz]),
     "fmx_next_substr": (_i32, [_vp, _u64, _u32, _vp, _P(_u32)]),
     "fmx_prev_substr": (_i32, [_vp, _u64, _u32, _vp]),
+    "fmx_write_fm": (_i32, [_vp, _cp]),
     "fmx_regex_compile": (_i32, [_cp, _i32, _P(_vp)]),
     "fmx_regex_free": (_i32, [_vp]),
     "fmx_regex_tables": (_i32, [_vp, _P(_u32), _vp, _vp, _vp, _vp, _P(_u32), _vp, _P(_u32), _vp]),

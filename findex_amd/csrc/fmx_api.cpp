@@ -462,6 +462,42 @@ int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *ou
   return FMX_OK;
 }
 
+// ---------------------------------------------------------------- .fm writer (FMCreator.create)
+// Wire format, bwtmerger.scala:483-485,476-481: byte elSize (=4), int64 big-endian size, then
+// `size` big-endian int32 entries.  elSize 8 is `???` in the reference (:465-469), so n must stay
+// below 0xffffffff here too.
+int fmx_write_fm(const fmx_index *idx, const char *path) {
+  if (!idx || !path) return arg_fail("null argument");
+  const Index *h = H(idx);
+  if (h->n >= 0xffffffffull) { g_err = "the .fm format has no 8-byte entries (bwtmerger.scala:465-469)"; return FMX_ERR_UNSUPPORTED; }
+  int rc = use_device(h);
+  if (rc) return rc;
+  DevBuf dfm;
+  HIP_TRY(dfm.alloc(h->n * 4), "hipMalloc(fm)");
+  rc = timed(h, [&](hipStream_t st, EventPair &ev) {
+    HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
+    HIP_TRY(launch_fm_fill(h, dfm.p, st), "k_fm_fill");
+    HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
+    return (int)FMX_OK;
+  });
+  if (rc) return rc;
+  FILE *f = std::fopen(path, "wb");
+  if (!f) { g_err = std::string("cannot create ") + path; return FMX_ERR_IO; }
+  std::unique_ptr<FILE, int (*)(FILE *)> guard(f, std::fclose);
+  uint8_t hdr[9];
+  hdr[0] = 4;
+  for (int i = 0; i < 8; i++) hdr[1 + i] = (uint8_t)(h->n >> (56 - 8 * i));
+  if (std::fwrite(hdr, 1, 9, f) != 9) { g_err = "short write"; return FMX_ERR_IO; }
+  const size_t chunk = 64u << 20;
+  std::vector<uint8_t> buf(std::min<uint64_t>(chunk, h->n * 4));
+  for (uint64_t o = 0; o < h->n * 4; o += chunk) {
+    const size_t len = (size_t)std::min<uint64_t>(chunk, h->n * 4 - o);
+    HIP_TRY(hipMemcpy(buf.data(), (const uint8_t *)dfm.p + o, len, hipMemcpyDeviceToHost), "D2H(fm)");
+    if (std::fwrite(buf.data(), 1, len, f) != len) { g_err = "short write"; return FMX_ERR_IO; }
+  }
+  return FMX_OK;
+}
+
 // ---------------------------------------------------------------- statistics
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   if (!idx || !out) return arg_fail("null argument");

@@ -428,6 +428,7 @@ int fmx_regex_batch_free(fmx_regex_batch *b) {
 int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *b, const fmx_limits *lim, fmx_result *out,
                           size_t cap, size_t *n_out, uint32_t *per_regex_count) {
   if (!idx || !b || !n_out || (cap && !out)) { set_error("null argument"); return FMX_ERR_ARG; }
+  if (lim && lim->mode != FMX_MATCH_FRONTIER) { set_error("resident batches serve the frontier mode only"); return FMX_ERR_ARG; }
   return regex_batch_match(reinterpret_cast<const Index *>(idx), reinterpret_cast<RegexBatch *>(b), lim, out, cap, n_out,
                            per_regex_count);
 }
@@ -435,6 +436,14 @@ int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *b, const fmx_li
 int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,
                           fmx_result *out, size_t cap, size_t *n_out, uint32_t *per_regex_count) {
   if (!n_out) { set_error("null argument"); return FMX_ERR_ARG; }
+  if (lim && lim->mode == FMX_MATCH_REFERENCE) {
+    if (!idx || (k && !res) || (cap && !out)) { set_error("null argument"); return FMX_ERR_ARG; }
+    for (size_t r = 0; r < k; r++)
+      if (!res[r]) { set_error("null regex handle"); return FMX_ERR_ARG; }
+    if (lim->max_branching == 0) { set_error("max_branching must be positive"); return FMX_ERR_ARG; }
+    return regex_match_reference(reinterpret_cast<const Index *>(idx), reinterpret_cast<const Regex *const *>(res), k,
+                                 lim->max_branching, lim->max_iterations, out, cap, n_out, per_regex_count, nullptr);
+  }
   fmx_regex_batch *b = nullptr;
   int rc = fmx_regex_batch_create(idx, res, k, &b);
   if (rc != FMX_OK) return rc;

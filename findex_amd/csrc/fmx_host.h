@@ -47,8 +47,18 @@ hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, v
                          hipStream_t st);
 hipError_t launch_lf_walk(const Index *h, const void *d_rows, uint64_t k, uint32_t len, void *d_out, void *d_end,
                           hipStream_t st);
+hipError_t launch_fm_fill(const Index *h, void *d_fm, hipStream_t st);
 hipError_t launch_psi(const Index *h, const void *d_rows, void *d_out, uint64_t k, hipStream_t st);
 hipError_t launch_next_substr(const Index *h, const void *d_sps, uint64_t k, uint32_t len, void *d_out,
                               void *d_out_len, hipStream_t st);
+
+// fmx_refmatch.hip
+struct Regex;
+}  // namespace fmx
+struct fmx_result;
+namespace fmx {
+int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uint32_t max_branching,
+                          uint32_t max_iterations, fmx_result *out, size_t cap, size_t *n_out,
+                          uint32_t *per_regex_count, uint32_t *front_left);
 
 }  // namespace fmx

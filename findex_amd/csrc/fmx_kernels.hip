@@ -173,6 +173,23 @@ __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_
   if (t == 0 && done) atomicAdd(&counters[0], (unsigned long long)done);
 }
 
+// ---------------------------------------------------------------- .fm payload (FMCreator)
+// FMCreator.create (bwtmerger.scala:452-532) bucket-sorts BWT positions by symbol; entry r of the
+// result is the position p with LF(p) = r.  One LF step per position, scattered as 4-byte
+// big-endian ints (the wire format, :476-481).
+template <bool WIDE>
+__global__ __launch_bounds__(kThreads) void k_fm_fill(DevIndex ix, uint64_t p0, uint64_t p1, uint32_t *__restrict__ fm) {
+  __shared__ Tables tb;
+  stage_tables(ix, tb);
+  const LaneConst lc = lane_const();
+  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
+  for (uint64_t p = p0 + (((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3); p < p1; p += noct) {
+    const uint32_t b = p == ix.eof ? 0u : ix.bwt[p];
+    const uint64_t r = tb.cf[b] + rank_excl<WIDE>(ix, tb.slot[b], p, lc);
+    if (lc.t == 0) fm[r] = __builtin_bswap32((uint32_t)p);
+  }
+}
+
 // ---------------------------------------------------------------- Psi (getNextI = fm[row])
 // fm[row] is the BWT position of the (row - cf(c))-th occurrence of the symbol c whose bucket
 // holds `row` (FMCreator, bwtmerger.scala:424-533): a select on c's bit-vector.  One lane per
@@ -280,6 +297,11 @@ hipError_t launch_lf_walk(const Index *h, const void *d_rows, uint64_t k, uint32
   if (!k) return hipSuccess;
   FMX_WIDE_DISPATCH(h, k_lf_walk, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint64_t *)d_rows, k, len,
                     (uint8_t *)d_out, (uint64_t *)d_end, h->d_counters);
+  return hipGetLastError();
+}
+
+hipError_t launch_fm_fill(const Index *h, void *d_fm, hipStream_t st) {
+  FMX_WIDE_DISPATCH(h, k_fm_fill, grid_for(h, h->n, kOctetsPerBlock), st, h->dev, (uint64_t)0, h->n, (uint32_t *)d_fm);
   return hipGetLastError();
 }
 

@@ -1,0 +1,320 @@
+// fmx_refmatch.hip -- ReTree._matchSA in the reference's own order, limits included.
+//
+// Reference: re2/retree.scala:618-653.  One scala.collection.mutable.PriorityQueue of
+// StatePoint(len, sp, ep, state) ordered by smallest state.num (:562-567); the loop runs while
+// the queue is non-empty, shorter than maxBranching, and (maxIterations == 0 or i < maxIterations)
+// with i starting at 1 (:622,628).  When those limits bind, which results come out depends on the
+// exact pop order, ties included, so this mode replays the queue itself: one regex per octet of
+// lanes, the octet's lane 0 keeps the regex's binary heap in device memory and performs the same
+// fixUp / fixDown as the Scala 2.10.0 library (`+=`: append then sift up with `<`; `dequeue`:
+// swap root and last, sift down picking the right child only when left < right, stop when
+// parent >= child), the popped element is broadcast to the octet and stepped with the shared
+// rank primitive.  Results carry their discovery number so the host can return them newest
+// first, the order of the reference's `ret ::= ...` list.
+//
+// The frontier kernel (fmx_frontier.hip) is the throughput path; this one exists so that a
+// caller who keeps the reference's default limits (1024 / 1000) gets the reference's answer.
+#include <fmx.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "fmx_device.h"
+#include "fmx_host.h"
+#include "fmx_regex.h"
+
+namespace fmx {
+
+constexpr int kRThreads = 256;
+
+struct HeapElem {          // 32 bytes
+  uint32_t num;            // CharNode.num: the only key StatePoint.compare looks at (:564)
+  uint32_t state;          // global CharNode id
+  uint32_t len;
+  uint32_t pad;
+  uint64_t sp, ep;
+};
+
+struct RefTables {
+  const uint8_t *st_c;
+  const uint8_t *st_last;
+  const int32_t *st_num;
+  const uint32_t *fol_off;
+  const uint32_t *fol;
+  const uint32_t *first_off;   // k + 1: firsts of regex r are first[first_off[r] .. first_off[r+1])
+  const uint32_t *first;
+};
+
+struct RefResult {
+  uint32_t regex, len, seq, pad;
+  uint64_t sp, ep;
+};
+
+struct RefCtl {
+  unsigned long long res_count;
+  unsigned long long steps;
+  unsigned long long overflow;
+};
+
+// this < that  <=>  this.num > that.num   (StatePoint.compare, :564)
+__device__ __forceinline__ bool heap_lt(const HeapElem &x, const HeapElem &y) { return x.num > y.num; }
+
+__device__ void heap_push(HeapElem *a, uint32_t &size0, const HeapElem &e) {
+  a[size0] = e;
+  uint32_t k = size0;
+  while (k > 1) {
+    const HeapElem p = a[k / 2];
+    if (!heap_lt(p, e)) break;
+    a[k] = p;                     // swap(k, k/2) with e travelling up
+    k /= 2;
+  }
+  a[k] = e;
+  size0 += 1;
+}
+
+__device__ HeapElem heap_pop(HeapElem *a, uint32_t &size0) {
+  size0 -= 1;
+  const HeapElem top = a[1];
+  HeapElem x = a[size0];           // swap(1, size0): the last element goes to the root...
+  a[size0] = top;
+  const uint32_t n = size0 - 1;    // ...and sifts down inside a[1..n]
+  uint32_t k = 1;
+  while (n >= 2 * k) {
+    uint32_t j = 2 * k;
+    HeapElem c = a[j];
+    if (j < n) {
+      const HeapElem c2 = a[j + 1];
+      if (heap_lt(c, c2)) { j += 1; c = c2; }
+    }
+    if (!heap_lt(x, c)) break;     // as(k) >= as(j)
+    a[k] = c;
+    k = j;
+  }
+  if (n >= 1) a[k] = x;
+  return top;
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables rt, uint32_t k_regex,
+                                                          HeapElem *__restrict__ heaps, uint32_t heap_cap,
+                                                          uint32_t max_branching, uint32_t max_iterations,
+                                                          RefResult *__restrict__ res, uint64_t res_cap,
+                                                          uint32_t *__restrict__ front_left,
+                                                          RefCtl *__restrict__ ctl) {
+  __shared__ uint64_t s_cf[256];
+  __shared__ uint16_t s_slot[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  __syncthreads();
+  const LaneConst lc = lane_const();
+  const uint32_t t = lc.t;
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = lane & ~7u;
+  const uint32_t octet = (blockIdx.x * kRThreads + threadIdx.x) >> 3;
+  const uint32_t noct = gridDim.x * (kRThreads / kOctet);
+  HeapElem *heap = heaps + (size_t)octet * heap_cap;
+  uint32_t stepped = 0;
+  for (uint32_t r = octet; r < k_regex; r += noct) {
+    uint32_t size0 = 1, nres = 0, it = 1;
+    bool bad = false;
+    if (t == 0) {
+      for (uint32_t f = rt.first_off[r]; f < rt.first_off[r + 1]; f++) {     // pqFront ++= inputStates, :624
+        HeapElem e;
+        e.state = rt.first[f]; e.num = (uint32_t)rt.st_num[e.state]; e.len = 0; e.pad = 0; e.sp = 0; e.ep = ix.n;
+        if (size0 + 1 > heap_cap) { bad = true; break; }
+        heap_push(heap, size0, e);
+      }
+    }
+    for (;;) {
+      // loop condition, :628 (decided by the leader, shared with the octet)
+      uint32_t go = 0, state = 0, len = 0, splo = 0, sphi = 0, eplo = 0, ephi = 0;
+      if (t == 0 && !bad && size0 >= 2 && (size0 - 1) < max_branching && (max_iterations == 0 || it < max_iterations)) {
+        const HeapElem q = heap_pop(heap, size0);
+        go = 1; state = q.state; len = q.len;
+        splo = (uint32_t)q.sp; sphi = (uint32_t)(q.sp >> 32); eplo = (uint32_t)q.ep; ephi = (uint32_t)(q.ep >> 32);
+      }
+      go = __shfl(go, leader, 64);
+      if (!go) break;
+      state = __shfl(state, leader, 64);
+      len = __shfl(len, leader, 64);
+      uint64_t sp = ((uint64_t)__shfl(sphi, leader, 64) << 32) | __shfl(splo, leader, 64);
+      uint64_t ep = ((uint64_t)__shfl(ephi, leader, 64) << 32) | __shfl(eplo, leader, 64);
+      // sa.getPrevRange(q.sp, q.ep, q.state.c), :633
+      const uint32_t c = rt.st_c[state];
+      const uint16_t slot = s_slot[c];
+      const uint64_t cfc = s_cf[c];
+      uint64_t r1 = 0, r2 = 0;
+      if (slot < kSlotEof) {
+        uint32_t b1, b2, m1, m2;
+        split960(sp, b1, m1);
+        split960(ep, b2, m2);
+        const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
+        const uint4 w2 = load_line16(block_addr(ix, slot, b2, lc));
+        r1 = rank_finish<WIDE>(w1, m1, lc);
+        r2 = rank_finish<WIDE>(w2, m2, lc);
+      } else if (slot == kSlotEof) {
+        r1 = sp > ix.eof ? 1 : 0;
+        r2 = ep > ix.eof ? 1 : 0;
+      }
+      sp = cfc + r1;
+      ep = cfc + r2;
+      stepped++;
+      if (t == 0 && sp < ep) {
+        if (rt.st_last[state]) {                                   // :636-638
+          const unsigned long long at = atomicAdd(&ctl->res_count, 1ull);
+          if (at < res_cap) {
+            RefResult o;
+            o.regex = r; o.len = len + 1; o.seq = nres; o.pad = 0; o.sp = sp; o.ep = ep;
+            res[at] = o;
+          } else {
+            atomicOr(&ctl->overflow, 2ull);
+          }
+          nres++;
+        } else {                                                   // :641
+          for (uint32_t f = rt.fol_off[state]; f < rt.fol_off[state + 1]; f++) {
+            HeapElem e;
+            e.state = rt.fol[f]; e.num = (uint32_t)rt.st_num[e.state]; e.len = len + 1; e.pad = 0; e.sp = sp; e.ep = ep;
+            if (size0 + 1 > heap_cap) { bad = true; atomicOr(&ctl->overflow, 1ull); break; }
+            heap_push(heap, size0, e);
+          }
+        }
+      }
+      it++;
+    }
+    if (t == 0 && front_left) front_left[r] = size0 - 1;
+  }
+  if (t == 0 && stepped) atomicAdd(&ctl->steps, (unsigned long long)stepped);
+}
+
+#define HIP_TRY(call, what)                            \
+  do {                                                 \
+    hipError_t e__ = (call);                           \
+    if (e__ != hipSuccess) return hip_fail(e__, what); \
+  } while (0)
+
+namespace {
+struct DevMem {
+  std::vector<void *> ptrs;
+  ~DevMem() { for (void *p : ptrs) (void)hipFree(p); }
+  template <class T>
+  hipError_t alloc(T **out, size_t count) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+    if (e == hipSuccess) { ptrs.push_back(p); *out = (T *)p; }
+    return e;
+  }
+  template <class T>
+  hipError_t upload(T **out, const std::vector<T> &v) {
+    hipError_t e = alloc(out, v.size());
+    if (e == hipSuccess && !v.empty()) e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+};
+}  // namespace
+
+int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uint32_t max_branching,
+                          uint32_t max_iterations, fmx_result *out, size_t cap, size_t *n_out,
+                          uint32_t *per_regex_count, uint32_t *front_left) {
+  std::vector<uint8_t> st_c, st_last;
+  std::vector<int32_t> st_num;
+  std::vector<uint32_t> fol_off, fol, first_off, first;
+  fol_off.push_back(0);
+  first_off.push_back(0);
+  uint32_t max_fanout = 1;
+  for (size_t r = 0; r < k; r++) {
+    const Regex &re = *res[r];
+    const uint32_t base = (uint32_t)st_c.size();
+    for (size_t s = 0; s < re.st_c.size(); s++) {
+      st_c.push_back(re.st_c[s]);
+      st_last.push_back(re.st_last[s]);
+      st_num.push_back(re.st_num[s]);
+      for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol.push_back(base + (uint32_t)re.fol[j]);
+      fol_off.push_back((uint32_t)fol.size());
+      max_fanout = std::max<uint32_t>(max_fanout, (uint32_t)(re.fol_off[s + 1] - re.fol_off[s]));
+    }
+    for (int32_t f : re.firsts) first.push_back(base + (uint32_t)f);
+    first_off.push_back((uint32_t)first.size());
+    max_fanout = std::max<uint32_t>(max_fanout, (uint32_t)re.firsts.size());
+  }
+  if (per_regex_count) std::fill(per_regex_count, per_regex_count + k, 0u);
+  *n_out = 0;
+  if (!k) return FMX_OK;
+  // the queue is checked against maxBranching before a pop, then grows by at most one fan-out
+  const uint64_t heap_cap64 = (uint64_t)max_branching + max_fanout + 2;
+  if (heap_cap64 > (1u << 22)) { set_error("max_branching too large for the reference-order mode"); return FMX_ERR_ARG; }
+  const uint32_t heap_cap = (uint32_t)heap_cap64;
+  HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+  uint64_t want = (k + (kRThreads / kOctet) - 1) / (kRThreads / kOctet);
+  uint64_t gcap = (uint64_t)h->cu_count * 8;
+  // bound the heap arena (32 B x heap_cap per octet) to ~4 GiB
+  const uint64_t arena_octets = std::max<uint64_t>(32, (4ull << 30) / ((uint64_t)heap_cap * sizeof(HeapElem)));
+  gcap = std::min<uint64_t>(gcap, std::max<uint64_t>(1, arena_octets / (kRThreads / kOctet)));
+  const int grid = (int)std::min(want, gcap);
+  DevMem mem;
+  RefTables rt{};
+  uint8_t *d_c, *d_last; int32_t *d_num; uint32_t *d_foff, *d_fol, *d_fo, *d_f, *d_left = nullptr;
+  HIP_TRY(mem.upload(&d_c, st_c), "upload");
+  HIP_TRY(mem.upload(&d_last, st_last), "upload");
+  HIP_TRY(mem.upload(&d_num, st_num), "upload");
+  HIP_TRY(mem.upload(&d_foff, fol_off), "upload");
+  HIP_TRY(mem.upload(&d_fol, fol), "upload");
+  HIP_TRY(mem.upload(&d_fo, first_off), "upload");
+  HIP_TRY(mem.upload(&d_f, first), "upload");
+  rt = RefTables{d_c, d_last, d_num, d_foff, d_fol, d_fo, d_f};
+  HeapElem *d_heaps = nullptr;
+  RefResult *d_res = nullptr;
+  RefCtl *d_ctl = nullptr;
+  HIP_TRY(mem.alloc(&d_heaps, (size_t)grid * (kRThreads / kOctet) * heap_cap), "hipMalloc(heaps)");
+  HIP_TRY(mem.alloc(&d_res, cap ? cap : 1), "hipMalloc(results)");
+  HIP_TRY(mem.alloc(&d_ctl, 1), "hipMalloc(ctl)");
+  if (front_left) HIP_TRY(mem.alloc(&d_left, k), "hipMalloc(front_left)");
+  HIP_TRY(hipMemset(d_ctl, 0, sizeof(RefCtl)), "memset(ctl)");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0), "hipEventCreate");
+  HIP_TRY(hipEventCreate(&e1), "hipEventCreate");
+  struct EG { hipEvent_t a, b; ~EG() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
+  HIP_TRY(hipEventRecord(e0, nullptr), "hipEventRecord");
+  if (h->n > (1ull << 32))
+    k_match_ref<true><<<grid, kRThreads>>>(h->dev, rt, (uint32_t)k, d_heaps, heap_cap, max_branching, max_iterations,
+                                            d_res, (uint64_t)cap, d_left, d_ctl);
+  else
+    k_match_ref<false><<<grid, kRThreads>>>(h->dev, rt, (uint32_t)k, d_heaps, heap_cap, max_branching, max_iterations,
+                                             d_res, (uint64_t)cap, d_left, d_ctl);
+  HIP_TRY(hipGetLastError(), "k_match_ref");
+  HIP_TRY(hipEventRecord(e1, nullptr), "hipEventRecord");
+  RefCtl ctl{};
+  HIP_TRY(hipMemcpy(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost), "D2H(ctl)");
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->last_kernel_ms = ms;
+    h->launches += 1;
+  }
+  if (ctl.steps) {
+    unsigned long long cur_cnt[2];
+    HIP_TRY(hipMemcpy(cur_cnt, h->d_counters, sizeof cur_cnt, hipMemcpyDeviceToHost), "D2H(counters)");
+    cur_cnt[0] += 2ull * ctl.steps;
+    cur_cnt[1] += ctl.steps;
+    HIP_TRY(hipMemcpy(h->d_counters, cur_cnt, sizeof cur_cnt, hipMemcpyHostToDevice), "H2D(counters)");
+  }
+  if (ctl.overflow & 1ull) { set_error("reference-order heap overflow (internal bound)"); return FMX_ERR_OVERFLOW; }
+  *n_out = (size_t)ctl.res_count;
+  if (ctl.res_count > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
+  if (front_left) HIP_TRY(hipMemcpy(front_left, d_left, k * 4, hipMemcpyDeviceToHost), "D2H(front_left)");
+  if (ctl.res_count) {
+    std::vector<RefResult> tmp((size_t)ctl.res_count);
+    HIP_TRY(hipMemcpy(tmp.data(), d_res, tmp.size() * sizeof(RefResult), hipMemcpyDeviceToHost), "D2H(results)");
+    // per regex, newest first: the order of the reference's prepended list (:638)
+    std::sort(tmp.begin(), tmp.end(), [](const RefResult &a, const RefResult &b) {
+      if (a.regex != b.regex) return a.regex < b.regex;
+      return a.seq > b.seq;
+    });
+    for (size_t j = 0; j < tmp.size(); j++) {
+      out[j].regex = tmp[j].regex; out[j].len = tmp[j].len; out[j].sp = tmp[j].sp; out[j].ep = tmp[j].ep;
+      if (per_regex_count) per_regex_count[tmp[j].regex]++;
+    }
+  }
+  return FMX_OK;
+}
+
+}  // namespace fmx

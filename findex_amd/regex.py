@@ -104,12 +104,18 @@ class ReTree:
                 "follows": [fol[off[k]:off[k + 1]].tolist() for k in range(n)],
                 "firsts": firsts[: nfi.value].tolist()}
 
-    last_truncated = False      # True when the last matchSA* call stopped at max_steps (FMX_TRUNCATED)
+    last_truncated = False      # True when the last frontier call stopped at max_steps (FMX_TRUNCATED)
 
-    def matchSA(self, sa, max_steps=0, max_frontier=0, cap=1 << 20):
-        """ReTree.matchSA (retree.scala:570-617) -> list of SAResult, sorted by (len, sp, ep).
-        Equals the reference's result multiset whenever its limits do not bind."""
-        return ReTree.matchSA_batch(sa, [self], max_steps, max_frontier, cap)[0]
+    def matchSA(self, sa, debugLevel=0, maxBranching=1024, maxIterations=1000, cap=1 << 20):
+        """ReTree.matchSA (retree.scala:570-617) with the reference's own limits, pop order and
+        result order: list of SAResult, newest first, exactly `ret` of the first _matchSA pass."""
+        return ReTree.matchSA_batch(sa, [self], mode="reference", maxBranching=maxBranching,
+                                    maxIterations=maxIterations, cap=cap)[0]
+
+    def matchAll(self, sa, max_steps=0, max_frontier=0, cap=1 << 20):
+        """Every match (frontier mode): what matchSA returns when its limits do not bind, sorted by
+        (len, sp, ep)."""
+        return ReTree.matchSA_batch(sa, [self], max_steps=max_steps, max_frontier=max_frontier, cap=cap)[0]
 
     @staticmethod
     def prepare_batch(sa, trees):
@@ -117,11 +123,16 @@ class ReTree:
         return RegexBatch(sa, trees)
 
     @staticmethod
-    def matchSA_batch(sa, trees, max_steps=0, max_frontier=0, cap=1 << 20):
+    def matchSA_batch(sa, trees, max_steps=0, max_frontier=0, cap=1 << 20, mode="frontier", maxBranching=1024,
+                      maxIterations=1000):
+        """A batch of regexes in one call.  mode="frontier": breadth-first over the whole batch,
+        every match; mode="reference": ReTree._matchSA's queue replayed per regex with
+        maxBranching / maxIterations."""
         L = _lib.load()
         k = len(trees)
         arr = (ctypes.c_void_p * max(k, 1))(*[t._h for t in trees])
-        lim = _lib.fmx_limits(int(max_steps), int(max_frontier))
+        lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_REFERENCE if mode == "reference" else _lib.FMX_MATCH_FRONTIER,
+                              int(max_frontier), int(maxBranching), int(maxIterations))
         out = (_lib.fmx_result * cap)()
         n_out = ctypes.c_size_t()
         per = np.zeros(max(k, 1), dtype=np.uint32)
@@ -161,7 +172,7 @@ class RegexBatch:
 
     def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22):
         """-> (results as a structured array sorted by (regex, len, sp, ep), per-regex counts)"""
-        lim = _lib.fmx_limits(int(max_steps), int(max_frontier))
+        lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_FRONTIER, int(max_frontier), 0, 0)
         out = np.zeros(cap, dtype=RESULT_DTYPE)
         per = np.zeros(max(self.k, 1), dtype=np.uint32)
         n_out = ctypes.c_size_t()

@@ -143,6 +143,10 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_prev_substr(self._h, int(sp), int(length), _ptr(out)))
         return bytes(out[: int(length)])
 
+    def write_fm(self, path):
+        """FMCreator.create (bwtmerger.scala:452-532): write the reference's .fm file."""
+        _lib.check(self._L.fmx_write_fm(self._h, str(path).encode()))
+
     # ---- batched forms (host arrays in, host arrays out)
     def occ_batch(self, c, i):
         c = np.ascontiguousarray(c, dtype=np.uint8)

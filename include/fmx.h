@@ -136,6 +136,12 @@ int fmx_psi_batch(const fmx_index *idx, const uint64_t *rows, uint64_t *out, siz
 int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out, uint32_t *out_len);
 int fmx_prev_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out);
 
+/* ---- FMCreator.create, bwtmerger.scala:424-533: writes the reference's .fm file (inverted position
+ * lists, 4-byte big-endian entries) from the device structure, so that findex's own NaiveFMSearcher
+ * and tests can consume an index this engine prepared.  n must be < 0xffffffff (the reference has
+ * no 8-byte entry format, :465-469). */
+int fmx_write_fm(const fmx_index *idx, const char *path);
+
 /* ---- regex: REParser.re2post (re2/re2.scala:50-185) + ReTree.apply (re2/retree.scala:156-370).
  * Bytes of `re` are Latin-1 characters.  FMX_ERR_SYNTAX / FMX_ERR_MATCH mirror the reference's
  * "re2post syntax" exception and scala.MatchError. */
@@ -151,19 +157,30 @@ int fmx_regex_tables(const fmx_regex *re, uint32_t *n_states, uint8_t *st_c, int
 /* re2poststr, re2/re2.scala:187 (UTF-8). */
 int fmx_regex_post_string(const char *re, int line_only, char *out, size_t cap);
 
+enum {
+  FMX_MATCH_FRONTIER = 0,   /* breadth-first over the whole batch: every match, the throughput path */
+  FMX_MATCH_REFERENCE = 1   /* the reference's own pop order and limits, one regex per lane group */
+};
+
 typedef struct fmx_limits {
-  /* ReTree.matchSA defaults: maxBranching=1024, maxIterations=1000 (re2/retree.scala:570); with them
-   * no reference result is longer than 999.  The frontier kernel expands every regex's frontier
-   * breadth-first, so results equal the reference's whenever its limits do not bind; here:
+  /* mode = FMX_MATCH_FRONTIER.  The frontier kernel expands every regex's frontier breadth-first, so
+   * its results equal the reference's (as a multiset) whenever the reference's limits do not bind:
    * max_steps   = longest match explored (levels); 0 = default 4096.  When the frontier is still alive
    *               there, the call returns FMX_TRUNCATED with every match of length <= max_steps.  (On
    *               the BWT of a real text a frontier always dies -- no match is longer than the text --
    *               but on a synthetic "BWT" that is just a random string, LF has short cycles and x* can
    *               run forever.)
    * max_frontier= capacity of the device work queue in elements, 0 = default (1<<22); FMX_ERR_OVERFLOW
-   *               when exceeded. */
+   *               when exceeded.
+   * mode = FMX_MATCH_REFERENCE.  ReTree._matchSA exactly (re2/retree.scala:618-653): the priority queue
+   * of Scala 2.10 replayed per regex, loop while queue non-empty && queue.length < max_branching &&
+   * (max_iterations == 0 || i < max_iterations), i from 1.  Results come back per regex in the
+   * reference's list order (newest first).  ReTree.matchSA's defaults are 1024 / 1000 (:570). */
   uint32_t max_steps;
+  uint32_t mode;
   uint64_t max_frontier;
+  uint32_t max_branching;
+  uint32_t max_iterations;
 } fmx_limits;
 
 typedef struct fmx_result {   /* SAResult(sa,len,sp,ep), re2/re2.scala:9-19, + which regex */
@@ -175,9 +192,9 @@ typedef struct fmx_result {   /* SAResult(sa,len,sp,ep), re2/re2.scala:9-19, + w
 
 /* ReTree.matchSA over a batch of compiled regexes (re2/retree.scala:570-653): frontier items
  * (regex, CharNode, len, sp, ep) start at root.firsts x (0, 0, n); each is stepped with
- * getPrevRange; isLast states emit a result, the others push their follows.  Results are written
- * sorted by (regex, len, sp, ep) -- the reference's list order is its priority queue's discovery
- * order, which is not part of this contract.  per_regex_count (optional, k entries) = results per
+ * getPrevRange; isLast states emit a result, the others push their follows.  In frontier mode results
+ * are written sorted by (regex, len, sp, ep); in reference mode per regex in the reference's own
+ * list order.  per_regex_count (optional, k entries) = results per
  * regex.  FMX_ERR_OVERFLOW if out (cap entries) or the work queue was too small: *n_out then
  * holds the number of results found so far / needed.  FMX_TRUNCATED: see fmx_limits.max_steps. */
 int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,

@@ -148,6 +148,20 @@ def test_walks_all_rows(testdata, name, be):
         assert hip.prevSubstr(sp, ln) == orc.prevSubstr(sp, ln)
 
 
+@pytest.mark.parametrize("name,be", [("test1024.cmp", False), ("test3072.cmp", False), ("words", True)])
+def test_fm_file_is_byte_identical(testdata, name, be, tmp_path):
+    """T/Indexer.scala:841-900 BWTCreatorTest through the product: the .fm written from the device
+    structure equals FMCreator's (oracle restatement) byte for byte: header 0x04 + int64 BE size,
+    then 4-byte BE entries == bwt2occ(bwt with eof := 0)."""
+    hip, orc = pair_from_files(testdata, name, be)
+    a, b = str(tmp_path / "hip.fm"), str(tmp_path / "orc.fm")
+    hip.write_fm(a)
+    orc.write_fm(b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    raw = np.fromfile(a, dtype=np.uint8)
+    assert raw[0] == 4 and raw.size == 9 + 4 * hip.n
+
+
 # ---------------------------------------------------------------- synthetic indexes
 @pytest.mark.parametrize("n,lo,hi,seed", [
     (1, 1, 1, 1), (2, 1, 2, 2), (959, 1, 4, 3), (960, 1, 4, 4), (961, 1, 4, 5), (1920, 1, 4, 6), (1921, 65, 68, 7),
@@ -237,7 +251,7 @@ def test_regex_frontier_parity(testdata, name, be):
         assert [r.key() for r in g] == want, re
     assert hip.stats()["backward_steps"] == total_pops
     # single-regex entry point and SAResult rendering (re2.scala:9-19)
-    one = trees[1].matchSA(hip, max_steps=1 << 20)
+    one = trees[1].matchAll(hip, max_steps=1 << 20)
     assert [r.key() for r in one] == oracle_results(orc, REGEXES[1])[0]
     for r in one[:5]:
         sub = orc.nextSubstr(r.sp, r.len).decode("latin-1")
@@ -247,7 +261,9 @@ def test_regex_frontier_parity(testdata, name, be):
 def test_regex_reference_vectors():
     """T/REParser.scala:591-605: '.*(a|b)ca' over reversed 'mmabcacamabbbca' -> 2 results."""
     hip, orc = pair_from_mem(*bwt_of_text(b"mmabcacamabbbca"[::-1]))
-    got = findex_amd.ReTree(findex_amd.REParser.re2post(".*(a|b)ca")).matchSA(hip)
+    ref = findex_amd.ReTree(findex_amd.REParser.re2post(".*(a|b)ca")).matchSA(hip, debugLevel=0)
+    assert len(ref) == 2        # ret.length == 2, T/REParser.scala:602-603
+    got = findex_amd.ReTree(findex_amd.REParser.re2post(".*(a|b)ca")).matchAll(hip)
     assert len(got) == 2
     assert [r.key() for r in got] == oracle_results(orc, ".*(a|b)ca")[0]
 
@@ -258,10 +274,32 @@ def test_regex_duplicate_follows_give_duplicate_results():
     hip, orc = pair_from_mem(*bwt_of_text(b"xxabxxabyab"[::-1]))
     for re in ("x(a|a)", "(a*b*)*c", "a(b|b|b)", "b(a*b*)*x"):
         want, _ = oracle_results(orc, re)
-        got = findex_amd.ReTree(findex_amd.REParser.re2post(re)).matchSA(hip)
+        got = findex_amd.ReTree(findex_amd.REParser.re2post(re)).matchAll(hip)
         assert [r.key() for r in got] == want, re
-    keys = [r.key() for r in findex_amd.ReTree(findex_amd.REParser.re2post("x(a|a)")).matchSA(hip)]
+    keys = [r.key() for r in findex_amd.ReTree(findex_amd.REParser.re2post("x(a|a)")).matchAll(hip)]
     assert keys and all(keys.count(k) == 2 for k in keys)
+
+
+REF_REGEXES = ["th(e|a)", "q[a-z]*k", "co(m|n)+e", "a.*(b|c)d.*f", "s[aeiou]+t", "a[b-d]*e", "e.*", "(a|b|d|c)", "ab?j",
+               "in.*g", "z(a|e)*b", "x?yz"]
+
+
+@pytest.mark.parametrize("name,be", [("test.cmp", False), ("words", True)])
+def test_regex_reference_order_and_limits(testdata, name, be):
+    """ReTree.matchSA as the reference runs it: default limits 1024 / 1000 (which bind for '.*'
+    regexes) and tighter ones; results must equal the oracle's replay of _matchSA -- same
+    elements, same (newest-first) order."""
+    hip, orc = pair_from_files(testdata, name, be)
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re, lineOnly=True)) for re in REF_REGEXES]
+    for mb, mi in ((1024, 1000), (16, 50), (4, 0), (1 << 14, 3000), (1024, 2)):
+        got = findex_amd.ReTree.matchSA_batch(hip, trees, mode="reference", maxBranching=mb, maxIterations=mi)
+        for re, g in zip(REF_REGEXES, got):
+            want, left, pops = orc.match_tables(R.ReTree(R.re2post(re, True)).tables(), mb, mi)
+            assert [r.key() for r in g] == want, (re, mb, mi)
+    # the Scala-signature entry point
+    one = trees[3].matchSA(hip)
+    want, _, _ = orc.match_tables(R.ReTree(R.re2post(REF_REGEXES[3], True)).tables(), 1024, 1000)
+    assert [r.key() for r in one] == want
 
 
 def oracle_results_capped(bwt, eof, counts, re, max_len):
@@ -289,10 +327,10 @@ def test_regex_overflow_is_reported():
     hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
     t = findex_amd.ReTree(findex_amd.REParser.re2post("a[a-d]*b"))
     with pytest.raises(findex_amd.FmxError) as e:
-        t.matchSA(hip, max_frontier=64)
+        t.matchAll(hip, max_frontier=64)
     assert e.value.code == 9
     # a level cap is not an error: every match of length <= 3 comes back and the call says so
-    part = t.matchSA(hip, max_steps=3, max_frontier=1 << 22)
+    part = t.matchAll(hip, max_steps=3, max_frontier=1 << 22)
     assert findex_amd.ReTree.last_truncated and part and all(r.len <= 3 for r in part)
     assert {r.key() for r in part} == {k for k in oracle_results_capped(bwt, eof, counts, "a[a-d]*b", 3)}
 

@@ -17,4 +17,12 @@ from ._lib import FmxError, MatchError, Re2PostSyntax, LIB_PATH, load  # noqa: F
 from .searcher import HipFMSearcher  # noqa: F401
 from .regex import REParser, ReTree, SAResult  # noqa: F401
 
-__all__ = ["HipFMSearcher", "REParser", "ReTree", "SAResult", "FmxError", "MatchError", "Re2PostSyntax"]
+
+
+def set_layout(name):
+    """fmx_config_set("layout", ...): "auto" | "onehot" | "bytes" for indexes opened afterwards."""
+    from . import _lib
+    _lib.check(_lib.load().fmx_config_set(b"layout", name.encode()))
+
+
+__all__ = ["set_layout", "HipFMSearcher", "REParser", "ReTree", "SAResult", "FmxError", "MatchError", "Re2PostSyntax"]

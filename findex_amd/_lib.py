@@ -44,7 +44,8 @@ class fmx_stats_t(ctypes.Structure):
     _fields_ = [("rank_queries", ctypes.c_uint64), ("backward_steps", ctypes.c_uint64),
                 ("launches", ctypes.c_uint64), ("last_kernel_ms", ctypes.c_double),
                 ("index_bytes", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("n_symbols", ctypes.c_uint32),
-                ("block_bytes", ctypes.c_uint32), ("build_ms", ctypes.c_double)]
+                ("block_bytes", ctypes.c_uint32), ("build_ms", ctypes.c_double), ("layout", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/fmx.h declares
@@ -54,6 +55,7 @@ _P = ctypes.POINTER
 SYMBOLS = {
     "fmx_last_error": (_cp, []),
     "fmx_abi_version": (_i32, []),
+    "fmx_config_set": (_i32, [_cp, _cp]),
     "fmx_device_count": (_i32, [_P(_i32)]),
     "fmx_open": (_i32, [_cp, _cp, _i32, _i32, _P(_vp)]),
     "fmx_open_mem": (_i32, [_vp, _u64, _u64, _vp, _i32, _P(_vp)]),

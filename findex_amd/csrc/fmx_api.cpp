@@ -23,6 +23,9 @@ int hip_fail(hipError_t e, const char *what) {
   return FMX_ERR_HIP;
 }
 
+static int g_layout_pref = -1;
+int layout_preference() { return g_layout_pref; }
+
 static int arg_fail(const char *msg) {
   g_err = msg;
   return FMX_ERR_ARG;
@@ -102,6 +105,8 @@ static void destroy(Index *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->d_bv) (void)hipFree(h->d_bv);
+  if (h->d_chk) (void)hipFree(h->d_chk);
+  if (h->d_sup) (void)hipFree(h->d_sup);
   if (h->d_bwt) (void)hipFree(h->d_bwt);
   if (h->d_cf) (void)hipFree(h->d_cf);
   if (h->d_slot) (void)hipFree(h->d_slot);
@@ -138,10 +143,22 @@ static int open_common(const void *src, bool src_on_device, uint64_t n, uint64_t
       if ((e = hipStreamCreate(&own.s)) != hipSuccess) { rc = hip_fail(e, "hipStreamCreate"); break; }
       st = own.s;
     }
-    if ((e = hipMalloc(&h->d_bwt, n)) != hipSuccess) { rc = hip_fail(e, "hipMalloc(bwt)"); break; }
+    // device copy of the BWT: zero-padded to whole 128-position blocks, slot eof set to 0 (BWT' has the
+    // EOF symbol there; the stored byte is a filler, bwtmerger.scala:799-806)
+    const uint64_t padded = (n / kByteBlock + 2) * kByteBlock;
+    if ((e = hipMalloc(&h->d_bwt, padded)) != hipSuccess) { rc = hip_fail(e, "hipMalloc(bwt)"); break; }
+    if ((e = hipMemsetAsync((uint8_t *)h->d_bwt + n, 0, padded - n, st)) != hipSuccess) { rc = hip_fail(e, "memset"); break; }
     e = hipMemcpyAsync(h->d_bwt, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { rc = hip_fail(e, "copy bwt"); break; }
+    if ((e = hipMemsetAsync((uint8_t *)h->d_bwt + eof, 0, 1, st)) != hipSuccess) { rc = hip_fail(e, "memset"); break; }
+    const int pref = layout_preference();
+    h->layout = pref == (int)kLayoutBytes ? kLayoutBytes : kLayoutOneHot;
     rc = build_index(h, st, counts);
+    if (rc == -1) {                      // one-hot vectors do not fit: fall back unless one-hot was forced
+      if (pref == (int)kLayoutOneHot) { rc = FMX_ERR_NOMEM; break; }
+      h->layout = kLayoutBytes;
+      rc = build_index(h, st, counts);
+    }
   } while (0);
   if (rc != FMX_OK) { destroy(h); return rc; }
   *out = reinterpret_cast<fmx_index *>(h);
@@ -179,6 +196,18 @@ extern "C" {
 
 const char *fmx_last_error(void) { return g_err.c_str(); }
 int fmx_abi_version(void) { return FMX_ABI_VERSION; }
+
+int fmx_config_set(const char *key, const char *value) {
+  if (!key || !value) return arg_fail("null argument");
+  if (std::strcmp(key, "layout") == 0) {
+    if (std::strcmp(value, "auto") == 0) g_layout_pref = -1;
+    else if (std::strcmp(value, "onehot") == 0) g_layout_pref = (int)kLayoutOneHot;
+    else if (std::strcmp(value, "bytes") == 0) g_layout_pref = (int)kLayoutBytes;
+    else return arg_fail("layout must be auto, onehot or bytes");
+    return FMX_OK;
+  }
+  return arg_fail("unknown configuration key");
+}
 
 int fmx_device_count(int *count) {
   if (!count) return arg_fail("count is null");
@@ -515,7 +544,8 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->index_bytes = h->index_bytes;
   out->n_blocks = h->nblocks;
   out->n_symbols = h->nslots;
-  out->block_bytes = kBlockBytes;
+  out->block_bytes = h->layout == kLayoutBytes ? kByteBlock + 4 : kBlockBytes;
+  out->layout = h->layout;
   out->build_ms = h->build_ms;
   return FMX_OK;
 }

@@ -99,6 +99,55 @@ __global__ __launch_bounds__(kBuildThreads) void k_fill(const uint8_t *__restric
   }
 }
 
+// ---- bytes layout (fmx_device.h): per-superblock histogram = k_hist with the superblock as the
+// chunk; then one workgroup per superblock walks its 2^15 blocks, writing each block's checkpoint row
+// (counts since the superblock start) before adding the block's own bytes.
+__global__ __launch_bounds__(kBuildThreads) void k_hist_bytes(const uint8_t *__restrict__ bwt, uint64_t n,
+                                                               uint64_t *__restrict__ hist /* [nsb][256] */) {
+  __shared__ uint32_t h[4][256];
+  const int wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * 256; i += blockDim.x) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const uint64_t lo = ((uint64_t)blockIdx.x << kSuperShift) * kByteBlock;
+  uint64_t hi = lo + ((uint64_t)kByteBlock << kSuperShift);
+  if (hi > n) hi = n;
+  for (uint64_t p = lo + threadIdx.x; p < hi; p += blockDim.x) atomicAdd(&h[wave][bwt[p]], 1u);   // slot eof holds 0
+  __syncthreads();
+  for (int c = threadIdx.x; c < 256; c += blockDim.x)
+    hist[(uint64_t)blockIdx.x * 256 + c] = (uint64_t)h[0][c] + h[1][c] + h[2][c] + h[3][c];
+}
+
+__global__ __launch_bounds__(kBuildThreads) void k_fill_bytes(const uint8_t *__restrict__ bwt, uint64_t nbb,
+                                                               uint32_t nslots, const uint16_t *__restrict__ slot_of,
+                                                               const uint16_t *__restrict__ sym_of,
+                                                               const uint64_t *__restrict__ base /* [nsb][256] */,
+                                                               uint32_t *__restrict__ chk, uint64_t *__restrict__ sup) {
+  __shared__ uint32_t run[256];       // per slot: count since the superblock start
+  __shared__ uint16_t s_slot[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_slot[c] = slot_of[c]; run[c] = 0; }
+  for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x)
+    sup[(uint64_t)blockIdx.x * nslots + s] = base[(uint64_t)blockIdx.x * 256 + sym_of[s]];
+  __syncthreads();
+  const uint64_t b0 = (uint64_t)blockIdx.x << kSuperShift;
+  uint64_t b1 = b0 + (1ull << kSuperShift);
+  if (b1 > nbb) b1 = nbb;
+  // two blocks per trip: threads 0..127 take block b, 128..255 block b+1 (bwt is zero-padded)
+  for (uint64_t b = b0; b < b1; b += 2) {
+    for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x) chk[b * nslots + s] = run[s];
+    __syncthreads();
+    const uint32_t half = threadIdx.x >> 7;
+    uint16_t sl = kSlotNone;
+    if (b + half < b1) sl = s_slot[bwt[(b + half) * kByteBlock + (threadIdx.x & 127)]];
+    if (half == 0 && sl < kSlotEof) atomicAdd(&run[sl], 1u);
+    __syncthreads();
+    if (b + 1 < b1)
+      for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x) chk[(b + 1) * nslots + s] = run[s];
+    __syncthreads();
+    if (half == 1 && sl < kSlotEof) atomicAdd(&run[sl], 1u);
+    __syncthreads();
+  }
+}
+
 // Builds the whole device side of an index from h->d_bwt / h->n / h->eof:
 //   1. symbol histogram on the device (authoritative; EOF slot excluded),
 //   2. validation against the caller's .aux counts when given,
@@ -107,7 +156,11 @@ __global__ __launch_bounds__(kBuildThreads) void k_fill(const uint8_t *__restric
 //   4. the fill pass.
 // Returns an FMX_* status.
 int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
-  const uint64_t nsuper = (h->nblocks + kSuper - 1) / kSuper;
+  // Layout: one-hot vectors when they fit comfortably (decided from n and a sigma upper bound before
+  // the histogram, re-checked after), the bytes+checkpoints layout otherwise or when forced.
+  bool bytes_layout = h->layout == kLayoutBytes;
+  if (bytes_layout) h->nblocks = h->n / kByteBlock + 1;
+  const uint64_t nsuper = bytes_layout ? ((h->nblocks >> kSuperShift) + 1) : (h->nblocks + kSuper - 1) / kSuper;
   uint64_t *d_hist = nullptr, *d_tot = nullptr;
   uint16_t *d_sym = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -127,13 +180,15 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
     FMX_TRY(hipMalloc(&d_tot, 256 * sizeof(uint64_t)), "hipMalloc(totals)");
     FMX_TRY(hipMalloc(&d_sym, 256 * sizeof(uint16_t)), "hipMalloc(sym)");
     FMX_TRY(hipEventRecord(ev0, st), "hipEventRecord");
-    k_hist<<<(int)nsuper, kBuildThreads, 0, st>>>((const uint8_t *)h->d_bwt, h->n, h->eof, d_hist);
+    if (bytes_layout) k_hist_bytes<<<(int)nsuper, kBuildThreads, 0, st>>>((const uint8_t *)h->d_bwt, h->n, d_hist);
+    else k_hist<<<(int)nsuper, kBuildThreads, 0, st>>>((const uint8_t *)h->d_bwt, h->n, h->eof, d_hist);
     FMX_TRY(hipGetLastError(), "k_hist");
     k_scan<<<1, 256, 0, st>>>(d_hist, nsuper, d_tot);
     FMX_TRY(hipGetLastError(), "k_scan");
     FMX_TRY(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st), "copy totals");
     FMX_TRY(hipStreamSynchronize(st), "sync(hist)");
 
+    if (bytes_layout) tot[0] -= 1;          // the EOF slot itself holds the one 0 byte of BWT'
     if (tot[0] != 0) {
       set_error("BWT holds byte 0 outside the EOF slot: findex escapes 0 on input (bwtreader.scala:136-155) and its "
                 "FMCreator gives symbol 0 exactly one slot (bwtmerger.scala:440-450)");
@@ -161,16 +216,22 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
       if (tot[c]) { sym_of[h->nslots] = (uint16_t)c; h->slot[c] = (uint16_t)h->nslots++; }
       else h->slot[c] = kSlotNone;
     }
-    const uint64_t bv_bytes = (uint64_t)h->nslots * h->nblocks * kBlockBytes;
+    const uint64_t bv_bytes = bytes_layout ? (uint64_t)h->nslots * (h->nblocks * 4 + nsuper * 8)
+                                           : (uint64_t)h->nslots * h->nblocks * kBlockBytes;
     size_t free_b = 0, total_b = 0;
     FMX_TRY(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
     if (bv_bytes + (64ull << 20) > free_b) {
       set_error("rank dictionary needs " + std::to_string(bv_bytes >> 20) + " MiB of device memory, " +
                 std::to_string(free_b >> 20) + " MiB free");
-      rc = 4 /* FMX_ERR_NOMEM */;
+      rc = bytes_layout ? 4 /* FMX_ERR_NOMEM */ : -1 /* retry with the bytes layout */;
       break;
     }
-    FMX_TRY(hipMalloc(&h->d_bv, bv_bytes ? bv_bytes : 16), "hipMalloc(rank dictionary)");
+    if (bytes_layout) {
+      FMX_TRY(hipMalloc(&h->d_chk, (uint64_t)h->nslots * h->nblocks * 4 + 16), "hipMalloc(checkpoints)");
+      FMX_TRY(hipMalloc(&h->d_sup, (uint64_t)h->nslots * nsuper * 8 + 16), "hipMalloc(superblocks)");
+    } else {
+      FMX_TRY(hipMalloc(&h->d_bv, bv_bytes ? bv_bytes : 16), "hipMalloc(rank dictionary)");
+    }
     FMX_TRY(hipMalloc(&h->d_cf, sizeof h->cf), "hipMalloc(cf)");
     FMX_TRY(hipMalloc(&h->d_slot, sizeof h->slot), "hipMalloc(slot)");
     FMX_TRY(hipMalloc((void **)&h->d_counters, 4 * sizeof(unsigned long long)), "hipMalloc(counters)");
@@ -178,7 +239,14 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
     FMX_TRY(hipMemcpyAsync(h->d_cf, h->cf, sizeof h->cf, hipMemcpyHostToDevice, st), "copy cf");
     FMX_TRY(hipMemcpyAsync(h->d_slot, h->slot, sizeof h->slot, hipMemcpyHostToDevice, st), "copy slot");
     FMX_TRY(hipMemcpyAsync(d_sym, sym_of, sizeof sym_of, hipMemcpyHostToDevice, st), "copy sym");
-    if (h->nslots) {
+    if (bytes_layout) {
+      if (h->nslots) {
+        k_fill_bytes<<<(int)nsuper, kBuildThreads, 0, st>>>((const uint8_t *)h->d_bwt, h->nblocks, h->nslots,
+                                                           (const uint16_t *)h->d_slot, d_sym, d_hist,
+                                                           (uint32_t *)h->d_chk, (uint64_t *)h->d_sup);
+        FMX_TRY(hipGetLastError(), "k_fill_bytes");
+      }
+    } else if (h->nslots) {
       size_t lds = (size_t)((h->nslots * kWordsPerBlock + 1) & ~1u) * 4 + (size_t)h->nslots * 8 + 256 * 2;
       k_fill<<<(int)nsuper, kBuildThreads, lds, st>>>((const uint8_t *)h->d_bwt, h->n, h->eof, h->nblocks, h->nslots,
                                                        (const uint16_t *)h->d_slot, d_sym, d_hist,
@@ -192,6 +260,10 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
     h->build_ms = ms;
     h->index_bytes = bv_bytes + h->n + sizeof h->cf + sizeof h->slot;
     h->dev.bv = (const uint4 *)h->d_bv;
+    h->dev.chk = (const uint32_t *)h->d_chk;
+    h->dev.sup = (const uint64_t *)h->d_sup;
+    h->dev.layout = h->layout;
+    h->dev.nslots = h->nslots;
     h->dev.bwt = (const uint8_t *)h->d_bwt;
     h->dev.cf = (const uint64_t *)h->d_cf;
     h->dev.slot = (const uint16_t *)h->d_slot;

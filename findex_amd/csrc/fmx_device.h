@@ -32,14 +32,31 @@ constexpr uint32_t kOctet = 8;           // lanes per query
 constexpr uint16_t kSlotNone = 0xFFFF;   // symbol absent from the BWT: rank is 0
 constexpr uint16_t kSlotEof = 0xFFFE;    // symbol 0: rank0(x) = (x > eof)
 
+// Second layout, for indexes whose one-hot vectors (sigma * n / 8 bytes) do not fit in HBM
+// (BASELINE config C5: n = 2^34, sigma = 128 -> 289 GB): the BWT bytes themselves in 128-byte
+// blocks (slot eof holds 0, which no real symbol has) + per-block checkpoints
+//     chk[blk][slot]  uint32  occurrences of the symbol in its superblock before this block
+//     sup[sb][slot]   uint64  occurrences before superblock sb (2^15 blocks = 2^22 positions)
+// rank = sup + chk + #{bytes of the block below the boundary that equal c}: two HBM lines per rank
+// query (the block and the checkpoint; sup stays cache-resident), 132 B algorithmic as SURVEY 8d.
+constexpr uint32_t kLayoutOneHot = 0;
+constexpr uint32_t kLayoutBytes = 1;
+constexpr uint32_t kByteBlock = 128;     // BWT positions per byte-layout block
+constexpr uint32_t kSuperShift = 15;     // blocks per superblock = 2^15
+
 struct DevIndex {
-  const uint4 *bv;        // rank dictionary
-  const uint8_t *bwt;     // raw BWT bytes (slot eof holds a filler)
+  const uint4 *bv;        // one-hot layout: rank dictionary
+  const uint8_t *bwt;     // BWT bytes (one-hot: raw, slot eof holds a filler; bytes: slot eof holds 0,
+                          // zero-padded to whole blocks)
   const uint64_t *cf;     // [256] C[] = first row of each symbol, NaiveFMSearcher.cf
-  const uint16_t *slot;   // [256] symbol -> bit-vector slot | kSlotNone | kSlotEof
+  const uint16_t *slot;   // [256] symbol -> slot | kSlotNone | kSlotEof
   uint64_t n;
   uint64_t eof;
-  uint64_t nblocks;
+  uint64_t nblocks;       // one-hot: blocks per vector; bytes: number of 128-position blocks
+  const uint32_t *chk;    // bytes layout
+  const uint64_t *sup;    // bytes layout
+  uint32_t layout;
+  uint32_t nslots;
 };
 
 // ---- DPP helpers: reductions inside an octet stay in the VALU (no LDS crossbar).
@@ -126,15 +143,85 @@ __device__ __forceinline__ uint64_t block_addr(const DevIndex &ix, uint32_t s, u
   return (uint64_t)(uintptr_t)ix.bv + ((uint64_t)s * ix.nblocks + blk) * kBlockBytes + lc.t * 16u;
 }
 
-// rank_excl(c, x) = #{p < x : BWT'[p] == c}, 0 <= x <= n, evaluated by the whole octet.
-// occ(c, i) of the reference is rank_excl(c, i + 1).
+// ---- bytes layout: occurrences of byte c among the first `nbytes` (0..16, may exceed) of this
+// lane's 16 block bytes.  Per dword: exact SWAR zero-byte detect on w ^ cccc, keep the wanted bytes.
+__device__ __forceinline__ uint32_t match_count16(uint4 w, uint32_t c, uint32_t nbytes, uint32_t acc) {
+  const uint32_t pat = c * 0x01010101u;
+  const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t z = ww[j] ^ pat;
+    const uint32_t eq = ~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z | 0x7F7F7F7Fu);   // 0x80 per equal byte
+    const uint32_t kb = __builtin_elementwise_sub_sat(nbytes, 4u * j);            // bytes wanted of this dword
+    uint32_t m = __builtin_amdgcn_ubfe(eq, 0u, 8u * kb);
+    m = kb > 3u ? eq : m;
+    acc = bcnt_acc(m, acc);
+  }
+  return acc;
+}
+
+struct ByteRankReq {      // the two lines of a bytes-layout rank query, requested before use
+  uint4 w;
+  uint32_t chk;
+  uint64_t sup;
+  uint32_t rem;
+};
+
+__device__ __forceinline__ ByteRankReq byte_rank_issue(const DevIndex &ix, uint16_t slot, uint64_t x, const LaneConst &lc) {
+  ByteRankReq q;
+  const uint64_t blk = x >> 7;
+  q.rem = (uint32_t)x & 127u;
+  q.w = load_line16((uint64_t)(uintptr_t)ix.bwt + blk * kByteBlock + lc.t * 16u);
+  q.chk = lc.t == 0 ? ix.chk[blk * ix.nslots + slot] : 0u;
+  q.sup = ix.sup[(blk >> kSuperShift) * ix.nslots + slot];
+  return q;
+}
+
+__device__ __forceinline__ uint64_t byte_rank_finish(const ByteRankReq &q, uint32_t c, const LaneConst &lc) {
+  const uint32_t nbytes = __builtin_elementwise_sub_sat(q.rem, 16u * lc.t);
+  return q.sup + octet_sum(match_count16(q.w, c, nbytes, q.chk));
+}
+
+// rank_excl(c, x) = #{p < x : BWT'[p] == c}, 0 <= x <= n, evaluated by the whole octet, for
+// either layout.  occ(c, i) of the reference is rank_excl(c, i + 1).
 template <bool WIDE>
-__device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint16_t slot, uint64_t x, const LaneConst &lc) {
+__device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t x,
+                                              const LaneConst &lc) {
   if (slot == kSlotNone) return 0;
   if (slot == kSlotEof) return x > ix.eof ? 1 : 0;
+  if (ix.layout == kLayoutBytes) return byte_rank_finish(byte_rank_issue(ix, slot, x, lc), c, lc);
   uint32_t blk, rem;
   split960(x, blk, rem);
   return rank_finish<WIDE>(load_line16(block_addr(ix, slot, blk, lc)), rem, lc);
+}
+
+// One backward step for the whole octet: (sp, ep) -> (C[c]+rank(c,sp), C[c]+rank(c,ep)), the body
+// of SuffixAlgo.getPrevRange (findex.scala:32-36).  All lines are requested before any is consumed.
+template <bool WIDE>
+__device__ __forceinline__ void backward_step(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t cfc,
+                                              const LaneConst &lc, uint64_t &sp, uint64_t &ep) {
+  uint64_t r1 = 0, r2 = 0;
+  if (slot < kSlotEof) {
+    if (ix.layout == kLayoutBytes) {
+      const ByteRankReq q1 = byte_rank_issue(ix, slot, sp, lc);
+      const ByteRankReq q2 = byte_rank_issue(ix, slot, ep, lc);
+      r1 = byte_rank_finish(q1, c, lc);
+      r2 = byte_rank_finish(q2, c, lc);
+    } else {
+      uint32_t b1, b2, m1, m2;
+      split960(sp, b1, m1);
+      split960(ep, b2, m2);
+      const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
+      const uint4 w2 = load_line16(block_addr(ix, slot, b2, lc));
+      r1 = rank_finish<WIDE>(w1, m1, lc);
+      r2 = rank_finish<WIDE>(w2, m2, lc);
+    }
+  } else if (slot == kSlotEof) {
+    r1 = sp > ix.eof ? 1 : 0;
+    r2 = ep > ix.eof ? 1 : 0;
+  }
+  sp = cfc + r1;
+  ep = cfc + r2;
 }
 
 }  // namespace fmx

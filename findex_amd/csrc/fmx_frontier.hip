@@ -102,21 +102,7 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
       const uint32_t c = nfa.st_c[s];
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
-      uint64_t r1 = 0, r2 = 0;
-      if (slot < kSlotEof) {
-        uint32_t b1, b2, m1, m2;
-        split960(sp, b1, m1);
-        split960(ep, b2, m2);
-        const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
-        const uint4 w2 = load_line16(block_addr(ix, slot, b2, lc));
-        r1 = rank_finish<WIDE>(w1, m1, lc);
-        r2 = rank_finish<WIDE>(w2, m2, lc);
-      } else if (slot == kSlotEof) {
-        r1 = sp > ix.eof ? 1 : 0;
-        r2 = ep > ix.eof ? 1 : 0;
-      }
-      sp = cfc + r1;
-      ep = cfc + r2;
+      backward_step<WIDE>(ix, c, slot, cfc, lc, sp, ep);
       stepped++;
       if (sp < ep) {                                   // Some((sp1,ep1)), retree.scala:634
         if (nfa.st_last[s]) emit = true;               // :636-638

@@ -19,7 +19,10 @@ struct Index {
   uint64_t cf[256] = {0};
   uint16_t slot[256] = {0};
   // device memory owned by the handle
+  uint32_t layout = 0;          // kLayoutOneHot | kLayoutBytes
   void *d_bv = nullptr;
+  void *d_chk = nullptr;        // bytes layout: checkpoints
+  void *d_sup = nullptr;        // bytes layout: superblock counts
   void *d_bwt = nullptr;
   void *d_cf = nullptr;
   void *d_slot = nullptr;
@@ -34,6 +37,7 @@ struct Index {
 };
 
 void set_error(const std::string &msg);
+int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP
 
 // fmx_build.hip

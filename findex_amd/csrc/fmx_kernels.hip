@@ -25,28 +25,10 @@ __device__ __forceinline__ void stage_tables(const DevIndex &ix, Tables &tb) {
   __syncthreads();
 }
 
-// One backward step for the whole octet: (sp, ep) -> (cf(c)+rank(c,sp), cf(c)+rank(c,ep)).
-// Both lines are requested before either is consumed.
 template <bool WIDE>
 __device__ __forceinline__ void step(const DevIndex &ix, const Tables &tb, uint32_t c, const LaneConst &lc,
                                      uint64_t &sp, uint64_t &ep) {
-  const uint16_t slot = tb.slot[c];
-  const uint64_t cfc = tb.cf[c];
-  uint64_t r1 = 0, r2 = 0;
-  if (slot < kSlotEof) {
-    uint32_t b1, b2, m1, m2;
-    split960(sp, b1, m1);
-    split960(ep, b2, m2);
-    const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
-    const uint4 w2 = load_line16(block_addr(ix, slot, b2, lc));
-    r1 = rank_finish<WIDE>(w1, m1, lc);
-    r2 = rank_finish<WIDE>(w2, m2, lc);
-  } else if (slot == kSlotEof) {
-    r1 = sp > ix.eof ? 1 : 0;
-    r2 = ep > ix.eof ? 1 : 0;
-  }
-  sp = cfc + r1;
-  ep = cfc + r2;
+  backward_step<WIDE>(ix, c, tb.slot[c], tb.cf[c], lc, sp, ep);
 }
 
 // ---------------------------------------------------------------- K2: occ_batch
@@ -64,7 +46,8 @@ __global__ __launch_bounds__(kThreads) void k_occ(DevIndex ix, const uint8_t *__
   for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
     int64_t key = i[q];
     uint64_t x = key < 0 ? 0 : ((uint64_t)key >= ix.n ? ix.n : (uint64_t)key + 1);
-    uint64_t r = rank_excl<WIDE>(ix, tb.slot[c[q]], x, lc);
+    const uint32_t cq = c[q];
+    uint64_t r = rank_excl<WIDE>(ix, cq, tb.slot[cq], x, lc);
     if (t == 0) out[q] = r;
     done++;
   }
@@ -165,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_
     for (uint32_t s = 0; s < len; s++) {
       const uint32_t b = r == ix.eof ? 0u : ix.bwt[r];
       if (out_bytes && t == 0) out_bytes[q * len + s] = (uint8_t)b;
-      r = tb.cf[b] + rank_excl<WIDE>(ix, tb.slot[b], r, lc);
+      r = tb.cf[b] + rank_excl<WIDE>(ix, b, tb.slot[b], r, lc);
     }
     if (end_rows && t == 0) end_rows[q] = r;
     done += len;
@@ -185,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void k_fm_fill(DevIndex ix, uint64_t p0, 
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
   for (uint64_t p = p0 + (((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3); p < p1; p += noct) {
     const uint32_t b = p == ix.eof ? 0u : ix.bwt[p];
-    const uint64_t r = tb.cf[b] + rank_excl<WIDE>(ix, tb.slot[b], p, lc);
+    const uint64_t r = tb.cf[b] + rank_excl<WIDE>(ix, b, tb.slot[b], p, lc);
     if (lc.t == 0) fm[r] = __builtin_bswap32((uint32_t)p);
   }
 }
@@ -207,6 +190,21 @@ __device__ uint64_t psi_one(const DevIndex &ix, const uint64_t *cf, const uint16
   const uint16_t s = slot[c];
   if (s >= kSlotEof) return ix.n;              // unreachable for row < n
   const uint64_t j = row - cf[c];              // 0-based occurrence wanted
+  if (ix.layout == kLayoutBytes) {
+    auto before = [&](uint64_t blk) { return ix.sup[(blk >> kSuperShift) * ix.nslots + s] + ix.chk[blk * ix.nslots + s]; };
+    uint64_t a = 0, b = ix.nblocks - 1;        // last block with count-before <= j
+    while (a < b) {
+      uint64_t mid = (a + b + 1) >> 1;
+      if (before(mid) <= j) a = mid; else b = mid - 1;
+    }
+    uint64_t need = j - before(a);
+    for (uint32_t q = 0; q < kByteBlock; q++)
+      if (ix.bwt[a * kByteBlock + q] == (uint8_t)c) {
+        if (need == 0) return a * kByteBlock + q;
+        need--;
+      }
+    return ix.n;                               // unreachable for row < n
+  }
   const uint64_t *hdr = reinterpret_cast<const uint64_t *>(ix.bv + (uint64_t)s * ix.nblocks * (kBlockBytes / 16));
   uint64_t a = 0, b = ix.nblocks - 1;          // last block with header <= j
   while (a < b) {

@@ -198,7 +198,8 @@ hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, v
                          hipStream_t st) {
   if (!k) return hipSuccess;
   const int variant = search_variant();
-  if (variant == 1 || k > 0xFFFFFFF0ull) return launch_search_v1(h, d_pat, d_off, d_sp, d_ep, k, st);
+  // the tuned kernel serves the one-hot layout; the bytes layout uses the generic step kernel
+  if (variant == 1 || k > 0xFFFFFFF0ull || h->layout != kLayoutOneHot) return launch_search_v1(h, d_pat, d_off, d_sp, d_ep, k, st);
   PatDesc *desc = nullptr;
   hipError_t e = hipMallocAsync((void **)&desc, k * sizeof(PatDesc), st);
   if (e != hipSuccess) return e;

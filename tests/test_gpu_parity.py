@@ -335,6 +335,99 @@ def test_regex_overflow_is_reported():
     assert {r.key() for r in part} == {k for k in oracle_results_capped(bwt, eof, counts, "a[a-d]*b", 3)}
 
 
+# ---------------------------------------------------------------- second layout: BWT bytes + checkpoints
+@pytest.fixture
+def bytes_layout():
+    findex_amd.set_layout("bytes")
+    yield
+    findex_amd.set_layout("auto")
+
+
+def test_bytes_layout_fixtures(testdata, bytes_layout, tmp_path):
+    """The compact layout (two lines per rank query, for sigma*n/8 > HBM) must answer exactly like
+    the one-hot layout: every primitive against the oracle on the reference's fixtures."""
+    for name, be in (("test1024.cmp", False), ("test.cmp", False), ("words", True)):
+        hip, orc = pair_from_files(testdata, name, be)
+        assert hip.stats()["layout"] == 1
+        rng = np.random.default_rng(5)
+        present = [c for c in range(256) if orc.occ(c, orc.n - 1) > 0]
+        check_occ(hip, orc, rng, 4000, present + [0, 1, 255])
+        pats = lf_walk_patterns(orc, rng, 300, 9, 0.15, alphabet=present) + [b"", b"\x00", b"\xff\x80", bytes([present[0]])]
+        assert check_search(hip, orc, pats) > 150
+        rows = rng.integers(0, orc.n, 3000).astype(np.uint64)
+        rows[:3] = [0, orc.eof, orc.n - 1]
+        assert np.array_equal(hip.psi_batch(rows), orc.fm()[rows.astype(np.int64)].astype(np.uint64))
+        _, e1 = hip.lf_walk_batch(rows[:500], 1, want_bytes=False)
+        assert np.array_equal(e1, np.array([orc.getPrevI(int(r)) for r in rows[:500]], dtype=np.uint64))
+        assert hip.nextSubstr(int(orc.eof), 40) == orc.nextSubstr(int(orc.eof), 40)
+        assert hip.getIntervalPrevRange(0, orc.n, 0, 255) == orc.getIntervalPrevRange(0, orc.n, 0, 255)
+        a, b = str(tmp_path / "h.fm"), str(tmp_path / "o.fm")
+        hip.write_fm(a)
+        orc.write_fm(b)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re)) for re in REGEXES[:8]]
+        got = findex_amd.ReTree.matchSA_batch(hip, trees, max_steps=1 << 20)
+        for re, g in zip(REGEXES[:8], got):
+            assert [r.key() for r in g] == oracle_results(orc, re)[0], re
+        ref = findex_amd.ReTree.matchSA_batch(hip, trees, mode="reference", maxBranching=16, maxIterations=50)
+        for re, g in zip(REGEXES[:8], ref):
+            assert [r.key() for r in g] == orc.match_tables(R.ReTree(R.re2post(re)).tables(), 16, 50)[0], re
+
+
+@pytest.mark.parametrize("n,lo,hi", [(1, 1, 1), (127, 1, 4), (128, 1, 4), (129, 1, 4), (4_194_304 + 5, 1, 128),
+                                     (300_007, 1, 255)])
+def test_bytes_layout_synthetic(n, lo, hi, bytes_layout):
+    """Block (128) and superblock (2^22 positions) edges of the compact layout."""
+    rng = np.random.default_rng(n)
+    for eof in sorted({0, n // 3, n - 1}):
+        bwt, eof, counts = synth_bwt(n, lo, hi, n + 1, eof=eof)
+        hip, orc = pair_from_mem(bwt, eof, counts)
+        assert hip.stats()["layout"] == 1
+        syms = list(range(lo, hi + 1))
+        check_occ(hip, orc, rng, 3000, syms + [0, 255])
+        m = 1 if n < 10 else (12 if hi - lo < 8 else 5)
+        check_search(hip, orc, lf_walk_patterns(orc, rng, 300, m, 0.1, alphabet=syms) + [b"", b"\x00"])
+
+
+def test_bytes_layout_c5_shape(bytes_layout):
+    """BASELINE config C5's index shape at a quarter of its size (n = 2^32 + 999, sigma = 128: the
+    one-hot vectors would still fit, the compact layout is forced): positions beyond 32 bits, the
+    same size-independent properties as test_full_size_properties."""
+    torch = _torch()
+    n = (1 << 32) + 999
+    g = torch.Generator(device="cuda")
+    g.manual_seed(55)
+    bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for a in range(0, n, 1 << 28):
+        b = min(n, a + (1 << 28))
+        bwt[a:b] = torch.randint(1, 129, (b - a,), generator=g, device="cuda", dtype=torch.uint8)
+    eof = n // 3
+    torch.cuda.synchronize()
+    hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None)
+    st = hip.stats()
+    assert st["layout"] == 1 and st["block_bytes"] == 132
+    rng = np.random.default_rng(2)
+    qs_i = np.concatenate([rng.integers(0, n, 5), [0, eof, n - 1]]).astype(np.int64)
+    qs_c = rng.integers(1, 129, qs_i.size).astype(np.uint8)
+    got = hip.occ_batch(qs_c, qs_i)
+    for c, i, gv in zip(qs_c, qs_i, got):
+        want = 0
+        for a in range(0, int(i) + 1, 1 << 28):
+            b = min(int(i) + 1, a + (1 << 28))
+            want += int((bwt[a:b] == int(c)).sum().item())
+        if eof <= i and int(bwt[eof].item()) == int(c):
+            want -= 1
+        assert int(gv) == want, (c, i)
+    col = hip.occ_batch(np.arange(0, 129, dtype=np.uint8), np.full(129, n - 1, dtype=np.int64))
+    assert int(col.sum()) == n
+    k, m = 20000, 24
+    rows = rng.integers(0, n, k).astype(np.uint64)
+    b, end = hip.lf_walk_batch(rows, m)
+    pats = np.ascontiguousarray(b[:, ::-1])
+    sp, ep = hip.search_batch(pats.reshape(-1), np.arange(k + 1, dtype=np.uint64) * m)
+    assert (sp < ep).all() and (sp <= end).all() and (end < ep).all()
+
+
 # ---------------------------------------------------------------- full-size properties (on device)
 def _torch():
     import torch

@@ -40,7 +40,7 @@ WORKLOADS = {
 }
 
 
-def pmc_traffic(workload, kernel="k_search3"):
+def pmc_traffic(workload, kernel="k_search4"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/<tag>_<workload>_counters.csv, written by tools/summarize_prof.py from separate
     `--pmc` runs of tools/prof_workload.py -- the same step): reads = 2 x FETCH_SIZE KiB (gfx950
@@ -229,7 +229,7 @@ def main():
 
     if rank == 0:
         bytes_per_rank = int(st["block_bytes"])
-        kernel_name = "k_search3" if st["layout"] == 0 else "k_search"
+        kernel_name = "k_search4" if st["layout"] == 0 else "k_search"
         achieved = ranks_per_step * bytes_per_rank / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "rank_queries_per_sec",

@@ -161,6 +161,126 @@ __global__ __launch_bounds__(kSThreads) void k_search3(DevIndex ix, const uint8_
   if (t == 0 && steps) { atomicAdd(&counters[0], 2ull * steps); atomicAdd(&counters[1], (unsigned long long)steps); }
 }
 
+
+// ---------------------------------------------------------------- lockstep batches + single-row shortcut
+// A wave takes 8 consecutive patterns (one per octet), steps them together and retires them
+// together.  What that buys: the choice between the two step bodies below is wave-uniform.
+//   * general step: two rank queries (sp and ep lines);
+//   * single-row step, taken when every stepping octet holds an interval of exactly one row
+//     (sigma = 128, n = 2^32: from the 6th of 32 steps on): one rank query plus one bit test --
+//     [sp, sp+1) maps to [C[c] + rank(c, sp), + BWT'[sp] == c), and BWT'[sp] == c is bit sp of c's
+//     own vector, i.e. a bit of the line already fetched.  Same result as getPrevRange
+//     (findex.scala:32-36), half the popcount work and one line request instead of two.
+// Octets whose pattern ends early idle until the batch ends (patterns of one batch should have
+// similar lengths; the benchmark's do).
+template <bool WIDE>
+__global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_t *__restrict__ pat,
+                                                        const PatDesc *__restrict__ desc,
+                                                        uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
+                                                        uint32_t k, unsigned long long *__restrict__ counters) {
+  __shared__ uint4 s_tab[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) {
+    const uint64_t cf = ix.cf[c];
+    const uint16_t s = ix.slot[c];
+    uint64_t vb = 0;
+    if (s < kSlotEof) vb = (uint64_t)(uintptr_t)ix.bv + (uint64_t)s * ix.nblocks * kBlockBytes;
+    else if (s == kSlotEof) vb = 1;
+    s_tab[c] = make_uint4((uint32_t)cf, (uint32_t)(cf >> 32), (uint32_t)vb, (uint32_t)(vb >> 32));
+  }
+  __syncthreads();
+  const LaneConst lc = lane_const();
+  const uint32_t t = lc.t;
+  const uint32_t lane_off = t * 16;
+  const uint32_t wave = (blockIdx.x * kSThreads + threadIdx.x) >> 6;
+  const uint32_t nwaves = gridDim.x * (kSThreads / 64);
+  const uint32_t oct = (threadIdx.x & 63) >> 3;
+  const uint32_t nbatch = (k + 7) / 8;
+  uint32_t steps = 0;
+  PatDesc nd;
+  nd.end = 0; nd.len = 0; nd.tail4 = 0;
+  if (wave < nbatch && wave * 8 + oct < k) nd = desc[wave * 8 + oct];
+  for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
+    const uint32_t pid = batch * 8 + oct;
+    const bool act = pid < k;
+    uint64_t cur = nd.end, sp = 0, ep = ix.n;
+    uint32_t left = act ? nd.len : 0u, ch = nd.tail4, nch = 4, nx = 0;
+    if (left > 4) nx = fetch4(pat, cur - 4);
+    {
+      const uint64_t np = (uint64_t)(batch + nwaves) * 8 + oct;     // descriptor of the next batch
+      if (np < k) nd = desc[np];
+    }
+    auto next_char = [&]() {
+      ch >>= 8;
+      nch -= 1;
+      left -= 1;
+      cur -= 1;
+      if (nch == 0) {
+        ch = nx;
+        nch = 4;
+        if (left > 4) nx = fetch4(pat, cur - 4);
+      }
+    };
+    for (;;) {
+      const bool stepping = left > 0 && sp < ep;
+      if (!__builtin_amdgcn_ballot_w64(stepping)) break;
+      const bool wide_iv = stepping && (ep - sp) != 1;
+      if (!__builtin_amdgcn_ballot_w64(wide_iv)) {
+        // ---- every stepping octet holds one row
+        if (stepping) {
+          const uint4 e = s_tab[ch & 0xFFu];
+          const uint64_t cfc = ((uint64_t)e.y << 32) | e.x;
+          const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
+          if (vb > 1) {
+            uint32_t b1, m1;
+            split960(sp, b1, m1);
+            const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
+            next_char();
+            const uint32_t d = (m1 >> 5) + 2;                    // dword of the line that holds bit sp
+            const uint32_t comp = d & 3u;
+            const uint32_t word = comp < 2u ? (comp == 0u ? w1.x : w1.y) : (comp == 2u ? w1.z : w1.w);
+            uint32_t bit = __builtin_amdgcn_ubfe(word, m1, 1u);   // offset taken mod 32
+            bit = (d >> 2) == t ? bit : 0u;
+            sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+            ep = sp + octet_or(bit);
+          } else {
+            next_char();
+            const uint64_t r1 = (vb == 1 && sp > ix.eof) ? 1 : 0;
+            const uint64_t r2 = (vb == 1 && ep > ix.eof) ? 1 : 0;
+            sp = cfc + r1;
+            ep = cfc + r2;
+          }
+          steps++;
+        }
+      } else if (stepping) {
+        // ---- general step: two rank queries
+        const uint4 e = s_tab[ch & 0xFFu];
+        const uint64_t cfc = ((uint64_t)e.y << 32) | e.x;
+        const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
+        if (vb > 1) {
+          uint32_t b1, b2, m1, m2;
+          split960(sp, b1, m1);
+          split960(ep, b2, m2);
+          const uint64_t base = vb + lane_off;
+          const uint4 w1 = load_line16(base + (uint64_t)b1 * kBlockBytes);
+          const uint4 w2 = load_line16(base + (uint64_t)b2 * kBlockBytes);
+          next_char();
+          sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+          ep = cfc + rank_finish<WIDE>(w2, m2, lc);
+        } else {
+          next_char();
+          const uint64_t r1 = (vb == 1 && sp > ix.eof) ? 1 : 0;
+          const uint64_t r2 = (vb == 1 && ep > ix.eof) ? 1 : 0;
+          sp = cfc + r1;
+          ep = cfc + r2;
+        }
+        steps++;
+      }
+    }
+    if (act && t == 0) { sp_out[pid] = sp; ep_out[pid] = ep; }
+  }
+  if (t == 0 && steps) { atomicAdd(&counters[0], 2ull * steps); atomicAdd(&counters[1], (unsigned long long)steps); }
+}
+
 // v1 kernel (fmx_kernels.hip), kept for A/B runs
 hipError_t launch_search_v1(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
                             hipStream_t st);
@@ -169,7 +289,7 @@ static int search_variant() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("FMX_SEARCH_VARIANT");
-    v = e ? atoi(e) : 2;
+    v = e ? atoi(e) : 3;      // 1 generic step kernel, 2 k_search3 (dynamic refill), 3 k_search4 (lockstep)
   }
   return v;
 }
@@ -194,6 +314,17 @@ static hipError_t launch_v3w(const Index *h, const uint8_t *pat, const PatDesc *
   return hipGetLastError();
 }
 
+template <bool WIDE>
+static hipError_t launch_v4w(const Index *h, const uint8_t *pat, const PatDesc *desc, uint64_t *sp, uint64_t *ep,
+                             uint32_t k, hipStream_t st) {
+  static const int per_cu = blocks_per_cu(k_search4<WIDE>);
+  uint64_t want = ((uint64_t)k + kSOctets - 1) / kSOctets;
+  uint64_t cap = (uint64_t)h->cu_count * per_cu;
+  int grid = (int)(want < cap ? (want ? want : 1) : cap);
+  k_search4<WIDE><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters);
+  return hipGetLastError();
+}
+
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
                          hipStream_t st) {
   if (!k) return hipSuccess;
@@ -207,10 +338,13 @@ hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, v
   if (pg > h->cu_count * 8) pg = h->cu_count * 8;
   k_prep<<<pg, 256, 0, st>>>((const uint8_t *)d_pat, (const uint64_t *)d_off, desc, (uint32_t)k);
   e = hipGetLastError();
-  if (e == hipSuccess)
-    e = h->n > (1ull << 32)
-            ? launch_v3w<true>(h, (const uint8_t *)d_pat, desc, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st)
-            : launch_v3w<false>(h, (const uint8_t *)d_pat, desc, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st);
+  if (e == hipSuccess) {
+    const bool wide = h->n > (1ull << 32);
+    const uint8_t *p = (const uint8_t *)d_pat;
+    uint64_t *osp = (uint64_t *)d_sp, *oep = (uint64_t *)d_ep;
+    if (variant == 3) e = wide ? launch_v4w<true>(h, p, desc, osp, oep, (uint32_t)k, st) : launch_v4w<false>(h, p, desc, osp, oep, (uint32_t)k, st);
+    else e = wide ? launch_v3w<true>(h, p, desc, osp, oep, (uint32_t)k, st) : launch_v3w<false>(h, p, desc, osp, oep, (uint32_t)k, st);
+  }
   hipError_t e2 = hipFreeAsync(desc, st);
   return e != hipSuccess ? e : e2;
 }

@@ -15,7 +15,7 @@ library and a HIP device and fails loudly otherwise.
 """
 from ._lib import FmxError, MatchError, Re2PostSyntax, LIB_PATH, load  # noqa: F401
 from .searcher import HipFMSearcher  # noqa: F401
-from .regex import REParser, ReTree, SAResult  # noqa: F401
+from .regex import DFA, NFA, REParser, ReTree, SAResult  # noqa: F401
 
 
 
@@ -25,4 +25,4 @@ def set_layout(name):
     _lib.check(_lib.load().fmx_config_set(b"layout", name.encode()))
 
 
-__all__ = ["set_layout", "HipFMSearcher", "REParser", "ReTree", "SAResult", "FmxError", "MatchError", "Re2PostSyntax"]
+__all__ = ["set_layout", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "FmxError", "MatchError", "Re2PostSyntax"]

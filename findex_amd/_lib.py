@@ -80,6 +80,8 @@ SYMBOLS = {
     "fmx_prev_substr": (_i32, [_vp, _u64, _u32, _vp]),
     "fmx_write_fm": (_i32, [_vp, _cp]),
     "fmx_regex_compile": (_i32, [_cp, _i32, _P(_vp)]),
+    "fmx_nfa_compile": (_i32, [_cp, _i32, _i32, _P(_vp)]),
+    "fmx_dfa_compile": (_i32, [_vp, _u32, _u32, _vp, _P(_vp)]),
     "fmx_regex_free": (_i32, [_vp]),
     "fmx_regex_tables": (_i32, [_vp, _P(_u32), _vp, _vp, _vp, _vp, _P(_u32), _vp, _P(_u32), _vp]),
     "fmx_regex_post_string": (_i32, [_cp, _i32, _vp, _sz]),

@@ -105,8 +105,11 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
       backward_step<WIDE>(ix, c, slot, cfc, lc, sp, ep);
       stepped++;
       if (sp < ep) {                                   // Some((sp1,ep1)), retree.scala:634
-        if (nfa.st_last[s]) emit = true;               // :636-638
-        else { f0 = nfa.fol_off[s]; nf = nfa.fol_off[s + 1] - f0; }   // :641
+        // Glushkov tables: an isLast state emits and has no follows here (:636-641); Thompson / DFA
+        // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282)
+        emit = nfa.st_last[s] != 0;
+        f0 = nfa.fol_off[s];
+        nf = nfa.fol_off[s + 1] - f0;
       }
     }
     // ---- compaction: results by ballot, pushes by wave prefix sum
@@ -181,6 +184,7 @@ struct RegexBatch {
   size_t k = 0;
   uint64_t n_index = 0;
   size_t n_first = 0;
+  std::vector<uint32_t> start_final;   // DFA engines whose start state is final: result (len 0, 0, n)
   DevMem mem;
   NfaTables nfa{};
   uint32_t *d_first_state = nullptr;
@@ -188,7 +192,7 @@ struct RegexBatch {
 
 int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexBatch **out) {
   std::vector<uint8_t> st_c, st_last;
-  std::vector<uint32_t> st_regex, fol_off, fol, q_state;
+  std::vector<uint32_t> st_regex, fol_off, fol, q_state, start_final;
   fol_off.push_back(0);
   for (size_t r = 0; r < k; r++) {
     const Regex &re = *res[r];
@@ -197,10 +201,13 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
       st_c.push_back(re.st_c[s]);
       st_last.push_back(re.st_last[s]);
       st_regex.push_back((uint32_t)r);
-      for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol.push_back(base + (uint32_t)re.fol[j]);
+      // ReTree: `if (q.state.isLast) ret ::= ... else pqFront ++= follows` -- last states do not expand
+      if (!(re.last_stops && re.st_last[s]))
+        for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol.push_back(base + (uint32_t)re.fol[j]);
       fol_off.push_back((uint32_t)fol.size());
     }
     for (int32_t f : re.firsts) q_state.push_back(base + (uint32_t)f);
+    if (re.start_is_final) start_final.push_back((uint32_t)r);
   }
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
   std::unique_ptr<RegexBatch> b(new RegexBatch());
@@ -208,6 +215,7 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   b->k = k;
   b->n_index = h->n;
   b->n_first = q_state.size();
+  b->start_final = start_final;
   uint8_t *d_c = nullptr, *d_last = nullptr;
   uint32_t *d_regex = nullptr, *d_foff = nullptr, *d_fol = nullptr;
   HIP_TRY(b->mem.alloc(&d_c, st_c.size()), "hipMalloc");
@@ -247,7 +255,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if (b->device != h->device || b->n_index != h->n) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
   if (per_regex_count) std::fill(per_regex_count, per_regex_count + b->k, 0u);
   *n_out = 0;
-  if (b->n_first == 0) return FMX_OK;
+  if (b->n_first == 0 && b->start_final.empty()) return FMX_OK;
   if (b->n_first > qcap) { set_error("initial frontier exceeds max_frontier"); return FMX_ERR_OVERFLOW; }
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
   DevMem mem;
@@ -317,10 +325,17 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     cur_cnt[1] += ctl.steps;
     HIP_TRY(hipMemcpy(h->d_counters, cur_cnt, sizeof cur_cnt, hipMemcpyHostToDevice), "H2D(counters)");
   }
-  *n_out = (size_t)ctl.res_count;
-  if (ctl.res_count > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
-  if (ctl.res_count) {
+  const size_t extra = b->start_final.size();
+  *n_out = (size_t)ctl.res_count + extra;
+  if (ctl.res_count + extra > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
+  if (ctl.res_count)
     HIP_TRY(hipMemcpy(out, d_res, (size_t)ctl.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost), "D2H(results)");
+  for (size_t j = 0; j < extra; j++) {           // dfa.scala:270-273 with the start StatePoint(0,0,0,n)
+    fmx_result &o = out[ctl.res_count + j];
+    o.regex = b->start_final[j]; o.len = 0; o.sp = 0; o.ep = h->n;
+  }
+  ctl.res_count += extra;
+  if (ctl.res_count) {
     std::sort(out, out + ctl.res_count, [](const fmx_result &a, const fmx_result &b) {
       if (a.regex != b.regex) return a.regex < b.regex;
       if (a.len != b.len) return a.len < b.len;
@@ -349,6 +364,39 @@ int fmx_regex_compile(const char *re, int line_only, fmx_regex **out) {
   try {
     Regex *r = new Regex(compile_regex(re, line_only != 0));
     *out = reinterpret_cast<fmx_regex *>(r);
+    return FMX_OK;
+  } catch (const RegexError &e) {
+    set_error(e.msg);
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return FMX_ERR_NOMEM;
+  }
+}
+
+// REParser.createNFA (re2/re2.scala:264-334): `src` is a regex (parsed by re2post) or, with
+// src_is_postfix, a postfix string for post2re (:188-205, '.' = concat) as the reference's tests use.
+int fmx_nfa_compile(const char *src, int line_only, int src_is_postfix, fmx_regex **out) {
+  if (!src || !out) { set_error("null argument"); return FMX_ERR_ARG; }
+  *out = nullptr;
+  try {
+    const std::vector<PostPoint> post = src_is_postfix ? post2re(src) : re2post(src, line_only != 0);
+    *out = reinterpret_cast<fmx_regex *>(new Regex(compile_thompson(post, src)));
+    return FMX_OK;
+  } catch (const RegexError &e) {
+    set_error(e.msg);
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return FMX_ERR_NOMEM;
+  }
+}
+
+int fmx_dfa_compile(const int32_t *moves, uint32_t nstates, uint32_t nchars, const uint8_t *finish, fmx_regex **out) {
+  if (!out) { set_error("null argument"); return FMX_ERR_ARG; }
+  *out = nullptr;
+  try {
+    *out = reinterpret_cast<fmx_regex *>(new Regex(compile_dfa(moves, nstates, nchars, finish)));
     return FMX_OK;
   } catch (const RegexError &e) {
     set_error(e.msg);
@@ -427,6 +475,11 @@ int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k,
     for (size_t r = 0; r < k; r++)
       if (!res[r]) { set_error("null regex handle"); return FMX_ERR_ARG; }
     if (lim->max_branching == 0) { set_error("max_branching must be positive"); return FMX_ERR_ARG; }
+    for (size_t r = 0; r < k; r++)
+      if (reinterpret_cast<const Regex *>(res[r])->engine != 0) {
+        set_error("the reference-order mode replays ReTree._matchSA; Thompson and DFA handles use the frontier mode");
+        return FMX_ERR_UNSUPPORTED;
+      }
     return regex_match_reference(reinterpret_cast<const Index *>(idx), reinterpret_cast<const Regex *const *>(res), k,
                                  lim->max_branching, lim->max_iterations, out, cap, n_out, per_regex_count, nullptr);
   }

@@ -518,3 +518,225 @@ Regex compile_regex(const std::string &re, bool line_only) {
 }
 
 }  // namespace fmx
+
+// ------------------------------------------------------------------------------ Thompson NFA (REParser)
+namespace fmx {
+
+std::vector<PostPoint> post2re(const std::string &s) {        // re2.scala:188-205
+  std::vector<PostPoint> out;
+  for (unsigned char ch : s) {
+    PostPoint p;
+    switch (ch) {
+      case '*': p.kind = PostPoint::Star; break;
+      case '.': p.kind = PostPoint::Concat; break;
+      case '|': p.kind = PostPoint::Or; break;
+      case '?': p.kind = PostPoint::Question; break;
+      case '+': p.kind = PostPoint::Plus; break;
+      default: p.kind = PostPoint::Char; p.c = ch;
+    }
+    out.push_back(p);
+  }
+  return out;
+}
+
+namespace {
+
+enum TKind { T_CONST, T_INTERVAL, T_SPLIT, T_MATCH };
+struct TState { TKind kind; int c = 0, start = 0, end = 0; int out = -1, out1 = -1, out2 = -1; };   // link ids
+struct Frag0 { int start; std::vector<int> out; };
+
+struct TNfa {
+  std::vector<TState> st;
+  std::vector<int> link;      // LinkState.s (state id or -1)
+  int new_link(int s = -1) { link.push_back(s); return (int)link.size() - 1; }
+  int add(TState t) { st.push_back(t); return (int)st.size() - 1; }
+
+  // BaseState.outStates, re2.scala:213-224 (a Set there: no duplicates; order not part of the results)
+  void out_states(int s, std::vector<char> &seen, std::vector<int> &acc) const {
+    if (s < 0 || seen[s]) return;
+    const TState &t = st[s];
+    if (t.kind == T_SPLIT) {
+      seen[s] = 1;
+      out_states(link[t.out1], seen, acc);
+      if (t.out2 >= 0) out_states(link[t.out2], seen, acc);
+    } else {
+      seen[s] = 1;
+      acc.push_back(s);
+    }
+  }
+  std::vector<int> out_states(int s) const {
+    std::vector<char> seen(st.size(), 0);
+    std::vector<int> acc;
+    out_states(s, seen, acc);
+    return acc;
+  }
+};
+
+Frag0 pop_frag(std::vector<Frag0> &s0) {
+  if (s0.empty()) throw RegexError{FMX_ERR_MATCH, "createNFA: pop of an empty stack (NoSuchElementException)"};
+  Frag0 f = s0.back();
+  s0.pop_back();
+  return f;
+}
+
+}  // namespace
+
+Regex compile_thompson(const std::vector<PostPoint> &post, const std::string &source) {
+  TNfa nfa;
+  std::vector<Frag0> s0;
+  const int match = nfa.add(TState{T_MATCH});
+  auto patch = [&](const Frag0 &f, int s) { for (int l : f.out) nfa.link[l] = s; };
+  for (const PostPoint &c : post) {                      // createNFA, re2.scala:286-326
+    switch (c.kind) {
+      case PostPoint::Question: {
+        Frag0 e = pop_frag(s0);
+        const int open = nfa.new_link();
+        TState t{T_SPLIT}; t.out1 = nfa.new_link(e.start); t.out2 = open;
+        const int ns = nfa.add(t);
+        std::vector<int> out{open};
+        out.insert(out.end(), e.out.begin(), e.out.end());
+        s0.push_back(Frag0{ns, out});
+        break;
+      }
+      case PostPoint::Star: {
+        Frag0 e = pop_frag(s0);
+        const int open = nfa.new_link();
+        TState t{T_SPLIT}; t.out1 = nfa.new_link(e.start); t.out2 = open;
+        const int ns = nfa.add(t);
+        patch(e, ns);
+        s0.push_back(Frag0{ns, {open}});
+        break;
+      }
+      case PostPoint::Plus: {
+        Frag0 e = pop_frag(s0);
+        const int open = nfa.new_link();
+        TState t{T_SPLIT}; t.out1 = nfa.new_link(e.start); t.out2 = open;
+        const int ns = nfa.add(t);
+        patch(e, ns);
+        s0.push_back(Frag0{e.start, {open}});
+        break;
+      }
+      case PostPoint::Concat: {
+        Frag0 e2 = pop_frag(s0), e1 = pop_frag(s0);
+        patch(e1, e2.start);
+        s0.push_back(Frag0{e1.start, e2.out});
+        break;
+      }
+      case PostPoint::Or: {
+        Frag0 e2 = pop_frag(s0), e1 = pop_frag(s0);
+        TState t{T_SPLIT}; t.out1 = nfa.new_link(e1.start); t.out2 = nfa.new_link(e2.start);
+        const int ns = nfa.add(t);
+        std::vector<int> out = e1.out;
+        out.insert(out.end(), e2.out.begin(), e2.out.end());
+        s0.push_back(Frag0{ns, out});
+        break;
+      }
+      case PostPoint::Char: {
+        TState t{T_CONST}; t.c = c.c; t.out = nfa.new_link();
+        const int ns = nfa.add(t);
+        s0.push_back(Frag0{ns, {nfa.st[ns].out}});
+        break;
+      }
+      case PostPoint::Interval: {
+        TState t{T_INTERVAL}; t.start = c.start; t.end = c.end; t.out = nfa.new_link();
+        const int ns = nfa.add(t);
+        s0.push_back(Frag0{ns, {nfa.st[ns].out}});
+        break;
+      }
+      case PostPoint::Alt:
+        throw RegexError{FMX_ERR_MATCH, "createNFA has no case for AltPoint ([..] sets)"};
+    }
+  }
+  Frag0 e0 = pop_frag(s0);
+  patch(e0, match);
+  const int start = e0.start;
+
+  // flatten: one kernel state per (TermState, char)
+  std::vector<int> first_id(nfa.st.size(), -1), n_chars(nfa.st.size(), 0);
+  Regex out;
+  out.source = source;
+  out.engine = 1;
+  out.last_stops = false;
+  std::vector<int> term_of;     // kernel state -> term state
+  for (size_t s = 0; s < nfa.st.size(); s++) {
+    const TState &t = nfa.st[s];
+    int lo = 0, hi = 0;
+    if (t.kind == T_CONST) { lo = t.c; hi = t.c + 1; }
+    else if (t.kind == T_INTERVAL) { lo = t.start; hi = t.end; }       // `start until end`, re2.scala:472
+    else continue;
+    first_id[s] = (int)out.st_c.size();
+    n_chars[s] = std::max(0, hi - lo);
+    for (int ch = lo; ch < hi; ch++) {
+      if (ch < 0 || ch > 255) throw RegexError{FMX_ERR_SYNTAX, "character outside 0..255"};
+      out.st_c.push_back((uint8_t)ch);
+      out.st_num.push_back(0);
+      term_of.push_back((int)s);
+    }
+  }
+  auto expand_targets = [&](const std::vector<int> &states, std::vector<int32_t> &dst, bool &has_match) {
+    has_match = false;
+    for (int s : states) {
+      if (nfa.st[s].kind == T_MATCH) { has_match = true; continue; }
+      for (int j = 0; j < n_chars[s]; j++) dst.push_back(first_id[s] + j);
+    }
+  };
+  out.fol_off.push_back(0);
+  for (size_t q = 0; q < out.st_c.size(); q++) {
+    const TState &t = nfa.st[term_of[q]];
+    bool m = false;
+    expand_targets(nfa.out_states(nfa.link[t.out]), out.fol, m);       // nextStates, re2.scala:450-453
+    out.st_last.push_back(m ? 1 : 0);
+    out.fol_off.push_back((int32_t)out.fol.size());
+  }
+  bool start_match = false;
+  expand_targets(nfa.out_states(start), out.firsts, start_match);
+  if (start_match)
+    throw RegexError{FMX_ERR_MATCH, "the regex matches the empty string: REParser.matchSA would expand a MatchState "
+                                    "start point, which StatePoint.expand has no case for (re2.scala:457-482)"};
+  return out;
+}
+
+Regex compile_dfa(const int32_t *moves, uint32_t nstates, uint32_t nchars, const uint8_t *finish) {
+  if (!moves || !finish || nstates == 0 || nchars == 0 || nchars > 256)
+    throw RegexError{FMX_ERR_ARG, "bad DFA table"};
+  Regex out;
+  out.source = "<dfa>";
+  out.engine = 2;
+  out.last_stops = false;
+  out.start_is_final = finish[0] != 0;
+  // compileBuckets, dfa.scala:190-213: maximal runs of equal targets; only runs of one character
+  // (DFAChar) are expanded by StatePoint.expand (:242-259)
+  std::vector<std::vector<std::pair<int, int>>> act(nstates);     // per state: (char, target)
+  for (uint32_t i = 0; i < nstates; i++) {
+    int last = -1, start_bucket = -1;
+    for (uint32_t j = 0; j < nchars; j++) {
+      const int v = moves[(size_t)i * nchars + j];
+      if (v < -1 || v >= (int)nstates) throw RegexError{FMX_ERR_ARG, "DFA target out of range"};
+      if (last != v) {
+        if (last != -1 && start_bucket == (int)j - 1) act[i].push_back({start_bucket, last});
+        start_bucket = (int)j;
+        last = v;
+      }
+    }
+    if (last != -1 && start_bucket == (int)nchars - 1) act[i].push_back({start_bucket, last});
+  }
+  std::vector<int> first_id(nstates, 0);
+  for (uint32_t i = 0; i < nstates; i++) {
+    first_id[i] = (int)out.st_c.size();
+    for (auto &a : act[i]) {
+      out.st_c.push_back((uint8_t)a.first);
+      out.st_num.push_back((int32_t)i);
+      out.st_last.push_back(finish[a.second] ? 1 : 0);          // the target is reported when popped, :270-273
+    }
+  }
+  out.fol_off.push_back(0);
+  for (uint32_t i = 0; i < nstates; i++)
+    for (auto &a : act[i]) {
+      for (size_t j = 0; j < act[a.second].size(); j++) out.fol.push_back(first_id[a.second] + (int)j);
+      out.fol_off.push_back((int32_t)out.fol.size());
+    }
+  for (size_t j = 0; j < act[0].size(); j++) out.firsts.push_back(first_id[0] + (int)j);
+  return out;
+}
+
+}  // namespace fmx

@@ -28,6 +28,9 @@ std::string re2poststr(const std::string &re, bool line_only);           // UTF-
 // What ReTree._matchSA (retree.scala:618-653) touches, per CharNode in tree order.
 struct Regex {
   std::string source;
+  int engine = 0;                  // 0 ReTree (Glushkov), 1 REParser.createNFA (Thompson), 2 DFA table
+  bool last_stops = true;          // ReTree: an isLast state emits and does not expand (retree.scala:636-641)
+  bool start_is_final = false;     // DFA whose state 0 is final: the reference reports (len 0, 0, n)
   std::vector<uint8_t> st_c;       // CharNode.c
   std::vector<int32_t> st_num;     // CharNode.num (retree.scala:393-423)
   std::vector<uint8_t> st_last;    // isLast (retree.scala:40-50)
@@ -37,5 +40,18 @@ struct Regex {
 };
 
 Regex compile_regex(const std::string &re, bool line_only);               // throws RegexError
+
+// REParser.post2re (re2.scala:188-205): a postfix string where '.' is the concat token.
+std::vector<PostPoint> post2re(const std::string &s);
+// REParser.createNFA (re2.scala:264-334) + the closure REParser.matchSA walks (outStates, :213-224):
+// per TermState char one kernel state; st_last = MatchState is among next.outStates (emit), fol = the
+// TermStates among them (push).  Throws RegexError(FMX_ERR_MATCH) where the reference throws
+// scala.MatchError (AltPoint tokens; a nullable regex, whose MatchState start point cannot expand).
+Regex compile_thompson(const std::vector<PostPoint> &post, const std::string &source);
+// DFA.compileBuckets + DFA.matchSA's expansion rule (dfa.scala:190-213,242-259): one kernel state per
+// single-character action (runs of two or more characters to one target are DFABuckets, which the
+// reference's expand ignores); moves is nstates x nchars, -1 = no transition; finish[s] != 0 marks
+// the final states.
+Regex compile_dfa(const int32_t *moves, uint32_t nstates, uint32_t nchars, const uint8_t *finish);
 
 }  // namespace fmx

@@ -24,7 +24,93 @@ class PostfixRe:
         return self.text
 
 
+class PostfixString(PostfixRe):
+    """REParser.post2re(str) (re2.scala:188-205): a postfix string, '.' = concat."""
+
+    def __init__(self, src):
+        self.src = src
+        self.lineOnly = False
+        self.text = src
+        self.is_postfix = True
+
+
+class NFA:
+    """REParser.createNFA(postfix) (re2.scala:264-334): the Thompson NFA handle for
+    REParser.matchSA.  Raises MatchError where the reference throws scala.MatchError."""
+
+    def __init__(self, postfix):
+        self._L = _lib.load()
+        self._h = ctypes.c_void_p()
+        _lib.check(self._L.fmx_nfa_compile(postfix.src.encode("latin-1"), 1 if postfix.lineOnly else 0,
+                                           1 if getattr(postfix, "is_postfix", False) else 0, ctypes.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.fmx_regex_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class DFA:
+    """class DFA(nstates, nchars) (dfa.scala:114-289) filled with addLink / finishStates, then
+    compileBuckets() and matchSA(sa) as in the reference."""
+
+    def __init__(self, nstates, nchars=256):
+        self.nstates, self.nchars = int(nstates), int(nchars)
+        self.moves = np.full((self.nstates, self.nchars), -1, dtype=np.int32)
+        self.finishStates = set()
+        self._h = None
+        self._L = _lib.load()
+
+    def addLink(self, frm, to, ch):
+        self.moves[int(frm), int(ch)] = int(to)
+        self._h = None
+
+    def compileBuckets(self):
+        fin = np.zeros(self.nstates, dtype=np.uint8)
+        for s in self.finishStates:
+            fin[s] = 1
+        h = ctypes.c_void_p()
+        _lib.check(self._L.fmx_dfa_compile(self.moves.ctypes.data_as(ctypes.c_void_p), self.nstates, self.nchars,
+                                           fin.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
+        self._h = h
+
+    def matchSA(self, sa, max_steps=0, cap=1 << 20):
+        """DFA.matchSA (dfa.scala:261-289) -> list of SAResult (DFAResult there), sorted."""
+        if self._h is None:
+            self.compileBuckets()
+        return ReTree.matchSA_batch(sa, [self], max_steps=max_steps, cap=cap)[0]
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.fmx_regex_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class REParser:
+    @staticmethod
+    def post2re(s):
+        """REParser.post2re, re2.scala:188-205"""
+        return PostfixString(s)
+
+    @staticmethod
+    def createNFA(postfix):
+        """REParser.createNFA, re2.scala:264-334"""
+        return NFA(postfix)
+
+    @staticmethod
+    def matchSA(nfa, sa, debugLevel=0, maxIterations=0, maxLength=0, cap=1 << 20):
+        """REParser.matchSA (re2.scala:568-693) -> list of SAResult, sorted by (len, sp, ep): the
+        reference's result multiset with its default maxIterations = 0 (unbounded)."""
+        if maxIterations:
+            raise NotImplementedError("REParser.matchSA's maxIterations cut depends on the reference's queue order")
+        return ReTree.matchSA_batch(sa, [nfa], max_steps=maxLength, cap=cap)[0]
+
     @staticmethod
     def re2post(s, lineOnly=False):
         """REParser.re2post, re2.scala:50-185 (raises Re2PostSyntax like the reference's Exception)."""

@@ -166,6 +166,22 @@ enum {
   FMX_MATCH_REFERENCE = 1   /* the reference's own pop order and limits, one regex per lane group */
 };
 
+/* ---- the reference's two other SA-interval engines, served by the same frontier kernel:
+ * fmx_nfa_compile : REParser.createNFA (re2/re2.scala:264-334) for REParser.matchSA (:568-693): Thompson
+ *                   NFA, epsilon closures folded into the tables.  `src` is a regex for re2post or, with
+ *                   src_is_postfix, a postfix string for post2re (:188-205) as the reference's tests use.
+ *                   FMX_ERR_MATCH where the reference throws scala.MatchError ([..] sets; a regex that
+ *                   matches the empty string).  matchSA's maxLength is fmx_limits.max_steps.
+ * fmx_dfa_compile : DFA.compileBuckets + DFA.matchSA (dfa.scala:190-213,231-289) over a caller-built
+ *                   transition table moves[nstates][nchars] (-1 = none), finish[nstates]: as in the
+ *                   reference only single-character actions expand (runs of equal targets are "buckets",
+ *                   which StatePoint.expand ignores, :247-251).  The reference's 500-pop cap is not
+ *                   emulated (results are equal whenever it does not bind).
+ * Both return an fmx_regex handle for fmx_regex_match_batch / fmx_regex_batch_* in frontier mode. */
+int fmx_nfa_compile(const char *src, int line_only, int src_is_postfix, fmx_regex **out);
+int fmx_dfa_compile(const int32_t *moves, uint32_t nstates, uint32_t nchars, const uint8_t *finish,
+                    fmx_regex **out);
+
 typedef struct fmx_limits {
   /* mode = FMX_MATCH_FRONTIER.  The frontier kernel expands every regex's frontier breadth-first, so
    * its results equal the reference's (as a multiset) whenever the reference's limits do not bind:

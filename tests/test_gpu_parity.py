@@ -335,6 +335,76 @@ def test_regex_overflow_is_reported():
     assert {r.key() for r in part} == {k for k in oracle_results_capped(bwt, eof, counts, "a[a-d]*b", 3)}
 
 
+# ---------------------------------------------------------------- the reference's other two engines
+class _OIdx:
+    def __init__(self, sa):
+        self.sa, self.n = sa, sa.n
+
+    def getPrevRange(self, sp, ep, c):
+        return self.sa.getPrevRange(sp, ep, c)
+
+
+def test_thompson_engine(testdata):
+    """REParser.createNFA + REParser.matchSA (re2.scala:264-334,568-693) on the frontier kernel:
+    the reference's vectors (T/REParser.scala:219-234,292-307) and the oracle's restatement."""
+    from oracle import engines as E
+    P = findex_amd.REParser
+    hip, orc = pair_from_mem(*bwt_of_text(b"mmabcacamabbbca"[::-1]))
+    for post in ("ma.b.", "ba|c.", "ab|*c.", "a?b.c."):
+        got = [r.key() for r in P.matchSA(P.createNFA(P.post2re(post)), hip)]
+        assert got == sorted(E.nfa_matchSA(E.createNFA(R.post2re(post)), _OIdx(orc))), post
+    got = P.matchSA(P.createNFA(P.post2re("ma.b.")), hip)
+    assert len(got) == 1 and got[0].cnt == 2 and got[0].len == 3          # "[2 Results] bam"
+    hip, orc = pair_from_files(testdata, "test1024.cmp", False)
+    res = P.matchSA(P.createNFA(P.post2re("ba|d|e|c.")), hip)
+    assert {str(r) for r in res} == {"ec", "dc", "[2 Results] ac", "bc"}   # T/REParser.scala:303-305
+    hip, orc = pair_from_files(testdata, "words", True)
+    for re in ("th(e|a)", "co(m|n)+e", "x?yz", "q\\wk", "ab(cd|ef)+gh", "z(a|e)*b", "e\\d", "un..ed"):
+        got = [r.key() for r in P.matchSA(P.createNFA(P.re2post(re, lineOnly=True)), hip)]
+        want = sorted(E.nfa_matchSA(E.createNFA(R.re2post(re, True)), _OIdx(orc)))
+        assert got == want, re
+    # maxLength: elements of length >= maxLength are not expanded (re2.scala:645)
+    nfa = P.createNFA(P.re2post("s(a|e|i|o|u)+t"))
+    got = [r.key() for r in P.matchSA(nfa, hip, maxLength=4)]
+    assert got == sorted(E.nfa_matchSA(E.createNFA(R.re2post("s(a|e|i|o|u)+t")), _OIdx(orc), maxLength=4))
+    for bad in ("[ab]c", "a*", "(a|b)*"):                                   # scala.MatchError there
+        with pytest.raises(findex_amd.MatchError):
+            P.createNFA(P.re2post(bad))
+
+
+def test_dfa_engine(testdata):
+    """DFA.compileBuckets + DFA.matchSA (dfa.scala:190-213,231-289): T/dfa.scala:110-122 and the
+    oracle's restatement, incl. the rule that multi-character buckets do not expand."""
+    from oracle import engines as E
+
+    def both(nstates, links, finish):
+        a, b = findex_amd.DFA(nstates), E.DFA(nstates)
+        for f, t_, ch in links:
+            a.addLink(f, t_, ch)
+            b.addLink(f, t_, ch)
+        a.finishStates = set(finish)
+        b.finishStates = set(finish)
+        a.compileBuckets()
+        b.compileBuckets()
+        return a, b
+
+    hip, orc = pair_from_mem(*bwt_of_text(b"mmabcacadabbbca"[::-1]))
+    links = [(0, 1, ord("a")), (1, 2, ord("b")), (2, 2, ord("b")), (2, 3, ord("c"))]
+    a, b = both(4, links, {3})
+    got = a.matchSA(hip)
+    assert [r.key() for r in got] == sorted(b.matchSA(_OIdx(orc))) and len(got) == 2
+    hip, orc = pair_from_files(testdata, "words", True)
+    cases = [
+        (4, links, {3}),
+        (4, [(0, 1, ord(ch)) for ch in "cdfmkl"] + links[1:], {3}),            # c-d and k-m are buckets: only 'f' starts
+        (3, [(0, 1, ord("q")), (1, 2, ord("u")), (2, 2, ord("e")), (2, 1, ord("i"))], {1, 2}),
+        (2, [(0, 1, ord("z"))], {0, 1}),                                       # final start state: (0, 0, n)
+    ]
+    for nst, lk, fin in cases:
+        a, b = both(nst, lk, fin)
+        assert [r.key() for r in a.matchSA(hip)] == sorted(b.matchSA(_OIdx(orc))), (nst, lk)
+
+
 # ---------------------------------------------------------------- second layout: BWT bytes + checkpoints
 @pytest.fixture
 def bytes_layout():

@@ -35,12 +35,26 @@ struct Queue {           // SoA frontier queue in HBM
   uint64_t *ep;
 };
 
+struct StateRec {        // 16 bytes: everything a frontier element needs about its state, one load
+  uint32_t fol_off;      // first entry of its follows in `fol`
+  uint32_t fol_cnt;
+  uint32_t regex;
+  uint32_t c_emit;       // byte in bits 0..7, emit flag in bit 8
+};
+
 struct NfaTables {       // all regexes of the batch, concatenated; state ids are global
-  const uint8_t *st_c;
-  const uint8_t *st_last;
-  const uint32_t *st_regex;
-  const uint32_t *fol_off;   // n_states + 1
+  const StateRec *st;
   const uint32_t *fol;
+};
+
+constexpr uint32_t kStageCap = 256;     // survivors a wave stages in LDS before reserving queue slots
+constexpr uint32_t kStageSmall = 16;    // follows lists up to this length go through the stage (8 x 16 <= cap / 2)
+
+struct Stage {
+  uint32_t state[kStageCap];
+  uint32_t len[kStageCap];
+  uint64_t sp[kStageCap];
+  uint64_t ep[kStageCap];
 };
 
 struct FrontierCtl {     // device-resident counters
@@ -86,12 +100,35 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
   const uint64_t noct = (uint64_t)gridDim.x * (kFThreads / kOctet);
   const uint64_t first = ((uint64_t)blockIdx.x * kFThreads + threadIdx.x) >> 3;
   uint32_t stepped = 0;
+  __shared__ Stage s_stage[kFThreads / 64];
+  Stage &stg = s_stage[threadIdx.x >> 6];
+  uint32_t staged = 0;                       // wave-uniform
+  auto flush = [&]() {
+    if (!staged) return;
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long base = 0;
+    if (__lane_id() == 0) base = atomicAdd(next_count, (unsigned long long)staged);
+    base = __shfl(base, 0, 64);
+    for (uint32_t i = __lane_id(); i < staged; i += 64) {
+      const unsigned long long at = base + i;
+      if (at < nxt_cap) {
+        nxt.state[at] = stg.state[i];
+        nxt.len[at] = stg.len[i];
+        nxt.sp[at] = stg.sp[i];
+        nxt.ep[at] = stg.ep[i];
+      } else {
+        atomicOr(&ctl->overflow, 1ull);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    staged = 0;
+  };
   // all octets of a wave run the same number of rounds so that the wave-wide scans stay convergent
   const uint64_t rounds = (cur_count + noct - 1) / noct;
   for (uint64_t rd = 0; rd < rounds; rd++) {
     const uint64_t q = first + rd * noct;
     const bool have = q < cur_count;
-    uint32_t s = 0, ln = 0, nf = 0, f0 = 0;
+    uint32_t s = 0, ln = 0, nf = 0, f0 = 0, rgx = 0;
     uint64_t sp = 0, ep = 0;
     bool emit = false;
     if (have) {
@@ -99,59 +136,89 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
       ln = cur.len[q];
       sp = cur.sp[q];
       ep = cur.ep[q];
-      const uint32_t c = nfa.st_c[s];
+      const StateRec rec = nfa.st[s];
+      const uint32_t c = rec.c_emit & 0xFFu;
+      rgx = rec.regex;
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
-      backward_step<WIDE>(ix, c, slot, cfc, lc, sp, ep);
+      if (ln == 0) {          // every level-0 element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
+        sp = cfc;
+        ep = (c == 255u) ? ix.n : s_cf[c + 1];
+        if (slot == kSlotNone) ep = sp;
+      } else {
+        backward_step<WIDE>(ix, c, slot, cfc, lc, sp, ep);
+      }
       stepped++;
       if (sp < ep) {                                   // Some((sp1,ep1)), retree.scala:634
         // Glushkov tables: an isLast state emits and has no follows here (:636-641); Thompson / DFA
         // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282)
-        emit = nfa.st_last[s] != 0;
-        f0 = nfa.fol_off[s];
-        nf = nfa.fol_off[s + 1] - f0;
+        emit = (rec.c_emit >> 8) != 0;
+        f0 = rec.fol_off;
+        nf = rec.fol_cnt;
       }
     }
-    // ---- compaction: results by ballot, pushes by wave prefix sum
+    // ---- compaction.  Results: ballot + one atomic per wave (they are few).  Pushes: a single
+    // queue-tail counter cannot take one atomic per wave and round (same-address device atomics run
+    // at ~90 per microsecond), so each wave stages its survivors in LDS and reserves queue slots only
+    // when the stage fills: one atomic per ~200 elements and coalesced queue writes.
     const bool lead = t == 0;
-    const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
-    uint32_t push_total = 0;
-    const uint32_t push_off = wave_excl_scan(lead ? nf : 0u, push_total);
     const uint32_t lane = __lane_id();
-    unsigned long long rbase = 0, qbase = 0;
-    if (lane == 0) {
-      if (em) rbase = atomicAdd(&ctl->res_count, (unsigned long long)__builtin_popcountll(em));
-      if (push_total) qbase = atomicAdd(next_count, (unsigned long long)push_total);
-    }
-    rbase = __shfl(rbase, 0, 64);
-    qbase = __shfl(qbase, 0, 64);
-    if (lead && emit) {
-      const unsigned long long at = rbase + __builtin_popcountll(em & ((1ull << lane) - 1ull));
-      if (at < res_cap) {
-        fmx_result r;
-        r.regex = nfa.st_regex[s];
-        r.len = ln + 1;
-        r.sp = sp;
-        r.ep = ep;
-        res[at] = r;
-      } else {
-        atomicOr(&ctl->overflow, 2ull);
+    const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
+    if (em) {
+      unsigned long long rbase = 0;
+      if (lane == 0) rbase = atomicAdd(&ctl->res_count, (unsigned long long)__builtin_popcountll(em));
+      rbase = __shfl(rbase, 0, 64);
+      if (lead && emit) {
+        const unsigned long long at = rbase + __builtin_popcountll(em & ((1ull << lane) - 1ull));
+        if (at < res_cap) {
+          fmx_result r;
+          r.regex = rgx;
+          r.len = ln + 1;
+          r.sp = sp;
+          r.ep = ep;
+          res[at] = r;
+        } else {
+          atomicOr(&ctl->overflow, 2ull);
+        }
       }
     }
-    // the octet's leader holds its offset; share it with the octet and write follows in parallel
-    const uint32_t my_off = __shfl(push_off, lane & ~7u, 64);
-    for (uint32_t j = t; j < nf; j += kOctet) {
-      const unsigned long long at = qbase + my_off + j;
-      if (at < nxt_cap) {
-        nxt.state[at] = nfa.fol[f0 + j];
-        nxt.len[at] = ln + 1;
-        nxt.sp[at] = sp;
-        nxt.ep[at] = ep;
-      } else {
-        atomicOr(&ctl->overflow, 1ull);
+    const uint32_t nsmall = nf <= kStageSmall ? nf : 0u;
+    uint32_t small_total = 0;
+    const uint32_t small_off = wave_excl_scan(lead ? nsmall : 0u, small_total);
+    if (staged + small_total > kStageCap) flush();
+    if (small_total) {
+      const uint32_t my_off = staged + __shfl(small_off, lane & ~7u, 64);
+      for (uint32_t j = t; j < nsmall; j += kOctet) {
+        stg.state[my_off + j] = nfa.fol[f0 + j];
+        stg.len[my_off + j] = ln + 1;
+        stg.sp[my_off + j] = sp;
+        stg.ep[my_off + j] = ep;
+      }
+      staged += small_total;
+    }
+    // long follows lists (a '.' has 253) go straight to the queue
+    if (__builtin_amdgcn_ballot_w64(nf > kStageSmall)) {
+      const uint32_t nlarge = nf > kStageSmall ? nf : 0u;
+      uint32_t large_total = 0;
+      const uint32_t large_off = wave_excl_scan(lead ? nlarge : 0u, large_total);
+      unsigned long long qbase = 0;
+      if (lane == 0) qbase = atomicAdd(next_count, (unsigned long long)large_total);
+      qbase = __shfl(qbase, 0, 64);
+      const uint32_t my_off = __shfl(large_off, lane & ~7u, 64);
+      for (uint32_t j = t; j < nlarge; j += kOctet) {
+        const unsigned long long at = qbase + my_off + j;
+        if (at < nxt_cap) {
+          nxt.state[at] = nfa.fol[f0 + j];
+          nxt.len[at] = ln + 1;
+          nxt.sp[at] = sp;
+          nxt.ep[at] = ep;
+        } else {
+          atomicOr(&ctl->overflow, 1ull);
+        }
       }
     }
   }
+  flush();
   if (t == 0 && stepped) atomicAdd(&ctl->steps, (unsigned long long)stepped);
 }
 
@@ -186,6 +253,13 @@ struct RegexBatch {
   size_t n_first = 0;
   std::vector<uint32_t> start_final;   // DFA engines whose start state is final: result (len 0, 0, n)
   DevMem mem;
+  // scratch reused across matches of this batch (one match at a time per batch object)
+  std::unique_ptr<DevMem> scratch;
+  Queue qa{}, qb{};
+  fmx_result *d_res = nullptr;
+  FrontierCtl *d_ctl = nullptr;
+  uint64_t qcap = 0;
+  size_t rcap = 0;
   NfaTables nfa{};
   uint32_t *d_first_state = nullptr;
 };
@@ -216,23 +290,18 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   b->n_index = h->n;
   b->n_first = q_state.size();
   b->start_final = start_final;
-  uint8_t *d_c = nullptr, *d_last = nullptr;
-  uint32_t *d_regex = nullptr, *d_foff = nullptr, *d_fol = nullptr;
-  HIP_TRY(b->mem.alloc(&d_c, st_c.size()), "hipMalloc");
-  HIP_TRY(b->mem.alloc(&d_last, st_last.size()), "hipMalloc");
-  HIP_TRY(b->mem.alloc(&d_regex, st_regex.size()), "hipMalloc");
-  HIP_TRY(b->mem.alloc(&d_foff, fol_off.size()), "hipMalloc");
+  std::vector<StateRec> recs(st_c.size());
+  for (size_t q = 0; q < recs.size(); q++)
+    recs[q] = StateRec{fol_off[q], fol_off[q + 1] - fol_off[q], st_regex[q], (uint32_t)st_c[q] | ((uint32_t)(st_last[q] ? 1 : 0) << 8)};
+  StateRec *d_st = nullptr;
+  uint32_t *d_fol = nullptr;
+  HIP_TRY(b->mem.alloc(&d_st, recs.size()), "hipMalloc");
   HIP_TRY(b->mem.alloc(&d_fol, fol.size()), "hipMalloc");
   HIP_TRY(b->mem.alloc(&b->d_first_state, q_state.size()), "hipMalloc");
-  if (!st_c.empty()) {
-    HIP_TRY(hipMemcpy(d_c, st_c.data(), st_c.size(), hipMemcpyHostToDevice), "H2D");
-    HIP_TRY(hipMemcpy(d_last, st_last.data(), st_last.size(), hipMemcpyHostToDevice), "H2D");
-    HIP_TRY(hipMemcpy(d_regex, st_regex.data(), st_regex.size() * 4, hipMemcpyHostToDevice), "H2D");
-  }
-  HIP_TRY(hipMemcpy(d_foff, fol_off.data(), fol_off.size() * 4, hipMemcpyHostToDevice), "H2D");
+  if (!recs.empty()) HIP_TRY(hipMemcpy(d_st, recs.data(), recs.size() * sizeof(StateRec), hipMemcpyHostToDevice), "H2D");
   if (!fol.empty()) HIP_TRY(hipMemcpy(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice), "H2D");
   if (!q_state.empty()) HIP_TRY(hipMemcpy(b->d_first_state, q_state.data(), q_state.size() * 4, hipMemcpyHostToDevice), "H2D");
-  b->nfa = NfaTables{d_c, d_last, d_regex, d_foff, d_fol};
+  b->nfa = NfaTables{d_st, d_fol};
   *out = b.release();
   return FMX_OK;
 }
@@ -258,18 +327,23 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if (b->n_first == 0 && b->start_final.empty()) return FMX_OK;
   if (b->n_first > qcap) { set_error("initial frontier exceeds max_frontier"); return FMX_ERR_OVERFLOW; }
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
-  DevMem mem;
-  Queue qa{}, qb{};
-  fmx_result *d_res = nullptr;
-  FrontierCtl *d_ctl = nullptr;
-  for (Queue *q : {&qa, &qb}) {
-    HIP_TRY(mem.alloc(&q->state, qcap), "hipMalloc(queue)");
-    HIP_TRY(mem.alloc(&q->len, qcap), "hipMalloc(queue)");
-    HIP_TRY(mem.alloc(&q->sp, qcap), "hipMalloc(queue)");
-    HIP_TRY(mem.alloc(&q->ep, qcap), "hipMalloc(queue)");
+  if (!b->scratch || b->qcap != qcap || b->rcap < (cap ? cap : 1)) {
+    b->scratch.reset(new DevMem());
+    b->qcap = 0;
+    for (Queue *q : {&b->qa, &b->qb}) {
+      HIP_TRY(b->scratch->alloc(&q->state, qcap), "hipMalloc(queue)");
+      HIP_TRY(b->scratch->alloc(&q->len, qcap), "hipMalloc(queue)");
+      HIP_TRY(b->scratch->alloc(&q->sp, qcap), "hipMalloc(queue)");
+      HIP_TRY(b->scratch->alloc(&q->ep, qcap), "hipMalloc(queue)");
+    }
+    HIP_TRY(b->scratch->alloc(&b->d_res, cap ? cap : 1), "hipMalloc(results)");
+    HIP_TRY(b->scratch->alloc(&b->d_ctl, 1), "hipMalloc(ctl)");
+    b->qcap = qcap;
+    b->rcap = cap ? cap : 1;
   }
-  HIP_TRY(mem.alloc(&d_res, cap ? cap : 1), "hipMalloc(results)");
-  HIP_TRY(mem.alloc(&d_ctl, 1), "hipMalloc(ctl)");
+  const Queue qa = b->qa, qb = b->qb;
+  fmx_result *d_res = b->d_res;
+  FrontierCtl *d_ctl = b->d_ctl;
   hipStream_t st = nullptr;
   HIP_TRY(hipStreamCreate(&st), "hipStreamCreate");
   struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{st};
@@ -284,7 +358,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // Levels are chained on the stream without host round trips; the host looks at the counters
   // every kChain levels.  A level with an empty queue returns at once.
   constexpr uint32_t kChain = 8;
-  const int grid = h->cu_count * 8;
+  const int grid = h->cu_count * 6;          // what stays resident with 24.5 KB of LDS per workgroup
   FrontierCtl ctl{};
   uint32_t level = 0;
   uint64_t launches = 1;

@@ -259,7 +259,7 @@ class RegexBatch:
     def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22):
         """-> (results as a structured array sorted by (regex, len, sp, ep), per-regex counts)"""
         lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_FRONTIER, int(max_frontier), 0, 0)
-        out = np.zeros(cap, dtype=RESULT_DTYPE)
+        out = np.empty(cap, dtype=RESULT_DTYPE)
         per = np.zeros(max(self.k, 1), dtype=np.uint32)
         n_out = ctypes.c_size_t()
         rc = _lib.check(self._L.fmx_regex_batch_match(self.sa.handle, self._h, ctypes.byref(lim),

@@ -229,7 +229,7 @@ def main():
 
     if rank == 0:
         bytes_per_rank = int(st["block_bytes"])
-        kernel_name = "k_search4" if st["layout"] == 0 else "k_search"
+        kernel_name = "k_search4"
         achieved = ranks_per_step * bytes_per_rank / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "rank_queries_per_sec",

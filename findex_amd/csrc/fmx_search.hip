@@ -173,17 +173,19 @@ __global__ __launch_bounds__(kSThreads) void k_search3(DevIndex ix, const uint8_
 //     (findex.scala:32-36), half the popcount work and one line request instead of two.
 // Octets whose pattern ends early idle until the batch ends (patterns of one batch should have
 // similar lengths; the benchmark's do).
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_t *__restrict__ pat,
                                                         const PatDesc *__restrict__ desc,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
                                                         uint32_t k, unsigned long long *__restrict__ counters) {
+  // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
+  // slot (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
   __shared__ uint4 s_tab[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) {
     const uint64_t cf = ix.cf[c];
     const uint16_t s = ix.slot[c];
     uint64_t vb = 0;
-    if (s < kSlotEof) vb = (uint64_t)(uintptr_t)ix.bv + (uint64_t)s * ix.nblocks * kBlockBytes;
+    if (s < kSlotEof) vb = LAYOUT == kLayoutBytes ? (uint64_t)s + 2 : (uint64_t)(uintptr_t)ix.bv + (uint64_t)s * ix.nblocks * kBlockBytes;
     else if (s == kSlotEof) vb = 1;
     s_tab[c] = make_uint4((uint32_t)cf, (uint32_t)(cf >> 32), (uint32_t)vb, (uint32_t)(vb >> 32));
   }
@@ -220,58 +222,80 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_
         if (left > 4) nx = fetch4(pat, cur - 4);
       }
     };
+    // symbols without a vector: absent (x = 0) or the EOF symbol (x = 1)
+    auto step_special = [&](uint64_t cfc, uint64_t vb) {
+      next_char();
+      const uint64_t r1 = (vb == 1 && sp > ix.eof) ? 1 : 0;
+      const uint64_t r2 = (vb == 1 && ep > ix.eof) ? 1 : 0;
+      sp = cfc + r1;
+      ep = cfc + r2;
+    };
     for (;;) {
       const bool stepping = left > 0 && sp < ep;
       if (!__builtin_amdgcn_ballot_w64(stepping)) break;
       const bool wide_iv = stepping && (ep - sp) != 1;
       if (!__builtin_amdgcn_ballot_w64(wide_iv)) {
-        // ---- every stepping octet holds one row
+        // ---- every stepping octet holds one row: one rank query + one bit (byte) test
         if (stepping) {
-          const uint4 e = s_tab[ch & 0xFFu];
+          const uint32_t c = ch & 0xFFu;
+          const uint4 e = s_tab[c];
           const uint64_t cfc = ((uint64_t)e.y << 32) | e.x;
           const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
           if (vb > 1) {
-            uint32_t b1, m1;
-            split960(sp, b1, m1);
-            const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
-            next_char();
-            const uint32_t d = (m1 >> 5) + 2;                    // dword of the line that holds bit sp
-            const uint32_t comp = d & 3u;
-            const uint32_t word = comp < 2u ? (comp == 0u ? w1.x : w1.y) : (comp == 2u ? w1.z : w1.w);
-            uint32_t bit = __builtin_amdgcn_ubfe(word, m1, 1u);   // offset taken mod 32
-            bit = (d >> 2) == t ? bit : 0u;
-            sp = cfc + rank_finish<WIDE>(w1, m1, lc);
-            ep = sp + octet_or(bit);
+            if (LAYOUT == kLayoutBytes) {
+              const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), sp, lc);
+              next_char();
+              const uint32_t bidx = q1.rem & 15u;                    // byte of this lane that holds row sp
+              const uint32_t comp = bidx >> 2;
+              const uint32_t word = comp < 2u ? (comp == 0u ? q1.w.x : q1.w.y) : (comp == 2u ? q1.w.z : q1.w.w);
+              const uint32_t byte = __builtin_amdgcn_ubfe(word, 8u * (bidx & 3u), 8u);
+              const uint32_t bit = ((q1.rem >> 4) == t && byte == c) ? 1u : 0u;
+              sp = cfc + byte_rank_finish(q1, c, lc);
+              ep = sp + octet_or(bit);
+            } else {
+              uint32_t b1, m1;
+              split960(sp, b1, m1);
+              const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
+              next_char();
+              const uint32_t d = (m1 >> 5) + 2;                    // dword of the line that holds bit sp
+              const uint32_t comp = d & 3u;
+              const uint32_t word = comp < 2u ? (comp == 0u ? w1.x : w1.y) : (comp == 2u ? w1.z : w1.w);
+              uint32_t bit = __builtin_amdgcn_ubfe(word, m1, 1u);   // offset taken mod 32
+              bit = (d >> 2) == t ? bit : 0u;
+              sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+              ep = sp + octet_or(bit);
+            }
           } else {
-            next_char();
-            const uint64_t r1 = (vb == 1 && sp > ix.eof) ? 1 : 0;
-            const uint64_t r2 = (vb == 1 && ep > ix.eof) ? 1 : 0;
-            sp = cfc + r1;
-            ep = cfc + r2;
+            step_special(cfc, vb);
           }
           steps++;
         }
       } else if (stepping) {
         // ---- general step: two rank queries
-        const uint4 e = s_tab[ch & 0xFFu];
+        const uint32_t c = ch & 0xFFu;
+        const uint4 e = s_tab[c];
         const uint64_t cfc = ((uint64_t)e.y << 32) | e.x;
         const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
         if (vb > 1) {
-          uint32_t b1, b2, m1, m2;
-          split960(sp, b1, m1);
-          split960(ep, b2, m2);
-          const uint64_t base = vb + lane_off;
-          const uint4 w1 = load_line16(base + (uint64_t)b1 * kBlockBytes);
-          const uint4 w2 = load_line16(base + (uint64_t)b2 * kBlockBytes);
-          next_char();
-          sp = cfc + rank_finish<WIDE>(w1, m1, lc);
-          ep = cfc + rank_finish<WIDE>(w2, m2, lc);
+          if (LAYOUT == kLayoutBytes) {
+            const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), sp, lc);
+            const ByteRankReq q2 = byte_rank_issue(ix, (uint16_t)(vb - 2), ep, lc);
+            next_char();
+            sp = cfc + byte_rank_finish(q1, c, lc);
+            ep = cfc + byte_rank_finish(q2, c, lc);
+          } else {
+            uint32_t b1, b2, m1, m2;
+            split960(sp, b1, m1);
+            split960(ep, b2, m2);
+            const uint64_t base = vb + lane_off;
+            const uint4 w1 = load_line16(base + (uint64_t)b1 * kBlockBytes);
+            const uint4 w2 = load_line16(base + (uint64_t)b2 * kBlockBytes);
+            next_char();
+            sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+            ep = cfc + rank_finish<WIDE>(w2, m2, lc);
+          }
         } else {
-          next_char();
-          const uint64_t r1 = (vb == 1 && sp > ix.eof) ? 1 : 0;
-          const uint64_t r2 = (vb == 1 && ep > ix.eof) ? 1 : 0;
-          sp = cfc + r1;
-          ep = cfc + r2;
+          step_special(cfc, vb);
         }
         steps++;
       }
@@ -314,14 +338,14 @@ static hipError_t launch_v3w(const Index *h, const uint8_t *pat, const PatDesc *
   return hipGetLastError();
 }
 
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 static hipError_t launch_v4w(const Index *h, const uint8_t *pat, const PatDesc *desc, uint64_t *sp, uint64_t *ep,
                              uint32_t k, hipStream_t st) {
-  static const int per_cu = blocks_per_cu(k_search4<WIDE>);
+  static const int per_cu = blocks_per_cu(k_search4<WIDE, LAYOUT>);
   uint64_t want = ((uint64_t)k + kSOctets - 1) / kSOctets;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search4<WIDE><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters);
+  k_search4<WIDE, LAYOUT><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters);
   return hipGetLastError();
 }
 
@@ -330,7 +354,8 @@ hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, v
   if (!k) return hipSuccess;
   const int variant = search_variant();
   // the tuned kernel serves the one-hot layout; the bytes layout uses the generic step kernel
-  if (variant == 1 || k > 0xFFFFFFF0ull || h->layout != kLayoutOneHot) return launch_search_v1(h, d_pat, d_off, d_sp, d_ep, k, st);
+  if (variant == 1 || k > 0xFFFFFFF0ull || (variant == 2 && h->layout != kLayoutOneHot))
+    return launch_search_v1(h, d_pat, d_off, d_sp, d_ep, k, st);
   PatDesc *desc = nullptr;
   hipError_t e = hipMallocAsync((void **)&desc, k * sizeof(PatDesc), st);
   if (e != hipSuccess) return e;
@@ -342,7 +367,11 @@ hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, v
     const bool wide = h->n > (1ull << 32);
     const uint8_t *p = (const uint8_t *)d_pat;
     uint64_t *osp = (uint64_t *)d_sp, *oep = (uint64_t *)d_ep;
-    if (variant == 3) e = wide ? launch_v4w<true>(h, p, desc, osp, oep, (uint32_t)k, st) : launch_v4w<false>(h, p, desc, osp, oep, (uint32_t)k, st);
+    if (variant == 3 && h->layout == kLayoutBytes)
+      e = launch_v4w<true, kLayoutBytes>(h, p, desc, osp, oep, (uint32_t)k, st);      // bytes-layout counts are 64-bit sums anyway
+    else if (variant == 3)
+      e = wide ? launch_v4w<true, kLayoutOneHot>(h, p, desc, osp, oep, (uint32_t)k, st)
+               : launch_v4w<false, kLayoutOneHot>(h, p, desc, osp, oep, (uint32_t)k, st);
     else e = wide ? launch_v3w<true>(h, p, desc, osp, oep, (uint32_t)k, st) : launch_v3w<false>(h, p, desc, osp, oep, (uint32_t)k, st);
   }
   hipError_t e2 = hipFreeAsync(desc, st);

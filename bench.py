@@ -98,6 +98,27 @@ def make_patterns(torch, hip, n, sigma, k, m, seed, device, stream):
     return pats.reshape(-1), off
 
 
+def effective_cores():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota
+    (the GPU boxes expose 256 CPUs but grant a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, -(-q // p)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(torch, hip_full, sigma, m, device, stream, rank):
     """The CPU path beside the GPU number: the oracle's restatement of the reference algorithm
     (inverted position lists + binary-search occ, bwtmerger.scala:354-375) on this host's cores,
@@ -122,7 +143,7 @@ def cpu_baseline(torch, hip_full, sigma, m, device, stream, rank):
     t_build = time.time() - t0
     h_pats = pats.cpu().numpy()
     h_off = off.cpu().numpy().astype(np.uint64)
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     t0 = time.time()
     wsp, wep, steps = orc.search_batch(h_pats, h_off, threads=cores)
     dt = time.time() - t0
@@ -149,6 +170,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # this image exports NCCL_DEBUG=VERSION, which makes RCCL print a banner on stdout; stdout carries
+    # the one JSON line, so drop that setting (any other value the user chose is kept)
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        del os.environ["NCCL_DEBUG"]
     import torch
     import torch.distributed as dist
     import findex_amd
@@ -160,7 +185,9 @@ def main():
         log(rank, "note: WORLD_SIZE=%d but --gpus=%d; using WORLD_SIZE" % (world, args.gpus))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # under torch.distributed.run (RANK/MASTER_* set) the RCCL path runs even for one rank
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -183,7 +210,7 @@ def main():
 
     def step():
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
-        if world > 1:       # the path's one exchange: gather the hit intervals over RCCL/xGMI
+        if use_dist:        # the path's one exchange: gather the hit intervals over RCCL/xGMI
             return gather_intervals_dev(sp, ep)
 
     # rank queries one step executes (device counter; identical every step)
@@ -198,7 +225,7 @@ def main():
     torch.cuda.synchronize()
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -206,16 +233,16 @@ def main():
         a.record()          # torch's current stream == the stream the kernel is launched on
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
         b.record()
-        if world > 1:
+        if use_dist:
             gather_intervals_dev(sp, ep)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
     tot = torch.tensor([dt, float(ranks_per_step), float(hits), kernel_ms], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone()
@@ -252,7 +279,7 @@ def main():
                 "hit_patterns_fraction": hits_all / (world * k),
                 "rank_queries_per_step": ranks_all,
                 "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
-                               % (world, ", all_gather of (sp,ep) per step" if world > 1 else ""),
+                               % (world, ", all_gather of (sp,ep) per step" if use_dist else ""),
                 "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
                 "index_layout": "one-hot bit-vectors, 128-B blocks" if st["layout"] == 0 else "BWT bytes + checkpoints",
             },
@@ -268,7 +295,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, hip, sigma, m, device, stream, rank)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -68,7 +68,10 @@ __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
   uint32_t done = 0;
   for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
+    // the device-pointer entry point cannot validate its operands on the host: keep them inside the index
     uint64_t sp = sp_in[q], ep = ep_in[q];
+    if (sp > ix.n) sp = ix.n;
+    if (ep > ix.n) ep = ix.n;
     step<WIDE>(ix, tb, c[q], lc, sp, ep);
     if (t == 0) { sp1[q] = sp; ep1[q] = ep; }
     done++;
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_
   uint32_t done = 0;
   for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
     uint64_t r = rows[q];
+    if (r >= ix.n) r = ix.n - 1;          // unvalidated device operands stay inside the index
     for (uint32_t s = 0; s < len; s++) {
       const uint32_t b = r == ix.eof ? 0u : ix.bwt[r];
       if (out_bytes && t == 0) out_bytes[q * len + s] = (uint8_t)b;
@@ -228,7 +232,7 @@ __device__ uint64_t psi_one(const DevIndex &ix, const uint64_t *cf, const uint16
 __global__ __launch_bounds__(kThreads) void k_psi(DevIndex ix, const uint64_t *__restrict__ rows,
                                                    uint64_t *__restrict__ out, uint64_t k) {
   for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < k; q += (uint64_t)gridDim.x * blockDim.x)
-    out[q] = psi_one(ix, ix.cf, ix.slot, rows[q]);
+    out[q] = psi_one(ix, ix.cf, ix.slot, rows[q] < ix.n ? rows[q] : ix.n - 1);
 }
 
 // NaiveFMSearcher.nextSubstr (bwtmerger.scala:394-405) for k independent (sp) starts: walk Psi,

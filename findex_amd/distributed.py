@@ -125,7 +125,7 @@ def gather_intervals_dev(sp, ep, group=None):
     one all_gather_into_tensor of 16 B per pattern; returns a (world, 2, k) tensor."""
     rank, world = _group_info(group)
     mine = torch.stack([sp, ep])
-    if world == 1:
+    if dist is None or not dist.is_initialized():
         return mine.unsqueeze(0)
     out = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
     dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group)

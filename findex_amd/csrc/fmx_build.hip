@@ -39,17 +39,33 @@ __global__ __launch_bounds__(kBuildThreads) void k_hist(const uint8_t *__restric
     hist[(uint64_t)blockIdx.x * 256 + c] = (uint64_t)h[0][c] + h[1][c] + h[2][c] + h[3][c];
 }
 
-// One thread per symbol walks the superchunks: hist becomes the exclusive prefix, totals[c] the sum.
+// One workgroup per symbol: exclusive scan of that symbol's per-superchunk counts, 256 superchunks
+// per trip with a carried total; hist becomes the exclusive prefix, totals[c] the sum.
 __global__ __launch_bounds__(256) void k_scan(uint64_t *__restrict__ hist, uint64_t nsuper,
                                                uint64_t *__restrict__ totals) {
-  const int c = threadIdx.x;
-  uint64_t run = 0;
-  for (uint64_t s = 0; s < nsuper; s++) {
-    uint64_t v = hist[s * 256 + c];
-    hist[s * 256 + c] = run;
-    run += v;
+  __shared__ uint64_t buf[256];
+  __shared__ uint64_t carry;
+  const int c = blockIdx.x;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint64_t s0 = 0; s0 < nsuper; s0 += 256) {
+    const uint64_t s = s0 + threadIdx.x;
+    const uint64_t v = s < nsuper ? hist[s * 256 + c] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {              // Hillis-Steele inclusive scan in LDS
+      const uint64_t add = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const uint64_t base = carry;
+    if (s < nsuper) hist[s * 256 + c] = base + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry = base + buf[255];
+    __syncthreads();
   }
-  totals[c] = run;
+  if (threadIdx.x == 0) totals[c] = carry;
 }
 
 __global__ __launch_bounds__(kBuildThreads) void k_fill(const uint8_t *__restrict__ bwt, uint64_t n, uint64_t eof,
@@ -183,7 +199,7 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
     if (bytes_layout) k_hist_bytes<<<(int)nsuper, kBuildThreads, 0, st>>>((const uint8_t *)h->d_bwt, h->n, d_hist);
     else k_hist<<<(int)nsuper, kBuildThreads, 0, st>>>((const uint8_t *)h->d_bwt, h->n, h->eof, d_hist);
     FMX_TRY(hipGetLastError(), "k_hist");
-    k_scan<<<1, 256, 0, st>>>(d_hist, nsuper, d_tot);
+    k_scan<<<256, 256, 0, st>>>(d_hist, nsuper, d_tot);
     FMX_TRY(hipGetLastError(), "k_scan");
     FMX_TRY(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st), "copy totals");
     FMX_TRY(hipStreamSynchronize(st), "sync(hist)");

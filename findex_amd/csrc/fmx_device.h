@@ -195,6 +195,45 @@ __device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint32_t c, ui
   return rank_finish<WIDE>(load_line16(block_addr(ix, slot, blk, lc)), rem, lc);
 }
 
+// The same in two halves, so that a kernel can have several independent rank queries in flight per
+// octet: rank_issue requests the line(s), rank_complete consumes them.
+struct RankReq {
+  uint4 w;            // one-hot: the block line; bytes: the BWT block line
+  uint32_t rem;
+  uint32_t chk;       // bytes layout
+  uint64_t sup;       // bytes layout; immediate value when kind == 0
+  uint32_t kind;      // 0 immediate, 1 one-hot, 2 bytes
+};
+
+__device__ __forceinline__ RankReq rank_issue(const DevIndex &ix, uint16_t slot, uint64_t x, const LaneConst &lc) {
+  RankReq q;
+  q.w = make_uint4(0, 0, 0, 0);
+  q.rem = 0; q.chk = 0; q.sup = 0; q.kind = 0;
+  if (slot == kSlotNone) return q;
+  if (slot == kSlotEof) { q.sup = x > ix.eof ? 1 : 0; return q; }
+  if (ix.layout == kLayoutBytes) {
+    const ByteRankReq b = byte_rank_issue(ix, slot, x, lc);
+    q.w = b.w; q.rem = b.rem; q.chk = b.chk; q.sup = b.sup; q.kind = 2;
+    return q;
+  }
+  uint32_t blk;
+  split960(x, blk, q.rem);
+  q.w = load_line16(block_addr(ix, slot, blk, lc));
+  q.kind = 1;
+  return q;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ uint64_t rank_complete(const RankReq &q, uint32_t c, const LaneConst &lc) {
+  if (q.kind == 0) return q.sup;
+  if (q.kind == 2) {
+    ByteRankReq b;
+    b.w = q.w; b.rem = q.rem; b.chk = q.chk; b.sup = q.sup;
+    return byte_rank_finish(b, c, lc);
+  }
+  return rank_finish<WIDE>(q.w, q.rem, lc);
+}
+
 // One backward step for the whole octet: (sp, ep) -> (C[c]+rank(c,sp), C[c]+rank(c,ep)), the body
 // of SuffixAlgo.getPrevRange (findex.scala:32-36).  All lines are requested before any is consumed.
 template <bool WIDE>

@@ -43,13 +43,23 @@ __global__ __launch_bounds__(kThreads) void k_occ(DevIndex ix, const uint8_t *__
   const uint32_t t = lc.t;
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
   uint32_t done = 0;
-  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
-    int64_t key = i[q];
-    uint64_t x = key < 0 ? 0 : ((uint64_t)key >= ix.n ? ix.n : (uint64_t)key + 1);
-    const uint32_t cq = c[q];
-    uint64_t r = rank_excl<WIDE>(ix, cq, tb.slot[cq], x, lc);
-    if (t == 0) out[q] = r;
+  auto boundary = [&](int64_t key) { return key < 0 ? 0 : ((uint64_t)key >= ix.n ? ix.n : (uint64_t)key + 1); };
+  // two independent queries per octet and trip: both lines are in flight together
+  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += 2 * noct) {
+    const uint64_t q2 = q + noct;
+    const bool two = q2 < k;
+    const uint32_t c1 = c[q], c2 = two ? c[q2] : 0u;
+    const RankReq r1 = rank_issue(ix, tb.slot[c1], boundary(i[q]), lc);
+    RankReq r2 = r1;
+    if (two) r2 = rank_issue(ix, tb.slot[c2], boundary(i[q2]), lc);
+    const uint64_t v1 = rank_complete<WIDE>(r1, c1, lc);
+    if (t == 0) out[q] = v1;
     done++;
+    if (two) {
+      const uint64_t v2 = rank_complete<WIDE>(r2, c2, lc);
+      if (t == 0) out[q2] = v2;
+      done++;
+    }
   }
   if (t == 0 && done) atomicAdd(&counters[0], (unsigned long long)done);
 }
@@ -146,16 +156,31 @@ __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_
   const uint32_t t = lc.t;
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
   uint32_t done = 0;
-  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
-    uint64_t r = rows[q];
-    if (r >= ix.n) r = ix.n - 1;          // unvalidated device operands stay inside the index
+  // two walks per octet, stepped together: their (dependent) chains overlap
+  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += 2 * noct) {
+    const uint64_t q2 = q + noct;
+    const bool two = q2 < k;
+    uint64_t ra = rows[q], rb = two ? rows[q2] : 0;
+    if (ra >= ix.n) ra = ix.n - 1;          // unvalidated device operands stay inside the index
+    if (rb >= ix.n) rb = ix.n - 1;
     for (uint32_t s = 0; s < len; s++) {
-      const uint32_t b = r == ix.eof ? 0u : ix.bwt[r];
-      if (out_bytes && t == 0) out_bytes[q * len + s] = (uint8_t)b;
-      r = tb.cf[b] + rank_excl<WIDE>(ix, b, tb.slot[b], r, lc);
+      const uint32_t ba = ra == ix.eof ? 0u : ix.bwt[ra];
+      const uint32_t bb = two ? (rb == ix.eof ? 0u : ix.bwt[rb]) : 0u;
+      if (out_bytes && t == 0) {
+        out_bytes[q * len + s] = (uint8_t)ba;
+        if (two) out_bytes[q2 * len + s] = (uint8_t)bb;
+      }
+      const RankReq qa = rank_issue(ix, tb.slot[ba], ra, lc);
+      RankReq qb = qa;
+      if (two) qb = rank_issue(ix, tb.slot[bb], rb, lc);
+      ra = tb.cf[ba] + rank_complete<WIDE>(qa, ba, lc);
+      if (two) rb = tb.cf[bb] + rank_complete<WIDE>(qb, bb, lc);
     }
-    if (end_rows && t == 0) end_rows[q] = r;
-    done += len;
+    if (end_rows && t == 0) {
+      end_rows[q] = ra;
+      if (two) end_rows[q2] = rb;
+    }
+    done += two ? 2 * len : len;
   }
   if (t == 0 && done) atomicAdd(&counters[0], (unsigned long long)done);
 }
@@ -170,10 +195,20 @@ __global__ __launch_bounds__(kThreads) void k_fm_fill(DevIndex ix, uint64_t p0, 
   stage_tables(ix, tb);
   const LaneConst lc = lane_const();
   const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
-  for (uint64_t p = p0 + (((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3); p < p1; p += noct) {
-    const uint32_t b = p == ix.eof ? 0u : ix.bwt[p];
-    const uint64_t r = tb.cf[b] + rank_excl<WIDE>(ix, b, tb.slot[b], p, lc);
-    if (lc.t == 0) fm[r] = __builtin_bswap32((uint32_t)p);
+  for (uint64_t p = p0 + (((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3); p < p1; p += 2 * noct) {
+    const uint64_t pb = p + noct;
+    const bool two = pb < p1;
+    const uint32_t b1 = p == ix.eof ? 0u : ix.bwt[p];
+    const uint32_t b2 = two ? (pb == ix.eof ? 0u : ix.bwt[pb]) : 0u;
+    const RankReq r1 = rank_issue(ix, tb.slot[b1], p, lc);
+    RankReq r2 = r1;
+    if (two) r2 = rank_issue(ix, tb.slot[b2], pb, lc);
+    const uint64_t v1 = tb.cf[b1] + rank_complete<WIDE>(r1, b1, lc);
+    if (lc.t == 0) fm[v1] = __builtin_bswap32((uint32_t)p);
+    if (two) {
+      const uint64_t v2 = tb.cf[b2] + rank_complete<WIDE>(r2, b2, lc);
+      if (lc.t == 0) fm[v2] = __builtin_bswap32((uint32_t)pb);
+    }
   }
 }
 

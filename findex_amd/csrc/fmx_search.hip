@@ -276,7 +276,14 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_
         const uint4 e = s_tab[c];
         const uint64_t cfc = ((uint64_t)e.y << 32) | e.x;
         const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
-        if (vb > 1) {
+        if (sp == 0 && ep == ix.n && vb > 1) {
+          // first step of every pattern: rank(c, 0) = 0 and rank(c, n) = the symbol's count, i.e. the
+          // interval is the symbol's whole bucket [C[c], C[c+1]) -- no line needed
+          const uint4 e2 = s_tab[(c + 1) & 0xFFu];
+          next_char();
+          sp = cfc;
+          ep = c == 255u ? ix.n : (((uint64_t)e2.y << 32) | e2.x);
+        } else if (vb > 1) {
           if (LAYOUT == kLayoutBytes) {
             const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), sp, lc);
             const ByteRankReq q2 = byte_rank_issue(ix, (uint16_t)(vb - 2), ep, lc);

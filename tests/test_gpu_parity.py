@@ -302,6 +302,55 @@ def test_regex_reference_order_and_limits(testdata, name, be):
     assert [r.key() for r in one] == want
 
 
+def test_random_regexes_all_engines_vs_oracle(testdata):
+    """Differential test: ~300 random regexes over a small alphabet (test_regex_compile.random_regex),
+    every one the reference can parse, through the three engines' tables on the GPU against the
+    oracle: ReTree frontier mode (all matches), ReTree reference-order mode under tight limits, and
+    the Thompson engine when createNFA accepts the regex."""
+    import random
+    from oracle import engines as E
+    from test_regex_compile import random_regex
+    hip, orc = pair_from_mem(*bwt_of_text((b"abcde" * 3 + b"badcebadce" + b"eeddccbbaa" + b"abacadaeab") * 4))
+    rng = random.Random(99)
+    regs = []
+    while len(regs) < 300:
+        re = random_regex(rng)
+        if "." in re or "\\w" in re or "\\d" in re:
+            continue
+        try:
+            tb = R.ReTree(R.re2post(re)).tables()
+        except (R.MatchError, R.Re2PostSyntax):
+            continue
+        # follows lists that repeat a node (nested stars) make the undeduplicated frontier grow
+        # exponentially, in the reference too: keep the regexes whose full search is small
+        if orc.match_tables(tb, 1 << 40, 5000)[1] != 0:
+            continue
+        regs.append(re)
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re)) for re in regs]
+    got = findex_amd.ReTree.matchSA_batch(hip, trees, max_steps=1 << 16, cap=1 << 22)
+    assert not findex_amd.ReTree.last_truncated
+    ref = findex_amd.ReTree.matchSA_batch(hip, trees, mode="reference", maxBranching=24, maxIterations=40, cap=1 << 22)
+    n_thompson = 0
+    for re, g, rf in zip(regs, got, ref):
+        t = R.ReTree(R.re2post(re)).tables()
+        want, left, _ = orc.match_tables(t, 1 << 40, 0, cap=1 << 22)
+        assert left == 0 and [r.key() for r in g] == sorted(want), re
+        assert [r.key() for r in rf] == orc.match_tables(t, 24, 40)[0], re
+        try:
+            onfa = E.createNFA(R.re2post(re))
+            if any(s is E.MatchState for s in onfa.outStates()):
+                raise R.MatchError("nullable")
+        except R.MatchError:
+            with pytest.raises(findex_amd.MatchError):
+                findex_amd.REParser.createNFA(findex_amd.REParser.re2post(re))
+            continue
+        nfa = findex_amd.REParser.createNFA(findex_amd.REParser.re2post(re))
+        assert [r.key() for r in findex_amd.REParser.matchSA(nfa, hip, maxLength=64)] == sorted(
+            E.nfa_matchSA(onfa, _OIdx(orc), maxLength=64)), re
+        n_thompson += 1
+    assert n_thompson > 50
+
+
 def oracle_results_capped(bwt, eof, counts, re, max_len):
     """All matches of length <= max_len: breadth-first over the oracle's getPrevRange."""
     orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)

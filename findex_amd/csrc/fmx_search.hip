@@ -38,16 +38,31 @@ __device__ __forceinline__ uint32_t fetch4(const uint8_t *__restrict__ pat, uint
   return r;
 }
 
+// Pre-pass: one descriptor per pattern, and a verdict on the batch's shape: `ragged` is set when some
+// group of 8 consecutive patterns (one lockstep batch of k_search4) has lengths that differ by more
+// than a quarter of its longest -- then the dynamic-refill kernel serves the call instead.
 __global__ __launch_bounds__(256) void k_prep(const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
-                                               PatDesc *__restrict__ desc, uint32_t k) {
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < k; q += gridDim.x * blockDim.x) {
-    const uint64_t b = off[q], e = off[q + 1];
-    const uint64_t len = e - b;
-    PatDesc d;
-    d.end = e;
-    d.len = (uint32_t)len;
-    d.tail4 = len ? fetch4(pat, e) : 0;
-    desc[q] = d;
+                                               PatDesc *__restrict__ desc, uint32_t k, uint32_t *__restrict__ ragged) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t rounds = (k + stride - 1) / stride;          // same trip count for every lane: DPP below
+  for (uint32_t rd = 0; rd < rounds; rd++) {
+    const uint32_t q = rd * stride + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t len32 = 0;
+    if (q < k) {
+      const uint64_t b = off[q], e = off[q + 1];
+      const uint64_t len = e - b;
+      PatDesc d;
+      d.end = e;
+      d.len = (uint32_t)len;
+      d.tail4 = len ? fetch4(pat, e) : 0;
+      desc[q] = d;
+      len32 = d.len;
+    }
+    // max and min over the octet = over one lockstep batch (patterns past k count as the last length)
+    uint32_t mx = len32, mn = q < k ? len32 : 0xFFFFFFFFu;
+    mx = max(mx, dpp<kDppXor1>(mx)); mx = max(mx, dpp<kDppXor2>(mx)); mx = max(mx, dpp<kDppHalfMirror>(mx));
+    mn = min(mn, dpp<kDppXor1>(mn)); mn = min(mn, dpp<kDppXor2>(mn)); mn = min(mn, dpp<kDppHalfMirror>(mn));
+    if (q < k && (threadIdx.x & 7) == 0 && (uint64_t)(mx - mn) * 4 > mx) *ragged = 1u;
   }
 }
 
@@ -68,7 +83,9 @@ template <bool WIDE>
 __global__ __launch_bounds__(kSThreads) void k_search3(DevIndex ix, const uint8_t *__restrict__ pat,
                                                         const PatDesc *__restrict__ desc,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
-                                                        uint32_t k, unsigned long long *__restrict__ counters) {
+                                                        uint32_t k, unsigned long long *__restrict__ counters,
+                                                        const uint32_t *__restrict__ ragged) {
+  if (*ragged == 0u) return;          // uniform batch: k_search4 serves it
   __shared__ uint4 s_tab[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) {
     const uint64_t cf = ix.cf[c];
@@ -177,7 +194,10 @@ template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_t *__restrict__ pat,
                                                         const PatDesc *__restrict__ desc,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
-                                                        uint32_t k, unsigned long long *__restrict__ counters) {
+                                                        uint32_t k, unsigned long long *__restrict__ counters,
+                                                        const uint32_t *__restrict__ ragged, uint32_t serve_ragged) {
+  // k_prep's verdict: very uneven batches go to the dynamic-refill kernel (one-hot layout only)
+  if (!serve_ragged && *ragged != 0u) return;
   // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
   // slot (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
   __shared__ uint4 s_tab[256];
@@ -320,7 +340,7 @@ static int search_variant() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("FMX_SEARCH_VARIANT");
-    v = e ? atoi(e) : 3;      // 1 generic step kernel, 2 k_search3 (dynamic refill), 3 k_search4 (lockstep)
+    v = e ? atoi(e) : 3;      // measured (tools/ragged_bench.py): lockstep wins or ties on every mix tried
   }
   return v;
 }
@@ -336,50 +356,65 @@ static int blocks_per_cu(K kernel) {
 
 template <bool WIDE>
 static hipError_t launch_v3w(const Index *h, const uint8_t *pat, const PatDesc *desc, uint64_t *sp, uint64_t *ep,
-                             uint32_t k, hipStream_t st) {
+                             uint32_t k, const uint32_t *ragged, hipStream_t st) {
   static const int per_cu = blocks_per_cu(k_search3<WIDE>);
   uint64_t want = ((uint64_t)k + kSOctets - 1) / kSOctets;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search3<WIDE><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters);
+  k_search3<WIDE><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters, ragged);
   return hipGetLastError();
 }
 
 template <bool WIDE, uint32_t LAYOUT>
 static hipError_t launch_v4w(const Index *h, const uint8_t *pat, const PatDesc *desc, uint64_t *sp, uint64_t *ep,
-                             uint32_t k, hipStream_t st) {
+                             uint32_t k, const uint32_t *ragged, uint32_t serve_ragged, hipStream_t st) {
   static const int per_cu = blocks_per_cu(k_search4<WIDE, LAYOUT>);
   uint64_t want = ((uint64_t)k + kSOctets - 1) / kSOctets;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search4<WIDE, LAYOUT><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters);
+  k_search4<WIDE, LAYOUT><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters, ragged, serve_ragged);
   return hipGetLastError();
 }
 
+// FMX_SEARCH_VARIANT: 1 generic step kernel; 2 always the dynamic-refill kernel (one-hot layout);
+// 3 (default) always the lockstep kernel; 0: k_prep decides per call -- the lockstep kernel for batches
+// whose groups of 8 have similar lengths, the dynamic-refill kernel for very uneven ones (both are
+// launched; the one that is not wanted returns at once).
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
                          hipStream_t st) {
   if (!k) return hipSuccess;
   const int variant = search_variant();
-  // the tuned kernel serves the one-hot layout; the bytes layout uses the generic step kernel
   if (variant == 1 || k > 0xFFFFFFF0ull || (variant == 2 && h->layout != kLayoutOneHot))
     return launch_search_v1(h, d_pat, d_off, d_sp, d_ep, k, st);
   PatDesc *desc = nullptr;
-  hipError_t e = hipMallocAsync((void **)&desc, k * sizeof(PatDesc), st);
+  hipError_t e = hipMallocAsync((void **)&desc, (k + 1) * sizeof(PatDesc), st);
   if (e != hipSuccess) return e;
+  uint32_t *ragged = reinterpret_cast<uint32_t *>(desc + k);        // the flag lives behind the descriptors
   int pg = (int)((k + 255) / 256);
   if (pg > h->cu_count * 8) pg = h->cu_count * 8;
-  k_prep<<<pg, 256, 0, st>>>((const uint8_t *)d_pat, (const uint64_t *)d_off, desc, (uint32_t)k);
-  e = hipGetLastError();
+  e = hipMemsetAsync(ragged, 0, sizeof(PatDesc), st);
+  if (e == hipSuccess) {
+    k_prep<<<pg, 256, 0, st>>>((const uint8_t *)d_pat, (const uint64_t *)d_off, desc, (uint32_t)k, ragged);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) {
     const bool wide = h->n > (1ull << 32);
+    const bool onehot = h->layout == kLayoutOneHot;
     const uint8_t *p = (const uint8_t *)d_pat;
     uint64_t *osp = (uint64_t *)d_sp, *oep = (uint64_t *)d_ep;
-    if (variant == 3 && h->layout == kLayoutBytes)
-      e = launch_v4w<true, kLayoutBytes>(h, p, desc, osp, oep, (uint32_t)k, st);      // bytes-layout counts are 64-bit sums anyway
-    else if (variant == 3)
-      e = wide ? launch_v4w<true, kLayoutOneHot>(h, p, desc, osp, oep, (uint32_t)k, st)
-               : launch_v4w<false, kLayoutOneHot>(h, p, desc, osp, oep, (uint32_t)k, st);
-    else e = wide ? launch_v3w<true>(h, p, desc, osp, oep, (uint32_t)k, st) : launch_v3w<false>(h, p, desc, osp, oep, (uint32_t)k, st);
+    const uint32_t kk = (uint32_t)k;
+    if (variant == 2) {                       // force: make the refill kernel see "ragged"
+      e = hipMemsetAsync(ragged, 1, 1, st);
+      if (e == hipSuccess) e = wide ? launch_v3w<true>(h, p, desc, osp, oep, kk, ragged, st) : launch_v3w<false>(h, p, desc, osp, oep, kk, ragged, st);
+    } else {
+      // lockstep kernel: serves everything when forced (variant 3) or when no refill kernel exists
+      const uint32_t serve_all = (variant == 3 || !onehot) ? 1u : 0u;
+      if (!onehot) e = launch_v4w<true, kLayoutBytes>(h, p, desc, osp, oep, kk, ragged, serve_all, st);   // counts are 64-bit sums there
+      else e = wide ? launch_v4w<true, kLayoutOneHot>(h, p, desc, osp, oep, kk, ragged, serve_all, st)
+                    : launch_v4w<false, kLayoutOneHot>(h, p, desc, osp, oep, kk, ragged, serve_all, st);
+      if (e == hipSuccess && !serve_all)
+        e = wide ? launch_v3w<true>(h, p, desc, osp, oep, kk, ragged, st) : launch_v3w<false>(h, p, desc, osp, oep, kk, ragged, st);
+    }
   }
   hipError_t e2 = hipFreeAsync(desc, st);
   return e != hipSuccess ? e : e2;

@@ -28,8 +28,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
-BYTES_PER_RANK = 128       # one-hot layout: one rank-dictionary block per rank query;
-                           # the bytes+checkpoints layout reports 132 through fmx_stats.block_bytes
+# Algorithmic bytes per rank query, the figure roofline.achieved is priced with: 128 B at
+# sigma = 4, 132 B (one 128-B block + a 4-B checkpoint) at sigma = 128.  What this build's layouts really
+# fetch per rank query (64 B one-hot block / 132 B bytes layout) is reported next to it.
+def survey_bytes_per_rank(sigma):
+    return 128 if sigma <= 4 else 132
+
+
+# Ceiling of the memory system for this access pattern, measured with tools/ubench/chain.hip on MI355X:
+# dependent random 64-byte requests at 16 chains per wave and full occupancy.
+REQUEST_CEILING_G_PER_S = 53.0
 
 WORKLOADS = {
     # name: (log2 n, sigma, patterns per GPU, pattern length, seed#)
@@ -219,6 +227,7 @@ def main():
     torch.cuda.synchronize()
     s1 = hip.stats()
     ranks_per_step = int(s1["rank_queries"])
+    requests_per_step = int(s1["search_requests"])
     hits = int((sp < ep).sum().item())
     for _ in range(max(0, args.warmup - 1)):
         step()
@@ -255,9 +264,10 @@ def main():
         ranks_all, hits_all, kernel_ms_max = float(ranks_per_step), float(hits), kernel_ms
 
     if rank == 0:
-        bytes_per_rank = int(st["block_bytes"])
+        bytes_per_rank = survey_bytes_per_rank(sigma)
         kernel_name = "k_search4"
         achieved = ranks_per_step * bytes_per_rank / (kernel_ms * 1e-3) / 1e9
+        req_rate = requests_per_step / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "rank_queries_per_sec",
             "value": ranks_all * args.steps / dt / 1e6,
@@ -281,7 +291,7 @@ def main():
                 "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
                                % (world, ", all_gather of (sp,ep) per step" if use_dist else ""),
                 "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
-                "index_layout": "one-hot bit-vectors, 128-B blocks" if st["layout"] == 0 else "BWT bytes + checkpoints",
+                "index_layout": "one-hot bit-vectors, 64-B blocks" if st["layout"] == 0 else "BWT bytes + checkpoints",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name,
@@ -290,6 +300,10 @@ def main():
                 "traffic_source": (pmc_traffic(args.workload) or (None, "no PMC profile of this workload committed"))[1],
                 "bytes_per_rank_query": bytes_per_rank, "rank_queries_per_launch": ranks_per_step,
                 "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                # what the layout really moves and the limit that binds it: distinct memory requests per second
+                "layout_bytes_per_request": 64 if st["layout"] == 0 else 66,
+                "requests_per_launch": requests_per_step, "requests_G_per_s": req_rate,
+                "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S, "request_frac": req_rate / REQUEST_CEILING_G_PER_S,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -153,6 +153,10 @@ static int open_common(const void *src, bool src_on_device, uint64_t n, uint64_t
     if ((e = hipMemsetAsync((uint8_t *)h->d_bwt + eof, 0, 1, st)) != hipSuccess) { rc = hip_fail(e, "memset"); break; }
     const int pref = layout_preference();
     h->layout = pref == (int)kLayoutBytes ? kLayoutBytes : kLayoutOneHot;
+    if (n >= kOneHotMaxN) {              // the one-hot block split is exact below 2^37 only
+      if (pref == (int)kLayoutOneHot) { g_err = "layout onehot needs n < 2^37"; rc = FMX_ERR_UNSUPPORTED; break; }
+      h->layout = kLayoutBytes;
+    }
     rc = build_index(h, st, counts);
     if (rc == -1) {                      // one-hot vectors do not fit: fall back unless one-hot was forced
       if (pref == (int)kLayoutOneHot) { rc = FMX_ERR_NOMEM; break; }
@@ -535,7 +539,12 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   if (rc) return rc;
   unsigned long long cnt[4] = {0, 0, 0, 0};
   HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
-  HIP_TRY(hipMemcpy(cnt, h->d_counters, sizeof cnt, hipMemcpyDeviceToHost), "D2H(counters)");
+  {   // the counters live in per-workgroup slots (fmx_device.h): sum them
+    std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
+    HIP_TRY(hipMemcpy(slots.data(), h->d_counters, kCounterBytes, hipMemcpyDeviceToHost), "D2H(counters)");
+    for (uint32_t sl = 0; sl < kCounterSlots; sl++)
+      for (int j = 0; j < 3; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
+  }
   std::lock_guard<std::mutex> lk(h->mu);
   out->rank_queries = cnt[0];
   out->backward_steps = cnt[1];
@@ -546,6 +555,7 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->n_symbols = h->nslots;
   out->block_bytes = h->layout == kLayoutBytes ? kByteBlock + 4 : kBlockBytes;
   out->layout = h->layout;
+  out->search_requests = cnt[2];
   out->build_ms = h->build_ms;
   return FMX_OK;
 }
@@ -556,7 +566,7 @@ int fmx_stats_reset(fmx_index *idx) {
   int rc = use_device(h);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
-  HIP_TRY(hipMemset(h->d_counters, 0, 4 * sizeof(unsigned long long)), "memset(counters)");
+  HIP_TRY(hipMemset(h->d_counters, 0, kCounterBytes), "memset(counters)");
   std::lock_guard<std::mutex> lk(h->mu);
   h->launches = 0;
   h->last_kernel_ms = 0;

@@ -5,12 +5,12 @@
 // 0, positions bucketed by symbol).  Instead of inverted position lists it emits, per symbol,
 // one-hot bit-vector blocks with a running count in each block header (layout: fmx_device.h).
 //
-// Three launches over "superchunks" of kSuper blocks (= kSuper*960 BWT positions):
+// Three launches over "superchunks" of kSuper blocks (= kSuper*448 BWT positions):
 //   k_hist : per-superchunk symbol histogram            (reads n bytes)
 //   k_scan : exclusive scan of the histograms per symbol (tiny)
 //   k_fill : per superchunk, block by block: bits via LDS atomicOr, headers from the running
-//            counts, whole 128-byte blocks written with coalesced dword stores
-//            (reads n bytes, writes nslots * nblocks * 128 bytes)
+//            counts, whole 64-byte blocks written with coalesced dword stores
+//            (reads n bytes, writes nslots * nblocks * 64 bytes)
 #include "fmx_device.h"
 #include "fmx_host.h"
 
@@ -20,7 +20,8 @@ namespace fmx {
 
 constexpr int kBuildThreads = 256;
 constexpr uint32_t kSuper = 256;                    // blocks per superchunk
-constexpr uint32_t kWordsPerBlock = kBlockBits / 32;  // 30 payload dwords
+constexpr uint32_t kPW = kBlockPayloadDwords;      // 14 payload dwords per one-hot block
+constexpr uint32_t kBD = kBlockBytes / 4;          // 16 dwords per block: [hdr lo, hdr hi, payload]
 
 __global__ __launch_bounds__(kBuildThreads) void k_hist(const uint8_t *__restrict__ bwt, uint64_t n, uint64_t eof,
                                                          uint64_t *__restrict__ hist /* [nsuper][256] */) {
@@ -75,15 +76,16 @@ __global__ __launch_bounds__(kBuildThreads) void k_fill(const uint8_t *__restric
                                                          const uint64_t *__restrict__ base /* [nsuper][256] */,
                                                          uint32_t *__restrict__ bv) {
   extern __shared__ uint32_t lds[];
-  uint32_t *bits = lds;                                      // [nslots][30]
-  uint64_t *run = reinterpret_cast<uint64_t *>(lds + ((nslots * kWordsPerBlock + 1) & ~1u));   // [nslots]
+  constexpr uint32_t pw = kPW;
+  uint32_t *bits = lds;                                      // [nslots][14]
+  uint64_t *run = reinterpret_cast<uint64_t *>(lds + ((nslots * pw + 1) & ~1u));               // [nslots]
   uint16_t *s_slot = reinterpret_cast<uint16_t *>(run + nslots);                               // [256]
   for (int c = threadIdx.x; c < 256; c += blockDim.x) s_slot[c] = slot_of[c];
   for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x) run[s] = base[(uint64_t)blockIdx.x * 256 + sym_of[s]];
   const uint64_t b0 = (uint64_t)blockIdx.x * kSuper;
   uint64_t b1 = b0 + kSuper;
   if (b1 > nblocks) b1 = nblocks;
-  const uint32_t nwords = nslots * kWordsPerBlock;
+  const uint32_t nwords = nslots * pw;
   for (uint64_t b = b0; b < b1; b++) {
     for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) bits[i] = 0;
     __syncthreads();
@@ -92,23 +94,23 @@ __global__ __launch_bounds__(kBuildThreads) void k_fill(const uint8_t *__restric
       const uint64_t p = p0 + r;
       if (p < n && p != eof) {
         const uint16_t s = s_slot[bwt[p]];
-        if (s < kSlotEof) atomicOr(&bits[s * kWordsPerBlock + (r >> 5)], 1u << (r & 31));
+        if (s < kSlotEof) atomicOr(&bits[s * pw + (r >> 5)], 1u << (r & 31));
       }
     }
     __syncthreads();
-    // write nslots blocks of 32 dwords: [hdr lo, hdr hi, 30 payload dwords]
-    for (uint32_t i = threadIdx.x; i < nslots * 32; i += blockDim.x) {
-      const uint32_t s = i >> 5, w = i & 31;
+    // write nslots blocks of kBD dwords: [hdr lo, hdr hi, payload dwords]
+    for (uint32_t i = threadIdx.x; i < nslots * kBD; i += blockDim.x) {
+      const uint32_t s = i / kBD, w = i % kBD;
       uint32_t v;
       if (w == 0) v = (uint32_t)run[s];
       else if (w == 1) v = (uint32_t)(run[s] >> 32);
-      else v = bits[s * kWordsPerBlock + w - 2];
-      bv[((uint64_t)s * nblocks + b) * 32 + w] = v;
+      else v = bits[s * pw + w - 2];
+      bv[((uint64_t)s * nblocks + b) * kBD + w] = v;
     }
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x) {
       uint32_t pc = 0;
-      for (uint32_t w = 0; w < kWordsPerBlock; w++) pc += __builtin_popcount(bits[s * kWordsPerBlock + w]);
+      for (uint32_t w = 0; w < pw; w++) pc += __builtin_popcount(bits[s * pw + w]);
       run[s] += pc;
     }
     __syncthreads();
@@ -175,7 +177,7 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
   // Layout: one-hot vectors when they fit comfortably (decided from n and a sigma upper bound before
   // the histogram, re-checked after), the bytes+checkpoints layout otherwise or when forced.
   bool bytes_layout = h->layout == kLayoutBytes;
-  if (bytes_layout) h->nblocks = h->n / kByteBlock + 1;
+  h->nblocks = bytes_layout ? h->n / kByteBlock + 1 : h->n / kBlockBits + 1;
   const uint64_t nsuper = bytes_layout ? ((h->nblocks >> kSuperShift) + 1) : (h->nblocks + kSuper - 1) / kSuper;
   uint64_t *d_hist = nullptr, *d_tot = nullptr;
   uint16_t *d_sym = nullptr;
@@ -233,7 +235,7 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
       else h->slot[c] = kSlotNone;
     }
     const uint64_t bv_bytes = bytes_layout ? (uint64_t)h->nslots * (h->nblocks * 4 + nsuper * 8)
-                                           : (uint64_t)h->nslots * h->nblocks * kBlockBytes;
+                                           : (uint64_t)h->nslots * h->nblocks * kBD * 4;
     size_t free_b = 0, total_b = 0;
     FMX_TRY(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
     if (bv_bytes + (64ull << 20) > free_b) {
@@ -250,8 +252,8 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
     }
     FMX_TRY(hipMalloc(&h->d_cf, sizeof h->cf), "hipMalloc(cf)");
     FMX_TRY(hipMalloc(&h->d_slot, sizeof h->slot), "hipMalloc(slot)");
-    FMX_TRY(hipMalloc((void **)&h->d_counters, 4 * sizeof(unsigned long long)), "hipMalloc(counters)");
-    FMX_TRY(hipMemsetAsync(h->d_counters, 0, 4 * sizeof(unsigned long long), st), "memset(counters)");
+    FMX_TRY(hipMalloc((void **)&h->d_counters, kCounterBytes), "hipMalloc(counters)");
+    FMX_TRY(hipMemsetAsync(h->d_counters, 0, kCounterBytes, st), "memset(counters)");
     FMX_TRY(hipMemcpyAsync(h->d_cf, h->cf, sizeof h->cf, hipMemcpyHostToDevice, st), "copy cf");
     FMX_TRY(hipMemcpyAsync(h->d_slot, h->slot, sizeof h->slot, hipMemcpyHostToDevice, st), "copy slot");
     FMX_TRY(hipMemcpyAsync(d_sym, sym_of, sizeof sym_of, hipMemcpyHostToDevice, st), "copy sym");
@@ -263,7 +265,7 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
         FMX_TRY(hipGetLastError(), "k_fill_bytes");
       }
     } else if (h->nslots) {
-      size_t lds = (size_t)((h->nslots * kWordsPerBlock + 1) & ~1u) * 4 + (size_t)h->nslots * 8 + 256 * 2;
+      size_t lds = (size_t)((h->nslots * (kBlockBits / 32) + 1) & ~1u) * 4 + (size_t)h->nslots * 8 + 256 * 2;
       k_fill<<<(int)nsuper, kBuildThreads, lds, st>>>((const uint8_t *)h->d_bwt, h->n, h->eof, h->nblocks, h->nslots,
                                                        (const uint16_t *)h->d_slot, d_sym, d_hist,
                                                        (uint32_t *)h->d_bv);

@@ -1,24 +1,28 @@
-// fmx_device.h -- device-side rank dictionary layout and the rank primitive (gfx950).
+// fmx_device.h -- device-side rank dictionary layouts and the rank primitive (gfx950).
 //
-// Layout in HBM (DESIGN.md "Rank dictionary"):
+// Layout kLayoutOneHot (DESIGN.md "Rank dictionary"):
 //   For every symbol c that occurs in the BWT there is one bit-vector of n one-hot bits
-//   (bit p set <=> BWT'[p] == c), cut into 128-byte blocks:
+//   (bit p set <=> BWT'[p] == c), cut into 64-byte blocks:
 //       bytes 0..7    uint64  number of set bits in all earlier blocks of this vector
-//       bytes 8..127  960 payload bits, position p of the block at dword 2 + p/32, bit p%32
-//   Block b of symbol-slot s lives at bv + (s * nblocks + b) * 128.  nblocks = n/960 + 1, so
+//       bytes 8..63   448 payload bits, position p of the block at dword 2 + p/32, bit p%32
+//   Block b of symbol-slot s lives at bv + (s * nblocks + b) * 64.  nblocks = n/448 + 1, so
 //   the query position x == n has a block too (its header is the symbol's total count).
-//   One rank query = ONE aligned 128-byte line: header + in-register popcount.
+//   One rank query = ONE aligned 64-byte request: header + in-register popcount.
 //   Symbol 0 (the EOF row, BWT' only) needs no vector: rank0(x) = (x > eof).
 //
-// A query is served by 8 adjacent lanes ("octet"): lane t loads bytes 16t..16t+15 of the line
-// with one global_load_dwordx4, so every wave-level load instruction fetches 8 whole lines and
-// each line is requested exactly once.  (Measured on MI355X: the memory system delivers about
-// 46-48 G distinct-line requests/s whatever the granule size up to 128 B, and a second load
-// instruction to the same line is a second request -- tools/ubench/gather.hip -- so wider
-// per-lane loads or fewer lanes per query do not pay.)
+// A query is served by 4 adjacent lanes (a "quad"): lane t loads bytes 16t..16t+15 of the block
+// with one global_load_dwordx4, so every wave-level load instruction fetches 16 whole blocks and
+// each block is requested exactly once.  Why 64 bytes and a quad: the memory system's limit for
+// this access pattern is distinct requests per second, whatever the granule up to 128 B
+// (tools/ubench/gather.hip: ~46-48 G independent requests/s; tools/ubench/chain.hip: dependent
+// chains reach ~53 G requests/s with 64-byte granules at 16 chains per wave against ~46 G/s with
+// 128-byte granules at 8 per wave), and a second load instruction to the same line is a second
+// request.  Against the 128-byte / 8-lane form this layout replaced (round 1, profiles/) the half
+// block costs nothing in request rate, halves the vector instructions per query and doubles the
+// queries a wave keeps in flight.
 //
-// The popcount side is written for instruction count: the search kernels turned out to be bound
-// by vector-instruction issue, not by HBM (profiles/).  Per dword: saturating
+// The popcount side is written for instruction count: the first search kernels were bound by
+// vector-instruction issue, not by HBM (profiles/).  Per dword: saturating
 // subtract, bit-field extract, compare, select, popcount-accumulate.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -26,28 +30,32 @@
 
 namespace fmx {
 
-constexpr uint32_t kBlockBits = 960;     // payload positions per block
-constexpr uint32_t kBlockBytes = 128;
-constexpr uint32_t kOctet = 8;           // lanes per query
+constexpr uint32_t kBlockBits = 448;     // payload positions per one-hot block
+constexpr uint32_t kBlockBytes = 64;
+constexpr uint32_t kBlockPayloadDwords = kBlockBits / 32;   // 14
 constexpr uint16_t kSlotNone = 0xFFFF;   // symbol absent from the BWT: rank is 0
 constexpr uint16_t kSlotEof = 0xFFFE;    // symbol 0: rank0(x) = (x > eof)
+constexpr uint64_t kOneHotMaxN = 1ull << 37;   // split448 is exact for positions below this
 
-// Second layout, for indexes whose one-hot vectors (sigma * n / 8 bytes) do not fit in HBM
-// (BASELINE config C5: n = 2^34, sigma = 128 -> 289 GB): the BWT bytes themselves in 128-byte
+// Second layout, for indexes whose one-hot vectors (sigma * n / 7 bytes) do not fit in HBM
+// (BASELINE config C5: n = 2^34, sigma = 128 -> 314 GB): the BWT bytes themselves in 128-byte
 // blocks (slot eof holds 0, which no real symbol has) + per-block checkpoints
 //     chk[blk][slot]  uint32  occurrences of the symbol in its superblock before this block
 //     sup[sb][slot]   uint64  occurrences before superblock sb (2^15 blocks = 2^22 positions)
 // rank = sup + chk + #{bytes of the block below the boundary that equal c}: two HBM lines per rank
 // query (the block and the checkpoint; sup stays cache-resident), 132 B algorithmic as SURVEY 8d.
+// A query is served by 8 lanes (an "octet"): 16 of the block's 128 bytes per lane.
 constexpr uint32_t kLayoutOneHot = 0;
 constexpr uint32_t kLayoutBytes = 1;
 constexpr uint32_t kByteBlock = 128;     // BWT positions per byte-layout block
 constexpr uint32_t kSuperShift = 15;     // blocks per superblock = 2^15
 
+// Lanes per query of a layout.
+template <uint32_t LAYOUT> struct Lay { static constexpr int G = LAYOUT == kLayoutBytes ? 8 : 4; };
+
 struct DevIndex {
   const uint4 *bv;        // one-hot layout: rank dictionary
-  const uint8_t *bwt;     // BWT bytes (one-hot: raw, slot eof holds a filler; bytes: slot eof holds 0,
-                          // zero-padded to whole blocks)
+  const uint8_t *bwt;     // BWT bytes, slot eof holds 0, zero-padded to whole 128-byte blocks
   const uint64_t *cf;     // [256] C[] = first row of each symbol, NaiveFMSearcher.cf
   const uint16_t *slot;   // [256] symbol -> slot | kSlotNone | kSlotEof
   uint64_t n;
@@ -59,7 +67,7 @@ struct DevIndex {
   uint32_t nslots;
 };
 
-// ---- DPP helpers: reductions inside an octet stay in the VALU (no LDS crossbar).
+// ---- DPP helpers: reductions inside a group of 4 or 8 lanes stay in the VALU (no LDS crossbar).
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
@@ -68,16 +76,18 @@ constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i <-> 7-i inside each 8
 
-__device__ __forceinline__ uint32_t octet_sum(uint32_t v) {
+template <int G>
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
   v += dpp<kDppXor1>(v);
   v += dpp<kDppXor2>(v);
-  v += dpp<kDppHalfMirror>(v);
+  if (G == 8) v += dpp<kDppHalfMirror>(v);
   return v;
 }
-__device__ __forceinline__ uint32_t octet_or(uint32_t v) {
+template <int G>
+__device__ __forceinline__ uint32_t group_or(uint32_t v) {
   v |= dpp<kDppXor1>(v);
   v |= dpp<kDppXor2>(v);
-  v |= dpp<kDppHalfMirror>(v);
+  if (G == 8) v |= dpp<kDppHalfMirror>(v);
   return v;
 }
 
@@ -88,31 +98,33 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
   return d;
 }
 
-// Per-lane constants of the octet layout.
+// Per-lane constants of a group of G lanes.
 struct LaneConst {
-  uint32_t k[4];      // first payload position of dword j of this lane (0xFFFFFFFF: header dword)
-  uint32_t t;         // lane index inside the octet
+  uint32_t k[4];      // one-hot: first payload position of dword j of this lane (0xFFFFFFFF: header dword)
+  uint32_t t;         // lane index inside the group
 };
 
+template <int G>
 __device__ __forceinline__ LaneConst lane_const() {
   LaneConst lc;
-  lc.t = threadIdx.x & (kOctet - 1);
+  lc.t = threadIdx.x & (G - 1);
 #pragma unroll
   for (int j = 0; j < 4; j++) lc.k[j] = (lc.t == 0 && j < 2) ? 0xFFFFFFFFu : (128u * lc.t - 64u + 32u * j);
   return lc;
 }
 
-// x / 960 and x % 960 for x < 2^38: one multiply (mul_hi) and shifts; 960 = 64 * 15.
-__device__ __forceinline__ void split960(uint64_t x, uint32_t &blk, uint32_t &rem) {
+// x / 448 and x % 448 for x < 2^37: one multiply (mul_hi) and shifts; 448 = 64 * 7, and the
+// multiply-shift division by 7 is exact for operands below 2^31.
+__device__ __forceinline__ void split448(uint64_t x, uint32_t &blk, uint32_t &rem) {
   const uint32_t y = (uint32_t)(x >> 6);
-  blk = __umulhi(y, 0x88888889u) >> 3;                 // y / 15
-  rem = (uint32_t)x - (blk << 10) + (blk << 6);        // x - 960 * blk (mod 2^32, exact: rem < 960)
+  blk = __umulhi(y, 0x92492493u) >> 2;                 // y / 7
+  rem = (uint32_t)x - (blk << 9) + (blk << 6);         // x - 448 * blk (mod 2^32, exact: rem < 448)
 }
 
-// The in-register half of a rank query: given this lane's 16 bytes `w` of the block and the
-// in-block boundary `rem`, returns (to every lane of the octet) header + #{set payload bits below
-// rem}.  WIDE = false when every count fits 32 bits (n <= 2^32): the header then rides in the
-// same 3-step DPP sum; WIDE = true carries the 64-bit header apart.
+// The in-register half of a one-hot rank query: given this lane's 16 bytes `w` of the block and
+// the in-block boundary `rem`, returns (to every lane of the quad) header + #{set payload bits
+// below rem}.  WIDE = false when every count fits 32 bits (n <= 2^32): the header then rides in
+// the same 2-step DPP sum; WIDE = true carries the 64-bit header apart.
 template <bool WIDE>
 __device__ __forceinline__ uint64_t rank_finish(uint4 w, uint32_t rem, const LaneConst &lc) {
   const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
@@ -126,9 +138,19 @@ __device__ __forceinline__ uint64_t rank_finish(uint4 w, uint32_t rem, const Lan
     x = nb > 31u ? ww[j] : x;                          // whole dword below the boundary
     cnt = bcnt_acc(x, cnt);
   }
-  if (!WIDE) return octet_sum(cnt);
-  const uint32_t hhi = octet_or(lc.t == 0 ? w.y : 0u);
-  return (((uint64_t)hhi << 32) | octet_or(hlo)) + octet_sum(cnt);
+  if (!WIDE) return group_sum<4>(cnt);
+  const uint32_t hhi = group_or<4>(lc.t == 0 ? w.y : 0u);
+  return (((uint64_t)hhi << 32) | group_or<4>(hlo)) + group_sum<4>(cnt);
+}
+
+// Bit `rem` of the block's payload, to every lane of the quad (BWT'[x] == c for the block's symbol).
+__device__ __forceinline__ uint32_t payload_bit(uint4 w, uint32_t rem, const LaneConst &lc) {
+  const uint32_t d = (rem >> 5) + 2;                     // dword of the block that holds the bit
+  const uint32_t comp = d & 3u;
+  const uint32_t word = comp < 2u ? (comp == 0u ? w.x : w.y) : (comp == 2u ? w.z : w.w);
+  uint32_t bit = __builtin_amdgcn_ubfe(word, rem, 1u);   // offset taken mod 32
+  bit = (d >> 2) == lc.t ? bit : 0u;
+  return group_or<4>(bit);
 }
 
 // Loads in the global (not flat) address space from an integer address.
@@ -179,54 +201,53 @@ __device__ __forceinline__ ByteRankReq byte_rank_issue(const DevIndex &ix, uint1
 
 __device__ __forceinline__ uint64_t byte_rank_finish(const ByteRankReq &q, uint32_t c, const LaneConst &lc) {
   const uint32_t nbytes = __builtin_elementwise_sub_sat(q.rem, 16u * lc.t);
-  return q.sup + octet_sum(match_count16(q.w, c, nbytes, q.chk));
+  return q.sup + group_sum<8>(match_count16(q.w, c, nbytes, q.chk));
 }
 
-// rank_excl(c, x) = #{p < x : BWT'[p] == c}, 0 <= x <= n, evaluated by the whole octet, for
-// either layout.  occ(c, i) of the reference is rank_excl(c, i + 1).
-template <bool WIDE>
-__device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t x,
-                                              const LaneConst &lc) {
-  if (slot == kSlotNone) return 0;
-  if (slot == kSlotEof) return x > ix.eof ? 1 : 0;
-  if (ix.layout == kLayoutBytes) return byte_rank_finish(byte_rank_issue(ix, slot, x, lc), c, lc);
-  uint32_t blk, rem;
-  split960(x, blk, rem);
-  return rank_finish<WIDE>(load_line16(block_addr(ix, slot, blk, lc)), rem, lc);
+// BWT'[x] == c from the block line of a bytes-layout request, to every lane of the octet.
+__device__ __forceinline__ uint32_t byte_match_bit(const ByteRankReq &q, uint32_t c, const LaneConst &lc) {
+  const uint32_t bidx = q.rem & 15u;                     // byte of this lane that holds row x
+  const uint32_t comp = bidx >> 2;
+  const uint32_t word = comp < 2u ? (comp == 0u ? q.w.x : q.w.y) : (comp == 2u ? q.w.z : q.w.w);
+  const uint32_t byte = __builtin_amdgcn_ubfe(word, 8u * (bidx & 3u), 8u);
+  return group_or<8>(((q.rem >> 4) == lc.t && byte == c) ? 1u : 0u);
 }
 
-// The same in two halves, so that a kernel can have several independent rank queries in flight per
-// octet: rank_issue requests the line(s), rank_complete consumes them.
+// ---- either layout.  A rank query in two halves, so that a kernel can have several independent
+// queries in flight per lane group: rank_issue requests the line(s), rank_complete consumes them.
+// rank_excl(c, x) = #{p < x : BWT'[p] == c}, 0 <= x <= n; occ(c, i) of the reference is
+// rank_excl(c, i + 1).
 struct RankReq {
-  uint4 w;            // one-hot: the block line; bytes: the BWT block line
+  uint4 w;            // one-hot: the block; bytes: the BWT block line
   uint32_t rem;
   uint32_t chk;       // bytes layout
   uint64_t sup;       // bytes layout; immediate value when kind == 0
-  uint32_t kind;      // 0 immediate, 1 one-hot, 2 bytes
+  uint32_t kind;      // 0 immediate, 1 from memory
 };
 
+template <uint32_t LAYOUT>
 __device__ __forceinline__ RankReq rank_issue(const DevIndex &ix, uint16_t slot, uint64_t x, const LaneConst &lc) {
   RankReq q;
   q.w = make_uint4(0, 0, 0, 0);
   q.rem = 0; q.chk = 0; q.sup = 0; q.kind = 0;
   if (slot == kSlotNone) return q;
   if (slot == kSlotEof) { q.sup = x > ix.eof ? 1 : 0; return q; }
-  if (ix.layout == kLayoutBytes) {
+  q.kind = 1;
+  if (LAYOUT == kLayoutBytes) {
     const ByteRankReq b = byte_rank_issue(ix, slot, x, lc);
-    q.w = b.w; q.rem = b.rem; q.chk = b.chk; q.sup = b.sup; q.kind = 2;
+    q.w = b.w; q.rem = b.rem; q.chk = b.chk; q.sup = b.sup;
     return q;
   }
   uint32_t blk;
-  split960(x, blk, q.rem);
+  split448(x, blk, q.rem);
   q.w = load_line16(block_addr(ix, slot, blk, lc));
-  q.kind = 1;
   return q;
 }
 
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __device__ __forceinline__ uint64_t rank_complete(const RankReq &q, uint32_t c, const LaneConst &lc) {
   if (q.kind == 0) return q.sup;
-  if (q.kind == 2) {
+  if (LAYOUT == kLayoutBytes) {
     ByteRankReq b;
     b.w = q.w; b.rem = q.rem; b.chk = q.chk; b.sup = q.sup;
     return byte_rank_finish(b, c, lc);
@@ -234,33 +255,59 @@ __device__ __forceinline__ uint64_t rank_complete(const RankReq &q, uint32_t c, 
   return rank_finish<WIDE>(q.w, q.rem, lc);
 }
 
-// One backward step for the whole octet: (sp, ep) -> (C[c]+rank(c,sp), C[c]+rank(c,ep)), the body
-// of SuffixAlgo.getPrevRange (findex.scala:32-36).  All lines are requested before any is consumed.
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
+__device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t x,
+                                              const LaneConst &lc) {
+  return rank_complete<WIDE, LAYOUT>(rank_issue<LAYOUT>(ix, slot, x, lc), c, lc);
+}
+
+// One backward step for the whole lane group: (sp, ep) -> (C[c]+rank(c,sp), C[c]+rank(c,ep)), the
+// body of SuffixAlgo.getPrevRange (findex.scala:32-36).  All lines are requested before any is consumed.
+template <bool WIDE, uint32_t LAYOUT>
 __device__ __forceinline__ void backward_step(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t cfc,
                                               const LaneConst &lc, uint64_t &sp, uint64_t &ep) {
-  uint64_t r1 = 0, r2 = 0;
-  if (slot < kSlotEof) {
-    if (ix.layout == kLayoutBytes) {
-      const ByteRankReq q1 = byte_rank_issue(ix, slot, sp, lc);
-      const ByteRankReq q2 = byte_rank_issue(ix, slot, ep, lc);
-      r1 = byte_rank_finish(q1, c, lc);
-      r2 = byte_rank_finish(q2, c, lc);
-    } else {
-      uint32_t b1, b2, m1, m2;
-      split960(sp, b1, m1);
-      split960(ep, b2, m2);
-      const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
-      const uint4 w2 = load_line16(block_addr(ix, slot, b2, lc));
-      r1 = rank_finish<WIDE>(w1, m1, lc);
-      r2 = rank_finish<WIDE>(w2, m2, lc);
-    }
-  } else if (slot == kSlotEof) {
-    r1 = sp > ix.eof ? 1 : 0;
-    r2 = ep > ix.eof ? 1 : 0;
-  }
-  sp = cfc + r1;
-  ep = cfc + r2;
+  const RankReq q1 = rank_issue<LAYOUT>(ix, slot, sp, lc);
+  const RankReq q2 = rank_issue<LAYOUT>(ix, slot, ep, lc);
+  sp = cfc + rank_complete<WIDE, LAYOUT>(q1, c, lc);
+  ep = cfc + rank_complete<WIDE, LAYOUT>(q2, c, lc);
 }
+
+// ---- statistics counters without a hot spot.  Same-address device atomics complete at roughly 100
+// per microsecond on MI355X; a kernel whose 8192 waves all end together and each add to one shared
+// counter spends its last ~100 us per counter draining them (measured: round 1).  So the
+// counters are kCounterSlots 128-byte slots, a workgroup adds to slot blockIdx.x % kCounterSlots
+// (one atomic per wave and counter after a wave-level reduction), and the host sums the slots.
+constexpr uint32_t kCounterSlots = 2048;
+constexpr uint32_t kCounterStride = 16;        // uint64 per slot: [0] rank queries, [1] backward steps, [2] search requests
+constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterStride * 8;
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// Called by EVERY lane of the workgroup (convergent), each with its private partial sums.
+__device__ __forceinline__ void counters_add(unsigned long long *__restrict__ counters, unsigned long long ranks,
+                                             unsigned long long steps, unsigned long long reqs) {
+  ranks = wave_sum(ranks);
+  steps = wave_sum(steps);
+  reqs = wave_sum(reqs);
+  if ((threadIdx.x & 63u) == 0) {
+    unsigned long long *slot = counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride;
+    if (ranks) atomicAdd(slot + 0, ranks);
+    if (steps) atomicAdd(slot + 1, steps);
+    if (reqs) atomicAdd(slot + 2, reqs);
+  }
+}
+
+// Launch-side dispatch over the three kernel instantiations an index can need: the bytes layout
+// (counts are 64-bit sums there), and the one-hot layout with 32-bit or 64-bit counts.
+#define FMX_LAYOUT_DISPATCH(h, CALL)                                                        \
+  do {                                                                                      \
+    if ((h)->layout == kLayoutBytes) { CALL(true, kLayoutBytes); }                          \
+    else if ((h)->n > (1ull << 32)) { CALL(true, kLayoutOneHot); }                          \
+    else { CALL(false, kLayoutOneHot); }                                                    \
+  } while (0)
 
 }  // namespace fmx

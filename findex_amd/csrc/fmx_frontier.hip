@@ -5,10 +5,10 @@
 // range either emits SAResult (isLast) or pushes one StatePoint per entry of state.follows.
 // Every frontier element is independent of the others, so the device keeps the whole batch's
 // frontier in two HBM work queues (SoA) and expands it level by level (level = len):
-//   - one frontier element per octet of lanes, stepped with the same one-line rank primitive
-//     as the literal search;
-//   - survivors are compacted into the next queue: per-octet push counts are prefix-summed
-//     across the wave, one atomicAdd per wave reserves the slots, and the octet's lanes write
+//   - one frontier element per lane group (a quad in the one-hot layout, an octet in the bytes
+//     layout), stepped with the same rank primitive as the literal search;
+//   - survivors are compacted into the next queue: per-group push counts are prefix-summed
+//     across the wave, one atomicAdd per wave reserves the slots, and the group's lanes write
 //     the follows in parallel; results are compacted the same way with __ballot.
 // The set of getPrevRange calls, and so the result multiset, equals the reference's whenever
 // its maxBranching / maxIterations limits do not bind.
@@ -48,7 +48,7 @@ struct NfaTables {       // all regexes of the batch, concatenated; state ids ar
 };
 
 constexpr uint32_t kStageCap = 256;     // survivors a wave stages in LDS before reserving queue slots
-constexpr uint32_t kStageSmall = 16;    // follows lists up to this length go through the stage (8 x 16 <= cap / 2)
+constexpr uint32_t kStageSmall = 16;    // follows lists up to this length go through the stage (16 groups x 16 <= cap)
 
 struct Stage {
   uint32_t state[kStageCap];
@@ -63,7 +63,6 @@ struct FrontierCtl {     // device-resident counters
   unsigned long long count[3];
   unsigned long long res_count;
   unsigned long long overflow;     // bit 0: queue, bit 1: results
-  unsigned long long steps;
 };
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
@@ -79,10 +78,11 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
   return x - v;
 }
 
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, Queue nxt, uint32_t level,
                                                          uint64_t nxt_cap, fmx_result *__restrict__ res,
-                                                         uint64_t res_cap, FrontierCtl *__restrict__ ctl) {
+                                                         uint64_t res_cap, FrontierCtl *__restrict__ ctl,
+                                                         unsigned long long *__restrict__ counters) {
   // After a queue overflow the appended count exceeds what was stored: later levels of the chain
   // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
   if (ctl->overflow & 1ull) return;
@@ -95,10 +95,11 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
   __syncthreads();
-  const LaneConst lc = lane_const();
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * (kFThreads / kOctet);
-  const uint64_t first = ((uint64_t)blockIdx.x * kFThreads + threadIdx.x) >> 3;
+  const uint64_t noct = (uint64_t)gridDim.x * (kFThreads / G);
+  const uint64_t first = ((uint64_t)blockIdx.x * kFThreads + threadIdx.x) / G;
   uint32_t stepped = 0;
   __shared__ Stage s_stage[kFThreads / 64];
   Stage &stg = s_stage[threadIdx.x >> 6];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
     __builtin_amdgcn_wave_barrier();
     staged = 0;
   };
-  // all octets of a wave run the same number of rounds so that the wave-wide scans stay convergent
+  // all groups of a wave run the same number of rounds so that the wave-wide scans stay convergent
   const uint64_t rounds = (cur_count + noct - 1) / noct;
   for (uint64_t rd = 0; rd < rounds; rd++) {
     const uint64_t q = first + rd * noct;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
         ep = (c == 255u) ? ix.n : s_cf[c + 1];
         if (slot == kSlotNone) ep = sp;
       } else {
-        backward_step<WIDE>(ix, c, slot, cfc, lc, sp, ep);
+        backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
       }
       stepped++;
       if (sp < ep) {                                   // Some((sp1,ep1)), retree.scala:634
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
     const uint32_t small_off = wave_excl_scan(lead ? nsmall : 0u, small_total);
     if (staged + small_total > kStageCap) flush();
     if (small_total) {
-      const uint32_t my_off = staged + __shfl(small_off, lane & ~7u, 64);
-      for (uint32_t j = t; j < nsmall; j += kOctet) {
+      const uint32_t my_off = staged + __shfl(small_off, lane & ~(uint32_t)(G - 1), 64);
+      for (uint32_t j = t; j < nsmall; j += G) {
         stg.state[my_off + j] = nfa.fol[f0 + j];
         stg.len[my_off + j] = ln + 1;
         stg.sp[my_off + j] = sp;
@@ -204,8 +205,8 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
       unsigned long long qbase = 0;
       if (lane == 0) qbase = atomicAdd(next_count, (unsigned long long)large_total);
       qbase = __shfl(qbase, 0, 64);
-      const uint32_t my_off = __shfl(large_off, lane & ~7u, 64);
-      for (uint32_t j = t; j < nlarge; j += kOctet) {
+      const uint32_t my_off = __shfl(large_off, lane & ~(uint32_t)(G - 1), 64);
+      for (uint32_t j = t; j < nlarge; j += G) {
         const unsigned long long at = qbase + my_off + j;
         if (at < nxt_cap) {
           nxt.state[at] = nfa.fol[f0 + j];
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
     }
   }
   flush();
-  if (t == 0 && stepped) atomicAdd(&ctl->steps, (unsigned long long)stepped);
+  counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
 }
 
 namespace {
@@ -312,7 +313,7 @@ __global__ void k_frontier_init(Queue q, const uint32_t *__restrict__ first_stat
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
     ctl->count[0] = count; ctl->count[1] = 0; ctl->count[2] = 0;
-    ctl->res_count = 0; ctl->overflow = 0; ctl->steps = 0;
+    ctl->res_count = 0; ctl->overflow = 0;
   }
   if (i < count) { q.state[i] = first_state[i]; q.len[i] = 0; q.sp[i] = 0; q.ep[i] = n; }
 }
@@ -367,10 +368,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     for (uint32_t j = 0; j < kChain && level < max_steps; j++, level++) {
       const Queue &cur = (level & 1) ? qb : qa;
       const Queue &nxt = (level & 1) ? qa : qb;
-      if (h->n > (1ull << 32))
-        k_frontier<true><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, qcap, d_res, (uint64_t)cap, d_ctl);
-      else
-        k_frontier<false><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, qcap, d_res, (uint64_t)cap, d_ctl);
+#define CALL(W, L) k_frontier<W, L><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, qcap, d_res, (uint64_t)cap, d_ctl, h->d_counters)
+      FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
       HIP_TRY(hipGetLastError(), "k_frontier");
       launches++;
     }
@@ -379,8 +379,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
     alive = ctl.count[level % 3] != 0;
     if (getenv("FMX_TRACE"))
-      fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, steps %llu, overflow %llu\n", level,
-              ctl.count[level % 3], ctl.res_count, ctl.steps, ctl.overflow);
+      fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
+              ctl.count[level % 3], ctl.res_count, ctl.overflow);
     if (alive && level >= max_steps) { truncated = true; alive = false; }
   }
   HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
@@ -391,13 +391,6 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     std::lock_guard<std::mutex> lk(h->mu);
     h->last_kernel_ms = ms;
     h->launches += launches;
-  }
-  if (ctl.steps) {   // fold this call's steps into the handle's counters
-    unsigned long long cur_cnt[2];
-    HIP_TRY(hipMemcpy(cur_cnt, h->d_counters, sizeof cur_cnt, hipMemcpyDeviceToHost), "D2H(counters)");
-    cur_cnt[0] += 2ull * ctl.steps;
-    cur_cnt[1] += ctl.steps;
-    HIP_TRY(hipMemcpy(h->d_counters, cur_cnt, sizeof cur_cnt, hipMemcpyHostToDevice), "H2D(counters)");
   }
   const size_t extra = b->start_final.size();
   *n_out = (size_t)ctl.res_count + extra;

@@ -1,16 +1,16 @@
 // fmx_kernels.hip -- query kernels over the rank dictionary (gfx950, wave64).
 //
 // K2 occ_batch, K3 literal backward search, K4 prev_range_batch, LF / Psi walks.
-// All are HBM-bound integer work: one 128-byte line per rank query, fetched whole by an octet
-// of lanes (fmx_device.h); C[] and the symbol->slot map are staged in LDS per workgroup.
+// All are HBM-bound integer work: one 64-byte block per rank query, fetched whole by a quad of
+// lanes (an octet and two lines in the bytes layout; fmx_device.h); C[] and the symbol->slot map
+// are staged in LDS per workgroup.  "group" below = the lanes that serve one query.
 // Reference semantics: SuffixAlgo (findex.scala:9-52), NaiveFMSearcher (bwtmerger.scala:335-421).
 #include "fmx_device.h"
 #include "fmx_host.h"
 
 namespace fmx {
 
-constexpr int kThreads = 256;                       // 4 waves, 32 octets per workgroup
-constexpr int kOctetsPerBlock = kThreads / kOctet;
+constexpr int kThreads = 256;                       // 4 waves, 64 quads (32 octets) per workgroup
 
 struct Tables {
   uint64_t cf[256];
@@ -25,47 +25,48 @@ __device__ __forceinline__ void stage_tables(const DevIndex &ix, Tables &tb) {
   __syncthreads();
 }
 
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __device__ __forceinline__ void step(const DevIndex &ix, const Tables &tb, uint32_t c, const LaneConst &lc,
                                      uint64_t &sp, uint64_t &ep) {
-  backward_step<WIDE>(ix, c, tb.slot[c], tb.cf[c], lc, sp, ep);
+  backward_step<WIDE, LAYOUT>(ix, c, tb.slot[c], tb.cf[c], lc, sp, ep);
 }
 
 // ---------------------------------------------------------------- K2: occ_batch
 // SuffixAlgo.occ(c,i) = rank_excl(c, i+1); i < 0 -> 0; i >= n clamps to n-1.
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kThreads) void k_occ(DevIndex ix, const uint8_t *__restrict__ c,
                                                    const int64_t *__restrict__ i, uint64_t *__restrict__ out,
                                                    uint64_t k, unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const LaneConst lc = lane_const();
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
+  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
   uint32_t done = 0;
   auto boundary = [&](int64_t key) { return key < 0 ? 0 : ((uint64_t)key >= ix.n ? ix.n : (uint64_t)key + 1); };
-  // two independent queries per octet and trip: both lines are in flight together
-  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += 2 * noct) {
+  // two independent queries per group and trip: both lines are in flight together
+  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G; q < k; q += 2 * noct) {
     const uint64_t q2 = q + noct;
     const bool two = q2 < k;
     const uint32_t c1 = c[q], c2 = two ? c[q2] : 0u;
-    const RankReq r1 = rank_issue(ix, tb.slot[c1], boundary(i[q]), lc);
+    const RankReq r1 = rank_issue<LAYOUT>(ix, tb.slot[c1], boundary(i[q]), lc);
     RankReq r2 = r1;
-    if (two) r2 = rank_issue(ix, tb.slot[c2], boundary(i[q2]), lc);
-    const uint64_t v1 = rank_complete<WIDE>(r1, c1, lc);
+    if (two) r2 = rank_issue<LAYOUT>(ix, tb.slot[c2], boundary(i[q2]), lc);
+    const uint64_t v1 = rank_complete<WIDE, LAYOUT>(r1, c1, lc);
     if (t == 0) out[q] = v1;
     done++;
     if (two) {
-      const uint64_t v2 = rank_complete<WIDE>(r2, c2, lc);
+      const uint64_t v2 = rank_complete<WIDE, LAYOUT>(r2, c2, lc);
       if (t == 0) out[q2] = v2;
       done++;
     }
   }
-  if (t == 0 && done) atomicAdd(&counters[0], (unsigned long long)done);
+  counters_add(counters, t == 0 ? done : 0u, 0, 0);
 }
 
 // ---------------------------------------------------------------- K4: prev_range_batch
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint64_t *__restrict__ sp_in,
                                                           const uint64_t *__restrict__ ep_in,
                                                           const uint8_t *__restrict__ c, uint64_t *__restrict__ sp1,
@@ -73,20 +74,21 @@ __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint
                                                           unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const LaneConst lc = lane_const();
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
+  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
   uint32_t done = 0;
-  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += noct) {
+  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G; q < k; q += noct) {
     // the device-pointer entry point cannot validate its operands on the host: keep them inside the index
     uint64_t sp = sp_in[q], ep = ep_in[q];
     if (sp > ix.n) sp = ix.n;
     if (ep > ix.n) ep = ix.n;
-    step<WIDE>(ix, tb, c[q], lc, sp, ep);
+    step<WIDE, LAYOUT>(ix, tb, c[q], lc, sp, ep);
     if (t == 0) { sp1[q] = sp; ep1[q] = ep; }
     done++;
   }
-  if (t == 0 && done) { atomicAdd(&counters[0], 2ull * done); atomicAdd(&counters[1], (unsigned long long)done); }
+  counters_add(counters, t == 0 ? 2ull * done : 0ull, t == 0 ? done : 0u, 0);
 }
 
 // ---------------------------------------------------------------- K3: literal backward search
@@ -94,17 +96,18 @@ __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint
 // grid stride and pick up their next pattern as soon as the current one ends (last byte consumed
 // or interval empty), so early exits do not idle lanes.  The next pattern's offsets and the next
 // pattern byte are requested a step early; only the two rank lines are on the dependent chain.
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t *__restrict__ pat,
                                                       const uint64_t *__restrict__ off, uint64_t *__restrict__ sp_out,
                                                       uint64_t *__restrict__ ep_out, uint64_t k,
                                                       unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const LaneConst lc = lane_const();
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
-  uint64_t p = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3;
+  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
+  uint64_t p = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   bool active = p < k;
   uint64_t base = 0, sp = 0, ep = ix.n;
   int64_t i = -1;          // index of the byte to consume next
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t 
     if (active) {
       if (i >= 0 && sp < ep) {
         const uint32_t cn = i > 0 ? pat[base + i - 1] : 0;   // next byte, off the critical path
-        step<WIDE>(ix, tb, c, lc, sp, ep);
+        step<WIDE, LAYOUT>(ix, tb, c, lc, sp, ep);
         c = cn;
         i--;
         steps++;
@@ -140,24 +143,25 @@ __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t 
       }
     }
   }
-  if (t == 0 && steps) { atomicAdd(&counters[0], 2ull * steps); atomicAdd(&counters[1], (unsigned long long)steps); }
+  counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, 0);
 }
 
 // ---------------------------------------------------------------- LF walk (prevSubstr / getPrevI)
 // NaiveFMSearcher.prevSubstr (bwtmerger.scala:409-419): emit BWT'[row], row = cf(b)+occ(b,row-1).
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_t *__restrict__ rows, uint64_t k,
                                                        uint32_t len, uint8_t *__restrict__ out_bytes,
                                                        uint64_t *__restrict__ end_rows,
                                                        unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const LaneConst lc = lane_const();
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
+  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
   uint32_t done = 0;
-  // two walks per octet, stepped together: their (dependent) chains overlap
-  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3; q < k; q += 2 * noct) {
+  // two walks per group, stepped together: their (dependent) chains overlap
+  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G; q < k; q += 2 * noct) {
     const uint64_t q2 = q + noct;
     const bool two = q2 < k;
     uint64_t ra = rows[q], rb = two ? rows[q2] : 0;
@@ -170,11 +174,11 @@ __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_
         out_bytes[q * len + s] = (uint8_t)ba;
         if (two) out_bytes[q2 * len + s] = (uint8_t)bb;
       }
-      const RankReq qa = rank_issue(ix, tb.slot[ba], ra, lc);
+      const RankReq qa = rank_issue<LAYOUT>(ix, tb.slot[ba], ra, lc);
       RankReq qb = qa;
-      if (two) qb = rank_issue(ix, tb.slot[bb], rb, lc);
-      ra = tb.cf[ba] + rank_complete<WIDE>(qa, ba, lc);
-      if (two) rb = tb.cf[bb] + rank_complete<WIDE>(qb, bb, lc);
+      if (two) qb = rank_issue<LAYOUT>(ix, tb.slot[bb], rb, lc);
+      ra = tb.cf[ba] + rank_complete<WIDE, LAYOUT>(qa, ba, lc);
+      if (two) rb = tb.cf[bb] + rank_complete<WIDE, LAYOUT>(qb, bb, lc);
     }
     if (end_rows && t == 0) {
       end_rows[q] = ra;
@@ -182,31 +186,32 @@ __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_
     }
     done += two ? 2 * len : len;
   }
-  if (t == 0 && done) atomicAdd(&counters[0], (unsigned long long)done);
+  counters_add(counters, t == 0 ? done : 0u, 0, 0);
 }
 
 // ---------------------------------------------------------------- .fm payload (FMCreator)
 // FMCreator.create (bwtmerger.scala:452-532) bucket-sorts BWT positions by symbol; entry r of the
 // result is the position p with LF(p) = r.  One LF step per position, scattered as 4-byte
 // big-endian ints (the wire format, :476-481).
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kThreads) void k_fm_fill(DevIndex ix, uint64_t p0, uint64_t p1, uint32_t *__restrict__ fm) {
   __shared__ Tables tb;
   stage_tables(ix, tb);
-  const LaneConst lc = lane_const();
-  const uint64_t noct = (uint64_t)gridDim.x * kOctetsPerBlock;
-  for (uint64_t p = p0 + (((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 3); p < p1; p += 2 * noct) {
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
+  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
+  for (uint64_t p = p0 + (((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G); p < p1; p += 2 * noct) {
     const uint64_t pb = p + noct;
     const bool two = pb < p1;
     const uint32_t b1 = p == ix.eof ? 0u : ix.bwt[p];
     const uint32_t b2 = two ? (pb == ix.eof ? 0u : ix.bwt[pb]) : 0u;
-    const RankReq r1 = rank_issue(ix, tb.slot[b1], p, lc);
+    const RankReq r1 = rank_issue<LAYOUT>(ix, tb.slot[b1], p, lc);
     RankReq r2 = r1;
-    if (two) r2 = rank_issue(ix, tb.slot[b2], pb, lc);
-    const uint64_t v1 = tb.cf[b1] + rank_complete<WIDE>(r1, b1, lc);
+    if (two) r2 = rank_issue<LAYOUT>(ix, tb.slot[b2], pb, lc);
+    const uint64_t v1 = tb.cf[b1] + rank_complete<WIDE, LAYOUT>(r1, b1, lc);
     if (lc.t == 0) fm[v1] = __builtin_bswap32((uint32_t)p);
     if (two) {
-      const uint64_t v2 = tb.cf[b2] + rank_complete<WIDE>(r2, b2, lc);
+      const uint64_t v2 = tb.cf[b2] + rank_complete<WIDE, LAYOUT>(r2, b2, lc);
       if (lc.t == 0) fm[v2] = __builtin_bswap32((uint32_t)pb);
     }
   }
@@ -252,7 +257,7 @@ __device__ uint64_t psi_one(const DevIndex &ix, const uint64_t *cf, const uint16
   }
   uint64_t need = j - hdr[a * (kBlockBytes / 8)];
   const uint32_t *w = reinterpret_cast<const uint32_t *>(hdr + a * (kBlockBytes / 8)) + 2;
-  for (uint32_t d = 0; d < 30; d++) {
+  for (uint32_t d = 0; d < kBlockPayloadDwords; d++) {
     uint32_t v = w[d];
     uint32_t pc = __builtin_popcount(v);
     if (need < pc) {
@@ -290,13 +295,7 @@ __global__ __launch_bounds__(kThreads) void k_next_substr(DevIndex ix, const uin
 }
 
 // ---------------------------------------------------------------- launchers
-// Counts fit 32 bits iff n <= 2^32; the kernels then reduce the block header with the popcounts.
-#define FMX_WIDE_DISPATCH(h, kern, grid, st, ...)                            \
-  do {                                                                       \
-    if ((h)->n > (1ull << 32)) kern<true><<<(grid), kThreads, 0, (st)>>>(__VA_ARGS__);  \
-    else kern<false><<<(grid), kThreads, 0, (st)>>>(__VA_ARGS__);            \
-  } while (0)
-
+// Counts fit 32 bits iff n <= 2^32; the one-hot kernels then reduce the block header with the popcounts.
 static inline int grid_for(const Index *h, uint64_t k, int per_block) {
   uint64_t want = (k + per_block - 1) / per_block;
   uint64_t cap = (uint64_t)h->cu_count * 8;   // 8 x 256 threads fill a CU's 32 wave slots
@@ -306,39 +305,54 @@ static inline int grid_for(const Index *h, uint64_t k, int per_block) {
 
 hipError_t launch_occ(const Index *h, const void *d_c, const void *d_i, void *d_out, uint64_t k, hipStream_t st) {
   if (!k) return hipSuccess;
-  FMX_WIDE_DISPATCH(h, k_occ, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint8_t *)d_c, (const int64_t *)d_i,
-                    (uint64_t *)d_out, k, h->d_counters);
+#define CALL(W, L)                                                                                              \
+  k_occ<W, L><<<grid_for(h, k, kThreads / Lay<L>::G), kThreads, 0, st>>>(h->dev, (const uint8_t *)d_c,         \
+                                                                         (const int64_t *)d_i, (uint64_t *)d_out, k, h->d_counters)
+  FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
   return hipGetLastError();
 }
 
 hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep, const void *d_c, void *d_sp1,
                              void *d_ep1, uint64_t k, hipStream_t st) {
   if (!k) return hipSuccess;
-  FMX_WIDE_DISPATCH(h, k_prev_range, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint64_t *)d_sp,
-                    (const uint64_t *)d_ep, (const uint8_t *)d_c, (uint64_t *)d_sp1, (uint64_t *)d_ep1, k,
-                    h->d_counters);
+#define CALL(W, L)                                                                                              \
+  k_prev_range<W, L><<<grid_for(h, k, kThreads / Lay<L>::G), kThreads, 0, st>>>(                               \
+      h->dev, (const uint64_t *)d_sp, (const uint64_t *)d_ep, (const uint8_t *)d_c, (uint64_t *)d_sp1, (uint64_t *)d_ep1, k, h->d_counters)
+  FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
   return hipGetLastError();
 }
 
-// v1: one pattern per octet, byte-at-a-time pattern reads (kept for A/B runs; FMX_SEARCH_VARIANT=1)
+// generic search kernel: one pattern per group, byte-at-a-time pattern reads (FMX_SEARCH_VARIANT=1,
+// and batches of 2^32 patterns or more)
 hipError_t launch_search_v1(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
                             hipStream_t st) {
   if (!k) return hipSuccess;
-  FMX_WIDE_DISPATCH(h, k_search, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint8_t *)d_pat,
-                    (const uint64_t *)d_off, (uint64_t *)d_sp, (uint64_t *)d_ep, k, h->d_counters);
+#define CALL(W, L)                                                                                              \
+  k_search<W, L><<<grid_for(h, k, kThreads / Lay<L>::G), kThreads, 0, st>>>(                                   \
+      h->dev, (const uint8_t *)d_pat, (const uint64_t *)d_off, (uint64_t *)d_sp, (uint64_t *)d_ep, k, h->d_counters)
+  FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
   return hipGetLastError();
 }
 
 hipError_t launch_lf_walk(const Index *h, const void *d_rows, uint64_t k, uint32_t len, void *d_out, void *d_end,
                           hipStream_t st) {
   if (!k) return hipSuccess;
-  FMX_WIDE_DISPATCH(h, k_lf_walk, grid_for(h, k, kOctetsPerBlock), st, h->dev, (const uint64_t *)d_rows, k, len,
-                    (uint8_t *)d_out, (uint64_t *)d_end, h->d_counters);
+#define CALL(W, L)                                                                                              \
+  k_lf_walk<W, L><<<grid_for(h, k, kThreads / Lay<L>::G), kThreads, 0, st>>>(                                  \
+      h->dev, (const uint64_t *)d_rows, k, len, (uint8_t *)d_out, (uint64_t *)d_end, h->d_counters)
+  FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
   return hipGetLastError();
 }
 
 hipError_t launch_fm_fill(const Index *h, void *d_fm, hipStream_t st) {
-  FMX_WIDE_DISPATCH(h, k_fm_fill, grid_for(h, h->n, kOctetsPerBlock), st, h->dev, (uint64_t)0, h->n, (uint32_t *)d_fm);
+#define CALL(W, L)                                                                                              \
+  k_fm_fill<W, L><<<grid_for(h, h->n, kThreads / Lay<L>::G), kThreads, 0, st>>>(h->dev, (uint64_t)0, h->n, (uint32_t *)d_fm)
+  FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
   return hipGetLastError();
 }
 

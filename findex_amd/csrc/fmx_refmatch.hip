@@ -4,11 +4,11 @@
 // StatePoint(len, sp, ep, state) ordered by smallest state.num (:562-567); the loop runs while
 // the queue is non-empty, shorter than maxBranching, and (maxIterations == 0 or i < maxIterations)
 // with i starting at 1 (:622,628).  When those limits bind, which results come out depends on the
-// exact pop order, ties included, so this mode replays the queue itself: one regex per octet of
-// lanes, the octet's lane 0 keeps the regex's binary heap in device memory and performs the same
+// exact pop order, ties included, so this mode replays the queue itself: one regex per lane group
+// (quad or octet, fmx_device.h), the group's lane 0 keeps the regex's binary heap in device memory and performs the same
 // fixUp / fixDown as the Scala 2.10.0 library (`+=`: append then sift up with `<`; `dequeue`:
 // swap root and last, sift down picking the right child only when left < right, stop when
-// parent >= child), the popped element is broadcast to the octet and stepped with the shared
+// parent >= child), the popped element is broadcast to the group and stepped with the shared
 // rank primitive.  Results carry their discovery number so the host can return them newest
 // first, the order of the reference's `ret ::= ...` list.
 //
@@ -52,7 +52,6 @@ struct RefResult {
 
 struct RefCtl {
   unsigned long long res_count;
-  unsigned long long steps;
   unsigned long long overflow;
 };
 
@@ -94,23 +93,25 @@ __device__ HeapElem heap_pop(HeapElem *a, uint32_t &size0) {
   return top;
 }
 
-template <bool WIDE>
+template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables rt, uint32_t k_regex,
                                                           HeapElem *__restrict__ heaps, uint32_t heap_cap,
                                                           uint32_t max_branching, uint32_t max_iterations,
                                                           RefResult *__restrict__ res, uint64_t res_cap,
                                                           uint32_t *__restrict__ front_left,
-                                                          RefCtl *__restrict__ ctl) {
+                                                          RefCtl *__restrict__ ctl,
+                                                          unsigned long long *__restrict__ counters) {
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
   __syncthreads();
-  const LaneConst lc = lane_const();
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
   const uint32_t lane = __lane_id();
-  const uint32_t leader = lane & ~7u;
-  const uint32_t octet = (blockIdx.x * kRThreads + threadIdx.x) >> 3;
-  const uint32_t noct = gridDim.x * (kRThreads / kOctet);
+  const uint32_t leader = lane & ~(uint32_t)(G - 1);
+  const uint32_t octet = (blockIdx.x * kRThreads + threadIdx.x) / G;
+  const uint32_t noct = gridDim.x * (kRThreads / G);
   HeapElem *heap = heaps + (size_t)octet * heap_cap;
   uint32_t stepped = 0;
   for (uint32_t r = octet; r < k_regex; r += noct) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
       }
     }
     for (;;) {
-      // loop condition, :628 (decided by the leader, shared with the octet)
+      // loop condition, :628 (decided by the leader, shared with the group)
       uint32_t go = 0, state = 0, len = 0, splo = 0, sphi = 0, eplo = 0, ephi = 0;
       if (t == 0 && !bad && size0 >= 2 && (size0 - 1) < max_branching && (max_iterations == 0 || it < max_iterations)) {
         const HeapElem q = heap_pop(heap, size0);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
       const uint32_t c = rt.st_c[state];
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
-      backward_step<WIDE>(ix, c, slot, cfc, lc, sp, ep);
+      backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
       stepped++;
       if (t == 0 && sp < ep) {
         if (rt.st_last[state]) {                                   // :636-638
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
     }
     if (t == 0 && front_left) front_left[r] = size0 - 1;
   }
-  if (t == 0 && stepped) atomicAdd(&ctl->steps, (unsigned long long)stepped);
+  counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
 }
 
 #define HIP_TRY(call, what)                            \
@@ -229,11 +230,12 @@ int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uin
   if (heap_cap64 > (1u << 22)) { set_error("max_branching too large for the reference-order mode"); return FMX_ERR_ARG; }
   const uint32_t heap_cap = (uint32_t)heap_cap64;
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
-  uint64_t want = (k + (kRThreads / kOctet) - 1) / (kRThreads / kOctet);
+  const uint64_t per_wg = kRThreads / (h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G);   // regexes per workgroup
+  uint64_t want = (k + per_wg - 1) / per_wg;
   uint64_t gcap = (uint64_t)h->cu_count * 8;
-  // bound the heap arena (32 B x heap_cap per octet) to ~4 GiB
-  const uint64_t arena_octets = std::max<uint64_t>(32, (4ull << 30) / ((uint64_t)heap_cap * sizeof(HeapElem)));
-  gcap = std::min<uint64_t>(gcap, std::max<uint64_t>(1, arena_octets / (kRThreads / kOctet)));
+  // bound the heap arena (32 B x heap_cap per lane group) to ~4 GiB
+  const uint64_t arena_groups = std::max<uint64_t>(64, (4ull << 30) / ((uint64_t)heap_cap * sizeof(HeapElem)));
+  gcap = std::min<uint64_t>(gcap, std::max<uint64_t>(1, arena_groups / per_wg));
   const int grid = (int)std::min(want, gcap);
   DevMem mem;
   RefTables rt{};
@@ -249,7 +251,7 @@ int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uin
   HeapElem *d_heaps = nullptr;
   RefResult *d_res = nullptr;
   RefCtl *d_ctl = nullptr;
-  HIP_TRY(mem.alloc(&d_heaps, (size_t)grid * (kRThreads / kOctet) * heap_cap), "hipMalloc(heaps)");
+  HIP_TRY(mem.alloc(&d_heaps, (size_t)grid * per_wg * heap_cap), "hipMalloc(heaps)");
   HIP_TRY(mem.alloc(&d_res, cap ? cap : 1), "hipMalloc(results)");
   HIP_TRY(mem.alloc(&d_ctl, 1), "hipMalloc(ctl)");
   if (front_left) HIP_TRY(mem.alloc(&d_left, k), "hipMalloc(front_left)");
@@ -259,12 +261,11 @@ int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uin
   HIP_TRY(hipEventCreate(&e1), "hipEventCreate");
   struct EG { hipEvent_t a, b; ~EG() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
   HIP_TRY(hipEventRecord(e0, nullptr), "hipEventRecord");
-  if (h->n > (1ull << 32))
-    k_match_ref<true><<<grid, kRThreads>>>(h->dev, rt, (uint32_t)k, d_heaps, heap_cap, max_branching, max_iterations,
-                                            d_res, (uint64_t)cap, d_left, d_ctl);
-  else
-    k_match_ref<false><<<grid, kRThreads>>>(h->dev, rt, (uint32_t)k, d_heaps, heap_cap, max_branching, max_iterations,
-                                             d_res, (uint64_t)cap, d_left, d_ctl);
+#define CALL(W, L)                                                                                          \
+  k_match_ref<W, L><<<grid, kRThreads>>>(h->dev, rt, (uint32_t)k, d_heaps, heap_cap, max_branching, max_iterations, \
+                                         d_res, (uint64_t)cap, d_left, d_ctl, h->d_counters)
+  FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
   HIP_TRY(hipGetLastError(), "k_match_ref");
   HIP_TRY(hipEventRecord(e1, nullptr), "hipEventRecord");
   RefCtl ctl{};
@@ -275,13 +276,6 @@ int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uin
     std::lock_guard<std::mutex> lk(h->mu);
     h->last_kernel_ms = ms;
     h->launches += 1;
-  }
-  if (ctl.steps) {
-    unsigned long long cur_cnt[2];
-    HIP_TRY(hipMemcpy(cur_cnt, h->d_counters, sizeof cur_cnt, hipMemcpyDeviceToHost), "D2H(counters)");
-    cur_cnt[0] += 2ull * ctl.steps;
-    cur_cnt[1] += ctl.steps;
-    HIP_TRY(hipMemcpy(h->d_counters, cur_cnt, sizeof cur_cnt, hipMemcpyHostToDevice), "H2D(counters)");
   }
   if (ctl.overflow & 1ull) { set_error("reference-order heap overflow (internal bound)"); return FMX_ERR_OVERFLOW; }
   *n_out = (size_t)ctl.res_count;

@@ -60,9 +60,9 @@ typedef struct fmx_regex_batch fmx_regex_batch;   /* a set of compiled regexes m
 
 const char *fmx_last_error(void);
 int fmx_abi_version(void);
-/* Process-wide options.  key "layout": "auto" (default: one-hot bit-vectors, one 128-byte line per
- * rank query, when sigma*n/8 bytes fit in free HBM; else BWT bytes + checkpoints, two lines per rank
- * query), "onehot", "bytes".  Affects indexes opened afterwards. */
+/* Process-wide options.  key "layout": "auto" (default: one-hot bit-vectors, one 64-byte block per
+ * rank query, when sigma*n/7 bytes fit in free HBM and n < 2^37; else BWT bytes + checkpoints, two
+ * lines per rank query), "onehot", "bytes".  Affects indexes opened afterwards. */
 int fmx_config_set(const char *key, const char *value);
 /* Number of HIP devices visible (0 and FMX_OK when there is none). */
 int fmx_device_count(int *count);
@@ -236,10 +236,11 @@ typedef struct fmx_stats_t {
   uint64_t index_bytes;      /* device bytes held: rank dictionary + BWT + tables */
   uint64_t n_blocks;         /* rank-dictionary blocks per symbol */
   uint32_t n_symbols;        /* symbols that own a bit-vector */
-  uint32_t block_bytes;      /* algorithmic bytes per rank query: 128 (one-hot block) or 132 (block + checkpoint) */
+  uint32_t block_bytes;      /* bytes fetched per rank query: 64 (one-hot block) or 132 (BWT block + checkpoint) */
   double build_ms;           /* device time to build the rank dictionary at open */
   uint32_t layout;           /* 0 = one-hot bit-vectors, 1 = BWT bytes + checkpoints */
   uint32_t reserved;
+  uint64_t search_requests;  /* memory requests for rank-dictionary lines issued by fmx_search_batch[_dev]'s kernel */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 int fmx_stats_reset(fmx_index *idx);

@@ -164,7 +164,8 @@ def test_fm_file_is_byte_identical(testdata, name, be, tmp_path):
 
 # ---------------------------------------------------------------- synthetic indexes
 @pytest.mark.parametrize("n,lo,hi,seed", [
-    (1, 1, 1, 1), (2, 1, 2, 2), (959, 1, 4, 3), (960, 1, 4, 4), (961, 1, 4, 5), (1920, 1, 4, 6), (1921, 65, 68, 7),
+    (1, 1, 1, 1), (2, 1, 2, 2), (447, 1, 4, 3), (448, 1, 4, 4), (449, 1, 4, 5), (896, 1, 4, 6), (897, 65, 68, 7),
+    (959, 1, 4, 3), (960, 1, 4, 4), (961, 1, 4, 5), (1344, 1, 3, 12),     # block edges of the one-hot layout (448)
     (100_003, 1, 4, 8),            # DNA-like sigma=4 (C2 shape, small)
     (300_007, 1, 128, 9),          # sigma=128 incl. byte 0x80 (C3 shape, small)
     (200_000, 1, 255, 10),         # every byte value

@@ -49,21 +49,23 @@ WORKLOADS = {
 
 
 def pmc_traffic(workload, kernel="k_search4"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<tag>_<workload>_counters.csv, written by tools/summarize_prof.py from separate
-    `--pmc` runs of tools/prof_workload.py -- the same step): reads = 2 x FETCH_SIZE KiB (gfx950
-    tallies these kernels' 128-byte requests at 64 B; calibrated on k_occ, see the summary file)
-    plus WRITE_SIZE KiB.  None when no profile of this workload is in the tree."""
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of this workload
+    (profiles/r*_<workload>_counters.csv, written by tools/summarize_prof.py from separate rocprofv3 --pmc
+    passes): FETCH_SIZE KiB x the bytes one KiB stands for in this access pattern (calibrated in the same
+    profile on a k_occ launch of known byte count, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB x 1024.
+    None when no profile of this workload is in the tree."""
     import csv
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters.csv" % workload))):
-        vals = {}
+        vals, per_kib = {}, None
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel"]:
                 vals[r["Counter"]] = float(r["Mean"])
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            best = (int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.basename(f))
+            if r["Counter"] == "FETCH_BYTES_PER_KIB":
+                per_kib = float(r["Mean"])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and per_kib:
+            best = (int(vals["FETCH_SIZE"] * per_kib + vals["WRITE_SIZE"] * 1024), os.path.basename(f))
     return best
 
 

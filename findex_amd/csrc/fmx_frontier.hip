@@ -403,14 +403,24 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   }
   ctl.res_count += extra;
   if (ctl.res_count) {
-    std::sort(out, out + ctl.res_count, [](const fmx_result &a, const fmx_result &b) {
-      if (a.regex != b.regex) return a.regex < b.regex;
-      if (a.len != b.len) return a.len < b.len;
-      if (a.sp != b.sp) return a.sp < b.sp;
-      return a.ep < b.ep;
-    });
+    // canonical order (regex, len, sp, ep): bucket by regex id (counting sort), then order each regex's
+    // few results -- a comparison sort over the whole array costs more than the device levels
+    const size_t nres = (size_t)ctl.res_count;
+    std::vector<uint32_t> start(b->k + 1, 0);
+    for (size_t j = 0; j < nres; j++) start[out[j].regex + 1]++;
+    for (size_t r = 0; r < b->k; r++) start[r + 1] += start[r];
     if (per_regex_count)
-      for (size_t j = 0; j < ctl.res_count; j++) per_regex_count[out[j].regex]++;
+      for (size_t r = 0; r < b->k; r++) per_regex_count[r] = start[r + 1] - start[r];
+    std::vector<fmx_result> tmp(out, out + nres);
+    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+    for (size_t j = 0; j < nres; j++) out[fill[tmp[j].regex]++] = tmp[j];
+    for (size_t r = 0; r < b->k; r++)
+      if (start[r + 1] - start[r] > 1)
+        std::sort(out + start[r], out + start[r + 1], [](const fmx_result &a, const fmx_result &b) {
+          if (a.len != b.len) return a.len < b.len;
+          if (a.sp != b.sp) return a.sp < b.sp;
+          return a.ep < b.ep;
+        });
   }
   if (truncated) {
     set_error("frontier still alive after max_steps levels: results hold every match of length <= max_steps");

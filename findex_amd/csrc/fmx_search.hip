@@ -194,11 +194,13 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_
             split448(ep, b2, m2);
             const uint64_t base = vb + lane_off;
             const uint4 w1 = load_line16(base + (uint64_t)b1 * kBlockBytes);
-            const uint4 w2 = load_line16(base + (uint64_t)b2 * kBlockBytes);
+            uint4 w2 = w1;                                     // narrow intervals: sp and ep share a block
+            if (b2 != b1) { w2 = load_line16(base + (uint64_t)b2 * kBlockBytes); reqs += 1; }
             sp = cfc + rank_finish<WIDE>(w1, m1, lc);
             ep = cfc + rank_finish<WIDE>(w2, m2, lc);
+            reqs += 1;
           }
-          reqs += 2 * R;
+          if (LAYOUT == kLayoutBytes) reqs += 2 * R;
         } else {
           const uint64_t r1 = special(cfc, vb, sp);
           ep = special(cfc, vb, ep);

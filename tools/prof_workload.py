@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Workload for rocprofv3 passes: the C3 bench step (k_search) plus a calibration launch of
+"""Workload for rocprofv3 passes: the C3 bench step (k_search4) plus a calibration launch of
 k_occ whose HBM byte count is known -- 2^24 uniformly random (c, i) rank queries over the
-72 GiB rank dictionary touch 2^24 distinct 128-byte lines (collisions < 0.4 %), i.e. 2 GiB.
-FETCH_SIZE read for k_occ calibrates the counter for this access pattern
-(MI355X_MICROARCH.md, HBM: FETCH_SIZE halves wide reads on gfx950; other widths uncalibrated).
+77 GiB rank dictionary touch 2^24 distinct 64-byte blocks (collisions < 0.2 %), i.e. 1 GiB, plus
+the 9 bytes of (c, i) streamed in per query.  FETCH_SIZE read for k_occ calibrates the counter
+for this access pattern (MI355X_MICROARCH.md, HBM: FETCH_SIZE halves wide reads on gfx950; other
+widths are uncalibrated -- calibrate on a known byte count in your own access pattern).
 
     rocprofv3 --kernel-trace --stats ... -- python3 tools/prof_workload.py [--workload c3] [--steps 5]
 """
@@ -50,9 +51,10 @@ for _ in range(a.steps):
     hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
 torch.cuda.synchronize()
 st = hip.stats()
-print("k_search: %d launches, %d rank queries per launch, algorithmic bytes per launch %d"
-      % (a.steps, st["rank_queries"] // a.steps, st["rank_queries"] // a.steps * 128))
+print("k_search4: %d launches, %d rank queries and %d block requests per launch"
+      % (a.steps, st["rank_queries"] // a.steps, st["search_requests"] // a.steps))
 for _ in range(3):
     hip.occ_batch_dev(qc.data_ptr(), qi.data_ptr(), qo.data_ptr(), kc, stream)
 torch.cuda.synchronize()
-print("k_occ: 3 launches, %d rank queries per launch = %d known bytes of 128-B lines" % (kc, kc * 128))
+line = int(st["block_bytes"])
+print("CALIB kernel=k_occ queries=%d line_bytes=%d read_bytes=%d" % (kc, line, kc * line + kc * 9))

@@ -28,18 +28,19 @@ namespace fmx {
 
 constexpr int kFThreads = 256;
 
-struct Queue {           // SoA frontier queue in HBM
+struct Queue {           // SoA frontier queue in HBM; every element of a level has len == level
   uint32_t *state;       // global CharNode id
-  uint32_t *len;
   uint64_t *sp;
   uint64_t *ep;
 };
 
-struct StateRec {        // 16 bytes: everything a frontier element needs about its state, one load
+constexpr uint32_t kInlineFollows = 4;
+struct StateRec {        // 32 bytes: everything a frontier element needs about its state, two 16-byte loads
   uint32_t fol_off;      // first entry of its follows in `fol`
   uint32_t fol_cnt;
   uint32_t regex;
   uint32_t c_emit;       // byte in bits 0..7, emit flag in bit 8
+  uint32_t f[kInlineFollows];   // the first follows, so that short lists need no further load
 };
 
 struct NfaTables {       // all regexes of the batch, concatenated; state ids are global
@@ -47,21 +48,32 @@ struct NfaTables {       // all regexes of the batch, concatenated; state ids ar
   const uint32_t *fol;
 };
 
-constexpr uint32_t kStageCap = 256;     // survivors a wave stages in LDS before reserving queue slots
-constexpr uint32_t kStageSmall = 16;    // follows lists up to this length go through the stage (16 groups x 16 <= cap)
+constexpr uint32_t kStageCap = 192;     // survivors a wave stages in LDS before reserving queue slots
+constexpr uint32_t kStageSmall = 12;    // follows lists up to this length go through the stage (16 groups x 12 <= cap)
 
-struct Stage {
+struct Stage {           // 20 bytes per entry: 4 waves x 192 entries + the symbol tables keep 8 workgroups per CU
   uint32_t state[kStageCap];
-  uint32_t len[kStageCap];
   uint64_t sp[kStageCap];
   uint64_t ep[kStageCap];
 };
 
+// The queues and the result buffer are cut into kSub slices with one tail counter each, every counter
+// on its own 128-byte line: a single tail cannot take the appends of a whole level (same-address device
+// atomics complete at ~100 per microsecond -- with one tail a 3.7 M-element level spent 250 us on 25 k
+// appends, and every level paid ~60 us for the 6144 waves' final flush).  A wave appends to slice
+// (wave + number of its earlier appends) % kSub, so slices stay balanced even when one wave produces
+// everything; at the next level slice j is read by the waves with id % kSub == j.
+constexpr uint32_t kSub = 64;
+struct alignas(128) PaddedCount {
+  unsigned long long v;
+  unsigned long long pad[15];
+};
+
 struct FrontierCtl {     // device-resident counters
-  // Level L reads count[L % 3] elements, appends to count[(L+1) % 3] and clears count[(L+2) % 3]
-  // (its predecessor's input), so a chain of level launches needs no host round trip in between.
-  unsigned long long count[3];
-  unsigned long long res_count;
+  // Level L reads count[L % 3], appends to count[(L+1) % 3] and clears count[(L+2) % 3] (its
+  // predecessor's input), so a chain of level launches needs no host round trip in between.
+  PaddedCount count[3][kSub];
+  PaddedCount res_count[kSub];
   unsigned long long overflow;     // bit 0: queue, bit 1: results
 };
 
@@ -78,45 +90,57 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
   return x - v;
 }
 
+// One level.  Each lane group walks the queue with a grid stride, one element per round, and the
+// rounds are software-pipelined: the queue entry of round r+2 and the state record of round r+1 are
+// requested before round r's rank blocks, so a round waits for one memory latency (the rank blocks),
+// not four in a row (entry -> record -> blocks -> follows).
 template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, Queue nxt, uint32_t level,
-                                                         uint64_t nxt_cap, fmx_result *__restrict__ res,
-                                                         uint64_t res_cap, FrontierCtl *__restrict__ ctl,
+                                                         uint64_t sub_cap, fmx_result *__restrict__ res,
+                                                         uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
                                                          unsigned long long *__restrict__ counters) {
   // After a queue overflow the appended count exceeds what was stored: later levels of the chain
   // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
   if (ctl->overflow & 1ull) return;
-  uint64_t cur_count = ctl->count[level % 3];
-  if (cur_count > nxt_cap) cur_count = nxt_cap;          // both queues have nxt_cap entries
-  unsigned long long *next_count = &ctl->count[(level + 1) % 3];
-  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->count[(level + 2) % 3] = 0;
-  if (cur_count == 0) return;
+  if (blockIdx.x == 0 && threadIdx.x < kSub) ctl->count[(level + 2) % 3][threadIdx.x].v = 0;
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
   __syncthreads();
   constexpr int G = Lay<LAYOUT>::G;
+  constexpr uint32_t P = 64 / G;             // elements per wave and round
   const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * (kFThreads / G);
-  const uint64_t first = ((uint64_t)blockIdx.x * kFThreads + threadIdx.x) / G;
+  const uint32_t w = (blockIdx.x * kFThreads + threadIdx.x) >> 6;      // this wave
+  const uint32_t nw = gridDim.x * (kFThreads / 64);
+  const uint32_t sub = w % kSub;             // the slice this wave reads
+  const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
+  uint64_t cur_count = ctl->count[level % 3][sub].v;
+  if (cur_count > sub_cap) cur_count = sub_cap;
+  if (cur_count == 0) return;                // wave-uniform; nothing below needs the other waves
+  const uint64_t in_off = (uint64_t)sub * sub_cap;
+  const uint64_t ngrp = (uint64_t)class_waves * P;
+  const uint64_t first = (uint64_t)(w / kSub) * P + (threadIdx.x & 63u) / G;
+  PaddedCount *next_count = ctl->count[(level + 1) % 3];
   uint32_t stepped = 0;
+  uint32_t appends = 0;                      // wave-uniform: rotates the slice this wave appends to
   __shared__ Stage s_stage[kFThreads / 64];
   Stage &stg = s_stage[threadIdx.x >> 6];
   uint32_t staged = 0;                       // wave-uniform
   auto flush = [&]() {
     if (!staged) return;
     __builtin_amdgcn_wave_barrier();
+    const uint32_t so = (w + appends++) % kSub;
     unsigned long long base = 0;
-    if (__lane_id() == 0) base = atomicAdd(next_count, (unsigned long long)staged);
+    if (__lane_id() == 0) base = atomicAdd(&next_count[so].v, (unsigned long long)staged);
     base = __shfl(base, 0, 64);
+    const uint64_t out_off = (uint64_t)so * sub_cap;
     for (uint32_t i = __lane_id(); i < staged; i += 64) {
       const unsigned long long at = base + i;
-      if (at < nxt_cap) {
-        nxt.state[at] = stg.state[i];
-        nxt.len[at] = stg.len[i];
-        nxt.sp[at] = stg.sp[i];
-        nxt.ep[at] = stg.ep[i];
+      if (at < sub_cap) {
+        nxt.state[out_off + at] = stg.state[i];
+        nxt.sp[out_off + at] = stg.sp[i];
+        nxt.ep[out_off + at] = stg.ep[i];
       } else {
         atomicOr(&ctl->overflow, 1ull);
       }
@@ -124,28 +148,43 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
     __builtin_amdgcn_wave_barrier();
     staged = 0;
   };
+  struct Entry { uint32_t state; uint64_t sp, ep; };
+  auto load_entry = [&](uint64_t q) {        // out-of-range rounds read element 0 (valid, unused)
+    const uint64_t i = in_off + (q < cur_count ? q : 0);
+    Entry e;
+    e.state = cur.state[i]; e.sp = cur.sp[i]; e.ep = cur.ep[i];
+    return e;
+  };
+  auto load_rec = [&](uint32_t state) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(nfa.st + state);
+    const uint4 a = p[0], b = p[1];
+    StateRec r;
+    r.fol_off = a.x; r.fol_cnt = a.y; r.regex = a.z; r.c_emit = a.w;
+    r.f[0] = b.x; r.f[1] = b.y; r.f[2] = b.z; r.f[3] = b.w;
+    return r;
+  };
   // all groups of a wave run the same number of rounds so that the wave-wide scans stay convergent
-  const uint64_t rounds = (cur_count + noct - 1) / noct;
+  const uint64_t rounds = (cur_count + ngrp - 1) / ngrp;
+  Entry e0 = load_entry(first), e1 = load_entry(first + ngrp);
+  StateRec rec0 = load_rec(e0.state);
   for (uint64_t rd = 0; rd < rounds; rd++) {
-    const uint64_t q = first + rd * noct;
+    const uint64_t q = first + rd * ngrp;
     const bool have = q < cur_count;
-    uint32_t s = 0, ln = 0, nf = 0, f0 = 0, rgx = 0;
-    uint64_t sp = 0, ep = 0;
+    const Entry e2 = load_entry(q + 2 * ngrp);          // prefetch: entry two rounds ahead,
+    const StateRec rec1 = load_rec(e1.state);            // record one round ahead
+    uint32_t nf = 0, f0 = 0, rgx = 0;
+    uint64_t sp = e0.sp, ep = e0.ep;
     bool emit = false;
     if (have) {
-      s = cur.state[q];
-      ln = cur.len[q];
-      sp = cur.sp[q];
-      ep = cur.ep[q];
-      const StateRec rec = nfa.st[s];
-      const uint32_t c = rec.c_emit & 0xFFu;
-      rgx = rec.regex;
+      const uint32_t c = rec0.c_emit & 0xFFu;
+      rgx = rec0.regex;
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
-      if (ln == 0) {          // every level-0 element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
+      if (level == 0) {       // every level-0 element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
         sp = cfc;
         ep = (c == 255u) ? ix.n : s_cf[c + 1];
         if (slot == kSlotNone) ep = sp;
+        else if (slot == kSlotEof) ep = sp + 1;
       } else {
         backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
       }
@@ -153,31 +192,32 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
       if (sp < ep) {                                   // Some((sp1,ep1)), retree.scala:634
         // Glushkov tables: an isLast state emits and has no follows here (:636-641); Thompson / DFA
         // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282)
-        emit = (rec.c_emit >> 8) != 0;
-        f0 = rec.fol_off;
-        nf = rec.fol_cnt;
+        emit = (rec0.c_emit >> 8) != 0;
+        f0 = rec0.fol_off;
+        nf = rec0.fol_cnt;
       }
     }
     // ---- compaction.  Results: ballot + one atomic per wave (they are few).  Pushes: a single
     // queue-tail counter cannot take one atomic per wave and round (same-address device atomics run
-    // at ~90 per microsecond), so each wave stages its survivors in LDS and reserves queue slots only
-    // when the stage fills: one atomic per ~200 elements and coalesced queue writes.
+    // at ~100 per microsecond), so each wave stages its survivors in LDS and reserves queue slots only
+    // when the stage fills: one atomic per ~150 elements and coalesced queue writes.
     const bool lead = t == 0;
     const uint32_t lane = __lane_id();
     const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
     if (em) {
+      const uint32_t so = (w + appends++) % kSub;
       unsigned long long rbase = 0;
-      if (lane == 0) rbase = atomicAdd(&ctl->res_count, (unsigned long long)__builtin_popcountll(em));
+      if (lane == 0) rbase = atomicAdd(&ctl->res_count[so].v, (unsigned long long)__builtin_popcountll(em));
       rbase = __shfl(rbase, 0, 64);
       if (lead && emit) {
         const unsigned long long at = rbase + __builtin_popcountll(em & ((1ull << lane) - 1ull));
-        if (at < res_cap) {
+        if (at < seg_cap) {
           fmx_result r;
           r.regex = rgx;
-          r.len = ln + 1;
+          r.len = level + 1;
           r.sp = sp;
           r.ep = ep;
-          res[at] = r;
+          res[(uint64_t)so * seg_cap + at] = r;
         } else {
           atomicOr(&ctl->overflow, 2ull);
         }
@@ -190,8 +230,11 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
     if (small_total) {
       const uint32_t my_off = staged + __shfl(small_off, lane & ~(uint32_t)(G - 1), 64);
       for (uint32_t j = t; j < nsmall; j += G) {
-        stg.state[my_off + j] = nfa.fol[f0 + j];
-        stg.len[my_off + j] = ln + 1;
+        // the first kInlineFollows follows ride in the state record
+        uint32_t fs;
+        if (j < kInlineFollows) fs = j < 2 ? (j == 0 ? rec0.f[0] : rec0.f[1]) : (j == 2 ? rec0.f[2] : rec0.f[3]);
+        else fs = nfa.fol[f0 + j];
+        stg.state[my_off + j] = fs;
         stg.sp[my_off + j] = sp;
         stg.ep[my_off + j] = ep;
       }
@@ -202,22 +245,26 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
       const uint32_t nlarge = nf > kStageSmall ? nf : 0u;
       uint32_t large_total = 0;
       const uint32_t large_off = wave_excl_scan(lead ? nlarge : 0u, large_total);
+      const uint32_t so = (w + appends++) % kSub;
+      const uint64_t out_off = (uint64_t)so * sub_cap;
       unsigned long long qbase = 0;
-      if (lane == 0) qbase = atomicAdd(next_count, (unsigned long long)large_total);
+      if (lane == 0) qbase = atomicAdd(&next_count[so].v, (unsigned long long)large_total);
       qbase = __shfl(qbase, 0, 64);
       const uint32_t my_off = __shfl(large_off, lane & ~(uint32_t)(G - 1), 64);
       for (uint32_t j = t; j < nlarge; j += G) {
         const unsigned long long at = qbase + my_off + j;
-        if (at < nxt_cap) {
-          nxt.state[at] = nfa.fol[f0 + j];
-          nxt.len[at] = ln + 1;
-          nxt.sp[at] = sp;
-          nxt.ep[at] = ep;
+        if (at < sub_cap) {
+          nxt.state[out_off + at] = nfa.fol[f0 + j];
+          nxt.sp[out_off + at] = sp;
+          nxt.ep[out_off + at] = ep;
         } else {
           atomicOr(&ctl->overflow, 1ull);
         }
       }
     }
+    e0 = e1;
+    e1 = e2;
+    rec0 = rec1;
   }
   flush();
   counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
@@ -257,7 +304,8 @@ struct RegexBatch {
   // scratch reused across matches of this batch (one match at a time per batch object)
   std::unique_ptr<DevMem> scratch;
   Queue qa{}, qb{};
-  fmx_result *d_res = nullptr;
+  fmx_result *d_res = nullptr;        // packed results
+  fmx_result *d_res_seg = nullptr;    // kSub result slices the levels append to
   FrontierCtl *d_ctl = nullptr;
   uint64_t qcap = 0;
   size_t rcap = 0;
@@ -292,8 +340,14 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   b->n_first = q_state.size();
   b->start_final = start_final;
   std::vector<StateRec> recs(st_c.size());
-  for (size_t q = 0; q < recs.size(); q++)
-    recs[q] = StateRec{fol_off[q], fol_off[q + 1] - fol_off[q], st_regex[q], (uint32_t)st_c[q] | ((uint32_t)(st_last[q] ? 1 : 0) << 8)};
+  for (size_t q = 0; q < recs.size(); q++) {
+    StateRec &r = recs[q];
+    r.fol_off = fol_off[q];
+    r.fol_cnt = fol_off[q + 1] - fol_off[q];
+    r.regex = st_regex[q];
+    r.c_emit = (uint32_t)st_c[q] | ((uint32_t)(st_last[q] ? 1 : 0) << 8);
+    for (uint32_t j = 0; j < kInlineFollows; j++) r.f[j] = j < r.fol_cnt ? fol[r.fol_off + j] : 0u;
+  }
   StateRec *d_st = nullptr;
   uint32_t *d_fol = nullptr;
   HIP_TRY(b->mem.alloc(&d_st, recs.size()), "hipMalloc");
@@ -307,15 +361,32 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   return FMX_OK;
 }
 
-// Level-0 queue: states = firsts, len = 0, sp = 0, ep = n.
+// Level-0 queue: states = firsts, sp = 0, ep = n, dealt round-robin over the slices.
 __global__ void k_frontier_init(Queue q, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n,
-                                FrontierCtl *__restrict__ ctl) {
+                                uint64_t sub_cap, FrontierCtl *__restrict__ ctl) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) {
-    ctl->count[0] = count; ctl->count[1] = 0; ctl->count[2] = 0;
-    ctl->res_count = 0; ctl->overflow = 0;
+  if (i < kSub) {
+    ctl->count[0][i].v = count > i ? (count - i + kSub - 1) / kSub : 0;
+    ctl->count[1][i].v = 0;
+    ctl->count[2][i].v = 0;
+    ctl->res_count[i].v = 0;
   }
-  if (i < count) { q.state[i] = first_state[i]; q.len[i] = 0; q.sp[i] = 0; q.ep[i] = n; }
+  if (i == 0) ctl->overflow = 0;
+  if (i < count) {
+    const uint64_t at = (i % kSub) * sub_cap + i / kSub;
+    q.state[at] = first_state[i]; q.sp[at] = 0; q.ep[at] = n;
+  }
+}
+
+// Packs the result slices into one array (workgroup j copies slice j behind the slices before it).
+__global__ __launch_bounds__(256) void k_pack_results(const fmx_result *__restrict__ seg, uint64_t seg_cap,
+                                                       const FrontierCtl *__restrict__ ctl,
+                                                       fmx_result *__restrict__ out, uint64_t out_cap) {
+  uint64_t before = 0;
+  for (uint32_t j = 0; j < blockIdx.x; j++) before += min((uint64_t)ctl->res_count[j].v, seg_cap);
+  const uint64_t mine = min((uint64_t)ctl->res_count[blockIdx.x].v, seg_cap);
+  for (uint64_t i = threadIdx.x; i < mine; i += blockDim.x)
+    if (before + i < out_cap) out[before + i] = seg[(uint64_t)blockIdx.x * seg_cap + i];
 }
 
 int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_result *out, size_t cap,
@@ -328,22 +399,27 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if (b->n_first == 0 && b->start_final.empty()) return FMX_OK;
   if (b->n_first > qcap) { set_error("initial frontier exceeds max_frontier"); return FMX_ERR_OVERFLOW; }
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+  // slices: each holds its share of max_frontier plus a quarter of headroom (appends rotate over the slices,
+  // so they fill evenly, not exactly); the result segments get 4x their share
+  const uint64_t sub_cap = (qcap + kSub - 1) / kSub + qcap / (4 * kSub) + 1024;
+  const uint64_t seg_cap = (uint64_t)cap / 16 + 1024;
   if (!b->scratch || b->qcap != qcap || b->rcap < (cap ? cap : 1)) {
     b->scratch.reset(new DevMem());
     b->qcap = 0;
     for (Queue *q : {&b->qa, &b->qb}) {
-      HIP_TRY(b->scratch->alloc(&q->state, qcap), "hipMalloc(queue)");
-      HIP_TRY(b->scratch->alloc(&q->len, qcap), "hipMalloc(queue)");
-      HIP_TRY(b->scratch->alloc(&q->sp, qcap), "hipMalloc(queue)");
-      HIP_TRY(b->scratch->alloc(&q->ep, qcap), "hipMalloc(queue)");
+      HIP_TRY(b->scratch->alloc(&q->state, kSub * sub_cap), "hipMalloc(queue)");
+      HIP_TRY(b->scratch->alloc(&q->sp, kSub * sub_cap), "hipMalloc(queue)");
+      HIP_TRY(b->scratch->alloc(&q->ep, kSub * sub_cap), "hipMalloc(queue)");
     }
     HIP_TRY(b->scratch->alloc(&b->d_res, cap ? cap : 1), "hipMalloc(results)");
+    HIP_TRY(b->scratch->alloc(&b->d_res_seg, kSub * seg_cap), "hipMalloc(result slices)");
     HIP_TRY(b->scratch->alloc(&b->d_ctl, 1), "hipMalloc(ctl)");
     b->qcap = qcap;
     b->rcap = cap ? cap : 1;
   }
   const Queue qa = b->qa, qb = b->qb;
   fmx_result *d_res = b->d_res;
+  fmx_result *d_res_seg = b->d_res_seg;
   FrontierCtl *d_ctl = b->d_ctl;
   hipStream_t st = nullptr;
   HIP_TRY(hipStreamCreate(&st), "hipStreamCreate");
@@ -354,13 +430,15 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   struct EG { hipEvent_t a, b; ~EG() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
 
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
-  k_frontier_init<<<(int)((b->n_first + 255) / 256), 256, 0, st>>>(qa, b->d_first_state, b->n_first, h->n, d_ctl);
+  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->d_first_state, b->n_first, h->n, sub_cap, d_ctl);
   HIP_TRY(hipGetLastError(), "k_frontier_init");
   // Levels are chained on the stream without host round trips; the host looks at the counters
   // every kChain levels.  A level with an empty queue returns at once.
-  constexpr uint32_t kChain = 8;
-  const int grid = h->cu_count * 6;          // what stays resident with 24.5 KB of LDS per workgroup
-  FrontierCtl ctl{};
+  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 8u;   // levels between host looks
+  const int grid = h->cu_count * 6;          // what stays resident at 80 vector registers per lane
+  std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());
+  FrontierCtl &ctl = *ctl_host;
+  uint64_t n_res = 0;
   uint32_t level = 0;
   uint64_t launches = 1;
   bool alive = true, truncated = false;
@@ -368,7 +446,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     for (uint32_t j = 0; j < kChain && level < max_steps; j++, level++) {
       const Queue &cur = (level & 1) ? qb : qa;
       const Queue &nxt = (level & 1) ? qa : qb;
-#define CALL(W, L) k_frontier<W, L><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, qcap, d_res, (uint64_t)cap, d_ctl, h->d_counters)
+#define CALL(W, L) k_frontier<W, L><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters)
       FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
       HIP_TRY(hipGetLastError(), "k_frontier");
@@ -377,11 +455,19 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
     HIP_TRY(hipStreamSynchronize(st), "sync(levels)");
     if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
-    alive = ctl.count[level % 3] != 0;
+    uint64_t next_total = 0;
+    n_res = 0;
+    for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
+    alive = next_total != 0;
     if (getenv("FMX_TRACE"))
       fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
-              ctl.count[level % 3], ctl.res_count, ctl.overflow);
+              (unsigned long long)next_total, (unsigned long long)n_res, ctl.overflow);
     if (alive && level >= max_steps) { truncated = true; alive = false; }
+  }
+  if (n_res && !(ctl.overflow & 2ull)) {
+    k_pack_results<<<kSub, 256, 0, st>>>(d_res_seg, seg_cap, d_ctl, d_res, (uint64_t)cap);
+    HIP_TRY(hipGetLastError(), "k_pack_results");
+    launches++;
   }
   HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
   HIP_TRY(hipStreamSynchronize(st), "sync");
@@ -392,20 +478,21 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     h->last_kernel_ms = ms;
     h->launches += launches;
   }
+  struct { unsigned long long res_count; } tot{n_res};
   const size_t extra = b->start_final.size();
-  *n_out = (size_t)ctl.res_count + extra;
-  if (ctl.res_count + extra > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
-  if (ctl.res_count)
-    HIP_TRY(hipMemcpy(out, d_res, (size_t)ctl.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost), "D2H(results)");
+  *n_out = (size_t)tot.res_count + extra;
+  if ((ctl.overflow & 2ull) || tot.res_count + extra > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
+  if (tot.res_count)
+    HIP_TRY(hipMemcpy(out, d_res, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost), "D2H(results)");
   for (size_t j = 0; j < extra; j++) {           // dfa.scala:270-273 with the start StatePoint(0,0,0,n)
-    fmx_result &o = out[ctl.res_count + j];
+    fmx_result &o = out[tot.res_count + j];
     o.regex = b->start_final[j]; o.len = 0; o.sp = 0; o.ep = h->n;
   }
-  ctl.res_count += extra;
-  if (ctl.res_count) {
+  tot.res_count += extra;
+  if (tot.res_count) {
     // canonical order (regex, len, sp, ep): bucket by regex id (counting sort), then order each regex's
     // few results -- a comparison sort over the whole array costs more than the device levels
-    const size_t nres = (size_t)ctl.res_count;
+    const size_t nres = (size_t)tot.res_count;
     std::vector<uint32_t> start(b->k + 1, 0);
     for (size_t j = 0; j < nres; j++) start[out[j].regex + 1]++;
     for (size_t r = 0; r < b->k; r++) start[r + 1] += start[r];

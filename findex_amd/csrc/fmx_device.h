@@ -91,6 +91,17 @@ __device__ __forceinline__ uint32_t group_or(uint32_t v) {
   return v;
 }
 
+// Value of lane U of the group, to every lane of the group (U < 4).
+template <int G, int U>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v) {
+  if (G == 4) return dpp<U * 0x55>(v);                  // quad_perm [U,U,U,U]
+  return (uint32_t)__shfl((int)v, (int)((__lane_id() & ~7u) | U), 64);
+}
+template <int G, int U>
+__device__ __forceinline__ uint64_t group_bcast64(uint64_t v) {
+  return ((uint64_t)group_bcast<G, U>((uint32_t)(v >> 32)) << 32) | group_bcast<G, U>((uint32_t)v);
+}
+
 // popcount(x) + acc in one instruction (the compiler otherwise splits it into bcnt + add3)
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
   uint32_t d;

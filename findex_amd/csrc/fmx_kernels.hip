@@ -5,6 +5,8 @@
 // lanes (an octet and two lines in the bytes layout; fmx_device.h); C[] and the symbol->slot map
 // are staged in LDS per workgroup.  "group" below = the lanes that serve one query.
 // Reference semantics: SuffixAlgo (findex.scala:9-52), NaiveFMSearcher (bwtmerger.scala:335-421).
+#include <type_traits>
+
 #include "fmx_device.h"
 #include "fmx_host.h"
 
@@ -42,27 +44,38 @@ __global__ __launch_bounds__(kThreads) void k_occ(DevIndex ix, const uint8_t *__
   constexpr int G = Lay<LAYOUT>::G;
   const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
   uint32_t done = 0;
   auto boundary = [&](int64_t key) { return key < 0 ? 0 : ((uint64_t)key >= ix.n ? ix.n : (uint64_t)key + 1); };
-  // two independent queries per group and trip: both lines are in flight together
-  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G; q < k; q += 2 * noct) {
-    const uint64_t q2 = q + noct;
-    const bool two = q2 < k;
-    const uint32_t c1 = c[q], c2 = two ? c[q2] : 0u;
-    const RankReq r1 = rank_issue<LAYOUT>(ix, tb.slot[c1], boundary(i[q]), lc);
-    RankReq r2 = r1;
-    if (two) r2 = rank_issue<LAYOUT>(ix, tb.slot[c2], boundary(i[q2]), lc);
-    const uint64_t v1 = rank_complete<WIDE, LAYOUT>(r1, c1, lc);
-    if (t == 0) out[q] = v1;
-    done++;
-    if (two) {
-      const uint64_t v2 = rank_complete<WIDE, LAYOUT>(r2, c2, lc);
-      if (t == 0) out[q2] = v2;
-      done++;
+  // A group takes 4 consecutive queries per trip: lane u reads the operands of query u (so a wave reads
+  // 64 consecutive operands with one coalesced instruction each, instead of every lane of a group asking
+  // for the same one), the group broadcasts them, requests the 4 blocks together and lane u stores answer u.
+  const uint64_t ngroups = (uint64_t)gridDim.x * (kThreads / G);
+  const uint64_t gid = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G;
+  const uint32_t tu = t < 4u ? t : 3u;
+  for (uint64_t base = gid * 4; base < k; base += ngroups * 4) {
+    const uint64_t myq = base + tu;
+    const bool own = myq < k;
+    const uint32_t myc = own ? c[myq] : 0u;
+    const uint64_t myx = own ? boundary(i[myq]) : 0;
+    RankReq r[4];
+    uint32_t cc[4];
+    auto issue = [&](auto U) {
+      constexpr int u = decltype(U)::value;
+      cc[u] = group_bcast<G, u>(myc);
+      const uint64_t x = group_bcast64<G, u>(myx);
+      r[u] = rank_issue<LAYOUT>(ix, base + u < k ? tb.slot[cc[u]] : kSlotNone, x, lc);
+    };
+    issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
+    issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
+    uint64_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint64_t v = rank_complete<WIDE, LAYOUT>(r[u], cc[u], lc);
+      if (t == (uint32_t)u) mine = v;
     }
+    if (t < 4u && own) { out[myq] = mine; done++; }
   }
-  counters_add(counters, t == 0 ? done : 0u, 0, 0);
+  counters_add(counters, done, 0, 0);
 }
 
 // ---------------------------------------------------------------- K4: prev_range_batch
@@ -77,18 +90,41 @@ __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint
   constexpr int G = Lay<LAYOUT>::G;
   const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
   uint32_t done = 0;
-  for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G; q < k; q += noct) {
+  // 4 consecutive steps per group and trip, operands read and results stored one per lane (as in k_occ)
+  const uint64_t ngroups = (uint64_t)gridDim.x * (kThreads / G);
+  const uint64_t gid = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G;
+  const uint32_t tu = t < 4u ? t : 3u;
+  for (uint64_t base = gid * 4; base < k; base += ngroups * 4) {
+    const uint64_t myq = base + tu;
+    const bool own = myq < k;
     // the device-pointer entry point cannot validate its operands on the host: keep them inside the index
-    uint64_t sp = sp_in[q], ep = ep_in[q];
-    if (sp > ix.n) sp = ix.n;
-    if (ep > ix.n) ep = ix.n;
-    step<WIDE, LAYOUT>(ix, tb, c[q], lc, sp, ep);
-    if (t == 0) { sp1[q] = sp; ep1[q] = ep; }
-    done++;
+    uint64_t mysp = own ? sp_in[myq] : 0, myep = own ? ep_in[myq] : 0;
+    if (mysp > ix.n) mysp = ix.n;
+    if (myep > ix.n) myep = ix.n;
+    const uint32_t myc = own ? c[myq] : 0u;
+    RankReq r1[4], r2[4];
+    uint32_t cc[4];
+    auto issue = [&](auto U) {
+      constexpr int u = decltype(U)::value;
+      cc[u] = group_bcast<G, u>(myc);
+      const uint16_t slot = base + u < k ? tb.slot[cc[u]] : kSlotNone;
+      r1[u] = rank_issue<LAYOUT>(ix, slot, group_bcast64<G, u>(mysp), lc);
+      r2[u] = rank_issue<LAYOUT>(ix, slot, group_bcast64<G, u>(myep), lc);
+    };
+    issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
+    issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
+    uint64_t osp = 0, oep = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint64_t cfc = tb.cf[cc[u]];
+      const uint64_t a1 = cfc + rank_complete<WIDE, LAYOUT>(r1[u], cc[u], lc);
+      const uint64_t a2 = cfc + rank_complete<WIDE, LAYOUT>(r2[u], cc[u], lc);
+      if (t == (uint32_t)u) { osp = a1; oep = a2; }
+    }
+    if (t < 4u && own) { sp1[myq] = osp; ep1[myq] = oep; done++; }
   }
-  counters_add(counters, t == 0 ? 2ull * done : 0ull, t == 0 ? done : 0u, 0);
+  counters_add(counters, 2ull * done, done, 0);
 }
 
 // ---------------------------------------------------------------- K3: literal backward search

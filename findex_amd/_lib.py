@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfmx.so")
+LIB_PATH = os.environ.get("FMX_LIB") or os.path.join(_HERE, "lib", "libfmx.so")     # FMX_LIB: A/B runs of two builds
 
 FMX_OK = 0
 ERR_NAMES = {1: "FMX_ERR_IO", 2: "FMX_ERR_FORMAT", 3: "FMX_ERR_ARG", 4: "FMX_ERR_NOMEM", 5: "FMX_ERR_HIP",

@@ -31,21 +31,17 @@ static int arg_fail(const char *msg) {
   return FMX_ERR_ARG;
 }
 
-// ---- device buffers with scope lifetime
-struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-};
-
 struct StreamGuard {
   hipStream_t s = nullptr;
   ~StreamGuard() { if (s) (void)hipStreamDestroy(s); }
 };
 
-struct EventPair {
+struct DevBuf {        // a device pointer borrowed from the call's context (Call::alloc)
+  void *p = nullptr;
+};
+
+struct EventPair {     // the call context's two events (not owned)
   hipEvent_t a = nullptr, b = nullptr;
-  ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
 
 #define HIP_TRY(call, what)                            \
@@ -58,6 +54,93 @@ static int use_device(const Index *h) {
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
   return FMX_OK;
 }
+
+static void free_ctx(CallCtx *c) {
+  if (!c) return;
+  for (void *b : c->buf) if (b) (void)hipFree(b);
+  if (c->pin) (void)hipHostFree(c->pin);
+  if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+  if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// One host-pointer call: borrows a context from the handle (or makes one), hands out scratch buffers from it,
+// runs the enqueue function on its stream between its two events, and returns the context on scope exit.
+// Contexts holding more than kKeepBytes of scratch, and contexts beyond kKeep idle ones, are released instead.
+class Call {
+ public:
+  explicit Call(const Index *h) : h_(h) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->ctx_pool.empty()) { c_ = h->ctx_pool.back(); h->ctx_pool.pop_back(); }
+  }
+  ~Call() {
+    if (!c_) return;
+    bool keep = c_->total() <= kKeepBytes;
+    if (keep) {
+      std::lock_guard<std::mutex> lk(h_->mu);
+      keep = h_->ctx_pool.size() < kKeep;
+      if (keep) h_->ctx_pool.push_back(c_);
+    }
+    if (!keep) free_ctx(c_);
+  }
+  int init() {
+    if (!c_) c_ = new (std::nothrow) CallCtx();
+    if (!c_) { g_err = "out of host memory"; return FMX_ERR_NOMEM; }
+    if (!c_->stream) HIP_TRY(hipStreamCreate(&c_->stream), "hipStreamCreate");
+    if (!c_->ev_a) HIP_TRY(hipEventCreate(&c_->ev_a), "hipEventCreate");
+    if (!c_->ev_b) HIP_TRY(hipEventCreate(&c_->ev_b), "hipEventCreate");
+    return FMX_OK;
+  }
+  // next scratch buffer of the call, at least `bytes` long
+  hipError_t alloc(DevBuf &b, size_t bytes) {
+    if (next_ >= CallCtx::kBufs) return hipErrorOutOfMemory;
+    const int i = next_++;
+    if (bytes < 16) bytes = 16;
+    if (c_->cap[i] < bytes) {
+      if (c_->buf[i]) { (void)hipFree(c_->buf[i]); c_->buf[i] = nullptr; c_->cap[i] = 0; }
+      const size_t want = bytes + bytes / 4;          // some slack: batches of similar size reuse the buffer
+      hipError_t e = hipMalloc(&c_->buf[i], want);
+      if (e != hipSuccess) return e;
+      c_->cap[i] = want;
+    }
+    b.p = c_->buf[i];
+    return hipSuccess;
+  }
+  // pinned host staging of at least `bytes`
+  hipError_t pinned(void **out, size_t bytes) {
+    if (c_->pin_cap < bytes) {
+      if (c_->pin) { (void)hipHostFree(c_->pin); c_->pin = nullptr; c_->pin_cap = 0; }
+      hipError_t e = hipHostMalloc(&c_->pin, bytes, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      c_->pin_cap = bytes;
+    }
+    *out = c_->pin;
+    return hipSuccess;
+  }
+  // Runs `enqueue` on the context's stream and records the device time between the two events.
+  template <class F>
+  int timed(F enqueue) {
+    EventPair ev{c_->ev_a, c_->ev_b};
+    int rc = enqueue(c_->stream, ev);
+    if (rc != FMX_OK) { (void)hipStreamSynchronize(c_->stream); return rc; }
+    HIP_TRY(hipStreamSynchronize(c_->stream), "hipStreamSynchronize");
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+      std::lock_guard<std::mutex> lk(h_->mu);
+      h_->last_kernel_ms = ms;
+      h_->launches++;
+    }
+    return FMX_OK;
+  }
+
+ private:
+  static constexpr size_t kKeep = 4;
+  static constexpr size_t kKeepBytes = 512u << 20;
+  const Index *h_;
+  CallCtx *c_ = nullptr;
+  int next_ = 0;
+};
 
 // ---- file formats
 static uint64_t rd_u64(const uint8_t *p, bool be) {
@@ -111,6 +194,7 @@ static void destroy(Index *h) {
   if (h->d_cf) (void)hipFree(h->d_cf);
   if (h->d_slot) (void)hipFree(h->d_slot);
   if (h->d_counters) (void)hipFree(h->d_counters);
+  for (CallCtx *c : h->ctx_pool) free_ctx(c);
   delete h;
 }
 
@@ -172,24 +256,69 @@ static int open_common(const void *src, bool src_on_device, uint64_t n, uint64_t
 static inline Index *H(fmx_index *p) { return reinterpret_cast<Index *>(p); }
 static inline const Index *H(const fmx_index *p) { return reinterpret_cast<const Index *>(p); }
 
-// Runs `enqueue` on a private stream bracketed by HIP events and records the device time.
-template <class F>
-static int timed(const Index *h, F enqueue) {
-  StreamGuard sg;
-  EventPair ev;
-  HIP_TRY(hipStreamCreate(&sg.s), "hipStreamCreate");
-  HIP_TRY(hipEventCreate(&ev.a), "hipEventCreate");
-  HIP_TRY(hipEventCreate(&ev.b), "hipEventCreate");
-  int rc = enqueue(sg.s, ev);
+// Operands in, kernel, results out.  Small calls (the single-query forms a per-call adapter makes) pack all
+// operands into one pinned staging buffer and travel as ONE copy each way; large calls copy each array
+// directly between the caller's memory and its own device buffer.
+struct HostIn { const void *src; size_t bytes; };
+struct HostOut { void *dst; size_t bytes; };
+constexpr size_t kSmallCall = 256u << 10;
+
+template <class Launch>
+static int run_io(const Index *h, const HostIn *ins, int nin, const HostOut *outs, int nout, Launch launch) {
+  Call call(h);
+  int rc = call.init();
   if (rc != FMX_OK) return rc;
-  HIP_TRY(hipStreamSynchronize(sg.s), "hipStreamSynchronize");
-  float ms = 0;
-  if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    h->last_kernel_ms = ms;
-    h->launches++;
+  auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  size_t in_total = 0, out_total = 0;
+  for (int j = 0; j < nin; j++) in_total += up16(ins[j].bytes);
+  for (int j = 0; j < nout; j++) out_total += up16(outs[j].bytes);
+  const void *din[CallCtx::kBufs] = {nullptr};
+  void *dout[CallCtx::kBufs] = {nullptr};
+  if (in_total + out_total <= kSmallCall) {
+    void *pin = nullptr;
+    HIP_TRY(call.pinned(&pin, kSmallCall), "hipHostMalloc");
+    DevBuf a, b;
+    HIP_TRY(call.alloc(a, kSmallCall), "hipMalloc");
+    HIP_TRY(call.alloc(b, kSmallCall), "hipMalloc");
+    uint8_t *hp = static_cast<uint8_t *>(pin);
+    size_t o = 0;
+    for (int j = 0; j < nin; j++) {
+      if (ins[j].bytes) std::memcpy(hp + o, ins[j].src, ins[j].bytes);
+      din[j] = static_cast<uint8_t *>(a.p) + o;
+      o += up16(ins[j].bytes);
+    }
+    size_t oo = 0;
+    for (int j = 0; j < nout; j++) { dout[j] = static_cast<uint8_t *>(b.p) + oo; oo += up16(outs[j].bytes); }
+    uint8_t *hout = hp + in_total;                 // results come back behind the operands
+    rc = call.timed([&](hipStream_t st, EventPair &ev) {
+      if (in_total) HIP_TRY(hipMemcpyAsync(a.p, hp, in_total, hipMemcpyHostToDevice, st), "H2D");
+      HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
+      HIP_TRY(launch(st, din, dout), "kernel launch");
+      HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
+      if (out_total) HIP_TRY(hipMemcpyAsync(hout, b.p, out_total, hipMemcpyDeviceToHost, st), "D2H");
+      return (int)FMX_OK;
+    });
+    if (rc != FMX_OK) return rc;
+    oo = 0;
+    for (int j = 0; j < nout; j++) {
+      if (outs[j].bytes) std::memcpy(outs[j].dst, hout + oo, outs[j].bytes);
+      oo += up16(outs[j].bytes);
+    }
+    return FMX_OK;
   }
-  return FMX_OK;
+  DevBuf bufs[CallCtx::kBufs];
+  for (int j = 0; j < nin; j++) { HIP_TRY(call.alloc(bufs[j], ins[j].bytes), "hipMalloc"); din[j] = bufs[j].p; }
+  for (int j = 0; j < nout; j++) { HIP_TRY(call.alloc(bufs[nin + j], outs[j].bytes), "hipMalloc"); dout[j] = bufs[nin + j].p; }
+  return call.timed([&](hipStream_t st, EventPair &ev) {
+    for (int j = 0; j < nin; j++)
+      if (ins[j].bytes) HIP_TRY(hipMemcpyAsync(bufs[j].p, ins[j].src, ins[j].bytes, hipMemcpyHostToDevice, st), "H2D");
+    HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
+    HIP_TRY(launch(st, din, dout), "kernel launch");
+    HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
+    for (int j = 0; j < nout; j++)
+      if (outs[j].bytes) HIP_TRY(hipMemcpyAsync(outs[j].dst, dout[j], outs[j].bytes, hipMemcpyDeviceToHost, st), "D2H");
+    return (int)FMX_OK;
+  });
 }
 
 }  // namespace fmx
@@ -318,18 +447,10 @@ int fmx_occ_batch(const fmx_index *idx, const uint8_t *c, const int64_t *i, uint
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc || !k) return rc;
-  DevBuf dc, di, dout;
-  HIP_TRY(dc.alloc(k), "hipMalloc");
-  HIP_TRY(di.alloc(k * 8), "hipMalloc");
-  HIP_TRY(dout.alloc(k * 8), "hipMalloc");
-  return timed(h, [&](hipStream_t st, EventPair &ev) {
-    HIP_TRY(hipMemcpyAsync(dc.p, c, k, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipMemcpyAsync(di.p, i, k * 8, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
-    HIP_TRY(launch_occ(h, dc.p, di.p, dout.p, k, st), "k_occ");
-    HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
-    HIP_TRY(hipMemcpyAsync(out, dout.p, k * 8, hipMemcpyDeviceToHost, st), "D2H");
-    return (int)FMX_OK;
+  const HostIn ins[] = {{c, k}, {i, k * 8}};
+  const HostOut outs[] = {{out, k * 8}};
+  return run_io(h, ins, 2, outs, 1, [&](hipStream_t st, const void *const *di, void *const *dout) {
+    return launch_occ(h, di[0], di[1], dout[0], k, st);
   });
 }
 
@@ -344,22 +465,17 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
   const uint64_t lo = off[0], total = off[k] - off[0];
   if (total && !pat) return arg_fail("pat is null");
   // offsets are rebased so that only the bytes in use travel
-  std::vector<uint64_t> roff(k + 1);
-  for (size_t q = 0; q <= k; q++) roff[q] = off[q] - lo;
-  DevBuf dpat, doff, dsp, dep;
-  HIP_TRY(dpat.alloc(total), "hipMalloc");
-  HIP_TRY(doff.alloc((k + 1) * 8), "hipMalloc");
-  HIP_TRY(dsp.alloc(k * 8), "hipMalloc");
-  HIP_TRY(dep.alloc(k * 8), "hipMalloc");
-  return timed(h, [&](hipStream_t st, EventPair &ev) {
-    if (total) HIP_TRY(hipMemcpyAsync(dpat.p, pat + lo, total, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipMemcpyAsync(doff.p, roff.data(), (k + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
-    HIP_TRY(launch_search(h, dpat.p, doff.p, dsp.p, dep.p, k, st), "k_search");
-    HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
-    HIP_TRY(hipMemcpyAsync(sp, dsp.p, k * 8, hipMemcpyDeviceToHost, st), "D2H");
-    HIP_TRY(hipMemcpyAsync(ep, dep.p, k * 8, hipMemcpyDeviceToHost, st), "D2H");
-    return (int)FMX_OK;
+  std::vector<uint64_t> roff;
+  const uint64_t *offp = off;
+  if (lo) {
+    roff.resize(k + 1);
+    for (size_t q = 0; q <= k; q++) roff[q] = off[q] - lo;
+    offp = roff.data();
+  }
+  const HostIn ins[] = {{total ? pat + lo : nullptr, (size_t)total}, {offp, (k + 1) * 8}};
+  const HostOut outs[] = {{sp, k * 8}, {ep, k * 8}};
+  return run_io(h, ins, 2, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
+    return launch_search(h, di[0], di[1], dout[0], dout[1], k, st);
   });
 }
 
@@ -371,22 +487,10 @@ int fmx_prev_range_batch(const fmx_index *idx, const uint64_t *sp, const uint64_
   if (rc || !k) return rc;
   for (size_t q = 0; q < k; q++)
     if (sp[q] > ep[q] || ep[q] > h->n) return arg_fail("need sp <= ep <= n");
-  DevBuf dsp, dep, dc, dsp1, dep1;
-  HIP_TRY(dsp.alloc(k * 8), "hipMalloc");
-  HIP_TRY(dep.alloc(k * 8), "hipMalloc");
-  HIP_TRY(dc.alloc(k), "hipMalloc");
-  HIP_TRY(dsp1.alloc(k * 8), "hipMalloc");
-  HIP_TRY(dep1.alloc(k * 8), "hipMalloc");
-  return timed(h, [&](hipStream_t st, EventPair &ev) {
-    HIP_TRY(hipMemcpyAsync(dsp.p, sp, k * 8, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipMemcpyAsync(dep.p, ep, k * 8, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipMemcpyAsync(dc.p, c, k, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
-    HIP_TRY(launch_prev_range(h, dsp.p, dep.p, dc.p, dsp1.p, dep1.p, k, st), "k_prev_range");
-    HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
-    HIP_TRY(hipMemcpyAsync(sp1, dsp1.p, k * 8, hipMemcpyDeviceToHost, st), "D2H");
-    HIP_TRY(hipMemcpyAsync(ep1, dep1.p, k * 8, hipMemcpyDeviceToHost, st), "D2H");
-    return (int)FMX_OK;
+  const HostIn ins[] = {{sp, k * 8}, {ep, k * 8}, {c, k}};
+  const HostOut outs[] = {{sp1, k * 8}, {ep1, k * 8}};
+  return run_io(h, ins, 3, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
+    return launch_prev_range(h, di[0], di[1], di[2], dout[0], dout[1], k, st);
   });
 }
 
@@ -427,18 +531,10 @@ int fmx_lf_walk_batch(const fmx_index *idx, const uint64_t *rows, size_t k, uint
   if (rc || !k) return rc;
   for (size_t q = 0; q < k; q++)
     if (rows[q] >= h->n) return arg_fail("row out of range (reference: seek past .bwt / ArrayIndexOutOfBounds)");
-  DevBuf drows, dout, dend;
-  HIP_TRY(drows.alloc(k * 8), "hipMalloc");
-  if (out_bytes) HIP_TRY(dout.alloc(k * (size_t)len), "hipMalloc");
-  if (end_rows) HIP_TRY(dend.alloc(k * 8), "hipMalloc");
-  return timed(h, [&](hipStream_t st, EventPair &ev) {
-    HIP_TRY(hipMemcpyAsync(drows.p, rows, k * 8, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
-    HIP_TRY(launch_lf_walk(h, drows.p, k, len, dout.p, dend.p, st), "k_lf_walk");
-    HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
-    if (out_bytes && len) HIP_TRY(hipMemcpyAsync(out_bytes, dout.p, k * (size_t)len, hipMemcpyDeviceToHost, st), "D2H");
-    if (end_rows) HIP_TRY(hipMemcpyAsync(end_rows, dend.p, k * 8, hipMemcpyDeviceToHost, st), "D2H");
-    return (int)FMX_OK;
+  const HostIn ins[] = {{rows, k * 8}};
+  const HostOut outs[] = {{out_bytes, out_bytes ? k * (size_t)len : 0}, {end_rows, end_rows ? k * 8 : 0}};
+  return run_io(h, ins, 1, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
+    return launch_lf_walk(h, di[0], k, len, out_bytes ? dout[0] : nullptr, end_rows ? dout[1] : nullptr, st);
   });
 }
 
@@ -454,16 +550,10 @@ int fmx_psi_batch(const fmx_index *idx, const uint64_t *rows, uint64_t *out, siz
   if (rc || !k) return rc;
   for (size_t q = 0; q < k; q++)
     if (rows[q] >= h->n) return arg_fail("row out of range");
-  DevBuf drows, dout;
-  HIP_TRY(drows.alloc(k * 8), "hipMalloc");
-  HIP_TRY(dout.alloc(k * 8), "hipMalloc");
-  return timed(h, [&](hipStream_t st, EventPair &ev) {
-    HIP_TRY(hipMemcpyAsync(drows.p, rows, k * 8, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
-    HIP_TRY(launch_psi(h, drows.p, dout.p, k, st), "k_psi");
-    HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
-    HIP_TRY(hipMemcpyAsync(out, dout.p, k * 8, hipMemcpyDeviceToHost, st), "D2H");
-    return (int)FMX_OK;
+  const HostIn ins[] = {{rows, k * 8}};
+  const HostOut outs[] = {{out, k * 8}};
+  return run_io(h, ins, 1, outs, 1, [&](hipStream_t st, const void *const *di, void *const *dout) {
+    return launch_psi(h, di[0], dout[0], k, st);
   });
 }
 
@@ -474,13 +564,15 @@ int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *ou
   if (sp >= h->n) return arg_fail("row out of range");
   int rc = use_device(h);
   if (rc) return rc;
+  Call call(h);
+  if ((rc = call.init()) != FMX_OK) return rc;
   DevBuf dsp, dout, dlen;
-  HIP_TRY(dsp.alloc(8), "hipMalloc");
-  HIP_TRY(dout.alloc(len), "hipMalloc");
-  HIP_TRY(dlen.alloc(4), "hipMalloc");
+  HIP_TRY(call.alloc(dsp, 8), "hipMalloc");
+  HIP_TRY(call.alloc(dout, len), "hipMalloc");
+  HIP_TRY(call.alloc(dlen, 4), "hipMalloc");
   std::vector<uint8_t> tmp(len ? len : 1);
   uint32_t w = 0;
-  rc = timed(h, [&](hipStream_t st, EventPair &ev) {
+  rc = call.timed([&](hipStream_t st, EventPair &ev) {
     HIP_TRY(hipMemcpyAsync(dsp.p, &sp, 8, hipMemcpyHostToDevice, st), "H2D");
     HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
     HIP_TRY(launch_next_substr(h, dsp.p, 1, len, dout.p, dlen.p, st), "k_next_substr");
@@ -505,9 +597,11 @@ int fmx_write_fm(const fmx_index *idx, const char *path) {
   if (h->n >= 0xffffffffull) { g_err = "the .fm format has no 8-byte entries (bwtmerger.scala:465-469)"; return FMX_ERR_UNSUPPORTED; }
   int rc = use_device(h);
   if (rc) return rc;
+  Call call(h);
+  if ((rc = call.init()) != FMX_OK) return rc;
   DevBuf dfm;
-  HIP_TRY(dfm.alloc(h->n * 4), "hipMalloc(fm)");
-  rc = timed(h, [&](hipStream_t st, EventPair &ev) {
+  HIP_TRY(call.alloc(dfm, h->n * 4), "hipMalloc(fm)");
+  rc = call.timed([&](hipStream_t st, EventPair &ev) {
     HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
     HIP_TRY(launch_fm_fill(h, dfm.p, st), "k_fm_fill");
     HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");

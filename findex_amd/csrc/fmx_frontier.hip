@@ -435,7 +435,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // Levels are chained on the stream without host round trips; the host looks at the counters
   // every kChain levels.  A level with an empty queue returns at once.
   static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 8u;   // levels between host looks
-  const int grid = h->cu_count * 6;          // what stays resident at 80 vector registers per lane
+  const int grid_full = h->cu_count * 6;     // what stays resident at 80 vector registers per lane
+  int grid = grid_full;
   std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());
   FrontierCtl &ctl = *ctl_host;
   uint64_t n_res = 0;
@@ -459,6 +460,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     n_res = 0;
     for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
     alive = next_total != 0;
+    // a nearly empty frontier is launch-bound: a small grid (still >= one wave per slice) starts and ends faster
+    grid = next_total <= 4096 ? (int)kSub : grid_full;
     if (getenv("FMX_TRACE"))
       fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
               (unsigned long long)next_total, (unsigned long long)n_res, ctl.overflow);

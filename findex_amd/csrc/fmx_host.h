@@ -5,10 +5,25 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "fmx_device.h"
 
 namespace fmx {
+
+// What one host-pointer call needs on the device side: a stream, two events and grow-only scratch buffers.
+// A handle keeps a few of them between calls (fmx_api.cpp, class Call), so that a call costs copies and
+// launches only -- creating them afresh took longer than a small batch's kernel.
+struct CallCtx {
+  static constexpr int kBufs = 8;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  void *buf[kBufs] = {nullptr};
+  size_t cap[kBufs] = {0};
+  void *pin = nullptr;            // pinned host staging for small calls (operands packed into one copy each way)
+  size_t pin_cap = 0;
+  size_t total() const { size_t t = 0; for (size_t c : cap) t += c; return t; }
+};
 
 struct Index {
   int device = 0;
@@ -32,6 +47,7 @@ struct Index {
   double build_ms = 0.0;
   // host-call bookkeeping
   mutable std::mutex mu;
+  mutable std::vector<CallCtx *> ctx_pool;      // idle call contexts (guarded by mu)
   mutable uint64_t launches = 0;
   mutable double last_kernel_ms = 0.0;
 };

@@ -37,3 +37,19 @@ st = hip.stats()
 ranks = st["rank_queries"] / reps
 print("host-pointer path %s: %.3f ms per call (kernel part %.3f ms), %.0f M rank-queries/s, %.1f M patterns/s "
       "PCIe-inclusive" % (wl, dt * 1e3, st["last_kernel_ms"], ranks / dt / 1e6, k / dt / 1e6))
+
+# per-call latency of the single-query forms the Scala adapter's search()/getPrevRange() map to
+one_p = h_p.reshape(k, m)[0].copy()
+one_o = np.array([0, m], dtype=np.uint64)
+for name, fn in (("search_batch k=1", lambda: hip.search_batch(one_p, one_o)),
+                 ("prev_range_batch k=1", lambda: hip.prev_range_batch(np.array([0], dtype=np.uint64), np.array([n], dtype=np.uint64), np.array([65], dtype=np.uint8))),
+                 ("occ_batch k=1", lambda: hip.occ_batch(np.array([65], dtype=np.uint8), np.array([12345], dtype=np.int64))),
+                 ("search_batch k=1000", lambda: hip.search_batch(h_p[:1000 * m], h_o[:1001]))):
+    best = 1e9
+    for _ in range(3):                      # best of three rounds: the first rounds of a process see clock ramps
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            fn()
+        best = min(best, (time.perf_counter() - t0) / 200)
+    print("%-22s %.1f us per call" % (name, best * 1e6))

@@ -202,6 +202,41 @@ def test_many_patterns_ragged_lengths():
     assert hits > 50_000
 
 
+def test_concurrent_calls_on_one_handle():
+    """An index handle is immutable after open: host-pointer calls from several threads (each borrows its own
+    call context from the handle's pool) must give the single-threaded answers -- small and large batches,
+    searches and single steps mixed."""
+    import threading
+    bwt, eof, counts = synth_bwt(300_000, 1, 20, 31)
+    hip, orc = pair_from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(9)
+    jobs = []
+    for j in range(8):
+        pats = lf_walk_patterns(orc, rng, 4000 if j % 2 else 3, 12, 0.2, alphabet=list(range(1, 21)))
+        buf, off = pack_patterns(pats)
+        wsp, wep, _ = orc.search_batch(buf, off)
+        jobs.append((buf, off, (wsp, wep)))
+    errors = []
+
+    def work(j):
+        try:
+            buf, off, want = jobs[j]
+            for _ in range(5):
+                sp, ep = hip.search_batch(buf, off)
+                assert np.array_equal(sp, want[0]) and np.array_equal(ep, want[1]), j
+                o = hip.occ_batch(np.array([j + 1], dtype=np.uint8), np.array([1000 * j], dtype=np.int64))
+                assert int(o[0]) == orc.occ(j + 1, 1000 * j)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(j,)) for j in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_counts_must_describe_bwt():
     bwt, eof, counts = synth_bwt(5000, 1, 4, 1)
     bad = counts.copy()

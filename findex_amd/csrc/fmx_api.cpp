@@ -65,32 +65,44 @@ static void free_ctx(CallCtx *c) {
   delete c;
 }
 
+CallCtx *ctx_acquire(const Index *h) {
+  CallCtx *c = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->ctx_pool.empty()) { c = h->ctx_pool.back(); h->ctx_pool.pop_back(); }
+  }
+  if (!c) c = new (std::nothrow) CallCtx();
+  if (!c) { g_err = "out of host memory"; return nullptr; }
+  hipError_t e = hipSuccess;
+  if (!c->stream) e = hipStreamCreate(&c->stream);
+  if (e == hipSuccess && !c->ev_a) e = hipEventCreate(&c->ev_a);
+  if (e == hipSuccess && !c->ev_b) e = hipEventCreate(&c->ev_b);
+  if (e != hipSuccess) { (void)hip_fail(e, "hipStreamCreate/hipEventCreate"); free_ctx(c); return nullptr; }
+  return c;
+}
+
+// Contexts holding more than kKeepBytes of scratch, and contexts beyond kKeep idle ones, are released.
+void ctx_release(const Index *h, CallCtx *c) {
+  constexpr size_t kKeep = 4;
+  constexpr size_t kKeepBytes = 512u << 20;
+  bool keep = c->total() <= kKeepBytes;
+  if (keep) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    keep = h->ctx_pool.size() < kKeep;
+    if (keep) h->ctx_pool.push_back(c);
+  }
+  if (!keep) free_ctx(c);
+}
+
 // One host-pointer call: borrows a context from the handle (or makes one), hands out scratch buffers from it,
 // runs the enqueue function on its stream between its two events, and returns the context on scope exit.
-// Contexts holding more than kKeepBytes of scratch, and contexts beyond kKeep idle ones, are released instead.
 class Call {
  public:
-  explicit Call(const Index *h) : h_(h) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->ctx_pool.empty()) { c_ = h->ctx_pool.back(); h->ctx_pool.pop_back(); }
-  }
-  ~Call() {
-    if (!c_) return;
-    bool keep = c_->total() <= kKeepBytes;
-    if (keep) {
-      std::lock_guard<std::mutex> lk(h_->mu);
-      keep = h_->ctx_pool.size() < kKeep;
-      if (keep) h_->ctx_pool.push_back(c_);
-    }
-    if (!keep) free_ctx(c_);
-  }
+  explicit Call(const Index *h) : h_(h) {}
+  ~Call() { if (c_) ctx_release(h_, c_); }
   int init() {
-    if (!c_) c_ = new (std::nothrow) CallCtx();
-    if (!c_) { g_err = "out of host memory"; return FMX_ERR_NOMEM; }
-    if (!c_->stream) HIP_TRY(hipStreamCreate(&c_->stream), "hipStreamCreate");
-    if (!c_->ev_a) HIP_TRY(hipEventCreate(&c_->ev_a), "hipEventCreate");
-    if (!c_->ev_b) HIP_TRY(hipEventCreate(&c_->ev_b), "hipEventCreate");
-    return FMX_OK;
+    if (!c_) c_ = ctx_acquire(h_);
+    return c_ ? FMX_OK : FMX_ERR_HIP;
   }
   // next scratch buffer of the call, at least `bytes` long
   hipError_t alloc(DevBuf &b, size_t bytes) {
@@ -135,8 +147,6 @@ class Call {
   }
 
  private:
-  static constexpr size_t kKeep = 4;
-  static constexpr size_t kKeepBytes = 512u << 20;
   const Index *h_;
   CallCtx *c_ = nullptr;
   int next_ = 0;

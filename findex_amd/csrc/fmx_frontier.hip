@@ -15,6 +15,7 @@
 #include <fmx.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -90,42 +91,31 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
   return x - v;
 }
 
-// One level.  Each lane group walks the queue with a grid stride, one element per round, and the
-// rounds are software-pipelined: the queue entry of round r+2 and the state record of round r+1 are
-// requested before round r's rank blocks, so a round waits for one memory latency (the rank blocks),
-// not four in a row (entry -> record -> blocks -> follows).
-template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, Queue nxt, uint32_t level,
-                                                         uint64_t sub_cap, fmx_result *__restrict__ res,
-                                                         uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
-                                                         unsigned long long *__restrict__ counters) {
-  // After a queue overflow the appended count exceeds what was stored: later levels of the chain
-  // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
-  if (ctl->overflow & 1ull) return;
-  if (blockIdx.x == 0 && threadIdx.x < kSub) ctl->count[(level + 2) % 3][threadIdx.x].v = 0;
-  __shared__ uint64_t s_cf[256];
-  __shared__ uint16_t s_slot[256];
-  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
-  __syncthreads();
+// The work of one wave on one queue slice at one level: it takes the elements part*P + g + r*nparts*P
+// (g = lane group, r = round) of slice `sub`, one element per group and round.  Rounds are
+// software-pipelined: the queue entry of round r+2 and the state record of round r+1 are requested before
+// round r's rank blocks, so a round waits for one memory latency (the rank blocks), not four in a row
+// (entry -> record -> blocks -> follows).  Wave-level operations only: the caller may be the grid kernel
+// (one slice per wave) or the single-workgroup tail kernel (several slices per wave, many levels).
+// ALL = true (tail kernel): the elements are those of all slices, numbered through `s_prefix` (exclusive
+// prefix sums of the slice counts, kSub + 1 entries in LDS), cur_count their total.
+template <bool WIDE, uint32_t LAYOUT, bool ALL = false>
+__device__ __forceinline__ void frontier_slice(const DevIndex &ix, const NfaTables &nfa, const Queue &cur, const Queue &nxt,
+                                               uint32_t level, uint64_t sub_cap, fmx_result *__restrict__ res,
+                                               uint64_t seg_cap, FrontierCtl *__restrict__ ctl, const uint64_t *s_cf,
+                                               const uint16_t *s_slot, Stage &stg, uint32_t w, uint32_t sub,
+                                               uint64_t part, uint64_t nparts, uint64_t cur_count, uint32_t &appends,
+                                               uint32_t &stepped, const uint64_t *s_prefix = nullptr) {
   constexpr int G = Lay<LAYOUT>::G;
   constexpr uint32_t P = 64 / G;             // elements per wave and round
   const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint32_t w = (blockIdx.x * kFThreads + threadIdx.x) >> 6;      // this wave
-  const uint32_t nw = gridDim.x * (kFThreads / 64);
-  const uint32_t sub = w % kSub;             // the slice this wave reads
-  const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
-  uint64_t cur_count = ctl->count[level % 3][sub].v;
-  if (cur_count > sub_cap) cur_count = sub_cap;
-  if (cur_count == 0) return;                // wave-uniform; nothing below needs the other waves
+  if (!ALL && cur_count > sub_cap) cur_count = sub_cap;
+  if (cur_count == 0) return;                // wave-uniform
   const uint64_t in_off = (uint64_t)sub * sub_cap;
-  const uint64_t ngrp = (uint64_t)class_waves * P;
-  const uint64_t first = (uint64_t)(w / kSub) * P + (threadIdx.x & 63u) / G;
+  const uint64_t ngrp = nparts * P;
+  const uint64_t first = part * P + (threadIdx.x & 63u) / G;
   PaddedCount *next_count = ctl->count[(level + 1) % 3];
-  uint32_t stepped = 0;
-  uint32_t appends = 0;                      // wave-uniform: rotates the slice this wave appends to
-  __shared__ Stage s_stage[kFThreads / 64];
-  Stage &stg = s_stage[threadIdx.x >> 6];
   uint32_t staged = 0;                       // wave-uniform
   auto flush = [&]() {
     if (!staged) return;
@@ -150,7 +140,16 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
   };
   struct Entry { uint32_t state; uint64_t sp, ep; };
   auto load_entry = [&](uint64_t q) {        // out-of-range rounds read element 0 (valid, unused)
-    const uint64_t i = in_off + (q < cur_count ? q : 0);
+    uint64_t i = q < cur_count ? q : 0;
+    if (ALL) {                               // the slice that holds logical element i: last s with prefix[s] <= i
+      uint32_t sl = 0;
+#pragma unroll
+      for (uint32_t step = kSub / 2; step; step >>= 1)
+        if (s_prefix[sl + step] <= i) sl += step;
+      i = (uint64_t)sl * sub_cap + (i - s_prefix[sl]);
+    } else {
+      i += in_off;
+    }
     Entry e;
     e.state = cur.state[i]; e.sp = cur.sp[i]; e.ep = cur.ep[i];
     return e;
@@ -267,8 +266,114 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
     rec0 = rec1;
   }
   flush();
+}
+
+// One level on the whole grid: wave w reads slice w % kSub together with the other waves of that class.
+template <bool WIDE, uint32_t LAYOUT>
+__global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, Queue nxt, uint32_t level,
+                                                         uint64_t sub_cap, fmx_result *__restrict__ res,
+                                                         uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
+                                                         unsigned long long *__restrict__ counters) {
+  // After a queue overflow the appended count exceeds what was stored: later levels of the chain
+  // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
+  if (ctl->overflow & 1ull) return;
+  if (blockIdx.x == 0 && threadIdx.x < kSub) ctl->count[(level + 2) % 3][threadIdx.x].v = 0;
+  __shared__ uint64_t s_cf[256];
+  __shared__ uint16_t s_slot[256];
+  __shared__ Stage s_stage[kFThreads / 64];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  __syncthreads();
+  const uint32_t w = (blockIdx.x * kFThreads + threadIdx.x) >> 6;      // this wave
+  const uint32_t nw = gridDim.x * (kFThreads / 64);
+  const uint32_t sub = w % kSub;             // the slice this wave reads
+  const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
+  uint32_t appends = 0, stepped = 0;
+  frontier_slice<WIDE, LAYOUT>(ix, nfa, cur, nxt, level, sub_cap, res, seg_cap, ctl, s_cf, s_slot,
+                               s_stage[threadIdx.x >> 6], w, sub, w / kSub, class_waves, ctl->count[level % 3][sub].v,
+                               appends, stepped);
+  const uint32_t t = threadIdx.x & (Lay<LAYOUT>::G - 1);
   counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
 }
+
+// The long tail of a match -- levels with a handful of elements -- is bound by launches and host looks,
+// not by work.  One persistent workgroup runs those levels back to back: its 16 waves share the 64 slices,
+// a workgroup barrier (with agent-scope release/acquire fences: the next level reads what other waves of
+// this workgroup appended) separates the levels, and it hands back to the grid kernel when the frontier
+// dies, reaches max_level, or outgrows what one workgroup should handle.
+struct TailState {
+  uint32_t level;      // first level not processed
+  uint32_t reason;     // 0 frontier empty, 1 max_level reached, 2 frontier outgrew the tail kernel, 3 queue overflow
+};
+constexpr int kTailThreads = 1024;
+constexpr uint64_t kTailMax = 8192;          // elements per level one workgroup keeps; it is entered below half of it
+
+template <bool WIDE, uint32_t LAYOUT>
+__global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, NfaTables nfa, Queue qa, Queue qb,
+                                                                 uint32_t level0, uint32_t max_level, uint64_t sub_cap,
+                                                                 fmx_result *__restrict__ res, uint64_t seg_cap,
+                                                                 FrontierCtl *__restrict__ ctl,
+                                                                 unsigned long long *__restrict__ counters,
+                                                                 TailState *__restrict__ ts) {
+  __shared__ uint64_t s_cf[256];
+  __shared__ uint16_t s_slot[256];
+  __shared__ Stage s_stage[kTailThreads / 64];
+  __shared__ uint32_t s_verdict;
+  __shared__ uint64_t s_prefix[kSub + 1];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  __syncthreads();
+  static_assert(kSub == 64, "one slice counter per lane below");
+  const uint32_t w = threadIdx.x >> 6;
+  constexpr uint32_t nw = kTailThreads / 64;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t appends = 0, stepped = 0;
+  uint32_t level = level0, reason = 1;
+  for (; level < max_level; level++) {
+    // lane j reads slice j's count (coherent load: other waves' atomics produced it).  Wave 0 decides for the
+    // whole workgroup -- the overflow flag can change while a level runs, and every thread must take the
+    // same way out of this loop (there is a barrier at its end)
+    const unsigned long long mine = __hip_atomic_load(&ctl->count[level % 3][lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == 0) {
+      const unsigned long long clamped = mine < sub_cap ? mine : sub_cap;
+      const unsigned long long total = wave_sum(clamped);
+      unsigned long long incl = clamped;                   // inclusive scan over the 64 lanes
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long y = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += y;
+      }
+      s_prefix[lane] = incl - clamped;
+      if (lane == 63) s_prefix[kSub] = incl;
+      const unsigned long long ovf = __hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) s_verdict = (ovf & 1ull) ? 3u : (total == 0 ? 0u : (total > kTailMax ? 2u : 4u));
+    }
+    __syncthreads();
+    const uint32_t verdict = s_verdict;
+    if (verdict != 4u) { reason = verdict; break; }
+    if (threadIdx.x < kSub) __hip_atomic_store(&ctl->count[(level + 2) % 3][threadIdx.x].v, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const Queue &cur = (level & 1u) ? qb : qa;
+    const Queue &nxt = (level & 1u) ? qa : qb;
+    frontier_slice<WIDE, LAYOUT, true>(ix, nfa, cur, nxt, level, sub_cap, res, seg_cap, ctl, s_cf, s_slot, s_stage[w], w, 0,
+                                       w, nw, s_prefix[kSub], appends, stepped, s_prefix);
+    // level boundary.  The appends of this level were made by waves of this workgroup: draining the stores
+    // (workgroup-scope release) makes them reach L2; the acquire invalidates this CU's L1, which may still
+    // hold lines of the queue buffer from two levels ago.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  if (threadIdx.x == 0) { ts->level = level; ts->reason = reason; }
+  const uint32_t t = threadIdx.x & (Lay<LAYOUT>::G - 1);
+  counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
+}
+
+// result groups the device leaves to the host (k_res_sort)
+constexpr uint32_t kSmallGroup = 32;
+constexpr uint32_t kBigMax = 1024;
+struct BigGroups {
+  uint32_t n;
+  uint32_t pad;
+  uint32_t ent[2 * kBigMax];     // (first result, count) of each group left unsorted
+};
 
 namespace {
 
@@ -307,6 +412,9 @@ struct RegexBatch {
   fmx_result *d_res = nullptr;        // packed results
   fmx_result *d_res_seg = nullptr;    // kSub result slices the levels append to
   FrontierCtl *d_ctl = nullptr;
+  TailState *d_tail = nullptr;
+  uint32_t *d_rcnt = nullptr, *d_rstart = nullptr, *d_rfill = nullptr;   // per-regex result counts / offsets
+  BigGroups *d_big = nullptr;
   uint64_t qcap = 0;
   size_t rcap = 0;
   NfaTables nfa{};
@@ -378,19 +486,84 @@ __global__ void k_frontier_init(Queue q, const uint32_t *__restrict__ first_stat
   }
 }
 
-// Packs the result slices into one array (workgroup j copies slice j behind the slices before it).
-__global__ __launch_bounds__(256) void k_pack_results(const fmx_result *__restrict__ seg, uint64_t seg_cap,
-                                                       const FrontierCtl *__restrict__ ctl,
-                                                       fmx_result *__restrict__ out, uint64_t out_cap) {
-  uint64_t before = 0;
-  for (uint32_t j = 0; j < blockIdx.x; j++) before += min((uint64_t)ctl->res_count[j].v, seg_cap);
-  const uint64_t mine = min((uint64_t)ctl->res_count[blockIdx.x].v, seg_cap);
-  for (uint64_t i = threadIdx.x; i < mine; i += blockDim.x)
-    if (before + i < out_cap) out[before + i] = seg[(uint64_t)blockIdx.x * seg_cap + i];
+// Results leave the device grouped by regex: count per regex, scan, scatter (three small kernels; ordering
+// 50 k results on the host cost half as much as all the levels together).
+__global__ __launch_bounds__(256) void k_res_count(const fmx_result *__restrict__ seg, uint64_t seg_cap,
+                                                    const FrontierCtl *__restrict__ ctl, uint32_t *__restrict__ rcnt) {
+  const uint32_t sl = blockIdx.y;
+  const uint64_t mine = min((uint64_t)ctl->res_count[sl].v, seg_cap);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mine; i += (uint64_t)gridDim.x * blockDim.x)
+    atomicAdd(&rcnt[seg[(uint64_t)sl * seg_cap + i].regex], 1u);
+}
+
+// exclusive prefix sums of cnt[0..k) into start[0..k] with one workgroup: a chunk per thread, a scan of the
+// chunk totals in LDS, then the chunk again
+__global__ __launch_bounds__(1024) void k_res_scan(const uint32_t *__restrict__ cnt, uint32_t k, uint32_t *__restrict__ start) {
+  __shared__ uint32_t part[1024];
+  const uint32_t chunk = (k + 1023) / 1024;
+  const uint32_t lo = min(k, threadIdx.x * chunk), hi = min(k, lo + chunk);
+  uint32_t sum = 0;
+  for (uint32_t j = lo; j < hi; j++) sum += cnt[j];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {               // Hillis-Steele inclusive scan
+    const uint32_t add = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;
+  for (uint32_t j = lo; j < hi; j++) { start[j] = run; run += cnt[j]; }
+  if (threadIdx.x == 1023) start[k] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_res_scatter(const fmx_result *__restrict__ seg, uint64_t seg_cap,
+                                                      const FrontierCtl *__restrict__ ctl,
+                                                      const uint32_t *__restrict__ start, uint32_t *__restrict__ fill,
+                                                      fmx_result *__restrict__ out, uint64_t out_cap) {
+  const uint32_t sl = blockIdx.y;
+  const uint64_t mine = min((uint64_t)ctl->res_count[sl].v, seg_cap);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mine; i += (uint64_t)gridDim.x * blockDim.x) {
+    const fmx_result r = seg[(uint64_t)sl * seg_cap + i];
+    const uint64_t at = (uint64_t)start[r.regex] + atomicAdd(&fill[r.regex], 1u);
+    if (at < out_cap) out[at] = r;
+  }
+}
+
+// Orders each regex's group by (len, sp, ep): one thread per regex, insertion sort for the usual handful of
+// results; larger groups are listed for the host.
+__global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ out, const uint32_t *__restrict__ start, uint32_t k,
+                                                   BigGroups *__restrict__ big) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= k) return;
+  const uint32_t lo = start[r], m = start[r + 1] - lo;
+  if (m < 2) return;
+  if (m > kSmallGroup) {
+    const uint32_t at = atomicAdd(&big->n, 1u);
+    if (at < kBigMax) { big->ent[2 * at] = lo; big->ent[2 * at + 1] = m; }
+    return;
+  }
+  auto less = [](const fmx_result &a, const fmx_result &b) {
+    if (a.len != b.len) return a.len < b.len;
+    if (a.sp != b.sp) return a.sp < b.sp;
+    return a.ep < b.ep;
+  };
+  for (uint32_t i = 1; i < m; i++) {
+    const fmx_result x = out[lo + i];
+    uint32_t j = i;
+    while (j > 0 && less(x, out[lo + j - 1])) { out[lo + j] = out[lo + j - 1]; j--; }
+    out[lo + j] = x;
+  }
 }
 
 int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_result *out, size_t cap,
                       size_t *n_out, uint32_t *per_regex_count) {
+  const bool trace = getenv("FMX_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (trace) fprintf(stderr, "[fmx] regex_batch_match %-18s +%.3f ms\n", what,
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
   const uint32_t max_steps = (lim && lim->max_steps) ? lim->max_steps : 4096u;
   const uint64_t qcap = (lim && lim->max_frontier) ? lim->max_frontier : (1ull << 22);
   if (b->device != h->device || b->n_index != h->n) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
@@ -414,6 +587,11 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     HIP_TRY(b->scratch->alloc(&b->d_res, cap ? cap : 1), "hipMalloc(results)");
     HIP_TRY(b->scratch->alloc(&b->d_res_seg, kSub * seg_cap), "hipMalloc(result slices)");
     HIP_TRY(b->scratch->alloc(&b->d_ctl, 1), "hipMalloc(ctl)");
+    HIP_TRY(b->scratch->alloc(&b->d_tail, 1), "hipMalloc(tail state)");
+    HIP_TRY(b->scratch->alloc(&b->d_rcnt, b->k + 1), "hipMalloc(result counts)");
+    HIP_TRY(b->scratch->alloc(&b->d_rstart, b->k + 1), "hipMalloc(result offsets)");
+    HIP_TRY(b->scratch->alloc(&b->d_rfill, b->k + 1), "hipMalloc(result fill)");
+    HIP_TRY(b->scratch->alloc(&b->d_big, 1), "hipMalloc(big groups)");
     b->qcap = qcap;
     b->rcap = cap ? cap : 1;
   }
@@ -421,14 +599,12 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   fmx_result *d_res = b->d_res;
   fmx_result *d_res_seg = b->d_res_seg;
   FrontierCtl *d_ctl = b->d_ctl;
-  hipStream_t st = nullptr;
-  HIP_TRY(hipStreamCreate(&st), "hipStreamCreate");
-  struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{st};
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIP_TRY(hipEventCreate(&e0), "hipEventCreate");
-  HIP_TRY(hipEventCreate(&e1), "hipEventCreate");
-  struct EG { hipEvent_t a, b; ~EG() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
+  CtxLease lease(h);                 // stream and events from the handle's pool
+  if (!lease.c) return FMX_ERR_HIP;
+  hipStream_t st = lease.c->stream;
+  hipEvent_t e0 = lease.c->ev_a, e1 = lease.c->ev_b;
 
+  mark("setup");
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
   k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->d_first_state, b->n_first, h->n, sub_cap, d_ctl);
   HIP_TRY(hipGetLastError(), "k_frontier_init");
@@ -437,6 +613,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 8u;   // levels between host looks
   const int grid_full = h->cu_count * 6;     // what stays resident at 80 vector registers per lane
   int grid = grid_full;
+  static const bool use_tail = !(getenv("FMX_FRONTIER_TAIL") && atoi(getenv("FMX_FRONTIER_TAIL")) == 0);   // A/B switch
   std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());
   FrontierCtl &ctl = *ctl_host;
   uint64_t n_res = 0;
@@ -465,17 +642,48 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (getenv("FMX_TRACE"))
       fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
               (unsigned long long)next_total, (unsigned long long)n_res, ctl.overflow);
+    if (alive && level < max_steps && next_total <= kTailMax / 2 && use_tail) {
+      // nearly empty frontier: one persistent workgroup runs the following levels without launches in between
+      TailState tsh{};
+#define CALL(W, L) k_frontier_tail<W, L><<<1, kTailThreads, 0, st>>>(h->dev, b->nfa, qa, qb, level, max_steps, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters, b->d_tail)
+      FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
+      HIP_TRY(hipGetLastError(), "k_frontier_tail");
+      launches++;
+      HIP_TRY(hipMemcpyAsync(&tsh, b->d_tail, sizeof tsh, hipMemcpyDeviceToHost, st), "D2H(tail)");
+      HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
+      HIP_TRY(hipStreamSynchronize(st), "sync(tail)");
+      if ((ctl.overflow & 1ull) || tsh.reason == 3) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
+      level = tsh.level;
+      next_total = 0;
+      n_res = 0;
+      for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
+      alive = next_total != 0;
+      grid = grid_full;
+      if (getenv("FMX_TRACE"))
+        fprintf(stderr, "[fmx] frontier tail kernel stopped at level %u (reason %u): next %llu, results %llu\n", level,
+                tsh.reason, (unsigned long long)next_total, (unsigned long long)n_res);
+    }
     if (alive && level >= max_steps) { truncated = true; alive = false; }
   }
-  if (n_res && !(ctl.overflow & 2ull)) {
-    k_pack_results<<<kSub, 256, 0, st>>>(d_res_seg, seg_cap, d_ctl, d_res, (uint64_t)cap);
-    HIP_TRY(hipGetLastError(), "k_pack_results");
-    launches++;
+  const bool grouped = n_res && !(ctl.overflow & 2ull) && n_res <= cap;
+  if (grouped) {
+    HIP_TRY(hipMemsetAsync(b->d_rcnt, 0, (b->k + 1) * 4, st), "memset(result counts)");
+    HIP_TRY(hipMemsetAsync(b->d_rfill, 0, (b->k + 1) * 4, st), "memset(result fill)");
+    const dim3 rg(8, kSub);
+    k_res_count<<<rg, 256, 0, st>>>(d_res_seg, seg_cap, d_ctl, b->d_rcnt);
+    k_res_scan<<<1, 1024, 0, st>>>(b->d_rcnt, (uint32_t)b->k, b->d_rstart);
+    k_res_scatter<<<rg, 256, 0, st>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)cap);
+    HIP_TRY(hipMemsetAsync(b->d_big, 0, 8, st), "memset(big groups)");
+    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, st>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);
+    HIP_TRY(hipGetLastError(), "result grouping kernels");
+    launches += 4;
   }
   HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
   HIP_TRY(hipStreamSynchronize(st), "sync");
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
+  mark("levels done");
   {
     std::lock_guard<std::mutex> lk(h->mu);
     h->last_kernel_ms = ms;
@@ -487,31 +695,49 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if ((ctl.overflow & 2ull) || tot.res_count + extra > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
   if (tot.res_count)
     HIP_TRY(hipMemcpy(out, d_res, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost), "D2H(results)");
+  mark("results copied");
   for (size_t j = 0; j < extra; j++) {           // dfa.scala:270-273 with the start StatePoint(0,0,0,n)
     fmx_result &o = out[tot.res_count + j];
     o.regex = b->start_final[j]; o.len = 0; o.sp = 0; o.ep = h->n;
   }
   tot.res_count += extra;
   if (tot.res_count) {
-    // canonical order (regex, len, sp, ep): bucket by regex id (counting sort), then order each regex's
-    // few results -- a comparison sort over the whole array costs more than the device levels
+    // canonical order (regex, len, sp, ep).  The device delivered the frontier's results grouped by regex
+    // (any order inside a group); regexes that start in a final DFA state add theirs on the host.
     const size_t nres = (size_t)tot.res_count;
-    std::vector<uint32_t> start(b->k + 1, 0);
-    for (size_t j = 0; j < nres; j++) start[out[j].regex + 1]++;
-    for (size_t r = 0; r < b->k; r++) start[r + 1] += start[r];
-    if (per_regex_count)
-      for (size_t r = 0; r < b->k; r++) per_regex_count[r] = start[r + 1] - start[r];
-    std::vector<fmx_result> tmp(out, out + nres);
-    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-    for (size_t j = 0; j < nres; j++) out[fill[tmp[j].regex]++] = tmp[j];
-    for (size_t r = 0; r < b->k; r++)
-      if (start[r + 1] - start[r] > 1)
-        std::sort(out + start[r], out + start[r + 1], [](const fmx_result &a, const fmx_result &b) {
-          if (a.len != b.len) return a.len < b.len;
-          if (a.sp != b.sp) return a.sp < b.sp;
-          return a.ep < b.ep;
-        });
+    const size_t ndev = nres - extra;
+    auto by_key = [](const fmx_result &a, const fmx_result &b) {
+      if (a.len != b.len) return a.len < b.len;
+      if (a.sp != b.sp) return a.sp < b.sp;
+      return a.ep < b.ep;
+    };
+    uint32_t nbig = 0;
+    if (ndev) HIP_TRY(hipMemcpy(&nbig, &b->d_big->n, 4, hipMemcpyDeviceToHost), "D2H(big groups)");
+    if (!extra && nbig <= kBigMax) {
+      // the device ordered every group of up to kSmallGroup results; the few larger ones are listed
+      if (nbig) {
+        std::vector<uint32_t> ent(2 * (size_t)nbig);
+        HIP_TRY(hipMemcpy(ent.data(), b->d_big->ent, ent.size() * 4, hipMemcpyDeviceToHost), "D2H(big groups)");
+        for (uint32_t g = 0; g < nbig; g++) std::sort(out + ent[2 * g], out + ent[2 * g] + ent[2 * g + 1], by_key);
+      }
+      if (per_regex_count && ndev)
+        HIP_TRY(hipMemcpy(per_regex_count, b->d_rcnt, b->k * 4, hipMemcpyDeviceToHost), "D2H(result counts)");
+    } else {
+      // host-made results to merge in (or too many large groups to list): bucket everything by regex id
+      std::vector<uint32_t> cnt(b->k + 1, 0);
+      for (size_t j = 0; j < nres; j++) cnt[out[j].regex]++;
+      std::vector<uint32_t> start(b->k + 1, 0);
+      for (size_t r = 0; r < b->k; r++) start[r + 1] = start[r] + cnt[r];
+      std::vector<fmx_result> tmp(out, out + nres);
+      std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+      for (size_t j = 0; j < nres; j++) out[fill[tmp[j].regex]++] = tmp[j];
+      for (size_t r = 0; r < b->k; r++)
+        if (cnt[r] > 1) std::sort(out + start[r], out + start[r + 1], by_key);
+      if (per_regex_count)
+        for (size_t r = 0; r < b->k; r++) per_regex_count[r] = cnt[r];
+    }
   }
+  mark("results ordered");
   if (truncated) {
     set_error("frontier still alive after max_steps levels: results hold every match of length <= max_steps");
     return FMX_TRUNCATED;

@@ -53,6 +53,18 @@ struct Index {
 };
 
 void set_error(const std::string &msg);
+// Borrow / return one of the handle's call contexts (stream + events created on first use).  ctx_acquire
+// returns nullptr and records the error when the stream or events cannot be created.
+CallCtx *ctx_acquire(const Index *h);
+void ctx_release(const Index *h, CallCtx *c);
+struct CtxLease {            // scope guard around ctx_acquire / ctx_release
+  const Index *h;
+  CallCtx *c;
+  explicit CtxLease(const Index *hh) : h(hh), c(ctx_acquire(hh)) {}
+  ~CtxLease() { if (c) ctx_release(h, c); }
+  CtxLease(const CtxLease &) = delete;
+  CtxLease &operator=(const CtxLease &) = delete;
+};
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP
 

@@ -94,6 +94,19 @@ void ctx_release(const Index *h, CallCtx *c) {
   if (!keep) free_ctx(c);
 }
 
+hipError_t ctx_scratch(CallCtx *c, int i, size_t bytes, void **out) {
+  if (bytes < 16) bytes = 16;
+  if (c->cap[i] < bytes) {
+    if (c->buf[i]) { (void)hipFree(c->buf[i]); c->buf[i] = nullptr; c->cap[i] = 0; }
+    const size_t want = bytes + bytes / 4;          // some slack: batches of similar size reuse the buffer
+    hipError_t e = hipMalloc(&c->buf[i], want);
+    if (e != hipSuccess) return e;
+    c->cap[i] = want;
+  }
+  *out = c->buf[i];
+  return hipSuccess;
+}
+
 // One host-pointer call: borrows a context from the handle (or makes one), hands out scratch buffers from it,
 // runs the enqueue function on its stream between its two events, and returns the context on scope exit.
 class Call {
@@ -107,17 +120,7 @@ class Call {
   // next scratch buffer of the call, at least `bytes` long
   hipError_t alloc(DevBuf &b, size_t bytes) {
     if (next_ >= CallCtx::kBufs) return hipErrorOutOfMemory;
-    const int i = next_++;
-    if (bytes < 16) bytes = 16;
-    if (c_->cap[i] < bytes) {
-      if (c_->buf[i]) { (void)hipFree(c_->buf[i]); c_->buf[i] = nullptr; c_->cap[i] = 0; }
-      const size_t want = bytes + bytes / 4;          // some slack: batches of similar size reuse the buffer
-      hipError_t e = hipMalloc(&c_->buf[i], want);
-      if (e != hipSuccess) return e;
-      c_->cap[i] = want;
-    }
-    b.p = c_->buf[i];
-    return hipSuccess;
+    return ctx_scratch(c_, next_++, bytes, &b.p);
   }
   // pinned host staging of at least `bytes`
   hipError_t pinned(void **out, size_t bytes) {

@@ -57,6 +57,7 @@ void set_error(const std::string &msg);
 // returns nullptr and records the error when the stream or events cannot be created.
 CallCtx *ctx_acquire(const Index *h);
 void ctx_release(const Index *h, CallCtx *c);
+hipError_t ctx_scratch(CallCtx *c, int i, size_t bytes, void **out);   // grow-only device scratch buffer i
 struct CtxLease {            // scope guard around ctx_acquire / ctx_release
   const Index *h;
   CallCtx *c;

@@ -17,6 +17,7 @@
 #include <fmx.h>
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "fmx_device.h"
@@ -178,25 +179,6 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
     if (e__ != hipSuccess) return hip_fail(e__, what); \
   } while (0)
 
-namespace {
-struct DevMem {
-  std::vector<void *> ptrs;
-  ~DevMem() { for (void *p : ptrs) (void)hipFree(p); }
-  template <class T>
-  hipError_t alloc(T **out, size_t count) {
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
-    if (e == hipSuccess) { ptrs.push_back(p); *out = (T *)p; }
-    return e;
-  }
-  template <class T>
-  hipError_t upload(T **out, const std::vector<T> &v) {
-    hipError_t e = alloc(out, v.size());
-    if (e == hipSuccess && !v.empty()) e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-    return e;
-  }
-};
-}  // namespace
 
 int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uint32_t max_branching,
                           uint32_t max_iterations, fmx_result *out, size_t cap, size_t *n_out,
@@ -237,37 +219,48 @@ int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uin
   const uint64_t arena_groups = std::max<uint64_t>(64, (4ull << 30) / ((uint64_t)heap_cap * sizeof(HeapElem)));
   gcap = std::min<uint64_t>(gcap, std::max<uint64_t>(1, arena_groups / per_wg));
   const int grid = (int)std::min(want, gcap);
-  DevMem mem;
-  RefTables rt{};
-  uint8_t *d_c, *d_last; int32_t *d_num; uint32_t *d_foff, *d_fol, *d_fo, *d_f, *d_left = nullptr;
-  HIP_TRY(mem.upload(&d_c, st_c), "upload");
-  HIP_TRY(mem.upload(&d_last, st_last), "upload");
-  HIP_TRY(mem.upload(&d_num, st_num), "upload");
-  HIP_TRY(mem.upload(&d_foff, fol_off), "upload");
-  HIP_TRY(mem.upload(&d_fol, fol), "upload");
-  HIP_TRY(mem.upload(&d_fo, first_off), "upload");
-  HIP_TRY(mem.upload(&d_f, first), "upload");
-  rt = RefTables{d_c, d_last, d_num, d_foff, d_fol, d_fo, d_f};
-  HeapElem *d_heaps = nullptr;
-  RefResult *d_res = nullptr;
-  RefCtl *d_ctl = nullptr;
-  HIP_TRY(mem.alloc(&d_heaps, (size_t)grid * per_wg * heap_cap), "hipMalloc(heaps)");
-  HIP_TRY(mem.alloc(&d_res, cap ? cap : 1), "hipMalloc(results)");
-  HIP_TRY(mem.alloc(&d_ctl, 1), "hipMalloc(ctl)");
-  if (front_left) HIP_TRY(mem.alloc(&d_left, k), "hipMalloc(front_left)");
-  HIP_TRY(hipMemset(d_ctl, 0, sizeof(RefCtl)), "memset(ctl)");
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIP_TRY(hipEventCreate(&e0), "hipEventCreate");
-  HIP_TRY(hipEventCreate(&e1), "hipEventCreate");
-  struct EG { hipEvent_t a, b; ~EG() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eg{e0, e1};
-  HIP_TRY(hipEventRecord(e0, nullptr), "hipEventRecord");
+  // One device arena from the handle's call context, one upload: [tables | ctl | heaps | results | front_left]
+  CtxLease lease(h);
+  if (!lease.c) return FMX_ERR_HIP;
+  hipStream_t st = lease.c->stream;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_c = 0, o_last = o_c + up(st_c.size()), o_num = o_last + up(st_last.size()),
+               o_foff = o_num + up(st_num.size() * 4), o_fol = o_foff + up(fol_off.size() * 4),
+               o_fo = o_fol + up(fol.size() * 4), o_f = o_fo + up(first_off.size() * 4),
+               o_ctl = o_f + up(first.size() * 4), tables_end = o_ctl + up(sizeof(RefCtl));
+  const size_t groups = (size_t)grid * per_wg;
+  const size_t o_heaps = tables_end, o_res = o_heaps + up(groups * heap_cap * sizeof(HeapElem)),
+               o_left = o_res + up((cap ? cap : 1) * sizeof(RefResult)), total = o_left + up(k * 4);
+  void *arena_v = nullptr;
+  HIP_TRY(ctx_scratch(lease.c, 0, total, &arena_v), "hipMalloc(reference-order arena)");
+  uint8_t *arena = static_cast<uint8_t *>(arena_v);
+  std::vector<uint8_t> host(tables_end, 0);
+  auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) std::memcpy(host.data() + off, src, bytes); };
+  put(o_c, st_c.data(), st_c.size());
+  put(o_last, st_last.data(), st_last.size());
+  put(o_num, st_num.data(), st_num.size() * 4);
+  put(o_foff, fol_off.data(), fol_off.size() * 4);
+  put(o_fol, fol.data(), fol.size() * 4);
+  put(o_fo, first_off.data(), first_off.size() * 4);
+  put(o_f, first.data(), first.size() * 4);            // RefCtl behind it stays zero
+  HIP_TRY(hipMemcpyAsync(arena, host.data(), tables_end, hipMemcpyHostToDevice, st), "H2D(tables)");
+  const RefTables rt{arena + o_c, arena + o_last, reinterpret_cast<const int32_t *>(arena + o_num),
+                     reinterpret_cast<const uint32_t *>(arena + o_foff), reinterpret_cast<const uint32_t *>(arena + o_fol),
+                     reinterpret_cast<const uint32_t *>(arena + o_fo), reinterpret_cast<const uint32_t *>(arena + o_f)};
+  HeapElem *d_heaps = reinterpret_cast<HeapElem *>(arena + o_heaps);
+  RefResult *d_res = reinterpret_cast<RefResult *>(arena + o_res);
+  RefCtl *d_ctl = reinterpret_cast<RefCtl *>(arena + o_ctl);
+  uint32_t *d_left = front_left ? reinterpret_cast<uint32_t *>(arena + o_left) : nullptr;
+  hipEvent_t e0 = lease.c->ev_a, e1 = lease.c->ev_b;
+  HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
 #define CALL(W, L)                                                                                          \
-  k_match_ref<W, L><<<grid, kRThreads>>>(h->dev, rt, (uint32_t)k, d_heaps, heap_cap, max_branching, max_iterations, \
-                                         d_res, (uint64_t)cap, d_left, d_ctl, h->d_counters)
+  k_match_ref<W, L><<<grid, kRThreads, 0, st>>>(h->dev, rt, (uint32_t)k, d_heaps, heap_cap, max_branching, max_iterations, \
+                                                d_res, (uint64_t)cap, d_left, d_ctl, h->d_counters)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
   HIP_TRY(hipGetLastError(), "k_match_ref");
-  HIP_TRY(hipEventRecord(e1, nullptr), "hipEventRecord");
+  HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
+  HIP_TRY(hipStreamSynchronize(st), "sync(k_match_ref)");
   RefCtl ctl{};
   HIP_TRY(hipMemcpy(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost), "D2H(ctl)");
   float ms = 0;

@@ -420,6 +420,21 @@ def test_regex_overflow_is_reported():
     assert {r.key() for r in part} == {k for k in oracle_results_capped(bwt, eof, counts, "a[a-d]*b", 3)}
 
 
+def test_regex_long_tail_levels():
+    """Frontiers that stay small for many levels, grow, and die slowly (n = 2M over 4 letters: "ab[a-c]*d"
+    holds min(3^k, 125k * 0.75^k) elements at level k + 2, i.e. ~700 at the first host look, ~9.4k at level
+    11, ~900 at level 19, dead near level 45).  The persistent tail kernel takes over at the first look
+    (<= 4096 elements), hands back to the grid kernel when the frontier outgrows it (> 8192), and takes over
+    again for the dying tail.  Every match must equal the oracle's."""
+    bwt, eof, counts = synth_bwt(2_000_000, 97, 100, 12)            # 4 letters: a..d
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    for re in ("ab[a-c]*d", "a[ab]*c", "dcba[ab]*d"):
+        want = sorted(oracle_results_capped(bwt, eof, counts, re, 60))
+        got = findex_amd.ReTree(findex_amd.REParser.re2post(re)).matchAll(hip, max_steps=60, max_frontier=1 << 22)
+        assert sorted(r.key() for r in got) == want, re
+        assert len(want) > 100, re
+
+
 # ---------------------------------------------------------------- the reference's other two engines
 class _OIdx:
     def __init__(self, sa):

@@ -190,8 +190,9 @@ typedef struct fmx_limits {
    *               the BWT of a real text a frontier always dies -- no match is longer than the text --
    *               but on a synthetic "BWT" that is just a random string, LF has short cycles and x* can
    *               run forever.)
-   * max_frontier= capacity of the device work queue in elements, 0 = default (1<<22); FMX_ERR_OVERFLOW
-   *               when exceeded.
+   * max_frontier= capacity of the device work queue in elements, 0 = default (1<<22): at least this many
+   *               elements fit per level (the queue is cut into 64 slices with some headroom each);
+   *               FMX_ERR_OVERFLOW when a level outgrows it.
    * mode = FMX_MATCH_REFERENCE.  ReTree._matchSA exactly (re2/retree.scala:618-653): the priority queue
    * of Scala 2.10 replayed per regex, loop while queue non-empty && queue.length < max_branching &&
    * (max_iterations == 0 || i < max_iterations), i from 1.  Results come back per regex in the

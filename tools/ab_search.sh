@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the search-kernel variants on the GPU box: parity subset + bench line per variant.
-# Usage: tools/ab_search.sh "1 2 3 4" [workload]
+# Usage: tools/ab_search.sh "1 4" [workload]     (1 = generic kernel, anything else = k_search4)
 WL=${2:-c3}
 mkdir -p gpurun_out/ab
 for v in $1; do

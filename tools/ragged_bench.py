@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Uniform vs ragged pattern batches through the default search path (k_prep picks the kernel)."""
+"""Uniform vs ragged pattern batches through the search path (lockstep batches of 16: groups whose pattern
+ends early idle until their batch ends).  FMX_SEARCH_VARIANT=1 selects the generic one-pattern-per-group kernel."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -33,7 +34,7 @@ def run(lens, tag):
         hip.search_batch_dev(buf.data_ptr(), offs.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 10
-    print("%-28s FMX_SEARCH_VARIANT=%s: %.3f ms, %.1f G rank-queries/s, hits %d" % (tag, os.environ.get("FMX_SEARCH_VARIANT", "auto"), ms, ranks / ms / 1e6, int((sp < ep).sum())))
+    print("%-28s FMX_SEARCH_VARIANT=%s: %.3f ms, %.1f G rank-queries/s, hits %d" % (tag, os.environ.get("FMX_SEARCH_VARIANT", "default"), ms, ranks / ms / 1e6, int((sp < ep).sum())))
 rng = np.random.default_rng(1)
 run(np.full(k, 32), "uniform 32")
 run(rng.integers(1, 65, k), "ragged 1..64")

@@ -13,7 +13,9 @@
 // 165 vector instructions per step and wave and was bound by instruction issue, not HBM.  Tried and
 // dropped on the way here: 2 or 3 patterns per lane group in one trip; skipping the second load when
 // sp and ep share a block; a dynamic-refill variant that hands a group its next pattern as soon as
-// one ends (at most 4 % faster than lockstep batches on lengths uniform in 1..64, slower otherwise).
+// one ends (at most 4 % faster than lockstep batches on lengths uniform in 1..64, slower otherwise); forming
+// the batches from patterns sorted by length (idle lanes issue no requests, and requests are the limit:
+// ragged batches already run at 91 % of the uniform rate, the sort only added its own 90 us).
 #include "fmx_device.h"
 #include "fmx_host.h"
 

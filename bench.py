@@ -299,6 +299,10 @@ def main():
                 "bound": "hbm", "kernel": kernel_name,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (pmc_traffic(args.workload) or (None, None))[0],
+                # the same in bandwidth terms: measured HBM bytes per launch / this run's kernel time, and its
+                # share of the 8 TB/s peak (what the hardware really moved; `frac` above prices SURVEY's 132 B)
+                "traffic_GBps": ((pmc_traffic(args.workload) or (0, None))[0] or 0) / (kernel_ms * 1e-3) / 1e9 or None,
+                "traffic_frac": ((pmc_traffic(args.workload) or (0, None))[0] or 0) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS or None,
                 "traffic_source": (pmc_traffic(args.workload) or (None, "no PMC profile of this workload committed"))[1],
                 "bytes_per_rank_query": bytes_per_rank, "rank_queries_per_launch": ranks_per_step,
                 "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,

@@ -214,18 +214,23 @@ def main():
         % (log2n, sigma, st["index_bytes"] / 2**30, st["n_symbols"], st["n_blocks"], st["block_bytes"],
            st["build_ms"], time.time() - t0))
     pats, off = make_patterns(torch, hip, n, sigma, k, m, seed * 1000 + rank, device, stream)
-    sp = torch.empty(k, dtype=torch.int64, device=device)
-    ep = torch.empty(k, dtype=torch.int64, device=device)
-    from findex_amd.distributed import gather_intervals_dev
+    # the intervals land in the slots of a pipelined gather: with N > 1 the all-gather of step i (RCCL over
+    # xGMI, 16 B per pattern) runs on the collective's stream while step i+1 is being searched
+    from findex_amd.distributed import IntervalGather
+    gather = IntervalGather(k, device)
+    step_no = [0]
 
     def step():
+        sp, ep = gather.slot(step_no[0])
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
-        if use_dist:        # the path's one exchange: gather the hit intervals over RCCL/xGMI
-            return gather_intervals_dev(sp, ep)
+        if use_dist:        # the path's one exchange: gather the hit intervals
+            gather.launch(step_no[0])
+        step_no[0] += 1
+        return sp, ep
 
     # rank queries one step executes (device counter; identical every step)
     hip.stats_reset()
-    step()
+    sp, ep = step()
     torch.cuda.synchronize()
     s1 = hip.stats()
     ranks_per_step = int(s1["rank_queries"])
@@ -241,11 +246,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for a, b in ev:
+        sp_i, ep_i = gather.slot(step_no[0])
         a.record()          # torch's current stream == the stream the kernel is launched on
-        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
+        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp_i.data_ptr(), ep_i.data_ptr(), k, stream)
         b.record()
         if use_dist:
-            gather_intervals_dev(sp, ep)
+            gather.launch(step_no[0])
+        step_no[0] += 1
+    gather.finish()         # every step's gather completes inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -291,7 +299,7 @@ def main():
                 "hit_patterns_fraction": hits_all / (world * k),
                 "rank_queries_per_step": ranks_all,
                 "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
-                               % (world, ", all_gather of (sp,ep) per step" if use_dist else ""),
+                               % (world, ", all_gather of (sp,ep) per step overlapped with the next step's search" if use_dist else ""),
                 "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
                 "index_layout": "one-hot bit-vectors, 64-B blocks" if st["layout"] == 0 else "BWT bytes + checkpoints",
             },

@@ -75,7 +75,21 @@ def _rank_main(rank, world, port, q):
         cuts = D.shard_bounds(off, world)
         t = torch.arange(3 + 2 * rank, dtype=torch.int64) + 100 * rank
         parts = D.all_gather_varlen(t)
-        q.put((rank, sp, ep, res, cuts, [p.tolist() for p in parts]))
+        # the pipelined gather bench.py uses: 5 batches through 2 slots, gather i overlapping batch i+1
+        g = D.IntervalGather(4, torch.device("cpu"))
+        seen = []
+        outs = []
+        for i in range(5):
+            a, b = g.slot(i)
+            a.copy_(torch.arange(4) + 10 * i + 1000 * rank)
+            b.copy_(torch.arange(4) + 10 * i + 1000 * rank + 5)
+            outs.append(g.launch(i))
+            if i >= 1:                      # batch i-1's gather has had a batch to finish; wait and read it
+                g.work[(i - 1) % g.depth].wait()
+                seen.append(outs[i - 1].clone().tolist())
+        g.finish()
+        seen.append(outs[4].clone().tolist())
+        q.put((rank, sp, ep, res, cuts, [p.tolist() for p in parts], seen))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -103,7 +117,11 @@ def test_two_rank_gloo_matches_single_process():
     s = OracleSearcher(*idx)
     wsp, wep = s.search_batch(buf, off)
     wres = oracle_match(s, REGEXES)
-    for rank, sp, ep, res, cuts, parts in got:
+    for rank, sp, ep, res, cuts, parts, seen in got:
+        for i, batch in enumerate(seen):    # (world, 2, k): every rank sees every rank's rows of batch i
+            for r in range(world):
+                assert batch[r][0] == [j + 10 * i + 1000 * r for j in range(4)]
+                assert batch[r][1] == [j + 10 * i + 1000 * r + 5 for j in range(4)]
         assert np.array_equal(sp, wsp) and np.array_equal(ep, wep)
         assert [sorted(r) for r in res] == wres
         assert cuts[0] == 0 and cuts[-1] == off.size - 1 and cuts == sorted(cuts)

@@ -83,3 +83,35 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.lower(), os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/fmx.h is the boundary a JNI / cgo / FFI stub compiles against: it must be valid strict C99 and
+    C++11 on its own, and a C program using only it must link against libfmx.so (no torch, no HIP headers)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "use_fmx.c"
+    src.write_text(
+        "#include <fmx.h>\n#include <stdio.h>\n"
+        "int main(void) {\n"
+        "  fmx_stats_t s; fmx_limits l; fmx_result r; int n = -1;\n"
+        "  (void)s; (void)l; (void)r;\n"
+        "  if (fmx_abi_version() <= 0) return 2;\n"
+        "  if (fmx_device_count(&n) != FMX_OK || n < 0) return 3;\n"
+        "  printf(\"%d %d %d\\n\", (int)sizeof(fmx_stats_t), (int)sizeof(fmx_limits), (int)sizeof(fmx_result));\n"
+        "  return 0;\n}\n")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + inc, "-c", str(src),
+                           "-o", str(tmp_path / "a.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-I" + inc, "-x", "c++", "-c", str(src),
+                           "-o", str(tmp_path / "b.o")])
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "use_fmx"
+    subprocess.check_call(["gcc", str(tmp_path / "a.o"), "-L" + libdir, "-lfmx", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stderr[-500:])
+    assert out.stdout.split() == [str(ctypes.sizeof(_lib.fmx_stats_t)), str(ctypes.sizeof(_lib.fmx_limits)),
+                                  str(ctypes.sizeof(_lib.fmx_result))]

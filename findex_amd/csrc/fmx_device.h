@@ -273,14 +273,36 @@ __device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint32_t c, ui
 }
 
 // One backward step for the whole lane group: (sp, ep) -> (C[c]+rank(c,sp), C[c]+rank(c,ep)), the
-// body of SuffixAlgo.getPrevRange (findex.scala:32-36).  All lines are requested before any is consumed.
+// body of SuffixAlgo.getPrevRange (findex.scala:32-36).  All lines are requested before any is consumed;
+// when sp and ep fall into the same block (narrow intervals: most steps of a search or a regex frontier)
+// the block is requested once.
 template <bool WIDE, uint32_t LAYOUT>
 __device__ __forceinline__ void backward_step(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t cfc,
                                               const LaneConst &lc, uint64_t &sp, uint64_t &ep) {
-  const RankReq q1 = rank_issue<LAYOUT>(ix, slot, sp, lc);
-  const RankReq q2 = rank_issue<LAYOUT>(ix, slot, ep, lc);
-  sp = cfc + rank_complete<WIDE, LAYOUT>(q1, c, lc);
-  ep = cfc + rank_complete<WIDE, LAYOUT>(q2, c, lc);
+  if (slot >= kSlotEof) {                       // absent symbol, or the EOF symbol 0
+    const uint64_t r1 = (slot == kSlotEof && sp > ix.eof) ? 1 : 0;
+    const uint64_t r2 = (slot == kSlotEof && ep > ix.eof) ? 1 : 0;
+    sp = cfc + r1;
+    ep = cfc + r2;
+    return;
+  }
+  if (LAYOUT == kLayoutBytes) {
+    const ByteRankReq q1 = byte_rank_issue(ix, slot, sp, lc);
+    ByteRankReq q2 = q1;
+    if ((ep >> 7) != (sp >> 7)) q2 = byte_rank_issue(ix, slot, ep, lc);
+    else q2.rem = (uint32_t)ep & 127u;
+    sp = cfc + byte_rank_finish(q1, c, lc);
+    ep = cfc + byte_rank_finish(q2, c, lc);
+    return;
+  }
+  uint32_t b1, b2, m1, m2;
+  split448(sp, b1, m1);
+  split448(ep, b2, m2);
+  const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
+  uint4 w2 = w1;
+  if (b2 != b1) w2 = load_line16(block_addr(ix, slot, b2, lc));
+  sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+  ep = cfc + rank_finish<WIDE>(w2, m2, lc);
 }
 
 // ---- statistics counters without a hot spot.  Same-address device atomics complete at roughly 100

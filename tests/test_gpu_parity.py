@@ -186,6 +186,43 @@ def test_synthetic_parity(n, lo, hi, seed):
             check_search(hip, orc, pats)
 
 
+@pytest.mark.parametrize("layout", ["onehot", "bytes"])
+def test_randomized_small_indexes(layout):
+    """Many small random indexes (n around the 448 / 128 block edges and beyond, random alphabet ranges, random
+    eof) and random operands -- hits, misses, empty patterns, absent symbols, the EOF symbol 0, keys outside
+    [0, n) -- through search, occ and single steps, against the oracle.  FMX_TEST_SEED picks other draws."""
+    seed = int(os.environ.get("FMX_TEST_SEED", "5"))
+    rng = np.random.default_rng(seed)
+    findex_amd.set_layout(layout)
+    try:
+        for trial in range(24):
+            n = int(rng.choice([1, 2, 3, 63, 127, 128, 129, 447, 448, 449, 895, 897, 5000, 40_000]) + rng.integers(0, 3))
+            lo = int(rng.integers(1, 250))
+            hi = int(min(255, lo + rng.integers(0, 40)))
+            eof = int(rng.integers(0, n))
+            bwt, eof, counts = synth_bwt(n, lo, hi, seed * 1000 + trial, eof=eof)
+            hip, orc = pair_from_mem(bwt, eof, counts)
+            symbols = list(range(max(0, lo - 2), min(255, hi + 2) + 1)) + [0, 255]
+            check_occ(hip, orc, rng, 300, symbols)
+            pats = []
+            for m in (0, 1, 2, 5, 9, 33):
+                pats += lf_walk_patterns(orc, rng, 12, m, 0.3, alphabet=symbols)
+            pats += [bytes(rng.choice(np.asarray(symbols, dtype=np.uint8), size=int(rng.integers(1, 12))).tolist())
+                     for _ in range(40)]
+            check_search(hip, orc, pats)
+            a = rng.integers(0, n + 1, size=200)
+            b = rng.integers(0, n + 1, size=200)
+            sp, ep = np.minimum(a, b).astype(np.uint64), np.maximum(a, b).astype(np.uint64)
+            c = rng.choice(np.asarray(symbols, dtype=np.uint8), size=200)
+            gsp, gep = hip.prev_range_batch(sp, ep, c)
+            for q in range(200):
+                w = orc.getPrevRange(int(sp[q]), int(ep[q]), int(c[q]))
+                g = (int(gsp[q]), int(gep[q])) if gsp[q] < gep[q] else None
+                assert g == w, (trial, n, q)
+    finally:
+        findex_amd.set_layout("auto")
+
+
 def test_many_patterns_ragged_lengths():
     """More patterns than resident octets, lengths 0..70, so octets chain through several patterns."""
     bwt, eof, counts = synth_bwt(400_000, 1, 4, 77)
@@ -347,9 +384,9 @@ def test_random_regexes_all_engines_vs_oracle(testdata):
     from oracle import engines as E
     from test_regex_compile import random_regex
     hip, orc = pair_from_mem(*bwt_of_text((b"abcde" * 3 + b"badcebadce" + b"eeddccbbaa" + b"abacadaeab") * 4))
-    rng = random.Random(99)
+    rng = random.Random(int(os.environ.get("FMX_TEST_SEED", "99")))          # stress runs: other seeds / counts
     regs = []
-    while len(regs) < 300:
+    while len(regs) < int(os.environ.get("FMX_TEST_NREGEX", "300")):
         re = random_regex(rng)
         if "." in re or "\\w" in re or "\\d" in re:
             continue

@@ -23,6 +23,7 @@
 
 #include "fmx_device.h"
 #include "fmx_host.h"
+#include "fmx_nfa.h"
 #include "fmx_regex.h"
 
 namespace fmx {
@@ -33,20 +34,6 @@ struct Queue {           // SoA frontier queue in HBM; every element of a level 
   uint32_t *state;       // global CharNode id
   uint64_t *sp;
   uint64_t *ep;
-};
-
-constexpr uint32_t kInlineFollows = 4;
-struct StateRec {        // 32 bytes: everything a frontier element needs about its state, two 16-byte loads
-  uint32_t fol_off;      // first entry of its follows in `fol`
-  uint32_t fol_cnt;
-  uint32_t regex;
-  uint32_t c_emit;       // byte in bits 0..7, emit flag in bit 8
-  uint32_t f[kInlineFollows];   // the first follows, so that short lists need no further load
-};
-
-struct NfaTables {       // all regexes of the batch, concatenated; state ids are global
-  const StateRec *st;
-  const uint32_t *fol;
 };
 
 constexpr uint32_t kStageCap = 192;     // survivors a wave stages in LDS before reserving queue slots
@@ -419,26 +406,48 @@ struct RegexBatch {
   size_t rcap = 0;
   NfaTables nfa{};
   uint32_t *d_first_state = nullptr;
+  // reference-order mode (ReTree batches only): heap keys, per-regex firsts, the largest fan-out
+  uint32_t *d_st_num = nullptr, *d_first_off = nullptr;
+  uint32_t max_fanout = 1;
+  bool all_retree = true;
 };
 
 int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexBatch **out) {
-  std::vector<uint8_t> st_c, st_last;
-  std::vector<uint32_t> st_regex, fol_off, fol, q_state, start_final;
-  fol_off.push_back(0);
+  // sizes first, then one pass that fills pre-sized arrays (100 k regexes: 1.3 M states, 2 M follows)
+  size_t n_states = 0, n_fol = 0, n_first = 0;
+  bool all_retree = true;
   for (size_t r = 0; r < k; r++) {
     const Regex &re = *res[r];
-    const uint32_t base = (uint32_t)st_c.size();
+    n_states += re.st_c.size();
+    n_first += re.firsts.size();
+    all_retree = all_retree && re.engine == 0;
+    for (size_t s = 0; s < re.st_c.size(); s++)
+      if (!(re.last_stops && re.st_last[s])) n_fol += (size_t)(re.fol_off[s + 1] - re.fol_off[s]);
+  }
+  std::vector<StateRec> recs(n_states);
+  std::vector<uint32_t> fol(n_fol), q_state(n_first), st_num(n_states), first_off(k + 1, 0), start_final;
+  uint32_t max_fanout = 1;
+  size_t base = 0, fo = 0, qo = 0;
+  for (size_t r = 0; r < k; r++) {
+    const Regex &re = *res[r];
     for (size_t s = 0; s < re.st_c.size(); s++) {
-      st_c.push_back(re.st_c[s]);
-      st_last.push_back(re.st_last[s]);
-      st_regex.push_back((uint32_t)r);
+      StateRec &rec = recs[base + s];
+      rec.fol_off = (uint32_t)fo;
       // ReTree: `if (q.state.isLast) ret ::= ... else pqFront ++= follows` -- last states do not expand
       if (!(re.last_stops && re.st_last[s]))
-        for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol.push_back(base + (uint32_t)re.fol[j]);
-      fol_off.push_back((uint32_t)fol.size());
+        for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol[fo++] = (uint32_t)base + (uint32_t)re.fol[j];
+      rec.fol_cnt = (uint32_t)fo - rec.fol_off;
+      rec.regex = (uint32_t)r;
+      rec.c_emit = (uint32_t)re.st_c[s] | ((uint32_t)(re.st_last[s] ? 1 : 0) << 8);
+      for (uint32_t j = 0; j < kInlineFollows; j++) rec.f[j] = j < rec.fol_cnt ? fol[rec.fol_off + j] : 0u;
+      st_num[base + s] = (uint32_t)re.st_num[s];
+      max_fanout = std::max(max_fanout, rec.fol_cnt);
     }
-    for (int32_t f : re.firsts) q_state.push_back(base + (uint32_t)f);
+    for (int32_t f : re.firsts) q_state[qo++] = (uint32_t)base + (uint32_t)f;
+    first_off[r + 1] = (uint32_t)qo;
+    max_fanout = std::max<uint32_t>(max_fanout, (uint32_t)re.firsts.size());
     if (re.start_is_final) start_final.push_back((uint32_t)r);
+    base += re.st_c.size();
   }
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
   std::unique_ptr<RegexBatch> b(new RegexBatch());
@@ -447,15 +456,8 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   b->n_index = h->n;
   b->n_first = q_state.size();
   b->start_final = start_final;
-  std::vector<StateRec> recs(st_c.size());
-  for (size_t q = 0; q < recs.size(); q++) {
-    StateRec &r = recs[q];
-    r.fol_off = fol_off[q];
-    r.fol_cnt = fol_off[q + 1] - fol_off[q];
-    r.regex = st_regex[q];
-    r.c_emit = (uint32_t)st_c[q] | ((uint32_t)(st_last[q] ? 1 : 0) << 8);
-    for (uint32_t j = 0; j < kInlineFollows; j++) r.f[j] = j < r.fol_cnt ? fol[r.fol_off + j] : 0u;
-  }
+  b->max_fanout = max_fanout;
+  b->all_retree = all_retree;
   StateRec *d_st = nullptr;
   uint32_t *d_fol = nullptr;
   HIP_TRY(b->mem.alloc(&d_st, recs.size()), "hipMalloc");
@@ -464,6 +466,12 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   if (!recs.empty()) HIP_TRY(hipMemcpy(d_st, recs.data(), recs.size() * sizeof(StateRec), hipMemcpyHostToDevice), "H2D");
   if (!fol.empty()) HIP_TRY(hipMemcpy(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice), "H2D");
   if (!q_state.empty()) HIP_TRY(hipMemcpy(b->d_first_state, q_state.data(), q_state.size() * 4, hipMemcpyHostToDevice), "H2D");
+  if (all_retree) {
+    HIP_TRY(b->mem.alloc(&b->d_st_num, st_num.size()), "hipMalloc");
+    HIP_TRY(b->mem.alloc(&b->d_first_off, first_off.size()), "hipMalloc");
+    if (!st_num.empty()) HIP_TRY(hipMemcpy(b->d_st_num, st_num.data(), st_num.size() * 4, hipMemcpyHostToDevice), "H2D");
+    HIP_TRY(hipMemcpy(b->d_first_off, first_off.data(), first_off.size() * 4, hipMemcpyHostToDevice), "H2D");
+  }
   b->nfa = NfaTables{d_st, d_fol};
   *out = b.release();
   return FMX_OK;
@@ -855,27 +863,26 @@ int fmx_regex_batch_free(fmx_regex_batch *b) {
 int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *b, const fmx_limits *lim, fmx_result *out,
                           size_t cap, size_t *n_out, uint32_t *per_regex_count) {
   if (!idx || !b || !n_out || (cap && !out)) { set_error("null argument"); return FMX_ERR_ARG; }
-  if (lim && lim->mode != FMX_MATCH_FRONTIER) { set_error("resident batches serve the frontier mode only"); return FMX_ERR_ARG; }
-  return regex_batch_match(reinterpret_cast<const Index *>(idx), reinterpret_cast<RegexBatch *>(b), lim, out, cap, n_out,
-                           per_regex_count);
+  const Index *h = reinterpret_cast<const Index *>(idx);
+  RegexBatch *rb = reinterpret_cast<RegexBatch *>(b);
+  if (lim && lim->mode == FMX_MATCH_REFERENCE) {
+    if (lim->max_branching == 0) { set_error("max_branching must be positive"); return FMX_ERR_ARG; }
+    if (!rb->all_retree) {
+      set_error("the reference-order mode replays ReTree._matchSA; Thompson and DFA handles use the frontier mode");
+      return FMX_ERR_UNSUPPORTED;
+    }
+    if (rb->device != h->device || rb->n_index != h->n) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
+    const RefTables rt{rb->nfa.st, rb->nfa.fol, rb->d_st_num, rb->d_first_off, rb->d_first_state};
+    return regex_match_reference(h, rt, rb->k, rb->max_fanout, lim->max_branching, lim->max_iterations, out, cap, n_out,
+                                 per_regex_count, nullptr);
+  }
+  if (lim && lim->mode != FMX_MATCH_FRONTIER) { set_error("unknown fmx_limits.mode"); return FMX_ERR_ARG; }
+  return regex_batch_match(h, rb, lim, out, cap, n_out, per_regex_count);
 }
 
 int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,
                           fmx_result *out, size_t cap, size_t *n_out, uint32_t *per_regex_count) {
   if (!n_out) { set_error("null argument"); return FMX_ERR_ARG; }
-  if (lim && lim->mode == FMX_MATCH_REFERENCE) {
-    if (!idx || (k && !res) || (cap && !out)) { set_error("null argument"); return FMX_ERR_ARG; }
-    for (size_t r = 0; r < k; r++)
-      if (!res[r]) { set_error("null regex handle"); return FMX_ERR_ARG; }
-    if (lim->max_branching == 0) { set_error("max_branching must be positive"); return FMX_ERR_ARG; }
-    for (size_t r = 0; r < k; r++)
-      if (reinterpret_cast<const Regex *>(res[r])->engine != 0) {
-        set_error("the reference-order mode replays ReTree._matchSA; Thompson and DFA handles use the frontier mode");
-        return FMX_ERR_UNSUPPORTED;
-      }
-    return regex_match_reference(reinterpret_cast<const Index *>(idx), reinterpret_cast<const Regex *const *>(res), k,
-                                 lim->max_branching, lim->max_iterations, out, cap, n_out, per_regex_count, nullptr);
-  }
   fmx_regex_batch *b = nullptr;
   int rc = fmx_regex_batch_create(idx, res, k, &b);
   if (rc != FMX_OK) return rc;

@@ -86,11 +86,11 @@ hipError_t launch_next_substr(const Index *h, const void *d_sps, uint64_t k, uin
                               void *d_out_len, hipStream_t st);
 
 // fmx_refmatch.hip
-struct Regex;
+struct RefTables;
 }  // namespace fmx
 struct fmx_result;
 namespace fmx {
-int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uint32_t max_branching,
+int regex_match_reference(const Index *h, const RefTables &rt, size_t k, uint32_t max_fanout, uint32_t max_branching,
                           uint32_t max_iterations, fmx_result *out, size_t cap, size_t *n_out,
                           uint32_t *per_regex_count, uint32_t *front_left);
 

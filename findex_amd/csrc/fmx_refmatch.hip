@@ -17,12 +17,15 @@
 #include <fmx.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "fmx_device.h"
 #include "fmx_host.h"
-#include "fmx_regex.h"
+#include "fmx_nfa.h"
 
 namespace fmx {
 
@@ -34,16 +37,6 @@ struct HeapElem {          // 32 bytes
   uint32_t len;
   uint32_t pad;
   uint64_t sp, ep;
-};
-
-struct RefTables {
-  const uint8_t *st_c;
-  const uint8_t *st_last;
-  const int32_t *st_num;
-  const uint32_t *fol_off;
-  const uint32_t *fol;
-  const uint32_t *first_off;   // k + 1: firsts of regex r are first[first_off[r] .. first_off[r+1])
-  const uint32_t *first;
 };
 
 struct RefResult {
@@ -121,7 +114,7 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
     if (t == 0) {
       for (uint32_t f = rt.first_off[r]; f < rt.first_off[r + 1]; f++) {     // pqFront ++= inputStates, :624
         HeapElem e;
-        e.state = rt.first[f]; e.num = (uint32_t)rt.st_num[e.state]; e.len = 0; e.pad = 0; e.sp = 0; e.ep = ix.n;
+        e.state = rt.first[f]; e.num = rt.st_num[e.state]; e.len = 0; e.pad = 0; e.sp = 0; e.ep = ix.n;
         if (size0 + 1 > heap_cap) { bad = true; break; }
         heap_push(heap, size0, e);
       }
@@ -141,13 +134,14 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
       uint64_t sp = ((uint64_t)__shfl(sphi, leader, 64) << 32) | __shfl(splo, leader, 64);
       uint64_t ep = ((uint64_t)__shfl(ephi, leader, 64) << 32) | __shfl(eplo, leader, 64);
       // sa.getPrevRange(q.sp, q.ep, q.state.c), :633
-      const uint32_t c = rt.st_c[state];
+      const StateRec rec = rt.st[state];
+      const uint32_t c = rec.c_emit & 0xFFu;
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
       backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
       stepped++;
       if (t == 0 && sp < ep) {
-        if (rt.st_last[state]) {                                   // :636-638
+        if (rec.c_emit >> 8) {                                     // isLast, :636-638
           const unsigned long long at = atomicAdd(&ctl->res_count, 1ull);
           if (at < res_cap) {
             RefResult o;
@@ -158,9 +152,9 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
           }
           nres++;
         } else {                                                   // :641
-          for (uint32_t f = rt.fol_off[state]; f < rt.fol_off[state + 1]; f++) {
+          for (uint32_t f = rec.fol_off; f < rec.fol_off + rec.fol_cnt; f++) {
             HeapElem e;
-            e.state = rt.fol[f]; e.num = (uint32_t)rt.st_num[e.state]; e.len = len + 1; e.pad = 0; e.sp = sp; e.ep = ep;
+            e.state = rt.fol[f]; e.num = rt.st_num[e.state]; e.len = len + 1; e.pad = 0; e.sp = sp; e.ep = ep;
             if (size0 + 1 > heap_cap) { bad = true; atomicOr(&ctl->overflow, 1ull); break; }
             heap_push(heap, size0, e);
           }
@@ -180,30 +174,9 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
   } while (0)
 
 
-int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uint32_t max_branching,
+int regex_match_reference(const Index *h, const RefTables &rt, size_t k, uint32_t max_fanout, uint32_t max_branching,
                           uint32_t max_iterations, fmx_result *out, size_t cap, size_t *n_out,
                           uint32_t *per_regex_count, uint32_t *front_left) {
-  std::vector<uint8_t> st_c, st_last;
-  std::vector<int32_t> st_num;
-  std::vector<uint32_t> fol_off, fol, first_off, first;
-  fol_off.push_back(0);
-  first_off.push_back(0);
-  uint32_t max_fanout = 1;
-  for (size_t r = 0; r < k; r++) {
-    const Regex &re = *res[r];
-    const uint32_t base = (uint32_t)st_c.size();
-    for (size_t s = 0; s < re.st_c.size(); s++) {
-      st_c.push_back(re.st_c[s]);
-      st_last.push_back(re.st_last[s]);
-      st_num.push_back(re.st_num[s]);
-      for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol.push_back(base + (uint32_t)re.fol[j]);
-      fol_off.push_back((uint32_t)fol.size());
-      max_fanout = std::max<uint32_t>(max_fanout, (uint32_t)(re.fol_off[s + 1] - re.fol_off[s]));
-    }
-    for (int32_t f : re.firsts) first.push_back(base + (uint32_t)f);
-    first_off.push_back((uint32_t)first.size());
-    max_fanout = std::max<uint32_t>(max_fanout, (uint32_t)re.firsts.size());
-  }
   if (per_regex_count) std::fill(per_regex_count, per_regex_count + k, 0u);
   *n_out = 0;
   if (!k) return FMX_OK;
@@ -219,34 +192,19 @@ int regex_match_reference(const Index *h, const Regex *const *res, size_t k, uin
   const uint64_t arena_groups = std::max<uint64_t>(64, (4ull << 30) / ((uint64_t)heap_cap * sizeof(HeapElem)));
   gcap = std::min<uint64_t>(gcap, std::max<uint64_t>(1, arena_groups / per_wg));
   const int grid = (int)std::min(want, gcap);
-  // One device arena from the handle's call context, one upload: [tables | ctl | heaps | results | front_left]
+  // One device arena from the handle's call context: [ctl | heaps | results | front_left]; the tables are
+  // the resident batch's.
   CtxLease lease(h);
   if (!lease.c) return FMX_ERR_HIP;
   hipStream_t st = lease.c->stream;
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t o_c = 0, o_last = o_c + up(st_c.size()), o_num = o_last + up(st_last.size()),
-               o_foff = o_num + up(st_num.size() * 4), o_fol = o_foff + up(fol_off.size() * 4),
-               o_fo = o_fol + up(fol.size() * 4), o_f = o_fo + up(first_off.size() * 4),
-               o_ctl = o_f + up(first.size() * 4), tables_end = o_ctl + up(sizeof(RefCtl));
   const size_t groups = (size_t)grid * per_wg;
-  const size_t o_heaps = tables_end, o_res = o_heaps + up(groups * heap_cap * sizeof(HeapElem)),
+  const size_t o_ctl = 0, o_heaps = up(sizeof(RefCtl)), o_res = o_heaps + up(groups * heap_cap * sizeof(HeapElem)),
                o_left = o_res + up((cap ? cap : 1) * sizeof(RefResult)), total = o_left + up(k * 4);
   void *arena_v = nullptr;
   HIP_TRY(ctx_scratch(lease.c, 0, total, &arena_v), "hipMalloc(reference-order arena)");
   uint8_t *arena = static_cast<uint8_t *>(arena_v);
-  std::vector<uint8_t> host(tables_end, 0);
-  auto put = [&](size_t off, const void *src, size_t bytes) { if (bytes) std::memcpy(host.data() + off, src, bytes); };
-  put(o_c, st_c.data(), st_c.size());
-  put(o_last, st_last.data(), st_last.size());
-  put(o_num, st_num.data(), st_num.size() * 4);
-  put(o_foff, fol_off.data(), fol_off.size() * 4);
-  put(o_fol, fol.data(), fol.size() * 4);
-  put(o_fo, first_off.data(), first_off.size() * 4);
-  put(o_f, first.data(), first.size() * 4);            // RefCtl behind it stays zero
-  HIP_TRY(hipMemcpyAsync(arena, host.data(), tables_end, hipMemcpyHostToDevice, st), "H2D(tables)");
-  const RefTables rt{arena + o_c, arena + o_last, reinterpret_cast<const int32_t *>(arena + o_num),
-                     reinterpret_cast<const uint32_t *>(arena + o_foff), reinterpret_cast<const uint32_t *>(arena + o_fol),
-                     reinterpret_cast<const uint32_t *>(arena + o_fo), reinterpret_cast<const uint32_t *>(arena + o_f)};
+  HIP_TRY(hipMemsetAsync(arena + o_ctl, 0, sizeof(RefCtl), st), "memset(ctl)");
   HeapElem *d_heaps = reinterpret_cast<HeapElem *>(arena + o_heaps);
   RefResult *d_res = reinterpret_cast<RefResult *>(arena + o_res);
   RefCtl *d_ctl = reinterpret_cast<RefCtl *>(arena + o_ctl);

@@ -256,9 +256,12 @@ class RegexBatch:
         except Exception:
             pass
 
-    def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22):
-        """-> (results as a structured array sorted by (regex, len, sp, ep), per-regex counts)"""
-        lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_FRONTIER, int(max_frontier), 0, 0)
+    def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22, mode="frontier", maxBranching=1024, maxIterations=1000):
+        """-> (results as a structured array, per-regex counts).  mode="frontier": every match, sorted by
+        (regex, len, sp, ep); mode="reference": ReTree._matchSA's own queue and limits, per regex in the
+        reference's list order."""
+        lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_REFERENCE if mode == "reference" else _lib.FMX_MATCH_FRONTIER,
+                              int(max_frontier), int(maxBranching), int(maxIterations))
         out = np.empty(cap, dtype=RESULT_DTYPE)
         per = np.zeros(max(self.k, 1), dtype=np.uint32)
         n_out = ctypes.c_size_t()

@@ -78,3 +78,13 @@ for j in rng.integers(0, out.size, 200):
     assert len(s) == r["len"]
     assert pyre.fullmatch(res[r["regex"]].encode(), s, pyre.S), (res[r["regex"]], s)
 print("properties ok on 200 sampled results")
+
+# the reference-order mode on the same resident batch (ReTree.matchSA's own queue and default limits
+# 1024 / 1000, one regex per lane group): what a caller who keeps the reference's defaults pays
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter()
+    outr, perr = batch.match_raw(mode="reference", maxBranching=1024, maxIterations=1000)
+    best = min(best, time.perf_counter() - t0)
+print("reference-order mode (maxBranching 1024, maxIterations 1000): %d results, kernel %.3f ms, call %.3f ms -> %.2f M regexes/s"
+      % (outr.size, sa.stats()["last_kernel_ms"], best * 1e3, k / best / 1e6))

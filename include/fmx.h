@@ -222,7 +222,8 @@ int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k,
                           fmx_result *out, size_t cap, size_t *n_out, uint32_t *per_regex_count);
 
 /* The same in two stages for serving: make a batch of compiled regexes resident on idx's device
- * once (concatenated tables + the level-0 frontier), then match it any number of times. */
+ * once (concatenated tables + the level-0 frontier), then match it any number of times, in either mode
+ * (FMX_MATCH_REFERENCE needs a batch of fmx_regex_compile handles only).  One match at a time per batch. */
 int fmx_regex_batch_create(const fmx_index *idx, fmx_regex *const *res, size_t k, fmx_regex_batch **out);
 int fmx_regex_batch_free(fmx_regex_batch *batch);
 int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *batch, const fmx_limits *lim, fmx_result *out,

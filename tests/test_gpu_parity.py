@@ -354,7 +354,8 @@ def test_regex_duplicate_follows_give_duplicate_results():
 
 
 REF_REGEXES = ["th(e|a)", "q[a-z]*k", "co(m|n)+e", "a.*(b|c)d.*f", "s[aeiou]+t", "a[b-d]*e", "e.*", "(a|b|d|c)", "ab?j",
-               "in.*g", "z(a|e)*b", "x?yz"]
+               "in.*g", "z(a|e)*b", "x?yz",
+               "a.*(b|c)da.*f"]        # the regex the reference's WordsDB suite runs on words (T/REParser.scala:630)
 
 
 @pytest.mark.parametrize("name,be", [("test.cmp", False), ("words", True)])
@@ -369,6 +370,13 @@ def test_regex_reference_order_and_limits(testdata, name, be):
         for re, g in zip(REF_REGEXES, got):
             want, left, pops = orc.match_tables(R.ReTree(R.re2post(re, True)).tables(), mb, mi)
             assert [r.key() for r in g] == want, (re, mb, mi)
+    # the same through a resident batch (fmx_regex_batch_match in reference mode): one flat, per-regex-ordered list
+    batch = findex_amd.ReTree.prepare_batch(hip, trees)
+    flat, per = batch.match_raw(mode="reference", maxBranching=1024, maxIterations=1000)
+    got = findex_amd.ReTree.matchSA_batch(hip, trees, mode="reference", maxBranching=1024, maxIterations=1000)
+    assert per.tolist() == [len(g) for g in got]
+    assert [(int(r["regex"]), int(r["len"]), int(r["sp"]), int(r["ep"])) for r in flat] == [
+        (j, *r.key()) for j, g in enumerate(got) for r in g]
     # the Scala-signature entry point
     one = trees[3].matchSA(hip)
     want, _, _ = orc.match_tables(R.ReTree(R.re2post(REF_REGEXES[3], True)).tables(), 1024, 1000)

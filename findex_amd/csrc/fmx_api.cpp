@@ -164,7 +164,9 @@ static uint64_t rd_u64(const uint8_t *p, bool be) {
 }
 
 // BWTLoader, bwtmerger.scala:144-174: int64 size, int64 eof, then `size` bytes; size+16 == file length.
-static int load_bwt(const char *path, bool be, std::vector<uint8_t> &bwt, uint64_t &n, uint64_t &eof) {
+// Checks the header and leaves the file positioned at the payload; the payload is then streamed to the
+// device in chunks (stream_file_to_device) -- a 16 GiB .bwt never sits in host memory whole.
+static int open_bwt_file(const char *path, bool be, FILE **out, uint64_t &n, uint64_t &eof) {
   FILE *f = std::fopen(path, "rb");
   if (!f) { g_err = std::string("File ") + path + " does not exists"; return FMX_ERR_IO; }
   std::unique_ptr<FILE, int (*)(FILE *)> guard(f, std::fclose);
@@ -179,8 +181,37 @@ static int load_bwt(const char *path, bool be, std::vector<uint8_t> &bwt, uint64
     return FMX_ERR_FORMAT;
   }
   if (fseeko(f, 16, SEEK_SET) != 0) { g_err = "seek failed"; return FMX_ERR_IO; }
-  try { bwt.resize(n); } catch (...) { g_err = "out of host memory"; return FMX_ERR_NOMEM; }
-  if (n && std::fread(bwt.data(), 1, n, f) != n) { g_err = std::string("short read on ") + path; return FMX_ERR_IO; }
+  *out = guard.release();
+  return FMX_OK;
+}
+
+// n bytes from the file's current position to device memory through two pinned staging buffers: the read of
+// chunk i+1 overlaps the DMA of chunk i.
+static int stream_file_to_device(FILE *f, void *dst, uint64_t n, hipStream_t st) {
+  constexpr size_t kChunk = 32u << 20;
+  struct Pin {
+    void *p[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    ~Pin() {
+      for (int i = 0; i < 2; i++) { if (p[i]) (void)hipHostFree(p[i]); if (ev[i]) (void)hipEventDestroy(ev[i]); }
+    }
+  } pin;
+  const size_t chunk = (size_t)std::min<uint64_t>(kChunk, n ? n : 1);
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(hipHostMalloc(&pin.p[i], chunk, hipHostMallocDefault), "hipHostMalloc(staging)");
+    HIP_TRY(hipEventCreateWithFlags(&pin.ev[i], hipEventDisableTiming), "hipEventCreate");
+  }
+  bool used[2] = {false, false};
+  int slot = 0;
+  for (uint64_t o = 0; o < n; o += chunk, slot ^= 1) {
+    const size_t len = (size_t)std::min<uint64_t>(chunk, n - o);
+    if (used[slot]) HIP_TRY(hipEventSynchronize(pin.ev[slot]), "hipEventSynchronize");     // its last DMA is done
+    if (std::fread(pin.p[slot], 1, len, f) != len) { g_err = "short read on the .bwt payload"; return FMX_ERR_IO; }
+    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(dst) + o, pin.p[slot], len, hipMemcpyHostToDevice, st), "H2D(bwt)");
+    HIP_TRY(hipEventRecord(pin.ev[slot], st), "hipEventRecord");
+    used[slot] = true;
+  }
+  HIP_TRY(hipStreamSynchronize(st), "hipStreamSynchronize");     // the staging buffers are freed on return
   return FMX_OK;
 }
 
@@ -212,11 +243,11 @@ static void destroy(Index *h) {
 }
 
 // Common tail of the three open flavours: `src` is host or device memory holding n BWT bytes.
-static int open_common(const void *src, bool src_on_device, uint64_t n, uint64_t eof, const int64_t *counts,
-                       int device, hipStream_t user_stream, fmx_index **out) {
+static int open_common(const void *src, bool src_on_device, FILE *src_file, uint64_t n, uint64_t eof,
+                       const int64_t *counts, int device, hipStream_t user_stream, fmx_index **out) {
   if (!out) return arg_fail("out is null");
   *out = nullptr;
-  if (!src && n) return arg_fail("bwt is null");
+  if (!src && !src_file && n) return arg_fail("bwt is null");
   if (n < 1 || eof >= n) return arg_fail("need n >= 1 and eof < n");
   if (n >= (1ull << 38)) { g_err = "n >= 2^38 is not supported"; return FMX_ERR_UNSUPPORTED; }
   int ndev = 0;
@@ -245,8 +276,12 @@ static int open_common(const void *src, bool src_on_device, uint64_t n, uint64_t
     const uint64_t padded = (n / kByteBlock + 2) * kByteBlock;
     if ((e = hipMalloc(&h->d_bwt, padded)) != hipSuccess) { rc = hip_fail(e, "hipMalloc(bwt)"); break; }
     if ((e = hipMemsetAsync((uint8_t *)h->d_bwt + n, 0, padded - n, st)) != hipSuccess) { rc = hip_fail(e, "memset"); break; }
-    e = hipMemcpyAsync(h->d_bwt, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) { rc = hip_fail(e, "copy bwt"); break; }
+    if (src_file) {
+      if ((rc = stream_file_to_device(src_file, h->d_bwt, n, st)) != FMX_OK) break;
+    } else {
+      e = hipMemcpyAsync(h->d_bwt, src, n, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) { rc = hip_fail(e, "copy bwt"); break; }
+    }
     if ((e = hipMemsetAsync((uint8_t *)h->d_bwt + eof, 0, 1, st)) != hipSuccess) { rc = hip_fail(e, "memset"); break; }
     const int pref = layout_preference();
     h->layout = pref == (int)kLayoutBytes ? kLayoutBytes : kLayoutOneHot;
@@ -365,25 +400,26 @@ int fmx_device_count(int *count) {
 
 int fmx_open(const char *bwt_path, const char *aux_path, int big_endian, int device, fmx_index **out) {
   if (!bwt_path || !aux_path) return arg_fail("path is null");
-  std::vector<uint8_t> bwt;
   uint64_t n = 0, eof = 0;
   int64_t counts[256];
-  int rc = load_bwt(bwt_path, big_endian != 0, bwt, n, eof);
+  FILE *f = nullptr;
+  int rc = open_bwt_file(bwt_path, big_endian != 0, &f, n, eof);
   if (rc != FMX_OK) return rc;
+  std::unique_ptr<FILE, int (*)(FILE *)> guard(f, std::fclose);
   rc = load_aux(aux_path, big_endian != 0, counts);
   if (rc != FMX_OK) return rc;
-  return open_common(bwt.data(), false, n, eof, counts, device, nullptr, out);
+  return open_common(nullptr, false, f, n, eof, counts, device, nullptr, out);
 }
 
 int fmx_open_mem(const uint8_t *bwt, uint64_t n, uint64_t eof, const int64_t counts[256], int device,
                  fmx_index **out) {
   if (!counts) return arg_fail("counts is null");
-  return open_common(bwt, false, n, eof, counts, device, nullptr, out);
+  return open_common(bwt, false, nullptr, n, eof, counts, device, nullptr, out);
 }
 
 int fmx_open_dev(const void *d_bwt, uint64_t n, uint64_t eof, const int64_t *counts_or_null, int device, void *stream,
                  fmx_index **out) {
-  return open_common(d_bwt, true, n, eof, counts_or_null, device, (hipStream_t)stream, out);
+  return open_common(d_bwt, true, nullptr, n, eof, counts_or_null, device, (hipStream_t)stream, out);
 }
 
 int fmx_close(fmx_index *idx) {

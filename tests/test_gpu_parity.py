@@ -162,6 +162,32 @@ def test_fm_file_is_byte_identical(testdata, name, be, tmp_path):
     assert raw[0] == 4 and raw.size == 9 + 4 * hip.n
 
 
+def test_open_streams_large_files(tmp_path):
+    """fmx_open streams the .bwt payload to the device in 32 MiB chunks through two pinned buffers; a 75 MB file
+    (3 chunks, the last one partial) must give the same index as the same bytes handed over in memory."""
+    n = 75_000_003
+    bwt, eof, counts = synth_bwt(n, 1, 4, 21)
+    base = tmp_path / "big"
+    with open(str(base) + ".bwt", "wb") as f:
+        f.write(np.array([n, eof], dtype="<i8").tobytes())
+        f.write(bwt.tobytes())
+    with open(str(base) + ".aux", "wb") as f:
+        f.write(counts.astype("<i8").tobytes())
+    a = findex_amd.HipFMSearcher(str(base) + ".bwt", bigEndian=False)
+    b = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    assert a.n == b.n == n and a.eof == b.eof == eof
+    assert [a.cf(c) for c in range(256)] == [b.cf(c) for c in range(256)]
+    rng = np.random.default_rng(3)
+    c = rng.integers(0, 6, size=200_000).astype(np.uint8)
+    i = rng.integers(-1, n + 1, size=200_000, dtype=np.int64)
+    i[:6] = [0, (32 << 20) - 1, 32 << 20, (64 << 20) - 1, 64 << 20, n - 1]        # chunk seams
+    assert np.array_equal(a.occ_batch(c, i), b.occ_batch(c, i))
+    # brute force at the seams
+    for q in range(6):
+        assert int(a.occ_batch(c[q:q + 1], i[q:q + 1])[0]) == int(
+            (np.where(np.arange(int(i[q]) + 1) == eof, 0, bwt[: int(i[q]) + 1]) == c[q]).sum())
+
+
 # ---------------------------------------------------------------- synthetic indexes
 @pytest.mark.parametrize("n,lo,hi,seed", [
     (1, 1, 1, 1), (2, 1, 2, 2), (447, 1, 4, 3), (448, 1, 4, 4), (449, 1, 4, 5), (896, 1, 4, 6), (897, 65, 68, 7),

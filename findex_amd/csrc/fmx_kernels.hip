@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint
 }
 
 // ---------------------------------------------------------------- K3: literal backward search
-// SuffixAlgo.search (findex.scala:15-31): one pattern per octet, octets walk the batch with a
+// SuffixAlgo.search (findex.scala:15-31): one pattern per lane group, groups walk the batch with a
 // grid stride and pick up their next pattern as soon as the current one ends (last byte consumed
 // or interval empty), so early exits do not idle lanes.  The next pattern's offsets and the next
 // pattern byte are requested a step early; only the two rank lines are on the dependent chain.
@@ -142,13 +142,13 @@ __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t 
   constexpr int G = Lay<LAYOUT>::G;
   const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
+  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);      // lane groups in the grid
   uint64_t p = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   bool active = p < k;
   uint64_t base = 0, sp = 0, ep = ix.n;
   int64_t i = -1;          // index of the byte to consume next
   uint32_t c = 0;
-  uint64_t nb = 0, ne = 0; // offsets of the pattern this octet takes next
+  uint64_t nb = 0, ne = 0; // offsets of the pattern this group takes next
   uint32_t steps = 0;
   if (active) {
     base = off[p];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void k_lf_walk(DevIndex ix, const uint64_
   constexpr int G = Lay<LAYOUT>::G;
   const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t;
-  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
+  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);      // lane groups in the grid
   uint32_t done = 0;
   // two walks per group, stepped together: their (dependent) chains overlap
   for (uint64_t q = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G; q < k; q += 2 * noct) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void k_fm_fill(DevIndex ix, uint64_t p0, 
   stage_tables(ix, tb);
   constexpr int G = Lay<LAYOUT>::G;
   const LaneConst lc = lane_const<G>();
-  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);
+  const uint64_t noct = (uint64_t)gridDim.x * (kThreads / G);      // lane groups in the grid
   for (uint64_t p = p0 + (((uint64_t)blockIdx.x * kThreads + threadIdx.x) / G); p < p1; p += 2 * noct) {
     const uint64_t pb = p + noct;
     const bool two = pb < p1;

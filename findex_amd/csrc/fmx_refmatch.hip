@@ -17,9 +17,6 @@
 #include <fmx.h>
 
 #include <algorithm>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -104,11 +101,11 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
   const uint32_t t = lc.t;
   const uint32_t lane = __lane_id();
   const uint32_t leader = lane & ~(uint32_t)(G - 1);
-  const uint32_t octet = (blockIdx.x * kRThreads + threadIdx.x) / G;
+  const uint32_t group = (blockIdx.x * kRThreads + threadIdx.x) / G;
   const uint32_t noct = gridDim.x * (kRThreads / G);
-  HeapElem *heap = heaps + (size_t)octet * heap_cap;
+  HeapElem *heap = heaps + (size_t)group * heap_cap;
   uint32_t stepped = 0;
-  for (uint32_t r = octet; r < k_regex; r += noct) {
+  for (uint32_t r = group; r < k_regex; r += noct) {
     uint32_t size0 = 1, nres = 0, it = 1;
     bool bad = false;
     if (t == 0) {

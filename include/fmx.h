@@ -103,7 +103,9 @@ int fmx_occ_batch_dev(const fmx_index *idx, const void *d_c, const void *d_i, vo
 /* ---- batched literal backward search: SuffixAlgo.search, findex.scala:15-31.
  * Pattern q is pat[off[q] .. off[q+1]) (off has k+1 entries), matched last byte first from (0, n);
  * sp[q], ep[q] receive the loop's final values: a hit iff sp < ep, a miss has sp == ep.
- * An empty pattern yields (0, n). */
+ * An empty pattern yields (0, n).  The host form validates the offsets (non-decreasing); the device form
+ * cannot look at them: d_off must hold k+1 non-decreasing offsets into the d_pat buffer, or the kernel reads
+ * outside it. */
 int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
                      size_t k);
 int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep,

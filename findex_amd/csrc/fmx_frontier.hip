@@ -628,8 +628,10 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   uint32_t level = 0;
   uint64_t launches = 1;
   bool alive = true, truncated = false;
+  // a small batch (a single regex, say) starts in the tail kernel: no grid levels, no look
+  bool grid_first = !(use_tail && b->n_first <= kTailMax / 2 && max_steps > 0);
   while (alive) {
-    for (uint32_t j = 0; j < kChain && level < max_steps; j++, level++) {
+    for (uint32_t j = 0; grid_first && j < kChain && level < max_steps; j++, level++) {
       const Queue &cur = (level & 1) ? qb : qa;
       const Queue &nxt = (level & 1) ? qa : qb;
 #define CALL(W, L) k_frontier<W, L><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters)
@@ -638,18 +640,22 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       HIP_TRY(hipGetLastError(), "k_frontier");
       launches++;
     }
-    HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
-    HIP_TRY(hipStreamSynchronize(st), "sync(levels)");
-    if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
-    uint64_t next_total = 0;
-    n_res = 0;
-    for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
-    alive = next_total != 0;
-    // a nearly empty frontier is launch-bound: a small grid (still >= one wave per slice) starts and ends faster
-    grid = next_total <= 4096 ? (int)kSub : grid_full;
-    if (getenv("FMX_TRACE"))
-      fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
-              (unsigned long long)next_total, (unsigned long long)n_res, ctl.overflow);
+    uint64_t next_total = b->n_first;
+    if (grid_first) {
+      HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
+      HIP_TRY(hipStreamSynchronize(st), "sync(levels)");
+      if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
+      next_total = 0;
+      n_res = 0;
+      for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
+      alive = next_total != 0;
+      // a nearly empty frontier is launch-bound: a small grid (still >= one wave per slice) starts and ends faster
+      grid = next_total <= 4096 ? (int)kSub : grid_full;
+      if (getenv("FMX_TRACE"))
+        fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
+                (unsigned long long)next_total, (unsigned long long)n_res, ctl.overflow);
+    }
+    grid_first = true;
     if (alive && level < max_steps && next_total <= kTailMax / 2 && use_tail) {
       // nearly empty frontier: one persistent workgroup runs the following levels without launches in between
       TailState tsh{};

@@ -636,6 +636,16 @@ int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *ou
   return FMX_OK;
 }
 
+int fmx_extract(const fmx_index *idx, uint64_t row, uint32_t len, int direction, uint8_t *out, uint32_t *out_len) {
+  if (!out_len) return arg_fail("null argument");
+  if (direction == 0) return arg_fail("direction must be positive (nextSubstr) or negative (prevSubstr)");
+  if (direction > 0) return fmx_next_substr(idx, row, len, out, out_len);
+  *out_len = 0;
+  int rc = fmx_prev_substr(idx, row, len, out);
+  if (rc == FMX_OK) *out_len = len;
+  return rc;
+}
+
 // ---------------------------------------------------------------- .fm writer (FMCreator.create)
 // Wire format, bwtmerger.scala:483-485,476-481: byte elSize (=4), int64 big-endian size, then
 // `size` big-endian int32 entries.  elSize 8 is `???` in the reference (:465-469), so n must stay

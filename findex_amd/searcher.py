@@ -143,6 +143,13 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_prev_substr(self._h, int(sp), int(length), _ptr(out)))
         return bytes(out[: int(length)])
 
+    def extract(self, row, length, direction=1):
+        """fmx_extract: direction > 0 = nextSubstr, < 0 = prevSubstr."""
+        out = np.zeros(max(int(length), 1), dtype=np.uint8)
+        w = ctypes.c_uint32()
+        _lib.check(self._L.fmx_extract(self._h, int(row), int(length), int(direction), _ptr(out), ctypes.byref(w)))
+        return bytes(out[: w.value])
+
     def write_fm(self, path):
         """FMCreator.create (bwtmerger.scala:452-532): write the reference's .fm file."""
         _lib.check(self._L.fmx_write_fm(self._h, str(path).encode()))

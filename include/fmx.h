@@ -141,6 +141,10 @@ int fmx_lf_walk_batch_dev(const fmx_index *idx, const void *d_rows, size_t k, ui
 int fmx_psi_batch(const fmx_index *idx, const uint64_t *rows, uint64_t *out, size_t k);
 int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out, uint32_t *out_len);
 int fmx_prev_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out);
+/* Both directions behind one entry point (the name SURVEY.md 8b lists): direction > 0 = nextSubstr (the text
+ * that starts at row's suffix, what SAResult.toString prints, re2.scala:11-15), direction < 0 = prevSubstr
+ * (len bytes, *out_len = len).  out needs len bytes. */
+int fmx_extract(const fmx_index *idx, uint64_t row, uint32_t len, int direction, uint8_t *out, uint32_t *out_len);
 
 /* ---- FMCreator.create, bwtmerger.scala:424-533: writes the reference's .fm file (inverted position
  * lists, 4-byte big-endian entries) from the device structure, so that findex's own NaiveFMSearcher

@@ -127,6 +127,16 @@ def test_reference_kats_through_the_product(testdata):
     assert [hip.getPrevI(i) for i in (3, 9, 10, 4, 5, 0)] == [9, 10, 4, 5, 0, 1]
 
 
+def test_extract_is_next_and_prev_substr(testdata):
+    hip, orc = pair_from_files(testdata, "test1024.cmp", False)
+    for row in (0, 1, 48, 462, 517, hip.n - 1):
+        for ln in (0, 1, 7, 40):
+            assert hip.extract(row, ln, +1) == hip.nextSubstr(row, ln)
+            assert hip.extract(row, ln, -1) == hip.prevSubstr(row, ln)
+    with pytest.raises(findex_amd.FmxError):
+        hip.extract(0, 3, 0)
+
+
 @pytest.mark.parametrize("name,be", [("test1024.cmp", False), ("test.cmp", False), ("words", True)])
 def test_walks_all_rows(testdata, name, be):
     """Psi == the reference's .fm payload and LF == getPrevI, for every row (a sample on words)."""

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fmx_host.h"
@@ -526,6 +527,44 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
   return run_io(h, ins, 2, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
     return launch_search(h, di[0], di[1], dout[0], dout[1], k, st);
   });
+}
+
+int fmx_search_batch_multi(fmx_index *const *idxs, size_t n_idx, const uint8_t *pat, const uint64_t *off,
+                           uint64_t *sp, uint64_t *ep, size_t k) {
+  if (!idxs || !n_idx || (k && (!off || !sp || !ep))) return arg_fail("null argument");
+  for (size_t r = 0; r < n_idx; r++) {
+    if (!idxs[r]) return arg_fail("null index handle");
+    if (H(idxs[r])->n != H(idxs[0])->n || H(idxs[r])->eof != H(idxs[0])->eof) return arg_fail("the handles are not replicas of one index");
+  }
+  if (!k) return FMX_OK;
+  for (size_t q = 0; q < k; q++)
+    if (off[q + 1] < off[q]) return arg_fail("pattern offsets must be non-decreasing");
+  // contiguous slices balanced by pattern bytes (by count when every pattern is empty)
+  std::vector<size_t> cut(n_idx + 1, k);
+  cut[0] = 0;
+  const uint64_t total = off[k] - off[0];
+  for (size_t r = 1; r < n_idx; r++) {
+    if (!total) { cut[r] = k * r / n_idx; continue; }
+    const uint64_t want = off[0] + total / n_idx * r;
+    cut[r] = (size_t)(std::lower_bound(off, off + k + 1, want) - off);
+    if (cut[r] < cut[r - 1]) cut[r] = cut[r - 1];
+    if (cut[r] > k) cut[r] = k;
+  }
+  std::vector<int> rc(n_idx, FMX_OK);
+  std::vector<std::string> msg(n_idx);
+  std::vector<std::thread> th;
+  for (size_t r = 0; r < n_idx; r++) {
+    const size_t a = cut[r], b = cut[r + 1];
+    if (a == b) continue;
+    th.emplace_back([&, r, a, b]() {
+      rc[r] = fmx_search_batch(idxs[r], pat, off + a, sp + a, ep + a, b - a);
+      if (rc[r] != FMX_OK) msg[r] = fmx_last_error();        // the message is thread-local: carry it over
+    });
+  }
+  for (std::thread &t : th) t.join();
+  for (size_t r = 0; r < n_idx; r++)
+    if (rc[r] != FMX_OK) { g_err = msg[r]; return rc[r]; }
+  return FMX_OK;
 }
 
 int fmx_prev_range_batch(const fmx_index *idx, const uint64_t *sp, const uint64_t *ep, const uint8_t *c,

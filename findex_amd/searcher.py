@@ -143,6 +143,18 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_prev_substr(self._h, int(sp), int(length), _ptr(out)))
         return bytes(out[: int(length)])
 
+    @staticmethod
+    def search_batch_multi(searchers, pat, off):
+        """fmx_search_batch_multi: one process, one replica handle per GPU; the batch is cut by pattern bytes."""
+        pat = np.ascontiguousarray(pat, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        k = off.size - 1
+        sp = np.zeros(max(k, 0), dtype=np.uint64)
+        ep = np.zeros(max(k, 0), dtype=np.uint64)
+        arr = (ctypes.c_void_p * len(searchers))(*[s._h for s in searchers])
+        _lib.check(_lib.load().fmx_search_batch_multi(arr, len(searchers), _ptr(pat), _ptr(off), _ptr(sp), _ptr(ep), max(k, 0)))
+        return sp, ep
+
     def extract(self, row, length, direction=1):
         """fmx_extract: direction > 0 = nextSubstr, < 0 = prevSubstr."""
         out = np.zeros(max(int(length), 1), dtype=np.uint8)

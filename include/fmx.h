@@ -110,6 +110,12 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
                      size_t k);
 int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep,
                          size_t k, void *stream);
+/* One process, several GPUs: the batch is cut into contiguous slices balanced by pattern bytes, slice r is
+ * searched on idxs[r] (one handle per device, every handle a replica of the same index) from its own host
+ * thread, and each slice's intervals land in their range of sp / ep -- the single-process form of SURVEY.md 8e
+ * (no collective; the one-process-per-GPU form with an RCCL all-gather is findex_amd/distributed.py). */
+int fmx_search_batch_multi(fmx_index *const *idxs, size_t n_idx, const uint8_t *pat, const uint64_t *off,
+                           uint64_t *sp, uint64_t *ep, size_t k);
 
 /* ---- batched single step: SuffixAlgo.getPrevRange(sp,ep,c), findex.scala:32-36.
  * sp1 = cf(c)+occ(c,sp-1), ep1 = cf(c)+occ(c,ep-1); empty iff sp1 >= ep1.  Needs sp <= ep <= n. */

@@ -310,6 +310,31 @@ def test_concurrent_calls_on_one_handle():
     assert not errors, errors[:3]
 
 
+def test_search_batch_multi_replicas():
+    """fmx_search_batch_multi over three replica handles (all on device 0 here; one per GPU in production): the
+    slices are searched from three host threads and land in their ranges of the output arrays."""
+    bwt, eof, counts = synth_bwt(200_000, 1, 12, 41)
+    hips = [findex_amd.HipFMSearcher.from_mem(bwt, eof, counts) for _ in range(3)]
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(2)
+    pats = []
+    for m in (0, 3, 11, 40):
+        pats += lf_walk_patterns(orc, rng, 500, m, 0.2, alphabet=list(range(1, 13)))
+    pats = [pats[i] for i in rng.permutation(len(pats))]
+    buf, off = pack_patterns(pats)
+    wsp, wep, _ = orc.search_batch(buf, off)
+    sp, ep = findex_amd.HipFMSearcher.search_batch_multi(hips, buf, off)
+    assert np.array_equal(sp, wsp) and np.array_equal(ep, wep)
+    # fewer patterns than handles, and all-empty patterns
+    sp, ep = findex_amd.HipFMSearcher.search_batch_multi(hips, buf[: int(off[1])], off[:2])
+    assert (int(sp[0]), int(ep[0])) == (int(wsp[0]), int(wep[0]))
+    sp, ep = findex_amd.HipFMSearcher.search_batch_multi(hips, np.zeros(0, dtype=np.uint8), np.zeros(6, dtype=np.uint64))
+    assert sp.tolist() == [0] * 5 and ep.tolist() == [hips[0].n] * 5
+    other = findex_amd.HipFMSearcher.from_mem(bwt[:1000], 5, np.bincount(np.delete(bwt[:1000], 5), minlength=256).astype(np.int64))
+    with pytest.raises(findex_amd.FmxError):
+        findex_amd.HipFMSearcher.search_batch_multi([hips[0], other], buf, off)
+
+
 def test_counts_must_describe_bwt():
     bwt, eof, counts = synth_bwt(5000, 1, 4, 1)
     bad = counts.copy()

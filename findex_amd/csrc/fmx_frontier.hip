@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -63,6 +64,10 @@ struct FrontierCtl {     // device-resident counters
   PaddedCount count[3][kSub];
   PaddedCount res_count[kSub];
   unsigned long long overflow;     // bit 0: queue, bit 1: results
+  // The level the next grid launch works on is level_base + its launch number, so that a chain of launches
+  // can be replayed as one hipGraph with fixed kernel arguments; levels >= max_level do nothing.
+  uint32_t level_base;
+  uint32_t max_level;
 };
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
@@ -256,14 +261,19 @@ __device__ __forceinline__ void frontier_slice(const DevIndex &ix, const NfaTabl
 }
 
 // One level on the whole grid: wave w reads slice w % kSub together with the other waves of that class.
+// `j` is the launch's number in its chain: it works on level ctl->level_base + j.
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue cur, Queue nxt, uint32_t level,
+__global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
                                                          uint64_t sub_cap, fmx_result *__restrict__ res,
                                                          uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
                                                          unsigned long long *__restrict__ counters) {
   // After a queue overflow the appended count exceeds what was stored: later levels of the chain
   // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
   if (ctl->overflow & 1ull) return;
+  const uint32_t level = ctl->level_base + j;
+  if (level >= ctl->max_level) return;
+  const Queue &cur = (level & 1u) ? qb : qa;
+  const Queue &nxt = (level & 1u) ? qa : qb;
   if (blockIdx.x == 0 && threadIdx.x < kSub) ctl->count[(level + 2) % 3][threadIdx.x].v = 0;
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
@@ -280,6 +290,11 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
                                appends, stepped);
   const uint32_t t = threadIdx.x & (Lay<LAYOUT>::G - 1);
   counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
+}
+
+// Closes a chain of grid launches: the next chain starts `by` levels further.
+__global__ void k_level_advance(FrontierCtl *__restrict__ ctl, uint32_t by) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->level_base += by;
 }
 
 // The long tail of a match -- levels with a handful of elements -- is bound by launches and host looks,
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  if (threadIdx.x == 0) { ts->level = level; ts->reason = reason; }
+  if (threadIdx.x == 0) { ts->level = level; ts->reason = reason; ctl->level_base = level; }
   const uint32_t t = threadIdx.x & (Lay<LAYOUT>::G - 1);
   counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
 }
@@ -402,6 +417,13 @@ struct RegexBatch {
   TailState *d_tail = nullptr;
   uint32_t *d_rcnt = nullptr, *d_rstart = nullptr, *d_rfill = nullptr;   // per-regex result counts / offsets
   BigGroups *d_big = nullptr;
+  FrontierCtl *h_ctl = nullptr;        // pinned host copy the chain's last node fills
+  hipGraphExec_t chain_exec = nullptr; // one chain of grid levels + advance + counter copy, captured once
+  uint32_t chain_len = 0;
+  ~RegexBatch() {
+    if (chain_exec) (void)hipGraphExecDestroy(chain_exec);
+    if (h_ctl) (void)hipHostFree(h_ctl);
+  }
   uint64_t qcap = 0;
   size_t rcap = 0;
   NfaTables nfa{};
@@ -479,7 +501,7 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
 
 // Level-0 queue: states = firsts, sp = 0, ep = n, dealt round-robin over the slices.
 __global__ void k_frontier_init(Queue q, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n,
-                                uint64_t sub_cap, FrontierCtl *__restrict__ ctl) {
+                                uint64_t sub_cap, uint32_t max_level, FrontierCtl *__restrict__ ctl) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kSub) {
     ctl->count[0][i].v = count > i ? (count - i + kSub - 1) / kSub : 0;
@@ -487,7 +509,7 @@ __global__ void k_frontier_init(Queue q, const uint32_t *__restrict__ first_stat
     ctl->count[2][i].v = 0;
     ctl->res_count[i].v = 0;
   }
-  if (i == 0) ctl->overflow = 0;
+  if (i == 0) { ctl->overflow = 0; ctl->level_base = 0; ctl->max_level = max_level; }
   if (i < count) {
     const uint64_t at = (i % kSub) * sub_cap + i / kSub;
     q.state[at] = first_state[i]; q.sp[at] = 0; q.ep[at] = n;
@@ -587,6 +609,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if (!b->scratch || b->qcap != qcap || b->rcap < (cap ? cap : 1)) {
     b->scratch.reset(new DevMem());
     b->qcap = 0;
+    if (b->chain_exec) { (void)hipGraphExecDestroy(b->chain_exec); b->chain_exec = nullptr; }   // it holds the old pointers
+    if (!b->h_ctl) HIP_TRY(hipHostMalloc((void **)&b->h_ctl, sizeof(FrontierCtl), hipHostMallocDefault), "hipHostMalloc(ctl)");
     for (Queue *q : {&b->qa, &b->qb}) {
       HIP_TRY(b->scratch->alloc(&q->state, kSub * sub_cap), "hipMalloc(queue)");
       HIP_TRY(b->scratch->alloc(&q->sp, kSub * sub_cap), "hipMalloc(queue)");
@@ -614,13 +638,12 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
 
   mark("setup");
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
-  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->d_first_state, b->n_first, h->n, sub_cap, d_ctl);
+  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->d_first_state, b->n_first, h->n, sub_cap, max_steps, d_ctl);
   HIP_TRY(hipGetLastError(), "k_frontier_init");
   // Levels are chained on the stream without host round trips; the host looks at the counters
   // every kChain levels.  A level with an empty queue returns at once.
   static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 8u;   // levels between host looks
   const int grid_full = h->cu_count * 6;     // what stays resident at 80 vector registers per lane
-  int grid = grid_full;
   static const bool use_tail = !(getenv("FMX_FRONTIER_TAIL") && atoi(getenv("FMX_FRONTIER_TAIL")) == 0);   // A/B switch
   std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());
   FrontierCtl &ctl = *ctl_host;
@@ -628,29 +651,51 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   uint32_t level = 0;
   uint64_t launches = 1;
   bool alive = true, truncated = false;
+  // One chain = kChain grid levels + k_level_advance + the counters' copy to pinned host memory.  Its kernel
+  // arguments do not change from chain to chain (the level comes from ctl->level_base), so it is captured
+  // into a hipGraph once per batch and replayed: one launch call per chain instead of kChain + 2.
+  static const bool use_graph = !(getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) == 0);
+  auto enqueue_chain = [&](hipStream_t s) -> hipError_t {
+    for (uint32_t j = 0; j < kChain; j++) {
+#define CALL(W, L) k_frontier<W, L><<<grid_full, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters)
+      FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
+    }
+    k_level_advance<<<1, 1, 0, s>>>(d_ctl, kChain);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(b->h_ctl, d_ctl, sizeof(FrontierCtl), hipMemcpyDeviceToHost, s);
+  };
+  if (use_graph && (!b->chain_exec || b->chain_len != kChain)) {
+    if (b->chain_exec) { (void)hipGraphExecDestroy(b->chain_exec); b->chain_exec = nullptr; }
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      const hipError_t e1 = enqueue_chain(st);
+      const hipError_t e2 = hipStreamEndCapture(st, &g);
+      e = e1 != hipSuccess ? e1 : e2;
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&b->chain_exec, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { (void)hipGetLastError(); b->chain_exec = nullptr; }    // fall back to plain launches
+    b->chain_len = kChain;
+  }
   // a small batch (a single regex, say) starts in the tail kernel: no grid levels, no look
   bool grid_first = !(use_tail && b->n_first <= kTailMax / 2 && max_steps > 0);
   while (alive) {
-    for (uint32_t j = 0; grid_first && j < kChain && level < max_steps; j++, level++) {
-      const Queue &cur = (level & 1) ? qb : qa;
-      const Queue &nxt = (level & 1) ? qa : qb;
-#define CALL(W, L) k_frontier<W, L><<<grid, kFThreads, 0, st>>>(h->dev, b->nfa, cur, nxt, level, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters)
-      FMX_LAYOUT_DISPATCH(h, CALL);
-#undef CALL
-      HIP_TRY(hipGetLastError(), "k_frontier");
-      launches++;
-    }
     uint64_t next_total = b->n_first;
     if (grid_first) {
-      HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
+      if (b->chain_exec) HIP_TRY(hipGraphLaunch(b->chain_exec, st), "hipGraphLaunch(level chain)");
+      else HIP_TRY(enqueue_chain(st), "k_frontier chain");
+      launches += kChain + 1;
       HIP_TRY(hipStreamSynchronize(st), "sync(levels)");
+      std::memcpy(&ctl, b->h_ctl, sizeof ctl);
+      level = std::min<uint64_t>((uint64_t)level + kChain, max_steps);
       if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
       next_total = 0;
       n_res = 0;
       for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
       alive = next_total != 0;
-      // a nearly empty frontier is launch-bound: a small grid (still >= one wave per slice) starts and ends faster
-      grid = next_total <= 4096 ? (int)kSub : grid_full;
       if (getenv("FMX_TRACE"))
         fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
                 (unsigned long long)next_total, (unsigned long long)n_res, ctl.overflow);
@@ -673,7 +718,6 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       n_res = 0;
       for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
       alive = next_total != 0;
-      grid = grid_full;
       if (getenv("FMX_TRACE"))
         fprintf(stderr, "[fmx] frontier tail kernel stopped at level %u (reason %u): next %llu, results %llu\n", level,
                 tsh.reason, (unsigned long long)next_total, (unsigned long long)n_res);

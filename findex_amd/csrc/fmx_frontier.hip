@@ -420,6 +420,8 @@ struct RegexBatch {
   FrontierCtl *h_ctl = nullptr;        // pinned host copy the chain's last node fills
   hipGraphExec_t chain_exec = nullptr; // one chain of grid levels + advance + counter copy, captured once
   uint32_t chain_len = 0;
+  uint32_t matches = 0;                // the chain is captured from a batch's second match on (a one-shot batch
+                                       // would pay the capture and never replay it)
   ~RegexBatch() {
     if (chain_exec) (void)hipGraphExecDestroy(chain_exec);
     if (h_ctl) (void)hipHostFree(h_ctl);
@@ -666,7 +668,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(b->h_ctl, d_ctl, sizeof(FrontierCtl), hipMemcpyDeviceToHost, s);
   };
-  if (use_graph && (!b->chain_exec || b->chain_len != kChain)) {
+  b->matches++;
+  if (use_graph && b->matches >= 2 && (!b->chain_exec || b->chain_len != kChain)) {
     if (b->chain_exec) { (void)hipGraphExecDestroy(b->chain_exec); b->chain_exec = nullptr; }
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);

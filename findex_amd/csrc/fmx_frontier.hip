@@ -369,8 +369,8 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
 }
 
 // result groups the device leaves to the host (k_res_sort)
-constexpr uint32_t kSmallGroup = 32;
-constexpr uint32_t kBigMax = 1024;
+constexpr uint32_t kSmallGroup = 12;
+constexpr uint32_t kBigMax = 16384;
 struct BigGroups {
   uint32_t n;
   uint32_t pad;
@@ -416,6 +416,7 @@ struct RegexBatch {
   FrontierCtl *d_ctl = nullptr;
   TailState *d_tail = nullptr;
   uint32_t *d_rcnt = nullptr, *d_rstart = nullptr, *d_rfill = nullptr;   // per-regex result counts / offsets
+  uint32_t *d_rpart = nullptr;         // chunk totals of the offsets' scan
   BigGroups *d_big = nullptr;
   FrontierCtl *h_ctl = nullptr;        // pinned host copy the chain's last node fills
   hipGraphExec_t chain_exec = nullptr; // one chain of grid levels + advance + counter copy, captured once
@@ -528,25 +529,53 @@ __global__ __launch_bounds__(256) void k_res_count(const fmx_result *__restrict_
     atomicAdd(&rcnt[seg[(uint64_t)sl * seg_cap + i].regex], 1u);
 }
 
-// exclusive prefix sums of cnt[0..k) into start[0..k] with one workgroup: a chunk per thread, a scan of the
-// chunk totals in LDS, then the chunk again
-__global__ __launch_bounds__(1024) void k_res_scan(const uint32_t *__restrict__ cnt, uint32_t k, uint32_t *__restrict__ start) {
-  __shared__ uint32_t part[1024];
-  const uint32_t chunk = (k + 1023) / 1024;
-  const uint32_t lo = min(k, threadIdx.x * chunk), hi = min(k, lo + chunk);
-  uint32_t sum = 0;
-  for (uint32_t j = lo; j < hi; j++) sum += cnt[j];
-  part[threadIdx.x] = sum;
+// Exclusive prefix sums of cnt[0..k] into start[0..k] in three small parallel launches: each workgroup scans
+// its chunk of 1024 counts (start = sums inside the chunk, part[chunk] = the chunk's total), one workgroup
+// scans the chunk totals, and every workgroup adds its chunk's offset.
+constexpr uint32_t kScanChunk = 1024;
+__device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s_wave /* [16] */, uint32_t &total) {
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  uint32_t wtot = 0;
+  const uint32_t ex = wave_excl_scan(v, wtot);          // inside the wave
+  if (lane == 0) s_wave[wv] = wtot;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {               // Hillis-Steele inclusive scan
-    const uint32_t add = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-    __syncthreads();
-    part[threadIdx.x] += add;
-    __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (uint32_t j = 0; j < 16; j++) {                   // 16 wave totals: every thread adds them up itself
+    const uint32_t x = s_wave[j];
+    before += j < wv ? x : 0u;
+    all += x;
   }
-  uint32_t run = part[threadIdx.x] - sum;
-  for (uint32_t j = lo; j < hi; j++) { start[j] = run; run += cnt[j]; }
-  if (threadIdx.x == 1023) start[k] = part[1023];
+  __syncthreads();
+  total = all;
+  return before + ex;
+}
+
+__global__ __launch_bounds__(kScanChunk) void k_res_scan_chunks(const uint32_t *__restrict__ cnt, uint32_t n,
+                                                                uint32_t *__restrict__ start, uint32_t *__restrict__ part) {
+  __shared__ uint32_t s_wave[16];
+  const uint32_t i = blockIdx.x * kScanChunk + threadIdx.x;
+  uint32_t total = 0;
+  const uint32_t ex = block_excl_scan_1024(i < n ? cnt[i] : 0u, s_wave, total);
+  if (i < n) start[i] = ex;
+  if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanChunk) void k_res_scan_parts(uint32_t *__restrict__ part, uint32_t nparts) {
+  __shared__ uint32_t s_wave[16];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nparts; base += kScanChunk) {        // one trip up to a million regexes
+    const uint32_t i = base + threadIdx.x;
+    uint32_t total = 0;
+    const uint32_t ex = block_excl_scan_1024(i < nparts ? part[i] : 0u, s_wave, total);
+    if (i < nparts) part[i] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ __launch_bounds__(kScanChunk) void k_res_scan_add(uint32_t *__restrict__ start, uint32_t n,
+                                                             const uint32_t *__restrict__ part) {
+  const uint32_t i = blockIdx.x * kScanChunk + threadIdx.x;
+  if (i < n) start[i] += part[blockIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_res_scatter(const fmx_result *__restrict__ seg, uint64_t seg_cap,
@@ -625,6 +654,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     HIP_TRY(b->scratch->alloc(&b->d_rcnt, b->k + 1), "hipMalloc(result counts)");
     HIP_TRY(b->scratch->alloc(&b->d_rstart, b->k + 1), "hipMalloc(result offsets)");
     HIP_TRY(b->scratch->alloc(&b->d_rfill, b->k + 1), "hipMalloc(result fill)");
+    HIP_TRY(b->scratch->alloc(&b->d_rpart, (b->k + 1) / kScanChunk + 2), "hipMalloc(scan parts)");
     HIP_TRY(b->scratch->alloc(&b->d_big, 1), "hipMalloc(big groups)");
     b->qcap = qcap;
     b->rcap = cap ? cap : 1;
@@ -733,12 +763,17 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     HIP_TRY(hipMemsetAsync(b->d_rfill, 0, (b->k + 1) * 4, st), "memset(result fill)");
     const dim3 rg(8, kSub);
     k_res_count<<<rg, 256, 0, st>>>(d_res_seg, seg_cap, d_ctl, b->d_rcnt);
-    k_res_scan<<<1, 1024, 0, st>>>(b->d_rcnt, (uint32_t)b->k, b->d_rstart);
+    {
+      const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: start[k] = total
+      k_res_scan_chunks<<<nparts, kScanChunk, 0, st>>>(b->d_rcnt, n_scan, b->d_rstart, b->d_rpart);
+      k_res_scan_parts<<<1, kScanChunk, 0, st>>>(b->d_rpart, nparts);
+      k_res_scan_add<<<nparts, kScanChunk, 0, st>>>(b->d_rstart, n_scan, b->d_rpart);
+    }
     k_res_scatter<<<rg, 256, 0, st>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)cap);
     HIP_TRY(hipMemsetAsync(b->d_big, 0, 8, st), "memset(big groups)");
     k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, st>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);
     HIP_TRY(hipGetLastError(), "result grouping kernels");
-    launches += 4;
+    launches += 6;
   }
   HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
   HIP_TRY(hipStreamSynchronize(st), "sync");

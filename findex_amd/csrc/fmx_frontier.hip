@@ -305,6 +305,8 @@ __global__ void k_level_advance(FrontierCtl *__restrict__ ctl, uint32_t by) {
 struct TailState {
   uint32_t level;      // first level not processed
   uint32_t reason;     // 0 frontier empty, 1 max_level reached, 2 frontier outgrew the tail kernel, 3 queue overflow
+  uint32_t pending;    // elements still alive in the kernel's LDS queue at max_level (the global counts read 0 then)
+  uint32_t pad;
 };
 constexpr int kTailThreads = 1024;
 constexpr uint64_t kTailMax = 8192;          // elements per level one workgroup keeps; it is entered below half of it
@@ -316,20 +318,31 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
                                                                  FrontierCtl *__restrict__ ctl,
                                                                  unsigned long long *__restrict__ counters,
                                                                  TailState *__restrict__ ts) {
+  constexpr int G = Lay<LAYOUT>::G;
+  constexpr uint32_t kTiny = kTailThreads / G;            // elements the LDS mode holds: one per lane group
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
   __shared__ Stage s_stage[kTailThreads / 64];
-  __shared__ uint32_t s_verdict;
+  __shared__ uint32_t s_verdict, s_tcnt, s_push;
   __shared__ uint64_t s_prefix[kSub + 1];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
   __syncthreads();
   static_assert(kSub == 64, "one slice counter per lane below");
+  // LDS mode keeps the frontier in two small queues that live in the (then unused) staging area
+  static_assert(sizeof(s_stage) >= 2 * kTiny * 20 + 64, "the LDS queues must fit in the staging area");
+  uint8_t *raw = reinterpret_cast<uint8_t *>(&s_stage[0]);
+  uint64_t *tq_sp[2] = {reinterpret_cast<uint64_t *>(raw), reinterpret_cast<uint64_t *>(raw) + 2 * kTiny};
+  uint64_t *tq_ep[2] = {tq_sp[0] + kTiny, tq_sp[1] + kTiny};
+  uint32_t *tq_state[2] = {reinterpret_cast<uint32_t *>(tq_sp[1] + 2 * kTiny), reinterpret_cast<uint32_t *>(tq_sp[1] + 2 * kTiny) + kTiny};
+  const LaneConst lc = lane_const<G>();
+  const uint32_t t = lc.t;
   const uint32_t w = threadIdx.x >> 6;
   constexpr uint32_t nw = kTailThreads / 64;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t grp = threadIdx.x / G;                   // this lane group's number in the workgroup
   uint32_t appends = 0, stepped = 0;
-  uint32_t level = level0, reason = 1;
-  for (; level < max_level; level++) {
+  uint32_t level = level0, reason = 1, pending = 0;
+  while (level < max_level) {
     // lane j reads slice j's count (coherent load: other waves' atomics produced it).  Wave 0 decides for the
     // whole workgroup -- the overflow flag can change while a level runs, and every thread must take the
     // same way out of this loop (there is a barrier at its end)
@@ -346,25 +359,159 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
       s_prefix[lane] = incl - clamped;
       if (lane == 63) s_prefix[kSub] = incl;
       const unsigned long long ovf = __hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane == 0) s_verdict = (ovf & 1ull) ? 3u : (total == 0 ? 0u : (total > kTailMax ? 2u : 4u));
+      if (lane == 0)
+        s_verdict = (ovf & 1ull) ? 3u : (total == 0 ? 0u : (total > kTailMax ? 2u : (total <= kTiny ? 5u : 4u)));
     }
     __syncthreads();
     const uint32_t verdict = s_verdict;
-    if (verdict != 4u) { reason = verdict; break; }
-    if (threadIdx.x < kSub) __hip_atomic_store(&ctl->count[(level + 2) % 3][threadIdx.x].v, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (verdict < 4u) { reason = verdict; break; }
     const Queue &cur = (level & 1u) ? qb : qa;
     const Queue &nxt = (level & 1u) ? qa : qb;
-    frontier_slice<WIDE, LAYOUT, true>(ix, nfa, cur, nxt, level, sub_cap, res, seg_cap, ctl, s_cf, s_slot, s_stage[w], w, 0,
-                                       w, nw, s_prefix[kSub], appends, stepped, s_prefix);
-    // level boundary.  The appends of this level were made by waves of this workgroup: draining the stores
-    // (workgroup-scope release) makes them reach L2; the acquire invalidates this CU's L1, which may still
-    // hold lines of the queue buffer from two levels ago.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (verdict == 4u) {
+      // ---- a level through the global queues
+      if (threadIdx.x < kSub) __hip_atomic_store(&ctl->count[(level + 2) % 3][threadIdx.x].v, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      frontier_slice<WIDE, LAYOUT, true>(ix, nfa, cur, nxt, level, sub_cap, res, seg_cap, ctl, s_cf, s_slot, s_stage[w], w, 0,
+                                         w, nw, s_prefix[kSub], appends, stepped, s_prefix);
+      // level boundary.  The appends of this level were made by waves of this workgroup: draining the stores
+      // (workgroup-scope release) makes them reach L2; the acquire invalidates this CU's L1, which may still
+      // hold lines of the queue buffer from two levels ago.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      level++;
+      continue;
+    }
+    // ---- LDS mode: at most one element per lane group.  The frontier moves into LDS and stays there, level
+    // after level, without queue traffic, counters or fences (a level is then: state record, rank blocks,
+    // three barriers), until it dies, reaches max_level, or a level's survivors no longer fit.
+    {
+      const uint32_t total = (uint32_t)s_prefix[kSub];
+      if (grp < total && t == 0) {
+        uint32_t sl = 0;
+#pragma unroll
+        for (uint32_t step = kSub / 2; step; step >>= 1)
+          if (s_prefix[sl + step] <= grp) sl += step;
+        const uint64_t i = (uint64_t)sl * sub_cap + (grp - s_prefix[sl]);
+        tq_state[0][grp] = cur.state[i];
+        tq_sp[0][grp] = cur.sp[i];
+        tq_ep[0][grp] = cur.ep[i];
+      }
+      // the global counts of this level are consumed; nothing is appended while the frontier lives in LDS
+      if (threadIdx.x < kSub)
+        for (int sct = 0; sct < 3; sct++)
+          __hip_atomic_store(&ctl->count[sct][threadIdx.x].v, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) { s_tcnt = total; s_push = 0; }
+    }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint32_t cq = 0;                                       // which LDS queue holds the current level
+    bool spilled = false;
+    for (;;) {
+      const uint32_t tc = s_tcnt;
+      if (tc == 0) { reason = 0; break; }
+      if (level >= max_level) { reason = 1; pending = tc; break; }
+      const bool have = grp < tc;
+      uint32_t nf = 0, f0 = 0, rgx = 0;
+      uint64_t sp = 0, ep = 0;
+      uint32_t inl[kInlineFollows] = {0, 0, 0, 0};
+      bool emit = false;
+      if (have) {
+        const uint32_t state = tq_state[cq][grp];
+        sp = tq_sp[cq][grp];
+        ep = tq_ep[cq][grp];
+        const uint4 *p = reinterpret_cast<const uint4 *>(nfa.st + state);
+        const uint4 ra = p[0], rb = p[1];
+        const uint32_t c = ra.w & 0xFFu;
+        rgx = ra.z;
+        const uint16_t slot = s_slot[c];
+        const uint64_t cfc = s_cf[c];
+        if (level == 0) {
+          sp = cfc;
+          ep = (c == 255u) ? ix.n : s_cf[c + 1];
+          if (slot == kSlotNone) ep = sp;
+          else if (slot == kSlotEof) ep = sp + 1;
+        } else {
+          backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
+        }
+        stepped++;
+        if (sp < ep) {
+          emit = (ra.w >> 8) != 0;
+          f0 = ra.x;
+          nf = ra.y;
+          inl[0] = rb.x; inl[1] = rb.y; inl[2] = rb.z; inl[3] = rb.w;
+        }
+      }
+      const bool lead = t == 0;
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
+      if (em) {
+        const uint32_t so = (w + appends++) % kSub;
+        unsigned long long rbase = 0;
+        if (lane == 0) rbase = atomicAdd(&ctl->res_count[so].v, (unsigned long long)__builtin_popcountll(em));
+        rbase = __shfl(rbase, 0, 64);
+        if (lead && emit) {
+          const unsigned long long at = rbase + __builtin_popcountll(em & ((1ull << lane) - 1ull));
+          if (at < seg_cap) {
+            fmx_result r;
+            r.regex = rgx; r.len = level + 1; r.sp = sp; r.ep = ep;
+            res[(uint64_t)so * seg_cap + at] = r;
+          } else {
+            atomicOr(&ctl->overflow, 2ull);
+          }
+        }
+      }
+      // reserve room in the next LDS queue
+      uint32_t off = 0;
+      if (lead && nf) off = atomicAdd(&s_push, nf);
+      off = __shfl(off, (int)(lane & ~(uint32_t)(G - 1)), 64);
+      __syncthreads();
+      const uint32_t tp = s_push;
+      if (tp <= kTiny) {
+        for (uint32_t j = t; j < nf; j += G) {
+          const uint32_t fs = j < kInlineFollows ? (j < 2 ? (j == 0 ? inl[0] : inl[1]) : (j == 2 ? inl[2] : inl[3])) : nfa.fol[f0 + j];
+          tq_state[cq ^ 1][off + j] = fs;
+          tq_sp[cq ^ 1][off + j] = sp;
+          tq_ep[cq ^ 1][off + j] = ep;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_tcnt = tp; s_push = 0; }
+        cq ^= 1;
+        level++;
+        __syncthreads();
+        continue;
+      }
+      // ---- the survivors no longer fit: append them to the global queue of the next level and leave LDS mode
+      {
+        uint32_t wave_total = 0;
+        const uint32_t woff = wave_excl_scan(lead ? nf : 0u, wave_total);
+        if (wave_total) {
+          const uint32_t so = (w + appends++) % kSub;
+          const uint64_t out_off = (uint64_t)so * sub_cap;
+          unsigned long long qbase = 0;
+          if (lane == 0) qbase = atomicAdd(&ctl->count[(level + 1) % 3][so].v, (unsigned long long)wave_total);
+          qbase = __shfl(qbase, 0, 64);
+          const uint32_t my_off = __shfl(woff, (int)(lane & ~(uint32_t)(G - 1)), 64);
+          const Queue &nq = (level & 1u) ? qa : qb;
+          for (uint32_t j = t; j < nf; j += G) {
+            const unsigned long long at = qbase + my_off + j;
+            if (at < sub_cap) {
+              nq.state[out_off + at] = j < kInlineFollows ? (j < 2 ? (j == 0 ? inl[0] : inl[1]) : (j == 2 ? inl[2] : inl[3])) : nfa.fol[f0 + j];
+              nq.sp[out_off + at] = sp;
+              nq.ep[out_off + at] = ep;
+            } else {
+              atomicOr(&ctl->overflow, 1ull);
+            }
+          }
+        }
+        level++;
+        spilled = true;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        break;
+      }
+    }
+    if (!spilled) break;              // died or reached max_level inside LDS mode
   }
-  if (threadIdx.x == 0) { ts->level = level; ts->reason = reason; ctl->level_base = level; }
-  const uint32_t t = threadIdx.x & (Lay<LAYOUT>::G - 1);
+  if (threadIdx.x == 0) { ts->level = level; ts->reason = reason; ts->pending = pending; ctl->level_base = level; }
   counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
 }
 
@@ -750,7 +897,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       next_total = 0;
       n_res = 0;
       for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
-      alive = next_total != 0;
+      alive = next_total != 0 || tsh.pending != 0;
       if (getenv("FMX_TRACE"))
         fprintf(stderr, "[fmx] frontier tail kernel stopped at level %u (reason %u): next %llu, results %llu\n", level,
                 tsh.reason, (unsigned long long)next_total, (unsigned long long)n_res);

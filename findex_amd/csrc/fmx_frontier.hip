@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ out, 
 
 int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_result *out, size_t cap,
                       size_t *n_out, uint32_t *per_regex_count) {
-  const bool trace = getenv("FMX_TRACE") != nullptr;
+  static const bool trace = getenv("FMX_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   auto mark = [&](const char *what) {
     if (trace) fprintf(stderr, "[fmx] regex_batch_match %-18s +%.3f ms\n", what,
@@ -876,7 +876,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       n_res = 0;
       for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
       alive = next_total != 0;
-      if (getenv("FMX_TRACE"))
+      if (trace)
         fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
                 (unsigned long long)next_total, (unsigned long long)n_res, ctl.overflow);
     }
@@ -898,7 +898,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       n_res = 0;
       for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
       alive = next_total != 0 || tsh.pending != 0;
-      if (getenv("FMX_TRACE"))
+      if (trace)
         fprintf(stderr, "[fmx] frontier tail kernel stopped at level %u (reason %u): next %llu, results %llu\n", level,
                 tsh.reason, (unsigned long long)next_total, (unsigned long long)n_res);
     }

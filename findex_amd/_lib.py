@@ -78,6 +78,7 @@ SYMBOLS = {
     "fmx_psi_batch": (_i32, [_vp, _vp, _vp, _sz]),
     "fmx_next_substr": (_i32, [_vp, _u64, _u32, _vp, _P(_u32)]),
     "fmx_prev_substr": (_i32, [_vp, _u64, _u32, _vp]),
+    "fmx_next_substr_batch": (_i32, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "fmx_search_batch_multi": (_i32, [_vp, _sz, _vp, _vp, _vp, _vp, _sz]),
     "fmx_extract": (_i32, [_vp, _u64, _u32, _i32, _vp, _P(_u32)]),
     "fmx_write_fm": (_i32, [_vp, _cp]),

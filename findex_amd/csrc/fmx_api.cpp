@@ -645,34 +645,31 @@ int fmx_psi_batch(const fmx_index *idx, const uint64_t *rows, uint64_t *out, siz
   });
 }
 
-int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out, uint32_t *out_len) {
-  if (!idx || !out_len || (len && !out)) return arg_fail("null argument");
+// nextSubstr for k rows in one call: out is k x len bytes (row q's string at q*len, out_len[q] bytes of it used).
+int fmx_next_substr_batch(const fmx_index *idx, const uint64_t *rows, size_t k, uint32_t len, uint8_t *out,
+                          uint32_t *out_len) {
+  if (!idx || (k && (!rows || !out_len || (len && !out)))) return arg_fail("null argument");
   const Index *h = H(idx);
-  *out_len = 0;
-  if (sp >= h->n) return arg_fail("row out of range");
+  for (size_t q = 0; q < k; q++) {
+    out_len[q] = 0;
+    if (rows[q] >= h->n) return arg_fail("row out of range");
+  }
   int rc = use_device(h);
-  if (rc) return rc;
-  Call call(h);
-  if ((rc = call.init()) != FMX_OK) return rc;
-  DevBuf dsp, dout, dlen;
-  HIP_TRY(call.alloc(dsp, 8), "hipMalloc");
-  HIP_TRY(call.alloc(dout, len), "hipMalloc");
-  HIP_TRY(call.alloc(dlen, 4), "hipMalloc");
-  std::vector<uint8_t> tmp(len ? len : 1);
-  uint32_t w = 0;
-  rc = call.timed([&](hipStream_t st, EventPair &ev) {
-    HIP_TRY(hipMemcpyAsync(dsp.p, &sp, 8, hipMemcpyHostToDevice, st), "H2D");
-    HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
-    HIP_TRY(launch_next_substr(h, dsp.p, 1, len, dout.p, dlen.p, st), "k_next_substr");
-    HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
-    if (len) HIP_TRY(hipMemcpyAsync(tmp.data(), dout.p, len, hipMemcpyDeviceToHost, st), "D2H");
-    HIP_TRY(hipMemcpyAsync(&w, dlen.p, 4, hipMemcpyDeviceToHost, st), "D2H");
-    return (int)FMX_OK;
+  if (rc || !k) return rc;
+  const HostIn ins[] = {{rows, k * 8}};
+  const HostOut outs[] = {{out, k * (size_t)len}, {out_len, k * 4}};
+  rc = run_io(h, ins, 1, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
+    return launch_next_substr(h, di[0], k, len, dout[0], dout[1], st);
   });
   if (rc) return rc;
-  for (uint32_t j = 0; j < w; j++) out[j] = tmp[w - 1 - j];   // ret.reverse, bwtmerger.scala:404
-  *out_len = w;
+  for (size_t q = 0; q < k; q++)                  // the kernel writes in walk order: ret.reverse, bwtmerger.scala:404
+    std::reverse(out + q * (size_t)len, out + q * (size_t)len + out_len[q]);
   return FMX_OK;
+}
+
+int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out, uint32_t *out_len) {
+  if (!out_len) return arg_fail("null argument");
+  return fmx_next_substr_batch(idx, &sp, 1, len, out, out_len);
 }
 
 int fmx_extract(const fmx_index *idx, uint64_t row, uint32_t len, int direction, uint8_t *out, uint32_t *out_len) {

@@ -138,6 +138,17 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_next_substr(self._h, int(sp), int(length), _ptr(out), ctypes.byref(w)))
         return bytes(out[: w.value])
 
+    def nextSubstr_batch(self, rows, length):
+        """nextSubstr for many rows in one call -> list of bytes (what SAResult.toString prints per result)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros((rows.size, max(int(length), 1)), dtype=np.uint8)
+        w = np.zeros(max(rows.size, 1), dtype=np.uint32)
+        _lib.check(self._L.fmx_next_substr_batch(self._h, _ptr(rows), rows.size, int(length), _ptr(out), _ptr(w)))
+        if int(length) == 0:
+            return [b""] * rows.size
+        flat = out.reshape(-1)
+        return [bytes(flat[q * int(length): q * int(length) + int(w[q])]) for q in range(rows.size)]
+
     def prevSubstr(self, sp, length):
         out = np.zeros(max(int(length), 1), dtype=np.uint8)
         _lib.check(self._L.fmx_prev_substr(self._h, int(sp), int(length), _ptr(out)))

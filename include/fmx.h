@@ -146,6 +146,10 @@ int fmx_lf_walk_batch_dev(const fmx_index *idx, const void *d_rows, size_t k, ui
  * out needs len bytes, *out_len = bytes written. */
 int fmx_psi_batch(const fmx_index *idx, const uint64_t *rows, uint64_t *out, size_t k);
 int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out, uint32_t *out_len);
+/* the same for k rows at once (rendering a result list): out is k*len bytes, row q's string at q*len, out_len[q]
+ * bytes of it written. */
+int fmx_next_substr_batch(const fmx_index *idx, const uint64_t *rows, size_t k, uint32_t len, uint8_t *out,
+                          uint32_t *out_len);
 int fmx_prev_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out);
 /* Both directions behind one entry point (the name SURVEY.md 8b lists): direction > 0 = nextSubstr (the text
  * that starts at row's suffix, what SAResult.toString prints, re2.scala:11-15), direction < 0 = prevSubstr

@@ -135,6 +135,9 @@ def test_extract_is_next_and_prev_substr(testdata):
             assert hip.extract(row, ln, -1) == hip.prevSubstr(row, ln)
     with pytest.raises(findex_amd.FmxError):
         hip.extract(0, 3, 0)
+    rows = np.arange(hip.n, dtype=np.uint64)
+    for ln in (0, 1, 9):
+        assert hip.nextSubstr_batch(rows, ln) == [orc.nextSubstr(int(r), ln) for r in rows]
 
 
 @pytest.mark.parametrize("name,be", [("test1024.cmp", False), ("test.cmp", False), ("words", True)])

@@ -255,7 +255,7 @@ typedef struct fmx_stats_t {
   uint64_t n_blocks;         /* rank-dictionary blocks per symbol */
   uint32_t n_symbols;        /* symbols that own a bit-vector */
   uint32_t block_bytes;      /* bytes fetched per rank query: 64 (one-hot block) or 132 (BWT block + checkpoint) */
-  double build_ms;           /* device time to build the rank dictionary at open */
+  double build_ms;           /* device time of the kernels that built the rank dictionary at open */
   uint32_t layout;           /* 0 = one-hot bit-vectors, 1 = BWT bytes + checkpoints */
   uint32_t reserved;
   uint64_t search_requests;  /* memory requests for rank-dictionary lines issued by fmx_search_batch[_dev]'s kernel */

@@ -115,3 +115,12 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert out.returncode == 0, (out.returncode, out.stderr[-500:])
     assert out.stdout.split() == [str(ctypes.sizeof(_lib.fmx_stats_t)), str(ctypes.sizeof(_lib.fmx_limits)),
                                   str(ctypes.sizeof(_lib.fmx_result))]
+
+
+def test_build_lists_cover_the_sources():
+    """Every source and header under findex_amd/csrc is named in findex_amd/build.py (the staleness check and
+    the compile list are driven by those lists)."""
+    from findex_amd import build
+    have = set(os.listdir(build.CSRC))
+    assert {f for f in have if f.endswith((".hip", ".cpp"))} == set(build.SOURCES)
+    assert {f for f in have if f.endswith(".h")} == set(build.HEADERS)

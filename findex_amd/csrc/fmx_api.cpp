@@ -240,6 +240,7 @@ static void destroy(Index *h) {
   if (h->d_slot) (void)hipFree(h->d_slot);
   if (h->d_counters) (void)hipFree(h->d_counters);
   for (CallCtx *c : h->ctx_pool) free_ctx(c);
+  if (h->d_desc) (void)hipFree(h->d_desc);
   delete h;
 }
 

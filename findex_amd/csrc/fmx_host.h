@@ -48,6 +48,12 @@ struct Index {
   // host-call bookkeeping
   mutable std::mutex mu;
   mutable std::vector<CallCtx *> ctx_pool;      // idle call contexts (guarded by mu)
+  // descriptor scratch of the literal search, reused by consecutive calls on one stream (stream order keeps
+  // them apart); a call on another stream while it is taken allocates its own (guarded by mu)
+  mutable void *d_desc = nullptr;
+  mutable size_t desc_cap = 0;
+  mutable hipStream_t desc_stream = nullptr;
+  mutable bool desc_used = false;
   mutable uint64_t launches = 0;
   mutable double last_kernel_ms = 0.0;
 };

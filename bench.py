@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- the reference's headline measurement on MI355X (BASELINE.json):
-M rank-queries/s and patterns/s of batched FM-index backward search over a 4 GiB BWT resident in
-HBM, with the achieved fraction of the HBM roofline and the CPU path timed beside it.
+"""bench.py -- the reference's headline measurement on MI355X (BASELINE.json): M rank-queries/s and
+patterns/s (regexes/s) of batched FM-index backward search over an index resident in HBM, with the
+achieved fraction of the HBM roofline and the CPU path timed beside it.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c4|c5|tiny|c4tiny]
 
-A "step" is one pass of the hot path (fmx_search_batch_dev: one k_search launch) over one batch
-of synthetic patterns that already sit in HBM.  Workload at every N (weak scaling): per GPU,
-config C3 -- 1M 32-char literal patterns over a 4 GiB sigma=128 synthetic BWT whose rank
-dictionary is replicated on each GPU; with N > 1 each rank searches its own 1M-pattern shard
-and the step ends with the RCCL all-gather of the (sp, ep) intervals.
+`--gpus N` with N > 1 starts the N ranks itself (a child `python -m torch.distributed.run
+--nproc-per-node N bench.py ...`, before this process touches any GPU) and relays rank 0's JSON line; when
+the driver has already started the ranks (RANK/WORLD_SIZE in the environment) it just takes its place.
 
-torch is plumbing here (device buffers, the stream, torch.distributed); the product path is
-libfmx.so through its C ABI.  Only the cpu_baseline leg touches oracle/.
+A "step" is one pass of the hot path over one batch that already sits in HBM:
+  literal workloads (c3 default, c2, c5, tiny): fmx_search_batch_dev = ONE launch of k_search4 over 1M
+    patterns per GPU; with N > 1 each rank searches its own shard and the step ends with the RCCL all-gather
+    of the (sp, ep) intervals (overlapped with the next step's search);
+  regex workloads (c4, c4tiny): fmx_regex_batch_match on a resident batch of compiled regexes (the Glushkov
+    SA-interval frontier, ReTree._matchSA), results delivered to the host; with N > 1 every rank matches its own
+    batch of the same size (weak scaling) and the per-rank result lists are all-gathered.
+
+torch is plumbing here (device buffers, the stream, torch.distributed); the product path is libfmx.so
+through its C ABI.  Only the cpu_baseline leg touches oracle/.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,46 +34,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
-# Algorithmic bytes per rank query, the figure roofline.achieved is priced with: 128 B at
-# sigma = 4, 132 B (one 128-B block + a 4-B checkpoint) at sigma = 128.  What this build's layouts really
-# fetch per rank query (64 B one-hot block / 132 B bytes layout) is reported next to it.
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming ceiling)
+
+
 def survey_bytes_per_rank(sigma):
+    """SURVEY.md 8d priced a rank query with the structure it assumed (128 B at sigma = 4, a 128-B block + a 4-B
+    checkpoint at sigma = 128).  Kept as a secondary figure (`survey_equiv_GBps`); roofline.achieved prices what
+    this build's layout really asks of memory."""
     return 128 if sigma <= 4 else 132
 
 
-# Ceiling of the memory system for this access pattern, measured with tools/ubench/chain.hip on MI355X:
-# dependent random 64-byte requests at 16 chains per wave and full occupancy.
+# Ceiling of the memory system for dependent random 64-byte requests, measured with tools/ubench/chain.hip on
+# MI355X (16 chains per wave, full occupancy; DESIGN.md section 4).  Quoted for HBM-resident workloads only.
 REQUEST_CEILING_G_PER_S = 53.0
+INFINITY_CACHE_BYTES = 256 << 20
 
-WORKLOADS = {
+LITERAL = {
     # name: (log2 n, sigma, patterns per GPU, pattern length, seed#)
     "c3": (32, 128, 1_000_000, 32, 3),
     "c2": (28, 4, 1_000_000, 16, 2),
-    "c5": (34, 128, 1_000_000, 24, 5),      # 16 GiB BWT: opens in the bytes+checkpoints layout (80 GiB)
+    "c5": (34, 128, 1_000_000, 24, 5),      # 16 GiB BWT: opens in the bytes+checkpoints layout
     "tiny": (22, 128, 100_000, 32, 9),
 }
-
-
-def pmc_traffic(workload, kernel="k_search4"):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of this workload
-    (profiles/r*_<workload>_counters.csv, written by tools/summarize_prof.py from separate rocprofv3 --pmc
-    passes): FETCH_SIZE KiB x the bytes one KiB stands for in this access pattern (calibrated in the same
-    profile on a k_occ launch of known byte count, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB x 1024.
-    None when no profile of this workload is in the tree."""
-    import csv
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters.csv" % workload))):
-        vals, per_kib = {}, None
-        for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel"]:
-                vals[r["Counter"]] = float(r["Mean"])
-            if r["Counter"] == "FETCH_BYTES_PER_KIB":
-                per_kib = float(r["Mean"])
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and per_kib:
-            best = (int(vals["FETCH_SIZE"] * per_kib + vals["WRITE_SIZE"] * 1024), os.path.basename(f))
-    return best
+REGEX = {
+    # name: (log2 n, regexes per GPU, seed#, max match length explored)
+    "c4": (30, 100_000, 4, 64),
+    "c4tiny": (22, 5_000, 4, 64),
+}
+C4_ALPHABET = "abcdefghijklmnopqrstuvwxyz \n"
 
 
 def log(rank, *a):
@@ -74,23 +69,103 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def make_bwt(torch, n, sigma, seed, device):
-    """i.i.d. uniform symbols 1..sigma on the device (any byte string is a valid
-    LF permutation); eof = n/3."""
+# ---------------------------------------------------------------- launching N ranks
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """--gpus N > 1 without a launcher above us: start the N ranks as a child process (nothing in this process
+    has touched a GPU yet), pass rank 0's JSON line through, fail if any rank fails."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in p.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = p.wait()
+    if rc != 0:
+        print("[bench] a rank failed (exit %d)" % rc, file=sys.stderr, flush=True)
+        return rc
+    if line is None:
+        print("[bench] the ranks printed no result line", file=sys.stderr, flush=True)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def check_launch(args, rank, world):
+    """--check-launch: everything of a multi-rank run except the GPU work -- rendezvous (gloo), the sharding of
+    the workload, the pipelined interval gather and the result line -- so that the launcher and the distributed
+    plumbing can be tested on a machine without GPUs.  No search happens: the intervals are made-up values each
+    rank can predict for every other rank."""
+    import torch
+    import torch.distributed as dist
+    from findex_amd.distributed import IntervalGather
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if use_dist:
+        dist.init_process_group("gloo")
+    if os.environ.get("FMX_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit("bench: rank %d told to fail (FMX_BENCH_FAIL_RANK)" % rank)
+    k = (LITERAL.get(args.workload) or (0, 0, 1000))[2]
+    gather = IntervalGather(k, torch.device("cpu"))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sp, ep = gather.slot(i)
+        sp.copy_(torch.arange(k, dtype=torch.int64) * (rank + 1) + i)
+        ep.copy_(sp + rank + 1)
+        out = gather.launch(i)
+        gather.finish()
+        for r in range(world):
+            assert int(out[r, 0, 7]) == 7 * (r + 1) + i and int(out[r, 1, 7]) == 7 * (r + 1) + i + r + 1, "gather content"
+    dt = time.perf_counter() - t0
+    if use_dist:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launch_check", "value": None, "unit": "", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                          "config": {"workload": "launch check (%s shapes), gloo, no GPU work" % args.workload,
+                                     "ranks_in_group": dist.get_world_size() if use_dist else 1}}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+    return 0
+
+
+# ---------------------------------------------------------------- synthetic inputs
+def make_bwt(torch, n, symbols, seed, device):
+    """i.i.d. uniform symbols on the device (any byte string is a valid LF permutation); eof = n/3.
+    `symbols` = sigma (bytes 1..sigma) or a string (its characters)."""
     g = torch.Generator(device=device)
     g.manual_seed(0xF1DE0000 + seed)
     bwt = torch.empty(n, dtype=torch.uint8, device=device)
+    alpha = None if isinstance(symbols, int) else torch.tensor([ord(c) for c in symbols], dtype=torch.uint8, device=device)
     step = 1 << 28
     for a in range(0, n, step):
         b = min(n, a + step)
-        bwt[a:b] = torch.randint(1, sigma + 1, (b - a,), generator=g, device=device, dtype=torch.uint8)
+        if alpha is None:
+            bwt[a:b] = torch.randint(1, symbols + 1, (b - a,), generator=g, device=device, dtype=torch.uint8)
+        else:
+            bwt[a:b] = alpha[torch.randint(0, alpha.numel(), (b - a,), generator=g, device=device)]
     return bwt, n // 3
 
 
 def make_patterns(torch, hip, n, sigma, k, m, seed, device, stream):
-    """90 % hit patterns by LF walk (every backward step keeps a non-empty interval), 10 % with
-    one byte replaced (early-exit path), SURVEY 8d.  Generated on the device with the library's
-    own LF-walk kernel; hit-ness is then verified from the search results."""
+    """90 % hit patterns by LF walk (every backward step keeps a non-empty interval), 10 % with one byte
+    replaced (early-exit path), SURVEY 8d.  Generated on the device with the library's own LF-walk kernel;
+    hit-ness is then verified from the search results."""
     g = torch.Generator(device=device)
     g.manual_seed(0x5EED0000 + seed)
     rows = torch.randint(0, n, (k,), generator=g, device=device, dtype=torch.int64)
@@ -106,6 +181,24 @@ def make_patterns(torch, hip, n, sigma, k, m, seed, device, stream):
     pats[idx, pos[idx]] = sym[idx]
     off = torch.arange(0, (k + 1) * m, m, dtype=torch.int64, device=device)
     return pats.reshape(-1), off
+
+
+def make_regexes(k, seed):
+    """The seeded C4 grammar (tools/regex_workload.py); only shapes the reference's ReTree.apply accepts are kept.
+    Returns (regex strings, compiled ReTree handles)."""
+    import findex_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import regex_workload
+    trees = []
+
+    def compiles(re):
+        try:
+            trees.append(findex_amd.ReTree(findex_amd.REParser.re2post(re)))
+            return True
+        except (findex_amd.MatchError, findex_amd.Re2PostSyntax):
+            return False
+    res = regex_workload.generate(k, seed, compiles)
+    return res, trees
 
 
 def effective_cores():
@@ -129,90 +222,138 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(torch, hip_full, sigma, m, device, stream, rank):
-    """The CPU path beside the GPU number: the oracle's restatement of the reference algorithm
-    (inverted position lists + binary-search occ, bwtmerger.scala:354-375) on this host's cores,
-    on a bounded sample of the same workload: the same generator and alphabet at n = 2^27 (so the
-    32 GiB position list of the full index need not be built) and 200k patterns of the same
-    length and hit mix.  The GPU answers for the sample are checked against it bit for bit."""
+def host_mem_available():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+                break
+        else:
+            return 0
+        for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            try:
+                txt = open(path).read().strip()
+                if txt != "max":
+                    used = 0
+                    for up in ("/sys/fs/cgroup/memory.current", "/sys/fs/cgroup/memory/memory.usage_in_bytes"):
+                        try:
+                            used = int(open(up).read())
+                            break
+                        except Exception:
+                            pass
+                    avail = min(avail, int(txt) - used)
+                break
+            except Exception:
+                continue
+        return avail
+    except Exception:
+        return 0
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of the dominant kernel from the newest COMMITTED PMC profile of this workload
+    (profiles/r*_<workload>_counters.csv, written by tools/summarize_prof.py from separate rocprofv3 --pmc
+    passes): FETCH_SIZE KiB x the bytes one KiB stands for in this access pattern (calibrated in the same
+    profile on a k_occ launch of known byte count, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB x 1024.
+    Not measured in this run: returns (bytes, file name) or None when no such profile is in the tree."""
+    import csv
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters.csv" % workload))):
+        vals, per_kib = {}, None
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel"]:
+                vals[r["Counter"]] = float(r["Mean"])
+            if r["Counter"] == "FETCH_BYTES_PER_KIB":
+                per_kib = float(r["Mean"])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and per_kib:
+            best = (int(vals["FETCH_SIZE"] * per_kib + vals["WRITE_SIZE"] * 1024), os.path.basename(f))
+    return best
+
+
+# ---------------------------------------------------------------- CPU baselines (the only users of oracle/)
+def oracle_index(torch, bwt_dev, eof, cores, rank):
+    """The oracle's index over the SAME BWT the GPU run uses: bytes copied to the host, symbol counts, inverted
+    position lists (4 bytes per row) sorted on all cores.  None when the host cannot hold it."""
     import oracle
-    import findex_amd
-    n_s, k_s = 1 << 27, 200_000
-    bwt_s, eof_s = make_bwt(torch, n_s, sigma, 77, device)
-    hip_s = findex_amd.HipFMSearcher.from_device(bwt_s.data_ptr(), n_s, eof_s, None, device=device.index, stream=stream)
-    pats, off = make_patterns(torch, hip_s, n_s, sigma, k_s, m, 78, device, stream)
-    sp = torch.empty(k_s, dtype=torch.int64, device=device)
-    ep = torch.empty(k_s, dtype=torch.int64, device=device)
-    hip_s.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k_s, stream)
-    torch.cuda.synchronize()
-    h_bwt = bwt_s.cpu().numpy()
-    counts = np.bincount(h_bwt, minlength=256).astype(np.int64)
-    counts[h_bwt[eof_s]] -= 1
+    n = bwt_dev.numel()
+    need = 6 * n + (2 << 30)
+    avail = host_mem_available()
+    if n > (1 << 32) or (avail and avail < need):
+        log(rank, "cpu_baseline: n=%d needs %.0f GiB of host memory (%.0f GiB available, lists hold 32-bit entries)"
+            % (n, need / 2**30, avail / 2**30))
+        return None, 0.0
     t0 = time.time()
-    orc = oracle.NaiveFMSearcher.from_mem(h_bwt, eof_s, counts)
-    t_build = time.time() - t0
-    h_pats = pats.cpu().numpy()
-    h_off = off.cpu().numpy().astype(np.uint64)
-    cores = effective_cores()
+    h_bwt = np.empty(n, dtype=np.uint8)
+    chunk = 1 << 28
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        h_bwt[a:b] = bwt_dev[a:b].cpu().numpy()
+    counts = oracle.histogram(h_bwt, eof, threads=cores)
+    orc = oracle.NaiveFMSearcher.from_mem(h_bwt, eof, counts, threads=cores)
+    del h_bwt
+    return orc, time.time() - t0
+
+
+def cpu_baseline_literal(torch, orc, t_build, n, pats, off, sp, ep, sample, m, cores, rank, note):
+    """The CPU path beside the GPU number: the oracle's restatement of the reference algorithm (inverted
+    position lists + binary-search occ, bwtmerger.scala:354-375) on this host's cores over the first `sample`
+    patterns of the timed batch.  The GPU answers for them are checked against it bit for bit."""
+    h_pats = pats[: sample * m].cpu().numpy()
+    h_off = off[: sample + 1].cpu().numpy().astype(np.uint64)
     t0 = time.time()
     wsp, wep, steps = orc.search_batch(h_pats, h_off, threads=cores)
     dt = time.time() - t0
-    ok = bool(np.array_equal(wsp, sp.cpu().numpy().astype(np.uint64)) and
-              np.array_equal(wep, ep.cpu().numpy().astype(np.uint64)))
+    ok = bool(np.array_equal(wsp, sp[:sample].cpu().numpy().astype(np.uint64)) and
+              np.array_equal(wep, ep[:sample].cpu().numpy().astype(np.uint64)))
     if not ok:
         raise SystemExit("bench: GPU results differ from the CPU oracle on the baseline sample")
     ranks = 2 * int(steps.sum())
-    log(rank, "cpu_baseline: %d cores, %.2fs for %d patterns (%d rank queries), list build %.1fs, parity ok"
-        % (cores, dt, k_s, ranks, t_build))
-    hip_s.close()
+    log(rank, "cpu_baseline: %d cores, %.2fs for %d patterns (%d rank queries), index build %.1fs, parity ok"
+        % (cores, dt, sample, ranks, t_build))
     return {"value": ranks / dt / 1e6, "unit": "M rank-queries/s", "cores": cores, "kind": "port",
-            "patterns_per_s": k_s / dt,
-            "sample": "same generator/alphabet at n=2^27 (not 2^32), 200k x %d-char patterns, 90%% LF-walk hits; "
-                      "inverted lists + binary-search occ in C with OpenMP; GPU results bit-equal" % m}
+            "patterns_per_s": sample / dt, "index_build_s": t_build, "n": n,
+            "sample": "%s; first %d of the timed batch's %d-char patterns; inverted lists + binary-search occ in C "
+                      "with OpenMP; the GPU's (sp, ep) for them are bit-equal" % (note, sample, m)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def cpu_baseline_regex(orc, t_build, n, trees, gpu_out, sample, max_len, cores, rank, note):
+    """ReTree._matchSA (re2/retree.scala:618-653) in C on this host's cores over the first `sample` regexes of
+    the timed batch, limits not binding, match length capped like the GPU run; result multisets compared."""
+    tables = [t.tables() for t in trees[:sample]]
+    t0 = time.time()
+    want, pops, trunc = orc.match_tables_batch(tables, max_len=max_len, threads=cores)
+    dt = time.time() - t0
+    got = gpu_out[gpu_out["regex"] < sample]
+    ok = got.size == want.size and all(np.array_equal(got[f], want[f]) for f in ("regex", "len", "sp", "ep"))
+    if not ok:
+        raise SystemExit("bench: GPU regex results differ from the CPU oracle on the baseline sample "
+                         "(%d vs %d results)" % (got.size, want.size))
+    log(rank, "cpu_baseline: %d cores, %.2fs for %d regexes (%d getPrevRange steps, %d results), index build %.1fs, parity ok"
+        % (cores, dt, sample, pops, want.size, t_build))
+    return {"value": 2 * pops / dt / 1e6, "unit": "M rank-queries/s", "cores": cores, "kind": "port",
+            "regexes_per_s": sample / dt, "index_build_s": t_build, "n": n,
+            "sample": "%s; first %d regexes of the timed batch; ReTree._matchSA with its priority queue in C, one "
+                      "regex per OpenMP task, limits not binding, match length capped at %d like the GPU run; "
+                      "result multisets bit-equal" % (note, sample, max_len)}
 
-    # this image exports NCCL_DEBUG=VERSION, which makes RCCL print a banner on stdout; stdout carries
-    # the one JSON line, so drop that setting (any other value the user chose is kept)
-    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        del os.environ["NCCL_DEBUG"]
-    import torch
-    import torch.distributed as dist
-    import findex_amd
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(rank, "note: WORLD_SIZE=%d but --gpus=%d; using WORLD_SIZE" % (world, args.gpus))
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    # under torch.distributed.run (RANK/MASTER_* set) the RCCL path runs even for one rank
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
-    if use_dist:
-        dist.init_process_group("nccl", device_id=device)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    log2n, sigma, k, m, seed = WORKLOADS[args.workload]
+# ---------------------------------------------------------------- the two kinds of workload
+def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream):
+    log2n, sigma, k, m, seed = LITERAL[args.workload]
     n = 1 << log2n
     t0 = time.time()
     bwt, eof = make_bwt(torch, n, sigma, seed, device)          # same seed on every rank: replicas
     torch.cuda.synchronize()
     hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=local, stream=stream)
-    del bwt
-    torch.cuda.empty_cache()
     st = hip.stats()
     log(rank, "index: n=2^%d sigma=%d, %.1f GiB in HBM (%d symbols x %d blocks x %d B), built in %.1f ms (+%.1fs setup)"
         % (log2n, sigma, st["index_bytes"] / 2**30, st["n_symbols"], st["n_blocks"], st["block_bytes"],
            st["build_ms"], time.time() - t0))
+    want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
+    if not want_cpu:
+        del bwt
+        torch.cuda.empty_cache()
     pats, off = make_patterns(torch, hip, n, sigma, k, m, seed * 1000 + rank, device, stream)
     # the intervals land in the slots of a pipelined gather: with N > 1 the all-gather of step i (RCCL over
     # xGMI, 16 B per pattern) runs on the collective's stream while step i+1 is being searched
@@ -236,6 +377,7 @@ def main():
     ranks_per_step = int(s1["rank_queries"])
     requests_per_step = int(s1["search_requests"])
     hits = int((sp < ep).sum().item())
+    sp0, ep0 = sp.clone(), ep.clone()
     for _ in range(max(0, args.warmup - 1)):
         step()
     torch.cuda.synchronize()
@@ -272,56 +414,269 @@ def main():
         kernel_ms_max = float(mx[3].item())
     else:
         ranks_all, hits_all, kernel_ms_max = float(ranks_per_step), float(hits), kernel_ms
+    if rank != 0:
+        return None
 
+    # ---- roofline of the one kernel a step launches (k_search4).  Algorithmic bytes of THIS layout per launch:
+    # every memory request for a rank-dictionary line the kernel issued (device counter), at the line's size, plus
+    # the operands it streams: pattern bytes, (k+1) offsets, 16 B of (sp, ep) per pattern.
+    onehot = st["layout"] == 0
+    line_bytes = 64.0 if onehot else 66.0        # bytes layout: a 128-B block and its 4-B checkpoint, one request each
+    operand_bytes = k * m + 8 * (k + 1) + 16 * k
+    alg_bytes = requests_per_step * line_bytes + operand_bytes
+    ksec = kernel_ms * 1e-3
+    achieved = alg_bytes / ksec / 1e9
+    resident = "hbm" if st["index_bytes"] > INFINITY_CACHE_BYTES else "infinity-cache"
+    traffic = pmc_traffic(args.workload, "k_search4")
+    roof = {
+        "bound": "hbm", "kernel": "k_search4",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic[0] if traffic else None,
+        "traffic_source": ("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
+                           % traffic[1]) if traffic else "no PMC profile of this workload committed",
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "algorithmic_bytes": "%d rank-line requests x %g B + %d operand bytes (patterns, offsets, intervals)"
+                             % (requests_per_step, line_bytes, operand_bytes),
+        "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+        "requests_per_launch": requests_per_step, "rank_queries_per_launch": ranks_per_step,
+        "rank_queries_per_request": ranks_per_step / max(requests_per_step, 1),
+        # SURVEY 8d's own pricing (its structure fetches 128/132 B per rank query; this layout does not): reported
+        # for comparison only, it is not a fraction of anything
+        "survey_equiv_GBps": ranks_per_step * survey_bytes_per_rank(sigma) / ksec / 1e9,
+        "index_resident_in": resident,
+    }
+    if resident == "hbm":
+        # the limit that binds this access pattern: distinct dependent memory requests per second
+        roof["requests_G_per_s"] = requests_per_step / ksec / 1e9
+        roof["request_ceiling_G_per_s"] = REQUEST_CEILING_G_PER_S
+        roof["request_frac"] = roof["requests_G_per_s"] / REQUEST_CEILING_G_PER_S
+    else:
+        roof["note"] = ("the rank dictionary (%.0f MB) stays in the 256 MiB Infinity Cache: bytes are served on die, the "
+                        "HBM peak is quoted because the contract asks for it, not because it binds"
+                        % (st["index_bytes"] / 1e6))
+    out = {
+        "metric": "rank_queries_per_sec",
+        "value": ranks_all * args.steps / dt / 1e6,
+        "unit": "M rank-queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "patterns_per_sec": world * k * args.steps / dt,
+        "config": {
+            "workload": "%s: %d x %d-char literal patterns per GPU, 2^%d-byte sigma=%d synthetic BWT resident "
+                        "in HBM (rank dictionary replicated per GPU)" % (args.workload.upper(), k, m, log2n, sigma),
+            "n": n, "sigma": sigma, "patterns_per_gpu": k, "pattern_len": m,
+            "hit_patterns_fraction": hits_all / (world * k),
+            "rank_queries_per_step": ranks_all,
+            "rank_queries_are": "occ evaluations of the reference's loop on these inputs (2 per backward step, early "
+                                "exits counted); the kernel serves them with rank_queries_per_request per memory request",
+            "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
+                           % (world, ", all_gather of (sp,ep) per step overlapped with the next step's search" if use_dist else ""),
+            "ranks_in_group": dist.get_world_size() if use_dist else 1,
+            "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
+            "index_layout": "one-hot bit-vectors, 64-B blocks" if onehot else "BWT bytes + checkpoints",
+        },
+        "roofline": roof,
+    }
+    if want_cpu:
+        cores = effective_cores()
+        sample = min(k, 200_000)
+        orc, t_build = oracle_index(torch, bwt, eof, cores, rank)
+        note = "the timed run's own index (n=2^%d)" % log2n
+        if orc is None:
+            # fallback: the same generator and alphabet at n = 2^27, its own pattern batch of the same shape
+            n_s = 1 << 27
+            bwt_s, eof_s = make_bwt(torch, n_s, sigma, 77, device)
+            hip_s = findex_amd.HipFMSearcher.from_device(bwt_s.data_ptr(), n_s, eof_s, None, device=local, stream=stream)
+            p_s, o_s = make_patterns(torch, hip_s, n_s, sigma, sample, m, 78, device, stream)
+            sp_s = torch.empty(sample, dtype=torch.int64, device=device)
+            ep_s = torch.empty(sample, dtype=torch.int64, device=device)
+            hip_s.search_batch_dev(p_s.data_ptr(), o_s.data_ptr(), sp_s.data_ptr(), ep_s.data_ptr(), sample, stream)
+            torch.cuda.synchronize()
+            orc, t_build = oracle_index(torch, bwt_s, eof_s, cores, rank)
+            out["cpu_baseline"] = cpu_baseline_literal(torch, orc, t_build, n_s, p_s, o_s, sp_s, ep_s, sample, m, cores, rank,
+                                                       "FALLBACK: the host cannot hold the 2^%d-row position list, so the same "
+                                                       "generator and alphabet at n=2^27 with its own pattern batch" % log2n)
+            hip_s.close()
+        else:
+            out["cpu_baseline"] = cpu_baseline_literal(torch, orc, t_build, n, pats, off, sp0, ep0, sample, m, cores, rank, note)
+        orc.close()
+    return out
+
+
+def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream):
+    log2n, k, seed, max_len = REGEX[args.workload]
+    n = 1 << log2n
+    t0 = time.time()
+    bwt, eof = make_bwt(torch, n, C4_ALPHABET, seed, device)
+    torch.cuda.synchronize()
+    hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=local, stream=stream)
+    st = hip.stats()
+    log(rank, "index: n=2^%d sigma=%d, %.1f GiB in HBM, built in %.1f ms (+%.1fs setup)"
+        % (log2n, len(C4_ALPHABET), st["index_bytes"] / 2**30, st["build_ms"], time.time() - t0))
+    want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
+    if not want_cpu:
+        del bwt
+        torch.cuda.empty_cache()
+    t0 = time.time()
+    res, trees = make_regexes(k, seed * 1000 + rank)           # weak scaling: every rank its own k regexes
+    batch = findex_amd.ReTree.prepare_batch(hip, trees)
+    log(rank, "compiled %d regexes and made them resident in %.1fs (host)" % (k, time.time() - t0))
+    cap = 1 << 22
+
+    from findex_amd.distributed import gather_results
+
+    def step():
+        r, per_regex = batch.match_raw(max_steps=max_len, cap=cap)
+        if use_dist:        # the path's one exchange: every rank receives every rank's result list
+            gather_results(r, device)
+        return r, per_regex
+
+    hip.stats_reset()
+    out_res, per = step()
+    s1 = hip.stats()
+    steps_per_call = int(s1["frontier_elements"])
+    ranks_per_step = 2 * steps_per_call
+    n_results = int(out_res.size)
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kms.append(hip.last_kernel_ms())
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = sum(kms) / len(kms)
+    tot = torch.tensor([dt, float(ranks_per_step), float(n_results), kernel_ms], dtype=torch.float64, device=device)
+    if use_dist:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt = float(mx[0].item())
+        ranks_all, results_all, kernel_ms_max = float(sm[1].item()), float(sm[2].item()), float(mx[3].item())
+    else:
+        ranks_all, results_all, kernel_ms_max = float(ranks_per_step), float(n_results), kernel_ms
+    if rank != 0:
+        return None
+    # ---- roofline of the frontier kernels (k_frontier*): bytes this design moves per call, from the device's
+    # own counters: 64 B per rank-line request, 32 B of state record per element stepped, 20 B per work-queue
+    # entry read or appended, 24 B per result written.
+    line_bytes = 64.0 if st["layout"] == 0 else 66.0
+    alg_bytes = (s1["frontier_requests"] * line_bytes + 32.0 * s1["frontier_elements"] +
+                 20.0 * (s1["frontier_queue_reads"] + s1["frontier_queue_writes"]) + 24.0 * s1["frontier_results"])
+    ksec = kernel_ms * 1e-3
+    achieved = alg_bytes / ksec / 1e9
+    traffic = pmc_traffic(args.workload, "k_frontier")
+    roof = {
+        "bound": "hbm", "kernel": "k_frontier* (all device work of one fmx_regex_batch_match: HIP events around the "
+                                   "level launches, host looks between them included)",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic[0] if traffic else None,
+        "traffic_source": ("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
+                           % traffic[1]) if traffic else "no PMC profile of this workload committed",
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "algorithmic_bytes": "%d rank-line requests x %g B + %d elements x 32 B state record + (%d + %d) queue entries x 20 B "
+                             "+ %d results x 24 B" % (s1["frontier_requests"], line_bytes, s1["frontier_elements"],
+                                                      s1["frontier_queue_reads"], s1["frontier_queue_writes"],
+                                                      s1["frontier_results"]),
+        "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+        "requests_per_launch": int(s1["frontier_requests"]), "rank_queries_per_launch": ranks_per_step,
+        "requests_G_per_s": s1["frontier_requests"] / ksec / 1e9,
+        "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S,
+        "request_frac": s1["frontier_requests"] / ksec / 1e9 / REQUEST_CEILING_G_PER_S,
+        "device_rank_queries_G_per_s": ranks_per_step / ksec / 1e9,
+    }
+    out = {
+        "metric": "rank_queries_per_sec",
+        "value": ranks_all * args.steps / dt / 1e6,
+        "unit": "M rank-queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "regexes_per_sec": world * k * args.steps / dt,
+        "config": {
+            "workload": "%s: %d seeded regexes (<= 32 Glushkov positions) per GPU, 2^%d-byte sigma=%d synthetic BWT "
+                        "resident in HBM, SA-interval frontier expansion, results to the host"
+                        % (args.workload.upper(), k, log2n, len(C4_ALPHABET)),
+            "n": n, "sigma": len(C4_ALPHABET), "regexes_per_gpu": k, "max_match_len": max_len,
+            "results_per_call": results_all, "backward_steps_per_call": ranks_all / 2,
+            "truncated_at_max_len": bool(batch.truncated),
+            "parallelism": "regexes sharded over %d GPU(s), index replicated" % world,
+            "ranks_in_group": dist.get_world_size() if use_dist else 1,
+            "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
+        },
+        "roofline": roof,
+    }
+    if want_cpu:
+        cores = effective_cores()
+        sample = min(k, 20_000)
+        orc, t_build = oracle_index(torch, bwt, eof, cores, rank)
+        if orc is not None:
+            out["cpu_baseline"] = cpu_baseline_regex(orc, t_build, n, trees, out_res, sample, max_len, cores, rank,
+                                                     "the timed run's own index (n=2^%d)" % log2n)
+            orc.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(LITERAL) + sorted(REGEX))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="rendezvous + sharding + gather over gloo without any GPU work (tests the launcher)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if args.check_launch:
+        sys.exit(check_launch(args, rank, world))
+
+    # this image exports NCCL_DEBUG=VERSION, which makes RCCL print a banner on stdout; stdout carries
+    # the one JSON line, so drop that setting (any other value the user chose is kept)
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        del os.environ["NCCL_DEBUG"]
+    import torch
+    import torch.distributed as dist
+    import findex_amd
+
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    # under torch.distributed.run (RANK/MASTER_* set) the RCCL path runs even for one rank
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
+        dist.init_process_group("nccl", device_id=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    run = run_regex if args.workload in REGEX else run_literal
+    out = run(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream)
     if rank == 0:
-        bytes_per_rank = survey_bytes_per_rank(sigma)
-        kernel_name = "k_search4"
-        achieved = ranks_per_step * bytes_per_rank / (kernel_ms * 1e-3) / 1e9
-        req_rate = requests_per_step / (kernel_ms * 1e-3) / 1e9
-        out = {
-            "metric": "rank_queries_per_sec",
-            "value": ranks_all * args.steps / dt / 1e6,
-            "unit": "M rank-queries/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u64",
-            "data": "synthetic",
-            "patterns_per_sec": world * k * args.steps / dt,
-            "config": {
-                "workload": "%s: %d x %d-char literal patterns per GPU, 2^%d-byte sigma=%d synthetic BWT resident "
-                            "in HBM (rank dictionary replicated per GPU)" % (args.workload.upper(), k, m, log2n, sigma),
-                "n": n, "sigma": sigma, "patterns_per_gpu": k, "pattern_len": m,
-                "hit_patterns_fraction": hits_all / (world * k),
-                "rank_queries_per_step": ranks_all,
-                "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
-                               % (world, ", all_gather of (sp,ep) per step overlapped with the next step's search" if use_dist else ""),
-                "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
-                "index_layout": "one-hot bit-vectors, 64-B blocks" if st["layout"] == 0 else "BWT bytes + checkpoints",
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": kernel_name,
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (pmc_traffic(args.workload) or (None, None))[0],
-                # the same in bandwidth terms: measured HBM bytes per launch / this run's kernel time, and its
-                # share of the 8 TB/s peak (what the hardware really moved; `frac` above prices SURVEY's 132 B)
-                "traffic_GBps": ((pmc_traffic(args.workload) or (0, None))[0] or 0) / (kernel_ms * 1e-3) / 1e9 or None,
-                "traffic_frac": ((pmc_traffic(args.workload) or (0, None))[0] or 0) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS or None,
-                "traffic_source": (pmc_traffic(args.workload) or (None, "no PMC profile of this workload committed"))[1],
-                "bytes_per_rank_query": bytes_per_rank, "rank_queries_per_launch": ranks_per_step,
-                "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
-                # what the layout really moves and the limit that binds it: distinct memory requests per second
-                "layout_bytes_per_request": 64 if st["layout"] == 0 else 66,
-                "requests_per_launch": requests_per_step, "requests_G_per_s": req_rate,
-                "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S, "request_frac": req_rate / REQUEST_CEILING_G_PER_S,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, hip, sigma, m, device, stream, rank)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

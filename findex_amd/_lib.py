@@ -45,7 +45,10 @@ class fmx_stats_t(ctypes.Structure):
                 ("launches", ctypes.c_uint64), ("last_kernel_ms", ctypes.c_double),
                 ("index_bytes", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("n_symbols", ctypes.c_uint32),
                 ("block_bytes", ctypes.c_uint32), ("build_ms", ctypes.c_double), ("layout", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32), ("search_requests", ctypes.c_uint64)]
+                ("reserved", ctypes.c_uint32), ("search_requests", ctypes.c_uint64),
+                ("frontier_requests", ctypes.c_uint64), ("frontier_elements", ctypes.c_uint64),
+                ("frontier_queue_reads", ctypes.c_uint64), ("frontier_queue_writes", ctypes.c_uint64),
+                ("frontier_results", ctypes.c_uint64), ("reserved2", ctypes.c_uint64 * 3)]
 
 
 # name -> (restype, argtypes); every symbol include/fmx.h declares
@@ -94,6 +97,7 @@ SYMBOLS = {
     "fmx_regex_batch_match": (_i32, [_vp, _vp, _vp, _vp, _sz, _P(_sz), _vp]),
     "fmx_stats": (_i32, [_vp, _P(fmx_stats_t)]),
     "fmx_stats_reset": (_i32, [_vp]),
+    "fmx_last_kernel_ms": (_i32, [_vp, _P(ctypes.c_double)]),
 }
 
 _lib = None

@@ -3,6 +3,7 @@
 #include <fmx.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -24,8 +25,9 @@ int hip_fail(hipError_t e, const char *what) {
   return FMX_ERR_HIP;
 }
 
-static int g_layout_pref = -1;
-int layout_preference() { return g_layout_pref; }
+static std::atomic<int> g_layout_pref{-1};       // fmx_config_set may race with fmx_open* on other threads
+int layout_preference() { return g_layout_pref.load(std::memory_order_relaxed); }
+static std::atomic<uint64_t> g_serial{0};
 
 static int arg_fail(const char *msg) {
   g_err = msg;
@@ -240,7 +242,6 @@ static void destroy(Index *h) {
   if (h->d_slot) (void)hipFree(h->d_slot);
   if (h->d_counters) (void)hipFree(h->d_counters);
   for (CallCtx *c : h->ctx_pool) free_ctx(c);
-  if (h->d_desc) (void)hipFree(h->d_desc);
   delete h;
 }
 
@@ -259,6 +260,7 @@ static int open_common(const void *src, bool src_on_device, FILE *src_file, uint
   HIP_TRY(hipSetDevice(device), "hipSetDevice");
   Index *h = new (std::nothrow) Index();
   if (!h) { g_err = "out of host memory"; return FMX_ERR_NOMEM; }
+  h->serial = ++g_serial;
   h->device = device;
   h->n = n;
   h->eof = eof;
@@ -383,9 +385,9 @@ int fmx_abi_version(void) { return FMX_ABI_VERSION; }
 int fmx_config_set(const char *key, const char *value) {
   if (!key || !value) return arg_fail("null argument");
   if (std::strcmp(key, "layout") == 0) {
-    if (std::strcmp(value, "auto") == 0) g_layout_pref = -1;
-    else if (std::strcmp(value, "onehot") == 0) g_layout_pref = (int)kLayoutOneHot;
-    else if (std::strcmp(value, "bytes") == 0) g_layout_pref = (int)kLayoutBytes;
+    if (std::strcmp(value, "auto") == 0) g_layout_pref.store(-1);
+    else if (std::strcmp(value, "onehot") == 0) g_layout_pref.store((int)kLayoutOneHot);
+    else if (std::strcmp(value, "bytes") == 0) g_layout_pref.store((int)kLayoutBytes);
     else return arg_fail("layout must be auto, onehot or bytes");
     return FMX_OK;
   }
@@ -727,13 +729,14 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
-  unsigned long long cnt[4] = {0, 0, 0, 0};
+  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::memset(out, 0, sizeof *out);
   HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   {   // the counters live in per-workgroup slots (fmx_device.h): sum them
     std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
     HIP_TRY(hipMemcpy(slots.data(), h->d_counters, kCounterBytes, hipMemcpyDeviceToHost), "D2H(counters)");
     for (uint32_t sl = 0; sl < kCounterSlots; sl++)
-      for (int j = 0; j < 3; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
+      for (int j = 0; j < 8; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
   }
   std::lock_guard<std::mutex> lk(h->mu);
   out->rank_queries = cnt[0];
@@ -746,7 +749,20 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->block_bytes = h->layout == kLayoutBytes ? kByteBlock + 4 : kBlockBytes;
   out->layout = h->layout;
   out->search_requests = cnt[2];
+  out->frontier_requests = cnt[3];
+  out->frontier_queue_writes = cnt[4];
+  out->frontier_results = cnt[5];
+  out->frontier_elements = cnt[6];
+  out->frontier_queue_reads = cnt[7];
   out->build_ms = h->build_ms;
+  return FMX_OK;
+}
+
+int fmx_last_kernel_ms(const fmx_index *idx, double *ms) {
+  if (!idx || !ms) return arg_fail("null argument");
+  const Index *h = H(idx);
+  std::lock_guard<std::mutex> lk(h->mu);
+  *ms = h->last_kernel_ms;
   return FMX_OK;
 }
 

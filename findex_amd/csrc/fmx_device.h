@@ -275,25 +275,26 @@ __device__ __forceinline__ uint64_t rank_excl(const DevIndex &ix, uint32_t c, ui
 // One backward step for the whole lane group: (sp, ep) -> (C[c]+rank(c,sp), C[c]+rank(c,ep)), the
 // body of SuffixAlgo.getPrevRange (findex.scala:32-36).  All lines are requested before any is consumed;
 // when sp and ep fall into the same block (narrow intervals: most steps of a search or a regex frontier)
-// the block is requested once.
+// the block is requested once.  Returns the number of memory requests for rank-dictionary lines it made.
 template <bool WIDE, uint32_t LAYOUT>
-__device__ __forceinline__ void backward_step(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t cfc,
-                                              const LaneConst &lc, uint64_t &sp, uint64_t &ep) {
+__device__ __forceinline__ uint32_t backward_step(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t cfc,
+                                                  const LaneConst &lc, uint64_t &sp, uint64_t &ep) {
   if (slot >= kSlotEof) {                       // absent symbol, or the EOF symbol 0
     const uint64_t r1 = (slot == kSlotEof && sp > ix.eof) ? 1 : 0;
     const uint64_t r2 = (slot == kSlotEof && ep > ix.eof) ? 1 : 0;
     sp = cfc + r1;
     ep = cfc + r2;
-    return;
+    return 0;
   }
   if (LAYOUT == kLayoutBytes) {
     const ByteRankReq q1 = byte_rank_issue(ix, slot, sp, lc);
     ByteRankReq q2 = q1;
-    if ((ep >> 7) != (sp >> 7)) q2 = byte_rank_issue(ix, slot, ep, lc);
+    const bool two = (ep >> 7) != (sp >> 7);
+    if (two) q2 = byte_rank_issue(ix, slot, ep, lc);
     else q2.rem = (uint32_t)ep & 127u;
     sp = cfc + byte_rank_finish(q1, c, lc);
     ep = cfc + byte_rank_finish(q2, c, lc);
-    return;
+    return two ? 4u : 2u;                        // block line + checkpoint line per distinct block
   }
   uint32_t b1, b2, m1, m2;
   split448(sp, b1, m1);
@@ -303,6 +304,7 @@ __device__ __forceinline__ void backward_step(const DevIndex &ix, uint32_t c, ui
   if (b2 != b1) w2 = load_line16(block_addr(ix, slot, b2, lc));
   sp = cfc + rank_finish<WIDE>(w1, m1, lc);
   ep = cfc + rank_finish<WIDE>(w2, m2, lc);
+  return b2 != b1 ? 2u : 1u;
 }
 
 // ---- statistics counters without a hot spot.  Same-address device atomics complete at roughly 100
@@ -311,7 +313,9 @@ __device__ __forceinline__ void backward_step(const DevIndex &ix, uint32_t c, ui
 // counters are kCounterSlots 128-byte slots, a workgroup adds to slot blockIdx.x % kCounterSlots
 // (one atomic per wave and counter after a wave-level reduction), and the host sums the slots.
 constexpr uint32_t kCounterSlots = 2048;
-constexpr uint32_t kCounterStride = 16;        // uint64 per slot: [0] rank queries, [1] backward steps, [2] search requests
+constexpr uint32_t kCounterStride = 16;        // uint64 per slot: [0] rank queries, [1] backward steps, [2] search requests,
+                                               // frontier kernels: [3] rank-line requests, [4] queue appends, [5] results,
+                                               // [6] elements stepped, [7] queue entries read
 constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterStride * 8;
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -331,6 +335,25 @@ __device__ __forceinline__ void counters_add(unsigned long long *__restrict__ co
     if (ranks) atomicAdd(slot + 0, ranks);
     if (steps) atomicAdd(slot + 1, steps);
     if (reqs) atomicAdd(slot + 2, reqs);
+  }
+}
+
+// The frontier kernels' own counters (slots 3..7), same calling rule.
+__device__ __forceinline__ void counters_add_frontier(unsigned long long *__restrict__ counters, unsigned long long reqs,
+                                                      unsigned long long pushes, unsigned long long results,
+                                                      unsigned long long elems, unsigned long long reads) {
+  reqs = wave_sum(reqs);
+  pushes = wave_sum(pushes);
+  results = wave_sum(results);
+  elems = wave_sum(elems);
+  reads = wave_sum(reads);
+  if ((threadIdx.x & 63u) == 0) {
+    unsigned long long *slot = counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride;
+    if (reqs) atomicAdd(slot + 3, reqs);
+    if (pushes) atomicAdd(slot + 4, pushes);
+    if (results) atomicAdd(slot + 5, results);
+    if (elems) atomicAdd(slot + 6, elems);
+    if (reads) atomicAdd(slot + 7, reads);
   }
 }
 

@@ -37,6 +37,10 @@ struct Queue {           // SoA frontier queue in HBM; every element of a level 
   uint64_t *ep;
 };
 
+struct FStat {           // per-lane partial sums for the frontier counters (fmx_device.h, slots 3..7)
+  uint32_t reqs = 0, pushes = 0, emits = 0, reads = 0;
+};
+
 constexpr uint32_t kStageCap = 192;     // survivors a wave stages in LDS before reserving queue slots
 constexpr uint32_t kStageSmall = 12;    // follows lists up to this length go through the stage (16 groups x 12 <= cap)
 
@@ -97,7 +101,7 @@ __device__ __forceinline__ void frontier_slice(const DevIndex &ix, const NfaTabl
                                                uint64_t seg_cap, FrontierCtl *__restrict__ ctl, const uint64_t *s_cf,
                                                const uint16_t *s_slot, Stage &stg, uint32_t w, uint32_t sub,
                                                uint64_t part, uint64_t nparts, uint64_t cur_count, uint32_t &appends,
-                                               uint32_t &stepped, const uint64_t *s_prefix = nullptr) {
+                                               uint32_t &stepped, FStat &fs, const uint64_t *s_prefix = nullptr) {
   constexpr int G = Lay<LAYOUT>::G;
   constexpr uint32_t P = 64 / G;             // elements per wave and round
   const LaneConst lc = lane_const<G>();
@@ -177,15 +181,18 @@ __device__ __forceinline__ void frontier_slice(const DevIndex &ix, const NfaTabl
         if (slot == kSlotNone) ep = sp;
         else if (slot == kSlotEof) ep = sp + 1;
       } else {
-        backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
+        fs.reqs += backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
       }
       stepped++;
+      fs.reads++;
       if (sp < ep) {                                   // Some((sp1,ep1)), retree.scala:634
         // Glushkov tables: an isLast state emits and has no follows here (:636-641); Thompson / DFA
         // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282)
         emit = (rec0.c_emit >> 8) != 0;
         f0 = rec0.fol_off;
         nf = rec0.fol_cnt;
+        fs.pushes += nf;
+        fs.emits += emit ? 1u : 0u;
       }
     }
     // ---- compaction.  Results: ballot + one atomic per wave (they are few).  Pushes: a single
@@ -285,11 +292,14 @@ __global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables n
   const uint32_t sub = w % kSub;             // the slice this wave reads
   const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
   uint32_t appends = 0, stepped = 0;
+  FStat fs;
   frontier_slice<WIDE, LAYOUT>(ix, nfa, cur, nxt, level, sub_cap, res, seg_cap, ctl, s_cf, s_slot,
                                s_stage[threadIdx.x >> 6], w, sub, w / kSub, class_waves, ctl->count[level % 3][sub].v,
-                               appends, stepped);
+                               appends, stepped, fs);
   const uint32_t t = threadIdx.x & (Lay<LAYOUT>::G - 1);
   counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
+  counters_add_frontier(counters, t == 0 ? fs.reqs : 0u, t == 0 ? fs.pushes : 0u, t == 0 ? fs.emits : 0u,
+                        t == 0 ? stepped : 0u, t == 0 ? fs.reads : 0u);
 }
 
 // Closes a chain of grid launches: the next chain starts `by` levels further.
@@ -341,6 +351,7 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t grp = threadIdx.x / G;                   // this lane group's number in the workgroup
   uint32_t appends = 0, stepped = 0;
+  FStat fs;
   uint32_t level = level0, reason = 1, pending = 0;
   while (level < max_level) {
     // lane j reads slice j's count (coherent load: other waves' atomics produced it).  Wave 0 decides for the
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
       // ---- a level through the global queues
       if (threadIdx.x < kSub) __hip_atomic_store(&ctl->count[(level + 2) % 3][threadIdx.x].v, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       frontier_slice<WIDE, LAYOUT, true>(ix, nfa, cur, nxt, level, sub_cap, res, seg_cap, ctl, s_cf, s_slot, s_stage[w], w, 0,
-                                         w, nw, s_prefix[kSub], appends, stepped, s_prefix);
+                                         w, nw, s_prefix[kSub], appends, stepped, fs, s_prefix);
       // level boundary.  The appends of this level were made by waves of this workgroup: draining the stores
       // (workgroup-scope release) makes them reach L2; the acquire invalidates this CU's L1, which may still
       // hold lines of the queue buffer from two levels ago.
@@ -430,13 +441,14 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
           if (slot == kSlotNone) ep = sp;
           else if (slot == kSlotEof) ep = sp + 1;
         } else {
-          backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
+          fs.reqs += backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
         }
         stepped++;
         if (sp < ep) {
           emit = (ra.w >> 8) != 0;
           f0 = ra.x;
           nf = ra.y;
+          fs.emits += emit ? 1u : 0u;
           inl[0] = rb.x; inl[1] = rb.y; inl[2] = rb.z; inl[3] = rb.w;
         }
       }
@@ -513,6 +525,8 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
   }
   if (threadIdx.x == 0) { ts->level = level; ts->reason = reason; ts->pending = pending; ctl->level_base = level; }
   counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
+  counters_add_frontier(counters, t == 0 ? fs.reqs : 0u, t == 0 ? fs.pushes : 0u, t == 0 ? fs.emits : 0u,
+                        t == 0 ? stepped : 0u, t == 0 ? fs.reads : 0u);
 }
 
 // result groups the device leaves to the host (k_res_sort)
@@ -552,6 +566,8 @@ struct RegexBatch {
   int device = 0;
   size_t k = 0;
   uint64_t n_index = 0;
+  uint64_t index_serial = 0;           // the fmx_index this batch was made for (Index::serial): its pointers are inside the
+                                       // captured level chain, so no other handle may match against the batch
   size_t n_first = 0;
   std::vector<uint32_t> start_final;   // DFA engines whose start state is final: result (len 0, 0, n)
   DevMem mem;
@@ -626,6 +642,7 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   b->device = h->device;
   b->k = k;
   b->n_index = h->n;
+  b->index_serial = h->serial;
   b->n_first = q_state.size();
   b->start_final = start_final;
   b->max_fanout = max_fanout;
@@ -774,7 +791,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   };
   const uint32_t max_steps = (lim && lim->max_steps) ? lim->max_steps : 4096u;
   const uint64_t qcap = (lim && lim->max_frontier) ? lim->max_frontier : (1ull << 22);
-  if (b->device != h->device || b->n_index != h->n) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
+  if (b->index_serial != h->serial) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
   if (per_regex_count) std::fill(per_regex_count, per_regex_count + b->k, 0u);
   *n_out = 0;
   if (b->n_first == 0 && b->start_final.empty()) return FMX_OK;
@@ -783,12 +800,12 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // slices: each holds its share of max_frontier plus a quarter of headroom (appends rotate over the slices,
   // so they fill evenly, not exactly); the result segments get 4x their share
   const uint64_t sub_cap = (qcap + kSub - 1) / kSub + qcap / (4 * kSub) + 1024;
-  const uint64_t seg_cap = (uint64_t)cap / 16 + 1024;
   if (!b->scratch || b->qcap != qcap || b->rcap < (cap ? cap : 1)) {
     b->scratch.reset(new DevMem());
     b->qcap = 0;
     if (b->chain_exec) { (void)hipGraphExecDestroy(b->chain_exec); b->chain_exec = nullptr; }   // it holds the old pointers
     if (!b->h_ctl) HIP_TRY(hipHostMalloc((void **)&b->h_ctl, sizeof(FrontierCtl), hipHostMallocDefault), "hipHostMalloc(ctl)");
+    const uint64_t seg_cap = (uint64_t)(cap ? cap : 1) / 16 + 1024;
     for (Queue *q : {&b->qa, &b->qb}) {
       HIP_TRY(b->scratch->alloc(&q->state, kSub * sub_cap), "hipMalloc(queue)");
       HIP_TRY(b->scratch->alloc(&q->sp, kSub * sub_cap), "hipMalloc(queue)");
@@ -806,6 +823,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     b->qcap = qcap;
     b->rcap = cap ? cap : 1;
   }
+  // Slice capacity of the result buffer: a function of the ALLOCATED size, so that it stays what the captured
+  // level chain was recorded with when a later call passes a smaller cap (the scratch is kept then).
+  const uint64_t seg_cap = (uint64_t)b->rcap / 16 + 1024;
   const Queue qa = b->qa, qb = b->qb;
   fmx_result *d_res = b->d_res;
   fmx_result *d_res_seg = b->d_res_seg;
@@ -1106,7 +1126,7 @@ int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *b, const fmx_li
       set_error("the reference-order mode replays ReTree._matchSA; Thompson and DFA handles use the frontier mode");
       return FMX_ERR_UNSUPPORTED;
     }
-    if (rb->device != h->device || rb->n_index != h->n) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
+    if (rb->index_serial != h->serial) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
     const RefTables rt{rb->nfa.st, rb->nfa.fol, rb->d_st_num, rb->d_first_off, rb->d_first_state};
     return regex_match_reference(h, rt, rb->k, rb->max_fanout, lim->max_branching, lim->max_iterations, out, cap, n_out,
                                  per_regex_count, nullptr);

@@ -26,6 +26,7 @@ struct CallCtx {
 };
 
 struct Index {
+  uint64_t serial = 0;          // unique per open in this process: what a resident regex batch remembers of its index
   int device = 0;
   int cu_count = 256;
   uint64_t n = 0, eof = 0, nblocks = 0;
@@ -41,19 +42,13 @@ struct Index {
   void *d_bwt = nullptr;
   void *d_cf = nullptr;
   void *d_slot = nullptr;
-  unsigned long long *d_counters = nullptr;   // [0] rank queries, [1] backward steps
+  unsigned long long *d_counters = nullptr;   // kCounterSlots slots of kCounterStride counters (fmx_device.h)
   DevIndex dev{};
   uint64_t index_bytes = 0;
   double build_ms = 0.0;
   // host-call bookkeeping
   mutable std::mutex mu;
   mutable std::vector<CallCtx *> ctx_pool;      // idle call contexts (guarded by mu)
-  // descriptor scratch of the literal search, reused by consecutive calls on one stream (stream order keeps
-  // them apart); a call on another stream while it is taken allocates its own (guarded by mu)
-  mutable void *d_desc = nullptr;
-  mutable size_t desc_cap = 0;
-  mutable hipStream_t desc_stream = nullptr;
-  mutable bool desc_used = false;
   mutable uint64_t launches = 0;
   mutable double last_kernel_ms = 0.0;
 };

@@ -5,8 +5,10 @@
 // (c, ep) and turns them into the next interval; the only dependent chain is block -> popcount ->
 // next block address.  What the kernel does so that nothing else sits on that chain:
 //   * pattern bytes are read 4 at a time, two dwords ahead, with branch-free address arithmetic; the
-//     descriptor of the pattern a group takes next (end offset, length, last 4 bytes; written by the
-//     k_prep pre-pass) is requested one whole batch earlier;
+//     pattern a group takes next is prepared while the current batch is searched: its offsets are
+//     requested two batches ahead and its last 4 bytes (which depend on the offsets) one batch ahead
+//     (round 1 did this with a pre-pass kernel that wrote 16-byte descriptors: one more launch, 32 bytes
+//     of traffic per pattern and a scratch buffer whose ownership had to be tracked per stream);
 //   * C[] and each symbol's bit-vector base address sit in LDS as one 16-byte entry per symbol;
 //   * the rank primitive of fmx_device.h (5 vector instructions per payload dword).
 // History (profiles/): the first version (FMX_SEARCH_VARIANT=1, fmx_kernels.hip) ran about
@@ -25,12 +27,6 @@ namespace fmx {
 
 constexpr int kSThreads = 256;
 
-struct PatDesc {      // 16 bytes, one per pattern
-  uint64_t end;       // offset one past the pattern's last byte
-  uint32_t len;
-  uint32_t tail4;     // byte j = pat[end-1-j] (the first four bytes the search consumes)
-};
-
 // Bytes pat[pos-1], pat[pos-2], pat[pos-3], pat[pos-4] in byte lanes 0..3 (fewer when pos < 4).
 __device__ __forceinline__ uint32_t fetch4(const uint8_t *__restrict__ pat, uint64_t pos) {
   if (pos >= 4) {
@@ -41,20 +37,6 @@ __device__ __forceinline__ uint32_t fetch4(const uint8_t *__restrict__ pat, uint
   uint32_t r = 0;
   for (uint32_t j = 0; j < (uint32_t)pos; j++) r |= (uint32_t)pat[pos - 1 - j] << (8 * j);
   return r;
-}
-
-// Pre-pass: one descriptor per pattern.
-__global__ __launch_bounds__(256) void k_prep(const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
-                                               PatDesc *__restrict__ desc, uint32_t k) {
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < k; q += stride) {
-    const uint64_t b = off[q], e = off[q + 1];
-    PatDesc d;
-    d.end = e;
-    d.len = (uint32_t)(e - b);
-    d.tail4 = d.len ? fetch4(pat, e) : 0;
-    desc[q] = d;
-  }
 }
 
 // ---------------------------------------------------------------- lockstep batches + single-row step
@@ -73,8 +55,8 @@ __global__ __launch_bounds__(256) void k_prep(const uint8_t *__restrict__ pat, c
 
 // Chunk j of a pattern = its bytes pat[end-1-4j-i], i = 0..3, in byte lanes 0..3: the four bytes the
 // search consumes at steps 4j..4j+3.  Branch-free; lanes whose pattern has no such chunk read their
-// own descriptor instead (any valid address: the value is never used).
-__device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, const PatDesc *__restrict__ own,
+// own offset entry instead (any valid address: the value is never used).
+__device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, const uint64_t *__restrict__ own,
                                               uint64_t end, uint32_t len, uint32_t j) {
   const uint32_t have = len > 4u * j ? len - 4u * j : 0u;     // pattern bytes left at chunk j
   const uint64_t pos = end - 4ull * j;                        // valid when have > 0 (then pos >= have >= 1)
@@ -91,7 +73,7 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 
 template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_t *__restrict__ pat,
-                                                        const PatDesc *__restrict__ desc,
+                                                        const uint64_t *__restrict__ off,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
                                                         uint32_t k, unsigned long long *__restrict__ counters) {
   constexpr int G = Lay<LAYOUT>::G;              // lanes per pattern
@@ -117,21 +99,34 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_
   const uint32_t grp = (threadIdx.x & 63) / G;
   const uint32_t nbatch = (k + P - 1) / P;
   uint32_t steps = 0, reqs = 0;     // reqs: memory requests for rank-dictionary lines (counters[2])
-  PatDesc nd;
-  nd.end = 0; nd.len = 0; nd.tail4 = 0;
-  if (wave < nbatch && wave * P + grp < k) nd = desc[wave * P + grp];
+  // Pattern pipeline, three batches deep: (end, len, tail4) of the batch being searched; (end, len) of the
+  // next one, whose tail4 -- the last four pattern bytes, an address that depends on the offsets -- is
+  // requested when this batch starts; and the offsets of the batch after that.  Nothing of it sits on the
+  // search's dependent chain except in the wave's very first batch.
+  auto load_off = [&](uint64_t bt, uint64_t &e, uint32_t &len) {
+    const uint64_t pid = bt * P + grp;
+    e = 0; len = 0;
+    if (pid < k) {
+      const uint64_t b = off[pid];
+      e = off[pid + 1];
+      len = (uint32_t)(e - b);
+    }
+  };
+  uint64_t end0, end1, end2;
+  uint32_t len0, len1, len2, tail0;
+  load_off(wave, end0, len0);
+  tail0 = len0 ? fetch4(pat, end0) : 0u;
+  load_off((uint64_t)wave + nwaves, end1, len1);
   for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
     const uint32_t pid = batch * P + grp;
     const bool act = pid < k;
-    const PatDesc *own = desc + (act ? pid : 0u);
-    const uint64_t end = nd.end;
-    const uint32_t len = act ? nd.len : 0u;
-    uint32_t ch = nd.tail4;                                   // chunk 0
+    const uint64_t *own = off + (act ? pid : 0u);
+    const uint64_t end = end0;
+    const uint32_t len = act ? len0 : 0u;
+    uint32_t ch = tail0;                                      // chunk 0
     uint32_t nx = pat_chunk(pat, own, end, len, 1);           // chunk 1, wanted from step 4 on
-    {
-      const uint64_t np = (uint64_t)(batch + nwaves) * P + grp;     // descriptor of the next batch
-      if (np < k) nd = desc[np];
-    }
+    const uint32_t tail1 = len1 ? fetch4(pat, end1) : 0u;     // the next batch's chunk 0
+    load_off((uint64_t)batch + 2ull * nwaves, end2, len2);
     uint64_t sp = 0, ep = ix.n;
     // symbols without a vector: absent (x = 0) or the EOF symbol (x = 1)
     auto special = [&](uint64_t cfc, uint64_t vb, uint64_t x) { return cfc + ((vb == 1 && x > ix.eof) ? 1u : 0u); };
@@ -220,6 +215,8 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_
       }
     }
     if (act && t == 0) { sp_out[pid] = sp; ep_out[pid] = ep; }
+    end0 = end1; len0 = len1; tail0 = tail1;
+    end1 = end2; len1 = len2;
   }
   counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
 }
@@ -247,56 +244,27 @@ static int blocks_per_cu(K kernel) {
 }
 
 template <bool WIDE, uint32_t LAYOUT>
-static hipError_t launch_v4(const Index *h, const uint8_t *pat, const PatDesc *desc, uint64_t *sp, uint64_t *ep,
+static hipError_t launch_v4(const Index *h, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
                             uint32_t k, hipStream_t st) {
   static const int per_cu = blocks_per_cu(k_search4<WIDE, LAYOUT>);
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search4<WIDE, LAYOUT><<<grid, kSThreads, 0, st>>>(h->dev, pat, desc, sp, ep, k, h->d_counters);
+  k_search4<WIDE, LAYOUT><<<grid, kSThreads, 0, st>>>(h->dev, pat, off, sp, ep, k, h->d_counters);
   return hipGetLastError();
 }
 
+// One launch per call: no scratch, nothing to own per stream, so concurrent calls on one handle need no lock.
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
                          hipStream_t st) {
   if (!k) return hipSuccess;
   if (search_variant() == 1 || k > 0xFFFFFFF0ull) return launch_search_v1(h, d_pat, d_off, d_sp, d_ep, k, st);
-  // Descriptor scratch: the handle's buffer when this stream is its user (consecutive calls on one stream are
-  // ordered by the stream; a stream-ordered allocation per call cost ~16 us of idle GPU between calls),
-  // a stream-ordered allocation otherwise.
-  PatDesc *desc = nullptr;
-  bool own_alloc = false;
   hipError_t e = hipSuccess;
-  {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->desc_used || h->desc_stream == st) {
-      const size_t need = k * sizeof(PatDesc);
-      if (h->desc_cap < need) {
-        if (h->d_desc) { (void)hipFree(h->d_desc); h->d_desc = nullptr; h->desc_cap = 0; }     // hipFree waits for the device
-        e = hipMalloc(&h->d_desc, need + need / 4);
-        if (e == hipSuccess) h->desc_cap = need + need / 4;
-      }
-      if (e == hipSuccess) { desc = static_cast<PatDesc *>(h->d_desc); h->desc_stream = st; h->desc_used = true; }
-    }
-  }
-  if (e != hipSuccess) return e;
-  if (!desc) {
-    e = hipMallocAsync((void **)&desc, k * sizeof(PatDesc), st);
-    if (e != hipSuccess) return e;
-    own_alloc = true;
-  }
-  int pg = (int)((k + 255) / 256);
-  if (pg > h->cu_count * 8) pg = h->cu_count * 8;
-  k_prep<<<pg, 256, 0, st>>>((const uint8_t *)d_pat, (const uint64_t *)d_off, desc, (uint32_t)k);
-  e = hipGetLastError();
-  if (e == hipSuccess) {
-#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, desc, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st)
-    FMX_LAYOUT_DISPATCH(h, CALL);
+#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, (const uint64_t *)d_off, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st)
+  FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
-  }
-  const hipError_t e2 = own_alloc ? hipFreeAsync(desc, st) : hipSuccess;
-  return e != hipSuccess ? e : e2;
+  return e;
 }
 
 }  // namespace fmx

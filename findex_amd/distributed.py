@@ -88,36 +88,68 @@ def search_batch_sharded(searcher, pat, off, group=None):
     return np.concatenate(sps), np.concatenate(eps)
 
 
-def match_batch_sharded(sa, trees, group=None, match_fn=None, **kw):
-    """ReTree.matchSA over a regex batch sharded by regex index; results come back per regex, as
-    (len, sp, ep) tuples, on every rank.  `match_fn(sa, trees_slice)` defaults to the GPU frontier
-    search (ReTree.matchSA_batch); it returns, per regex, objects with .len/.sp/.ep or tuples."""
+RESULT_DTYPE = np.dtype([("regex", np.uint32), ("len", np.uint32), ("sp", np.uint64), ("ep", np.uint64)])
+
+
+def work_bounds(weights, world):
+    """Cut k regexes into `world` contiguous slices of about equal total weight (an estimate of each regex's
+    frontier work: SURVEY.md 8e).  Returns world+1 indices."""
+    w = np.asarray(weights, dtype=np.float64)
+    k = w.size
+    if k == 0:
+        return [0] * (world + 1)
+    cum = np.cumsum(np.maximum(w, 1e-9))
+    # slice r ends with the first regex that brings the running weight to r/world of the total
+    cuts = [0] + [min(k, int(np.searchsorted(cum, cum[-1] * r / world, side="left")) + 1) for r in range(1, world)] + [k]
+    for r in range(1, world + 1):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return cuts
+
+
+def gather_results(res, device=None, group=None):
+    """The regex path's exchange: every rank contributes its result list (structured array, 24 bytes per
+    result) and receives all of them, concatenated in rank order.  Two collectives: the sizes, then the payload
+    padded to the longest list (all_gather_varlen)."""
+    rank, world = _group_info(group)
+    res = np.ascontiguousarray(res, dtype=RESULT_DTYPE)
+    if world == 1:
+        return res
+    t = torch.from_numpy(res.view(np.int64).reshape(-1).copy())      # 3 words per result, same bits
+    if dist.get_backend(group) == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    parts = [p.cpu().numpy().view(RESULT_DTYPE) for p in all_gather_varlen(t, group)]
+    return np.concatenate(parts)
+
+
+def group_results(res, k):
+    """Structured result array -> k lists of (len, sp, ep) tuples, by regex id (array operations only)."""
+    res = res[np.argsort(res["regex"], kind="stable")]
+    bounds = np.searchsorted(res["regex"], np.arange(k + 1))
+    cols = np.stack([res["len"].astype(np.uint64), res["sp"], res["ep"]], axis=1)
+    return [list(map(tuple, cols[bounds[r]:bounds[r + 1]].tolist())) for r in range(k)]
+
+
+def match_batch_sharded(sa, trees, group=None, match_fn=None, weights=None, **kw):
+    """ReTree.matchSA over a regex batch sharded across the ranks: contiguous slices balanced by `weights`
+    (estimated frontier work per regex; by count when None), each rank matches its slice, one gather of the
+    result lists.  Returns the structured array of all results, regex ids global, on every rank.
+    `match_fn(sa, trees_slice)` defaults to the GPU frontier search on a resident batch; it returns a structured
+    array with slice-local regex ids (or, per regex, a list of (len, sp, ep) tuples / SAResult objects)."""
     if match_fn is None:
         from .regex import ReTree
 
         def match_fn(sa_, ts):
-            return ReTree.matchSA_batch(sa_, ts, **kw)
+            return ReTree.prepare_batch(sa_, ts).match_raw(**kw)[0]
     rank, world = _group_info(group)
     k = len(trees)
-    cuts = [(k * r) // world for r in range(world + 1)]
+    cuts = work_bounds(weights if weights is not None else np.ones(k), world)
     mine = match_fn(sa, trees[cuts[rank]:cuts[rank + 1]])
-    flat = []
-    for j, res in enumerate(mine):
-        for r in res:
-            ln, a, b = (r.len, r.sp, r.ep) if hasattr(r, "len") else r
-            flat += [cuts[rank] + j, ln, a if a < 2**63 else a - 2**64, b if b < 2**63 else b - 2**64]
-    if world == 1:
-        parts = [np.asarray(flat, dtype=np.int64)]
-    else:
-        t = torch.tensor(flat, dtype=torch.int64)
-        if dist.get_backend(group) == "nccl":
-            t = t.to(torch.device("cuda", torch.cuda.current_device()))
-        parts = [p.cpu().numpy() for p in all_gather_varlen(t, group)]
-    out = [[] for _ in range(k)]
-    for p in parts:
-        for q in p.reshape(-1, 4):
-            out[int(q[0])].append((int(q[1]), int(q[2]) & (2**64 - 1), int(q[3]) & (2**64 - 1)))
-    return out
+    if not isinstance(mine, np.ndarray):      # per-regex lists (CPU stand-ins in the tests)
+        rows = [(j, r.len, r.sp, r.ep) if hasattr(r, "len") else (j,) + tuple(r) for j, res in enumerate(mine) for r in res]
+        mine = np.array(rows, dtype=RESULT_DTYPE) if rows else np.zeros(0, dtype=RESULT_DTYPE)
+    mine = mine.copy()
+    mine["regex"] += np.uint32(cuts[rank])
+    return gather_results(mine, group=group)
 
 
 def gather_intervals_dev(sp, ep, group=None):

@@ -247,5 +247,10 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_stats(self._h, ctypes.byref(s)))
         return {f: getattr(s, f) for f, _ in s._fields_}
 
+    def last_kernel_ms(self):
+        v = ctypes.c_double()
+        _lib.check(self._L.fmx_last_kernel_ms(self._h, ctypes.byref(v)))
+        return float(v.value)
+
     def stats_reset(self):
         _lib.check(self._L.fmx_stats_reset(self._h))

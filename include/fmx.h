@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 1
+#define FMX_ABI_VERSION 2
 
 enum {
   FMX_OK = 0,
@@ -245,9 +245,15 @@ int fmx_regex_batch_free(fmx_regex_batch *batch);
 int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *batch, const fmx_limits *lim, fmx_result *out,
                           size_t cap, size_t *n_out, uint32_t *per_regex_count);
 
-/* ---- statistics (since open or the last reset; device counters are read with a sync) */
+/* ---- statistics (since open or the last reset; device counters are read with a sync).
+ * rank_queries counts occ(c,i) evaluations in the REFERENCE's terms: two per backward step (findex.scala:26-27,
+ * 32-36), one per occ_batch operand or LF step -- the number the Scala path would execute on the same inputs
+ * (early exits included), which is what the CPU oracle counts too.  The kernels do less memory work than that:
+ * a search's first step needs no block, narrow intervals share one, a single-row step needs one; what they
+ * really asked of memory is in the *_requests fields (64-byte one-hot blocks, or in the bytes layout 128-byte
+ * BWT blocks and their 4-byte checkpoints, one request each). */
 typedef struct fmx_stats_t {
-  uint64_t rank_queries;     /* occ evaluations actually executed on the device */
+  uint64_t rank_queries;     /* occ evaluations the executed steps stand for (see above) */
   uint64_t backward_steps;   /* getPrevRange-equivalents executed (2 rank queries each) */
   uint64_t launches;         /* kernels launched by this handle */
   double last_kernel_ms;     /* device time of the last host-pointer call's kernel(s), HIP events */
@@ -257,10 +263,19 @@ typedef struct fmx_stats_t {
   uint32_t block_bytes;      /* bytes fetched per rank query: 64 (one-hot block) or 132 (BWT block + checkpoint) */
   double build_ms;           /* device time of the kernels that built the rank dictionary at open */
   uint32_t layout;           /* 0 = one-hot bit-vectors, 1 = BWT bytes + checkpoints */
-  uint32_t reserved;
+  uint32_t reserved;         /* 0 */
   uint64_t search_requests;  /* memory requests for rank-dictionary lines issued by fmx_search_batch[_dev]'s kernel */
+  /* the regex frontier kernels (fmx_regex_*match*), for their roofline: */
+  uint64_t frontier_requests;   /* memory requests for rank-dictionary lines */
+  uint64_t frontier_elements;   /* frontier elements stepped (= their backward steps) */
+  uint64_t frontier_queue_reads;   /* elements read from the HBM work queues */
+  uint64_t frontier_queue_writes;  /* elements appended to the HBM work queues */
+  uint64_t frontier_results;    /* results written */
+  uint64_t reserved2[3];        /* 0 */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
+/* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */
+int fmx_last_kernel_ms(const fmx_index *idx, double *ms);
 int fmx_stats_reset(fmx_index *idx);
 
 #ifdef __cplusplus

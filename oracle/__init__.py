@@ -50,6 +50,8 @@ def lib():
     P = ctypes.POINTER
     L.orc_open_mem.restype = vp
     L.orc_open_mem.argtypes = [vp, u64, u64, vp, P(i32)]
+    L.orc_open_mem_threads.restype = vp
+    L.orc_open_mem_threads.argtypes = [vp, u64, u64, vp, i32, P(i32)]
     L.orc_open_files.restype = vp
     L.orc_open_files.argtypes = [cp, cp, i32, P(i32)]
     L.orc_close.argtypes = [vp]
@@ -85,6 +87,11 @@ def lib():
     L.orc_match_sa.restype = i64
     L.orc_match_sa.argtypes = [vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.c_int32, i64, i64,
                                vp, vp, vp, i64, P(i64), P(i64)]
+    L.orc_histogram.restype = None
+    L.orc_histogram.argtypes = [vp, u64, u64, i32, vp]
+    L.orc_match_sa_batch.restype = i64
+    L.orc_match_sa_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32,
+                                     vp, vp, vp, vp, i64, P(i64), P(i64)]
     _lib = L
     return L
 
@@ -128,12 +135,20 @@ def load_aux_file(path, bigEndian=True):
     return raw.view((">" if bigEndian else "<") + "i8").astype(np.int64)
 
 
+def histogram(bwt, eof, threads=1):
+    """The .aux counts of an in-memory BWT (EOF slot excluded) -> int64[256]."""
+    bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+    out = np.zeros(256, dtype=np.int64)
+    lib().orc_histogram(_ptr(bwt), bwt.size, int(eof), int(threads), _ptr(out))
+    return out
+
+
 class NaiveFMSearcher:
     """Restates class NaiveFMSearcher (bwtmerger.scala:335-421) with the
     SuffixAlgo methods it inherits (findex.scala:9-52).  Positions are Python
     ints; `search`/`getPrevRange` return a tuple or None like the Scala Option."""
 
-    def __init__(self, filename=None, bigEndian=True, _mem=None, strict_signed=False):
+    def __init__(self, filename=None, bigEndian=True, _mem=None, strict_signed=False, threads=1):
         L = lib()
         err = ctypes.c_int(0)
         if _mem is not None:
@@ -141,7 +156,7 @@ class NaiveFMSearcher:
             bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
             counts = np.ascontiguousarray(counts, dtype=np.int64)
             assert bwt.size == n and counts.size == 256
-            self._h = L.orc_open_mem(_ptr(bwt), n, eof, _ptr(counts), ctypes.byref(err))
+            self._h = L.orc_open_mem_threads(_ptr(bwt), n, eof, _ptr(counts), int(threads), ctypes.byref(err))
         else:
             self._h = L.orc_open_files(swap_ext(filename, ".bwt").encode(), swap_ext(filename, ".aux").encode(),
                                        1 if bigEndian else 0, ctypes.byref(err))
@@ -155,6 +170,7 @@ class NaiveFMSearcher:
 
     @classmethod
     def from_mem(cls, bwt, eof, counts, **kw):
+        """threads=T sorts the position list on T cores (same list)."""
         bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
         return cls(_mem=(bwt, int(bwt.size), int(eof), counts), **kw)
 
@@ -311,6 +327,60 @@ class NaiveFMSearcher:
             raise OracleError("orc_match_sa: %d" % r)
         k = min(int(r), cap)
         return [(int(rl[j]), int(rs[j]), int(re_[j])) for j in range(k)], left.value, pops.value
+
+
+    def match_tables_batch(self, tables, maxBranching=1 << 40, maxIterations=0, max_len=0, threads=1):
+        """C _matchSA over a list of ReTree.tables() dicts on `threads` cores; max_len > 0 caps the match
+        length like the product's max_steps.  Returns (structured array of (regex, len, sp, ep) grouped by regex
+        and sorted by (len, sp, ep) inside a group, getPrevRange calls made, regexes cut at max_len)."""
+        k = len(tables)
+        st_off = np.zeros(k + 1, dtype=np.int64)
+        fol_base = np.zeros(k + 1, dtype=np.int64)
+        first_off = np.zeros(k + 1, dtype=np.int64)
+        for r, t in enumerate(tables):
+            st_off[r + 1] = st_off[r] + len(t["c"])
+            fol_base[r + 1] = fol_base[r] + sum(len(f) for f in t["follows"])
+            first_off[r + 1] = first_off[r] + len(t["firsts"])
+        ns = int(st_off[-1])
+        st_c = np.zeros(max(ns, 1), dtype=np.uint8)
+        st_num = np.zeros(max(ns, 1), dtype=np.int32)
+        st_last = np.zeros(max(ns, 1), dtype=np.uint8)
+        fol_off = np.zeros(ns + k + 1, dtype=np.int32)
+        fol = np.zeros(max(int(fol_base[-1]), 1), dtype=np.int32)
+        firsts = np.zeros(max(int(first_off[-1]), 1), dtype=np.int32)
+        for r, t in enumerate(tables):
+            a, b = int(st_off[r]), int(st_off[r + 1])
+            st_c[a:b] = t["c"]
+            st_num[a:b] = t["num"]
+            st_last[a:b] = t["isLast"]
+            lens = np.fromiter((len(f) for f in t["follows"]), dtype=np.int64, count=b - a)
+            fol_off[a + r + 1:b + r + 1] = np.cumsum(lens)
+            flat = [x for f in t["follows"] for x in f]
+            fol[int(fol_base[r]):int(fol_base[r]) + len(flat)] = flat
+            firsts[int(first_off[r]):int(first_off[r + 1])] = t["firsts"]
+        res_start = np.zeros(k + 1, dtype=np.int64)
+        cap = 1 << 16
+        while True:
+            out_len = np.zeros(cap, dtype=np.int64)
+            out_sp = np.zeros(cap, dtype=np.uint64)
+            out_ep = np.zeros(cap, dtype=np.uint64)
+            pops, trunc = ctypes.c_int64(), ctypes.c_int64()
+            got = self._L.orc_match_sa_batch(self._h, k, _ptr(st_off), _ptr(st_c), _ptr(st_num), _ptr(st_last),
+                                             _ptr(fol_off), _ptr(fol_base), _ptr(fol), _ptr(first_off), _ptr(firsts),
+                                             int(maxBranching), int(maxIterations), int(max_len), int(threads),
+                                             _ptr(res_start), _ptr(out_len), _ptr(out_sp), _ptr(out_ep), cap,
+                                             ctypes.byref(pops), ctypes.byref(trunc))
+            if got < 0:
+                raise OracleError("orc_match_sa_batch: %d" % got)
+            if got <= cap:
+                break
+            cap = int(got)
+        out = np.zeros(int(got), dtype=[("regex", np.uint32), ("len", np.uint32), ("sp", np.uint64), ("ep", np.uint64)])
+        out["regex"] = np.repeat(np.arange(k, dtype=np.uint32), np.diff(res_start))
+        out["len"] = out_len[:got]
+        out["sp"] = out_sp[:got]
+        out["ep"] = out_ep[:got]
+        return out, int(pops.value), int(trunc.value)
 
 
 class SAISNaiveSearcher(NaiveFMSearcher):

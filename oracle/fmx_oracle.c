@@ -90,6 +90,26 @@ int orc_load_aux(const char *path, int big_endian, int64_t aux[ALPHA_SIZE]) {
 
 void orc_free_buf(void *p) { free(p); }
 
+/* The .aux content for a BWT held in memory (AUXLoader's array, F/bwtmerger.scala:130-142): symbol counts
+ * without the EOF slot, on `threads` cores -- bench.py needs it for multi-GiB synthetic BWTs. */
+void orc_histogram(const uint8_t *bwt, uint64_t n, uint64_t eof, int threads, int64_t out[ALPHA_SIZE]) {
+  if (threads < 1) threads = 1;
+  int64_t *h = (int64_t *)calloc((size_t)threads * ALPHA_SIZE, sizeof(int64_t));
+  const uint64_t chunk = (n + (uint64_t)threads - 1) / (uint64_t)threads;
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+  for (int t = 0; t < threads; t++) {
+    uint64_t lo = chunk * (uint64_t)t, hi = lo + chunk;
+    if (hi > n) hi = n;
+    for (uint64_t i = lo; i < hi; i++) h[(size_t)t * ALPHA_SIZE + bwt[i]]++;
+  }
+  for (int c = 0; c < ALPHA_SIZE; c++) {
+    out[c] = 0;
+    for (int t = 0; t < threads; t++) out[c] += h[(size_t)t * ALPHA_SIZE + c];
+  }
+  if (eof < n) out[bwt[eof]]--;
+  free(h);
+}
+
 /* ------------------------------------------------------------ construction */
 
 /* c2bs, F/util.scala:109-119 */
@@ -123,8 +143,46 @@ static int build_fm(orc_index *ix) {
 }
 
 /* NaiveFMSearcher constructor, F/bwtmerger.scala:335-353 */
-orc_index *orc_open_mem(const uint8_t *bwt, uint64_t n, uint64_t eof,
-                        const int64_t aux[ALPHA_SIZE], int *err) {
+/* The same sort on `threads` cores (a 2^32-row list is built for bench.py's cpu_baseline): per-chunk symbol
+ * histograms, prefix sums per symbol over the chunks, then every chunk scatters its own positions -- the result
+ * is the stable order of build_fm.  Counts that do not match .aux are ORC_ERR_FORMAT as there. */
+static int build_fm_mt(orc_index *ix, int threads) {
+  if (threads < 2 || ix->n < (1u << 20)) return build_fm(ix);
+  ix->fm = (uint32_t *)malloc(ix->n * sizeof(uint32_t));
+  uint64_t *hist = (uint64_t *)calloc((size_t)threads * ALPHA_SIZE, sizeof(uint64_t));
+  if (!ix->fm || !hist) { free(hist); return ORC_ERR_NOMEM; }
+  const uint64_t chunk = (ix->n + (uint64_t)threads - 1) / (uint64_t)threads;
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+  for (int t = 0; t < threads; t++) {
+    uint64_t lo = chunk * (uint64_t)t, hi = lo + chunk;
+    if (hi > ix->n) hi = ix->n;
+    uint64_t *h = hist + (size_t)t * ALPHA_SIZE;
+    for (uint64_t i = lo; i < hi; i++) h[(i == ix->eof) ? 0 : ix->bwt[i]]++;
+  }
+  int rc = ORC_OK;
+  uint64_t start = 0;
+  for (int c = 0; c < ALPHA_SIZE; c++) {
+    uint64_t tot = 0;
+    for (int t = 0; t < threads; t++) { uint64_t v = hist[(size_t)t * ALPHA_SIZE + c]; hist[(size_t)t * ALPHA_SIZE + c] = start + tot; tot += v; }
+    const uint64_t want = c == 0 ? 1 : (uint64_t)ix->aux[c];
+    if (tot != want) rc = ORC_ERR_FORMAT;
+    start += tot;
+  }
+  if (rc == ORC_OK) {
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int t = 0; t < threads; t++) {
+      uint64_t lo = chunk * (uint64_t)t, hi = lo + chunk;
+      if (hi > ix->n) hi = ix->n;
+      uint64_t *h = hist + (size_t)t * ALPHA_SIZE;
+      for (uint64_t i = lo; i < hi; i++) ix->fm[h[(i == ix->eof) ? 0 : ix->bwt[i]]++] = (uint32_t)i;
+    }
+  }
+  free(hist);
+  return rc;
+}
+
+static orc_index *open_mem_impl(const uint8_t *bwt, uint64_t n, uint64_t eof, const int64_t aux[ALPHA_SIZE],
+                                int threads, int *err) {
   int e = ORC_OK;
   orc_index *ix = NULL;
   if (n > (1ull << 32) || eof >= (n ? n : 1)) { e = ORC_ERR_RANGE; goto done; }
@@ -140,11 +198,19 @@ orc_index *orc_open_mem(const uint8_t *bwt, uint64_t n, uint64_t eof,
   c2bs(c1, ix->bs0);          /* :341-345 */
   c1[0] = 1;                  /* :348 */
   c2bs(c1, ix->bs);           /* :349 */
-  e = build_fm(ix);
+  e = build_fm_mt(ix, threads);
 done:
   if (e != ORC_OK && ix) { free(ix->bwt); free(ix->fm); free(ix); ix = NULL; }
   if (err) *err = e;
   return ix;
+}
+
+orc_index *orc_open_mem(const uint8_t *bwt, uint64_t n, uint64_t eof, const int64_t aux[ALPHA_SIZE], int *err) {
+  return open_mem_impl(bwt, n, eof, aux, 1, err);
+}
+orc_index *orc_open_mem_threads(const uint8_t *bwt, uint64_t n, uint64_t eof, const int64_t aux[ALPHA_SIZE],
+                                int threads, int *err) {
+  return open_mem_impl(bwt, n, eof, aux, threads, err);
 }
 
 orc_index *orc_open_files(const char *bwt_path, const char *aux_path, int big_endian, int *err) {
@@ -415,11 +481,13 @@ static orc_sp pq_pop(orc_pq *q) {
  * of the leftover frontier, *pops = getPrevRange calls made.
  * matchSA itself (F/re2/retree.scala:570-617) returns this first-pass `ret`
  * whatever the exploratory restarts at :578-614 find, so they are not restated. */
-int64_t orc_match_sa(const orc_index *ix, int32_t nstates, const uint8_t *st_c, const int32_t *st_num,
-                     const uint8_t *st_last, const int32_t *fol_off, const int32_t *fol,
-                     const int32_t *firsts, int32_t nfirsts, int64_t max_branching, int64_t max_iterations,
-                     int64_t *res_len, uint64_t *res_sp, uint64_t *res_ep, int64_t cap,
-                     int64_t *front_left, int64_t *pops) {
+/* max_len > 0 caps the match length like the product's fmx_limits.max_steps (a bench / test variant, not in the
+ * reference): a popped element whose children would have len >= max_len is not expanded; *truncated says so. */
+static int64_t match_sa_core(const orc_index *ix, int32_t nstates, const uint8_t *st_c, const int32_t *st_num,
+                             const uint8_t *st_last, const int32_t *fol_off, const int32_t *fol,
+                             const int32_t *firsts, int32_t nfirsts, int64_t max_branching, int64_t max_iterations,
+                             int64_t max_len, int64_t *res_len, uint64_t *res_sp, uint64_t *res_ep, int64_t cap,
+                             int64_t *front_left, int64_t *pops, int *truncated) {
   (void)nstates;
   orc_pq q = {0};
   q.num = st_num;
@@ -450,6 +518,8 @@ int64_t orc_match_sa(const orc_index *ix, int32_t nstates, const uint8_t *st_c, 
           if (!rl || !rs || !re) { rc = ORC_ERR_NOMEM; goto out; }
         }
         rl[nres] = s.len + 1; rs[nres] = sp1; re[nres] = ep1; nres++;
+      } else if (max_len > 0 && s.len + 1 >= max_len) {
+        if (truncated && fol_off[s.state + 1] > fol_off[s.state]) *truncated = 1;
       } else {                                                                 /* :641 */
         for (int32_t j = fol_off[s.state]; j < fol_off[s.state + 1]; j++) {
           orc_sp e = {s.len + 1, (int64_t)sp1, (int64_t)ep1, fol[j]};
@@ -468,4 +538,91 @@ int64_t orc_match_sa(const orc_index *ix, int32_t nstates, const uint8_t *st_c, 
 out:
   free(q.a); free(rl); free(rs); free(re);
   return rc;
+}
+
+/* ReTree._matchSA, F/re2/retree.scala:618-653 (the reference's own loop, limits and pop order). */
+int64_t orc_match_sa(const orc_index *ix, int32_t nstates, const uint8_t *st_c, const int32_t *st_num,
+                     const uint8_t *st_last, const int32_t *fol_off, const int32_t *fol,
+                     const int32_t *firsts, int32_t nfirsts, int64_t max_branching, int64_t max_iterations,
+                     int64_t *res_len, uint64_t *res_sp, uint64_t *res_ep, int64_t cap,
+                     int64_t *front_left, int64_t *pops) {
+  return match_sa_core(ix, nstates, st_c, st_num, st_last, fol_off, fol, firsts, nfirsts, max_branching,
+                       max_iterations, 0, res_len, res_sp, res_ep, cap, front_left, pops, NULL);
+}
+
+/* The same over a batch of regexes on `threads` host cores (bench.py's cpu_baseline for the regex workload and
+ * full-size parity checks): regex r has states st_off[r] .. st_off[r+1] of the concatenated st_* arrays, its
+ * follows CSR (ns_r + 1 offsets, local state ids) at fol_off + st_off[r] + r with entries from fol + fol_base[r],
+ * and its firsts at firsts + first_off[r].  Results land in out_* grouped by regex, each group sorted by
+ * (len, sp, ep) -- the product's frontier-mode order; res_start gets k + 1 offsets.  Returns the number of results
+ * (more than cap: nothing was written), or a negative error.  *pops_total = getPrevRange calls made. */
+typedef struct { int64_t len; uint64_t sp, ep; } orc_res;
+static int res_cmp(const void *a, const void *b) {
+  const orc_res *x = (const orc_res *)a, *y = (const orc_res *)b;
+  if (x->len != y->len) return x->len < y->len ? -1 : 1;
+  if (x->sp != y->sp) return x->sp < y->sp ? -1 : 1;
+  if (x->ep != y->ep) return x->ep < y->ep ? -1 : 1;
+  return 0;
+}
+int64_t orc_match_sa_batch(const orc_index *ix, int64_t k, const int64_t *st_off, const uint8_t *st_c,
+                           const int32_t *st_num, const uint8_t *st_last, const int32_t *fol_off,
+                           const int64_t *fol_base, const int32_t *fol, const int64_t *first_off,
+                           const int32_t *firsts, int64_t max_branching, int64_t max_iterations, int64_t max_len,
+                           int threads, int64_t *res_start, int64_t *out_len, uint64_t *out_sp, uint64_t *out_ep,
+                           int64_t cap, int64_t *pops_total, int64_t *n_truncated) {
+  orc_res **per = (orc_res **)calloc((size_t)(k ? k : 1), sizeof(orc_res *));
+  int64_t *cnt = (int64_t *)calloc((size_t)(k ? k : 1), sizeof(int64_t));
+  if (!per || !cnt) { free(per); free(cnt); return ORC_ERR_NOMEM; }
+  int64_t pops_sum = 0, trunc_sum = 0, bad = 0;
+  if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads) reduction(+ : pops_sum, trunc_sum, bad)
+  for (int64_t r = 0; r < k; r++) {
+    const int64_t s0 = st_off[r];
+    const int32_t ns = (int32_t)(st_off[r + 1] - s0);
+    int64_t rcap = 64, got;
+    int64_t *rl = NULL; uint64_t *rs = NULL, *re = NULL;
+    int64_t left = 0, pops = 0;
+    int trunc = 0;
+    for (;;) {      /* grow until the regex's results fit */
+      rl = (int64_t *)malloc((size_t)rcap * sizeof(int64_t));
+      rs = (uint64_t *)malloc((size_t)rcap * sizeof(uint64_t));
+      re = (uint64_t *)malloc((size_t)rcap * sizeof(uint64_t));
+      if (!rl || !rs || !re) { got = ORC_ERR_NOMEM; break; }
+      trunc = 0;
+      got = match_sa_core(ix, ns, st_c + s0, st_num + s0, st_last + s0, fol_off + s0 + r, fol + fol_base[r],
+                          firsts + first_off[r], (int32_t)(first_off[r + 1] - first_off[r]), max_branching,
+                          max_iterations, max_len, rl, rs, re, rcap, &left, &pops, &trunc);
+      if (got <= rcap) break;
+      free(rl); free(rs); free(re);
+      rcap = got;
+    }
+    if (got < 0) { bad++; free(rl); free(rs); free(re); continue; }
+    pops_sum += pops;
+    trunc_sum += trunc;
+    cnt[r] = got;
+    if (got) {
+      per[r] = (orc_res *)malloc((size_t)got * sizeof(orc_res));
+      if (!per[r]) { bad++; cnt[r] = 0; }
+      else {
+        for (int64_t j = 0; j < got; j++) { per[r][j].len = rl[j]; per[r][j].sp = rs[j]; per[r][j].ep = re[j]; }
+        qsort(per[r], (size_t)got, sizeof(orc_res), res_cmp);
+      }
+    }
+    free(rl); free(rs); free(re);
+  }
+  int64_t total = 0;
+  for (int64_t r = 0; r < k; r++) { res_start[r] = total; total += cnt[r]; }
+  res_start[k] = total;
+  if (!bad && total <= cap)
+    for (int64_t r = 0; r < k; r++)
+      for (int64_t j = 0; j < cnt[r]; j++) {
+        out_len[res_start[r] + j] = per[r][j].len;
+        out_sp[res_start[r] + j] = per[r][j].sp;
+        out_ep[res_start[r] + j] = per[r][j].ep;
+      }
+  for (int64_t r = 0; r < k; r++) free(per[r]);
+  free(per); free(cnt);
+  if (pops_total) *pops_total = pops_sum;
+  if (n_truncated) *n_truncated = trunc_sum;
+  return bad ? ORC_ERR_NOMEM : total;
 }

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_device_count():
     L = _lib.load()
-    assert L.fmx_abi_version() == 1
+    assert L.fmx_abi_version() == 2
     n = ctypes.c_int(-1)
     assert L.fmx_device_count(ctypes.byref(n)) == 0 and n.value >= 0
 
@@ -36,7 +36,7 @@ def test_abi_version_and_device_count():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.fmx_result) == 24
     assert ctypes.sizeof(_lib.fmx_limits) == 24
-    assert ctypes.sizeof(_lib.fmx_stats_t) == 80
+    assert ctypes.sizeof(_lib.fmx_stats_t) == 144
 
 
 def test_open_errors_are_statuses_with_messages(tmp_path, testdata):

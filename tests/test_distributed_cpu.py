@@ -71,7 +71,7 @@ def _rank_main(rank, world, port, q):
         idx, buf, off = workload()
         s = OracleSearcher(*idx)
         sp, ep = D.search_batch_sharded(s, buf, off)
-        res = D.match_batch_sharded(s, REGEXES, match_fn=oracle_match)
+        res = D.group_results(D.match_batch_sharded(s, REGEXES, match_fn=oracle_match, weights=[1, 3, 9, 2, 8]), len(REGEXES))
         cuts = D.shard_bounds(off, world)
         t = torch.arange(3 + 2 * rank, dtype=torch.int64) + 100 * rank
         parts = D.all_gather_varlen(t)
@@ -131,6 +131,18 @@ def test_two_rank_gloo_matches_single_process():
     b0 = int(off[cuts[1]] - off[cuts[0]])
     b1 = int(off[cuts[2]] - off[cuts[1]])
     assert abs(b0 - b1) <= 20
+
+
+def test_work_bounds_balance_by_weight():
+    assert D.work_bounds([], 3) == [0, 0, 0, 0]
+    assert D.work_bounds([1, 1, 1, 1], 2) == [0, 2, 4]
+    c = D.work_bounds([100, 1, 1, 1, 1, 96], 2)                  # one heavy regex at each end
+    assert c == [0, 1, 6]
+    c = D.work_bounds(np.ones(10), 4)
+    assert c[0] == 0 and c[-1] == 10 and c == sorted(c)
+    r = np.array([(2, 3, 5, 9), (0, 1, 2, 3), (2, 1, 4, 6)], dtype=D.RESULT_DTYPE)
+    assert D.group_results(r, 3) == [[(1, 2, 3)], [], [(3, 5, 9), (1, 4, 6)]]
+    assert np.array_equal(D.gather_results(r), r)                # no process group: identity
 
 
 def test_shard_bounds_edge_cases():

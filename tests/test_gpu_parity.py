@@ -529,6 +529,36 @@ def test_regex_overflow_is_reported():
     assert {r.key() for r in part} == {k for k in oracle_results_capped(bwt, eof, counts, "a[a-d]*b", 3)}
 
 
+def test_regex_resident_batch_shrinking_cap_and_foreign_index(testdata):
+    """a resident batch keeps its scratch, and from its second match on a captured launch
+    chain, when a later call passes a smaller result capacity -- every size baked into that chain must then still
+    be the one the kernels outside it use.  Three matches with cap 2^20, 2^20, 2^12 must all equal the oracle;
+    and a batch made for one index must refuse another (its pointers are inside the chain)."""
+    hip, orc = pair_from_files(testdata, "words", True)
+    res = ["th(e|a)", "co(m|n)+e", "s[aeiou]+t", "un[a-z][a-z]ed", "q[a-z]*k", "ab(cd|ef)+gh", "ing\r\n"]
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re)) for re in res]
+    want = []
+    for j, re in enumerate(res):
+        want += [(j,) + key for key in oracle_results(orc, re)[0]]
+    assert 64 < len(want) < 4000          # several result slices in use, and everything fits the small cap
+    batch = findex_amd.ReTree.prepare_batch(hip, trees)
+    for cap in (1 << 20, 1 << 20, 1 << 12, 1 << 20, 1 << 12):
+        out, per = batch.match_raw(cap=cap)
+        got = [(int(r["regex"]), int(r["len"]), int(r["sp"]), int(r["ep"])) for r in out]
+        assert got == want, cap
+        assert per.sum() == len(want)
+    other, _ = pair_from_files(testdata, "words", True)          # same file, same n, same device: still another index
+    with pytest.raises(findex_amd.FmxError) as e:
+        import ctypes
+        from findex_amd import _lib
+        lim = _lib.fmx_limits(0, 0, 0, 1024, 1000)
+        buf = np.empty(16, dtype=findex_amd.regex.RESULT_DTYPE)
+        n_out = ctypes.c_size_t()
+        _lib.check(_lib.load().fmx_regex_batch_match(other.handle, batch._h, ctypes.byref(lim),
+                                                     buf.ctypes.data_as(ctypes.c_void_p), 16, ctypes.byref(n_out), None))
+    assert e.value.code == 3
+
+
 def test_regex_long_tail_levels():
     """Frontiers that stay small for many levels, grow, and die slowly (n = 2M over 4 letters: "ab[a-c]*d"
     holds min(3^k, 125k * 0.75^k) elements at level k + 2, i.e. ~700 at the first host look, ~9.4k at level
@@ -714,10 +744,13 @@ def _torch():
     return torch
 
 
-@pytest.mark.parametrize("log2n,extra,sigma", [(28, 0, 4), (32, 12345, 16)])
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("log2n,extra,sigma", [(28, 0, 4), (32, 12345, 16), (32, 0, 128)])
 def test_full_size_properties(log2n, extra, sigma):
-    """BASELINE-size indexes (C2: 256 MB sigma=4; and n > 2^32 to cross the 32-bit line): no CPU
-    oracle can hold these, so check size-independent properties:
+    """BASELINE-size indexes -- C2 (256 MB, sigma=4), n > 2^32 to cross the 32-bit line, and C3's own
+    instantiation (n = 2^32 exactly, sigma = 128: the one-hot layout with 32-bit counts, 77 GiB, a
+    1M x 32 pattern batch).  No CPU oracle is built at these sizes inside pytest, so check size-independent
+    properties:
       * occ(c, i) equals a brute-force count of the device BWT prefix (torch),
       * occ(c, n-1) equals the symbol total, sum_c occ(c, i) == i + 1 - [i >= eof],
       * LF-walk patterns hit, and the hit interval contains the row the walk ended on,
@@ -755,7 +788,10 @@ def test_full_size_properties(log2n, extra, sigma):
         col = hip.occ_batch(np.arange(0, sigma + 1, dtype=np.uint8), np.full(sigma + 1, i, dtype=np.int64))
         assert int(col.sum()) == i + 1
     # LF-walk patterns must hit and contain their end row
-    k, m = 20000, 16 if sigma == 4 else 12
+    k, m = (1_000_000, 32) if sigma == 128 else (20000, 16 if sigma == 4 else 12)
+    if sigma == 128:
+        st = hip.stats()
+        assert st["layout"] == 0 and st["n_symbols"] == 128 and st["index_bytes"] > 70 << 30
     rows = rng.integers(0, n, k).astype(np.uint64)
     b, end = hip.lf_walk_batch(rows, m)
     pats = np.ascontiguousarray(b[:, ::-1])
@@ -768,3 +804,66 @@ def test_full_size_properties(log2n, extra, sigma):
         assert sum(e - s for s, e in parts) == bnd - a
         srt = sorted(parts)
         assert all(srt[j][1] <= srt[j + 1][0] for j in range(len(srt) - 1))
+
+
+@pytest.mark.timeout(900)
+def test_c4_full_size_regex_batch():
+    """BASELINE config C4 at its own size: 100k seeded regexes (<= 32 Glushkov positions) over a 2^30-row
+    sigma=28 index.  Properties of the answer that need no CPU index of that size: every result interval is
+    non-empty and inside [0, n); for sampled results the rows really spell a string the regex matches (text
+    extracted with nextSubstr = Psi walks, checked with Python's `re`); the per-regex counts add up; and the
+    literal-only regexes of the batch give exactly what fmx_search_batch gives for the same strings."""
+    import re as pyre
+    import sys
+    torch = _torch()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import regex_workload
+    n, k = 1 << 30, 100_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0xF1DE0004)
+    alpha = torch.tensor([ord(c) for c in regex_workload.ALPHABET], dtype=torch.uint8, device="cuda")
+    bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for a in range(0, n, 1 << 28):
+        b = min(n, a + (1 << 28))
+        bwt[a:b] = alpha[torch.randint(0, alpha.numel(), (b - a,), generator=g, device="cuda")]
+    torch.cuda.synchronize()
+    hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, n // 3, None)
+    del bwt
+    trees = []
+
+    def compiles(re):
+        try:
+            trees.append(findex_amd.ReTree(findex_amd.REParser.re2post(re)))
+            return True
+        except (findex_amd.MatchError, findex_amd.Re2PostSyntax):
+            return False
+    res = regex_workload.generate(k, 4, compiles)
+    assert max(len(t.tables()["c"]) for t in trees[:500]) <= 32
+    batch = findex_amd.ReTree.prepare_batch(hip, trees)
+    hip.stats_reset()
+    out, per = batch.match_raw(max_steps=64)
+    st = hip.stats()
+    assert out.size > 10_000 and int(per.sum()) == out.size
+    assert (out["sp"] < out["ep"]).all() and (out["ep"] <= n).all() and (out["len"] >= 4).all() and (out["len"] <= 64).all()
+    assert st["frontier_results"] == out.size and st["frontier_elements"] == st["backward_steps"]
+    key = np.stack([out["regex"].astype(np.uint64), out["len"].astype(np.uint64), out["sp"], out["ep"]], axis=1)
+    assert (np.lexsort((key[:, 3], key[:, 2], key[:, 1], key[:, 0])) == np.arange(out.size)).all()     # canonical order
+    rng = np.random.default_rng(1)
+    pick = rng.integers(0, out.size, 300)
+    for ln in np.unique(out["len"][pick]):                       # one batched extraction per match length
+        sel = pick[out["len"][pick] == ln]
+        for j, s in zip(sel, hip.nextSubstr_batch(out["sp"][sel], int(ln))):
+            assert len(s) == ln and pyre.fullmatch(res[out[j]["regex"]].encode(), s, pyre.S), (res[out[j]["regex"]], s)
+    # regexes that are plain literals: the frontier's answer is the literal search's answer (the index is over
+    # the reversed text and the regex engine walks forward with getPrevRange, so the literal is searched reversed)
+    lit = [j for j, re in enumerate(res) if re.isalpha()][:2000]
+    assert len(lit) > 100
+    pats, off = pack_patterns([res[j].encode()[::-1] for j in lit])
+    sp, ep = hip.search_batch(pats, off)
+    starts = np.searchsorted(out["regex"], np.arange(k + 1))
+    for i, j in enumerate(lit):
+        rows = out[starts[j]:starts[j + 1]]
+        if sp[i] < ep[i]:
+            assert rows.size == 1 and rows[0]["len"] == len(res[j]) and rows[0]["sp"] == sp[i] and rows[0]["ep"] == ep[i]
+        else:
+            assert rows.size == 0

@@ -3,15 +3,26 @@
 // Reference: ReTree._matchSA, re2/retree.scala:618-653.  There one priority queue of
 // StatePoint(len, sp, ep, state) is popped serially; each pop is one getPrevRange; a non-empty
 // range either emits SAResult (isLast) or pushes one StatePoint per entry of state.follows.
-// Every frontier element is independent of the others, so the device keeps the whole batch's
-// frontier in two HBM work queues (SoA) and expands it level by level (level = len):
-//   - one frontier element per lane group (a quad in the one-hot layout, an octet in the bytes
-//     layout), stepped with the same rank primitive as the literal search;
-//   - survivors are compacted into the next queue: per-group push counts are prefix-summed
-//     across the wave, one atomicAdd per wave reserves the slots, and the group's lanes write
-//     the follows in parallel; results are compacted the same way with __ballot.
-// The set of getPrevRange calls, and so the result multiset, equals the reference's whenever
-// its maxBranching / maxIterations limits do not bind.
+// Every frontier element is independent of the others, so the order in which they are stepped does
+// not change the result multiset (whenever the reference's maxBranching / maxIterations do not bind),
+// and the device is free to choose the order that costs least memory traffic:
+//
+//   * A lane group (a quad in the one-hot layout, an octet in the bytes layout) HOLDS an element in
+//     registers and follows it: after a step that survives, the group keeps the first follow for
+//     itself (same sp/ep, len + 1) and goes on -- a literal stretch of a regex is walked like a
+//     literal pattern in k_search4, with no queue round trip per character.  The state record carries
+//     the bytes of its first follows, so the next step's rank blocks are requested together with the
+//     next state's record: one memory latency per step, not two.
+//   * The other follows go to the wave's own POOL in LDS (128 entries, newest first out: depth-first,
+//     so the live set stays small); lane groups whose element died take their next one from there.
+//   * Work enters and leaves a launch through two sliced HBM queues: a wave starts from its share of
+//     the input queue (batches of 16, requested one round ahead), spills the oldest pool entries to
+//     the output queue when the pool fills, and after `max_rounds` rounds hands everything it still
+//     holds to the output queue and ends.  The next launch deals that queue out evenly again: that is
+//     the whole load balancing -- no concurrent producer/consumer queue, no spin-waits, every wave
+//     reaches its exit after a bounded number of rounds.  Launches repeat until the output queue stays
+//     empty (round 1 ran one launch per match length: 64+ launches, most of them nearly empty, every
+//     element through HBM queues at every level; profiles/r02_c4_before_*).
 #include <fmx.h>
 
 #include <algorithm>
@@ -31,31 +42,19 @@ namespace fmx {
 
 constexpr int kFThreads = 256;
 
-struct Queue {           // SoA frontier queue in HBM; every element of a level has len == level
-  uint32_t *state;       // global CharNode id
+struct Queue {           // SoA work queue in HBM
+  uint32_t *state;       // global state id
+  uint32_t *meta;        // len in bits 0..15, the state's byte in bits 16..23
   uint64_t *sp;
   uint64_t *ep;
 };
-
-struct FStat {           // per-lane partial sums for the frontier counters (fmx_device.h, slots 3..7)
-  uint32_t reqs = 0, pushes = 0, emits = 0, reads = 0;
-};
-
-constexpr uint32_t kStageCap = 192;     // survivors a wave stages in LDS before reserving queue slots
-constexpr uint32_t kStageSmall = 12;    // follows lists up to this length go through the stage (16 groups x 12 <= cap)
-
-struct Stage {           // 20 bytes per entry: 4 waves x 192 entries + the symbol tables keep 8 workgroups per CU
-  uint32_t state[kStageCap];
-  uint64_t sp[kStageCap];
-  uint64_t ep[kStageCap];
-};
+constexpr uint32_t kMaxLen = 0xFFFFu;
 
 // The queues and the result buffer are cut into kSub slices with one tail counter each, every counter
-// on its own 128-byte line: a single tail cannot take the appends of a whole level (same-address device
-// atomics complete at ~100 per microsecond -- with one tail a 3.7 M-element level spent 250 us on 25 k
-// appends, and every level paid ~60 us for the 6144 waves' final flush).  A wave appends to slice
-// (wave + number of its earlier appends) % kSub, so slices stay balanced even when one wave produces
-// everything; at the next level slice j is read by the waves with id % kSub == j.
+// on its own 128-byte line: a single tail cannot take the appends of a whole launch (same-address device
+// atomics complete at ~100 per microsecond).  A wave appends to slice (wave + number of its earlier
+// appends) % kSub, so slices stay balanced even when one wave produces everything; in the next launch
+// slice j is dealt to the waves with id % kSub == j.
 constexpr uint32_t kSub = 64;
 struct alignas(128) PaddedCount {
   unsigned long long v;
@@ -63,15 +62,20 @@ struct alignas(128) PaddedCount {
 };
 
 struct FrontierCtl {     // device-resident counters
-  // Level L reads count[L % 3], appends to count[(L+1) % 3] and clears count[(L+2) % 3] (its
-  // predecessor's input), so a chain of level launches needs no host round trip in between.
+  // Pass p reads count[p % 3], appends to count[(p+1) % 3] and clears count[(p+2) % 3] (its
+  // predecessor's input), so a chain of launches needs no host round trip in between.
   PaddedCount count[3][kSub];
   PaddedCount res_count[kSub];
   unsigned long long overflow;     // bit 0: queue, bit 1: results
-  // The level the next grid launch works on is level_base + its launch number, so that a chain of launches
-  // can be replayed as one hipGraph with fixed kernel arguments; levels >= max_level do nothing.
-  uint32_t level_base;
-  uint32_t max_level;
+  unsigned long long truncated;    // some element was not expanded because its follows would have len >= max_len
+  // The pass the next launch works on is pass_base + its launch number, so that a chain of launches
+  // can be replayed as one hipGraph with fixed kernel arguments.
+  uint32_t pass_base;
+  uint32_t max_len;
+};
+
+struct FStat {           // wave-uniform sums for the frontier counters (fmx_device.h, slots 3..7)
+  uint32_t reqs = 0, writes = 0, emits = 0, reads = 0;
 };
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
@@ -87,372 +91,173 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
   return x - v;
 }
 
-// The work of one wave on one queue slice at one level: it takes the elements part*P + g + r*nparts*P
-// (g = lane group, r = round) of slice `sub`, one element per group and round.  Rounds are
-// software-pipelined: the queue entry of round r+2 and the state record of round r+1 are requested before
-// round r's rank blocks, so a round waits for one memory latency (the rank blocks), not four in a row
-// (entry -> record -> blocks -> follows).  Wave-level operations only: the caller may be the grid kernel
-// (one slice per wave) or the single-workgroup tail kernel (several slices per wave, many levels).
-// ALL = true (tail kernel): the elements are those of all slices, numbered through `s_prefix` (exclusive
-// prefix sums of the slice counts, kSub + 1 entries in LDS), cur_count their total.
-template <bool WIDE, uint32_t LAYOUT, bool ALL = false>
-__device__ __forceinline__ void frontier_slice(const DevIndex &ix, const NfaTables &nfa, const Queue &cur, const Queue &nxt,
-                                               uint32_t level, uint64_t sub_cap, fmx_result *__restrict__ res,
-                                               uint64_t seg_cap, FrontierCtl *__restrict__ ctl, const uint64_t *s_cf,
-                                               const uint16_t *s_slot, Stage &stg, uint32_t w, uint32_t sub,
-                                               uint64_t part, uint64_t nparts, uint64_t cur_count, uint32_t &appends,
-                                               uint32_t &stepped, FStat &fs, const uint64_t *s_prefix = nullptr) {
+// A wave's pool: a ring of kPoolCap entries in LDS, oldest at `pb`, `pn` entries.  Only the owning wave
+// touches it; the compiler is kept from moving LDS accesses across the hand-over points with
+// wavefront-scope fences (LDS operations of one wave execute in program order).
+constexpr uint32_t kPoolCap = 128;
+constexpr uint32_t kPoolMask = kPoolCap - 1;
+constexpr uint32_t kPoolSmall = 6;      // follow lists with up to this many pushed entries go through the pool
+struct Pool {            // 24 bytes per entry, 3 KiB per wave
+  uint32_t state[kPoolCap];
+  uint32_t meta[kPoolCap];
+  uint64_t sp[kPoolCap];
+  uint64_t ep[kPoolCap];
+};
+__device__ __forceinline__ void pool_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// One launch = one pass over the input queue.  `j` is the launch's number in its chain: it works on pass
+// ctl->pass_base + j.  Wave w reads slice w % kSub together with the other waves of that class: its share
+// is the batches part, part + class_waves, ... of P = 64/G entries each.
+template <bool WIDE, uint32_t LAYOUT>
+__global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
+                                                         uint32_t max_rounds, uint64_t sub_cap,
+                                                         fmx_result *__restrict__ res, uint64_t seg_cap,
+                                                         FrontierCtl *__restrict__ ctl,
+                                                         unsigned long long *__restrict__ counters) {
   constexpr int G = Lay<LAYOUT>::G;
-  constexpr uint32_t P = 64 / G;             // elements per wave and round
+  constexpr uint32_t P = 64 / G;             // lane groups per wave = entries per input batch
+  // After a queue overflow the appended count exceeds what was stored: later passes of the chain
+  // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
+  if (ctl->overflow & 1ull) return;
+  const uint32_t pass = ctl->pass_base + j;
+  const Queue &cur = (pass & 1u) ? qb : qa;
+  const Queue &nxt = (pass & 1u) ? qa : qb;
+  if (blockIdx.x == 0 && threadIdx.x < kSub) ctl->count[(pass + 2) % 3][threadIdx.x].v = 0;
+  const uint32_t w = (blockIdx.x * kFThreads + threadIdx.x) >> 6;      // this wave
+  const uint32_t nw = gridDim.x * (kFThreads / 64);
+  const uint32_t sub = w % kSub;             // the slice this wave reads
+  const uint32_t part = w / kSub;
+  const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
+  uint64_t cur_count = ctl->count[pass % 3][sub].v;
+  if (cur_count > sub_cap) cur_count = sub_cap;
+  const bool share = (uint64_t)part * P < cur_count;
+  if (!__syncthreads_or(share ? 1 : 0)) return;      // a workgroup without work leaves before staging anything
+  __shared__ uint64_t s_cf[256];
+  __shared__ uint16_t s_slot[256];
+  __shared__ Pool s_pool[kFThreads / 64];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  __syncthreads();
+  if (!share) return;                        // wave-uniform; no workgroup barrier below
+  Pool &pl = s_pool[threadIdx.x >> 6];
   const LaneConst lc = lane_const<G>();
-  const uint32_t t = lc.t;
-  if (!ALL && cur_count > sub_cap) cur_count = sub_cap;
-  if (cur_count == 0) return;                // wave-uniform
+  const uint32_t t = lc.t, lane = __lane_id();
+  const bool lead = t == 0;
+  const uint32_t lead_lane = lane & ~(uint32_t)(G - 1);
   const uint64_t in_off = (uint64_t)sub * sub_cap;
-  const uint64_t ngrp = nparts * P;
-  const uint64_t first = part * P + (threadIdx.x & 63u) / G;
-  PaddedCount *next_count = ctl->count[(level + 1) % 3];
-  uint32_t staged = 0;                       // wave-uniform
-  auto flush = [&]() {
-    if (!staged) return;
-    __builtin_amdgcn_wave_barrier();
+  PaddedCount *next_count = ctl->count[(pass + 1) % 3];
+  const uint32_t max_len = ctl->max_len;
+  uint32_t pb = 0, pn = 0, appends = 0, rounds = 0;     // wave-uniform
+  uint64_t a_next = part;                    // next batch of this wave's share
+  bool have = false;                         // the element this lane group holds
+  uint32_t state = 0, meta = 0;
+  uint64_t sp = 0, ep = 0;
+  FStat fs;
+  uint32_t stepped = 0, trunc = 0;
+
+  // the `cnt` oldest pool entries go to the output queue
+  auto spill = [&](uint32_t cnt) {
+    if (!cnt) return;
+    pool_sync();
     const uint32_t so = (w + appends++) % kSub;
     unsigned long long base = 0;
-    if (__lane_id() == 0) base = atomicAdd(&next_count[so].v, (unsigned long long)staged);
+    if (lane == 0) base = atomicAdd(&next_count[so].v, (unsigned long long)cnt);
     base = __shfl(base, 0, 64);
     const uint64_t out_off = (uint64_t)so * sub_cap;
-    for (uint32_t i = __lane_id(); i < staged; i += 64) {
+    for (uint32_t i = lane; i < cnt; i += 64) {
+      const uint32_t idx = (pb + i) & kPoolMask;
       const unsigned long long at = base + i;
       if (at < sub_cap) {
-        nxt.state[out_off + at] = stg.state[i];
-        nxt.sp[out_off + at] = stg.sp[i];
-        nxt.ep[out_off + at] = stg.ep[i];
+        nxt.state[out_off + at] = pl.state[idx];
+        nxt.meta[out_off + at] = pl.meta[idx];
+        nxt.sp[out_off + at] = pl.sp[idx];
+        nxt.ep[out_off + at] = pl.ep[idx];
       } else {
         atomicOr(&ctl->overflow, 1ull);
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    staged = 0;
+    pool_sync();
+    pb = (pb + cnt) & kPoolMask;
+    pn -= cnt;
+    fs.writes += cnt;
   };
-  struct Entry { uint32_t state; uint64_t sp, ep; };
-  auto load_entry = [&](uint64_t q) {        // out-of-range rounds read element 0 (valid, unused)
-    uint64_t i = q < cur_count ? q : 0;
-    if (ALL) {                               // the slice that holds logical element i: last s with prefix[s] <= i
-      uint32_t sl = 0;
-#pragma unroll
-      for (uint32_t step = kSub / 2; step; step >>= 1)
-        if (s_prefix[sl + step] <= i) sl += step;
-      i = (uint64_t)sl * sub_cap + (i - s_prefix[sl]);
-    } else {
-      i += in_off;
+  // The next batch of the wave's share enters the pool (wave-uniform; room: pn <= kPoolCap - P here).  It is
+  // asked for only when lane groups have run dry and the pool cannot feed them: every input entry roots a
+  // whole subtree, so this is rare next to the steps, and the other waves of the SIMD cover its latency.
+  auto take_batch = [&]() -> bool {
+    const uint64_t first = a_next * P;
+    if (first >= cur_count) return false;
+    const uint64_t left = cur_count - first;
+    const uint32_t cnt = left < P ? (uint32_t)left : P;
+    if (lane < cnt) {
+      const uint64_t i = in_off + first + lane;
+      const uint32_t idx = (pb + pn + lane) & kPoolMask;
+      pl.state[idx] = cur.state[i]; pl.meta[idx] = cur.meta[i]; pl.sp[idx] = cur.sp[i]; pl.ep[idx] = cur.ep[i];
     }
-    Entry e;
-    e.state = cur.state[i]; e.sp = cur.sp[i]; e.ep = cur.ep[i];
-    return e;
+    pn += cnt;
+    fs.reads += cnt;
+    a_next += class_waves;
+    pool_sync();
+    return true;
   };
-  auto load_rec = [&](uint32_t state) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(nfa.st + state);
-    const uint4 a = p[0], b = p[1];
-    StateRec r;
-    r.fol_off = a.x; r.fol_cnt = a.y; r.regex = a.z; r.c_emit = a.w;
-    r.f[0] = b.x; r.f[1] = b.y; r.f[2] = b.z; r.f[3] = b.w;
-    return r;
-  };
-  // all groups of a wave run the same number of rounds so that the wave-wide scans stay convergent
-  const uint64_t rounds = (cur_count + ngrp - 1) / ngrp;
-  Entry e0 = load_entry(first), e1 = load_entry(first + ngrp);
-  StateRec rec0 = load_rec(e0.state);
-  for (uint64_t rd = 0; rd < rounds; rd++) {
-    const uint64_t q = first + rd * ngrp;
-    const bool have = q < cur_count;
-    const Entry e2 = load_entry(q + 2 * ngrp);          // prefetch: entry two rounds ahead,
-    const StateRec rec1 = load_rec(e1.state);            // record one round ahead
-    uint32_t nf = 0, f0 = 0, rgx = 0;
-    uint64_t sp = e0.sp, ep = e0.ep;
+
+  for (;;) {
+    // ---- lane groups without an element take the newest pool entries
+    {
+      const unsigned long long idle = __builtin_amdgcn_ballot_w64(lead && !have);
+      if (idle) {
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (pn < n_idle) take_batch();
+        if (pn) {
+          const uint32_t take = n_idle < pn ? n_idle : pn;
+          const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lead_lane) - 1ull));
+          if (!have && rank < take) {
+            const uint32_t idx = (pb + pn - 1 - rank) & kPoolMask;
+            state = pl.state[idx]; meta = pl.meta[idx]; sp = pl.sp[idx]; ep = pl.ep[idx];
+            have = true;
+          }
+          pn -= take;
+          pool_sync();
+        }
+      }
+    }
+    if (!__builtin_amdgcn_ballot_w64(have)) break;      // nothing held, pool empty, share consumed
+    // ---- one backward step per holding lane group; the state's record is requested with the rank blocks
+    // The 32-byte record is fetched as 8 bytes per lane (lanes 0..3 of the group: {fol_off, cnt_c_emit}, {f0, f1},
+    // {f2, f3}, {fc, regex}) and its fields are read by broadcast when they are needed: two registers, not eight.
+    uint32_t nf = 0, len1 = 0;
+    uint2 rq8 = make_uint2(0u, 0u);
     bool emit = false;
     if (have) {
-      const uint32_t c = rec0.c_emit & 0xFFu;
-      rgx = rec0.regex;
+      rq8 = reinterpret_cast<const uint2 *>(nfa.st + state)[t & 3u];
+      const uint32_t c = (meta >> 16) & 0xFFu, len = meta & 0xFFFFu;
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
-      if (level == 0) {       // every level-0 element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
+      if (len == 0) {       // every start element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
         sp = cfc;
         ep = (c == 255u) ? ix.n : s_cf[c + 1];
         if (slot == kSlotNone) ep = sp;
         else if (slot == kSlotEof) ep = sp + 1;
       } else {
-        fs.reqs += backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
+        const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
+        if (lead) fs.reqs += rq;
       }
       stepped++;
-      fs.reads++;
-      if (sp < ep) {                                   // Some((sp1,ep1)), retree.scala:634
-        // Glushkov tables: an isLast state emits and has no follows here (:636-641); Thompson / DFA
-        // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282)
-        emit = (rec0.c_emit >> 8) != 0;
-        f0 = rec0.fol_off;
-        nf = rec0.fol_cnt;
-        fs.pushes += nf;
-        fs.emits += emit ? 1u : 0u;
-      }
     }
-    // ---- compaction.  Results: ballot + one atomic per wave (they are few).  Pushes: a single
-    // queue-tail counter cannot take one atomic per wave and round (same-address device atomics run
-    // at ~100 per microsecond), so each wave stages its survivors in LDS and reserves queue slots only
-    // when the stage fills: one atomic per ~150 elements and coalesced queue writes.
-    const bool lead = t == 0;
-    const uint32_t lane = __lane_id();
-    const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
-    if (em) {
-      const uint32_t so = (w + appends++) % kSub;
-      unsigned long long rbase = 0;
-      if (lane == 0) rbase = atomicAdd(&ctl->res_count[so].v, (unsigned long long)__builtin_popcountll(em));
-      rbase = __shfl(rbase, 0, 64);
-      if (lead && emit) {
-        const unsigned long long at = rbase + __builtin_popcountll(em & ((1ull << lane) - 1ull));
-        if (at < seg_cap) {
-          fmx_result r;
-          r.regex = rgx;
-          r.len = level + 1;
-          r.sp = sp;
-          r.ep = ep;
-          res[(uint64_t)so * seg_cap + at] = r;
-        } else {
-          atomicOr(&ctl->overflow, 2ull);
-        }
-      }
+    const uint32_t cce = group_bcast<G, 0>(rq8.y);
+    if (have && sp < ep) {                             // Some((sp1,ep1)), retree.scala:634
+      // Glushkov tables: an isLast state emits and has no follows here (:636-641); Thompson / DFA
+      // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282)
+      emit = ((cce >> 24) & 1u) != 0;
+      nf = cce & 0xFFFFu;
+      len1 = (meta & 0xFFFFu) + 1;
+      if (nf && len1 >= max_len) { nf = 0; trunc = 1; }
     }
-    const uint32_t nsmall = nf <= kStageSmall ? nf : 0u;
-    uint32_t small_total = 0;
-    const uint32_t small_off = wave_excl_scan(lead ? nsmall : 0u, small_total);
-    if (staged + small_total > kStageCap) flush();
-    if (small_total) {
-      const uint32_t my_off = staged + __shfl(small_off, lane & ~(uint32_t)(G - 1), 64);
-      for (uint32_t j = t; j < nsmall; j += G) {
-        // the first kInlineFollows follows ride in the state record
-        uint32_t fs;
-        if (j < kInlineFollows) fs = j < 2 ? (j == 0 ? rec0.f[0] : rec0.f[1]) : (j == 2 ? rec0.f[2] : rec0.f[3]);
-        else fs = nfa.fol[f0 + j];
-        stg.state[my_off + j] = fs;
-        stg.sp[my_off + j] = sp;
-        stg.ep[my_off + j] = ep;
-      }
-      staged += small_total;
-    }
-    // long follows lists (a '.' has 253) go straight to the queue
-    if (__builtin_amdgcn_ballot_w64(nf > kStageSmall)) {
-      const uint32_t nlarge = nf > kStageSmall ? nf : 0u;
-      uint32_t large_total = 0;
-      const uint32_t large_off = wave_excl_scan(lead ? nlarge : 0u, large_total);
-      const uint32_t so = (w + appends++) % kSub;
-      const uint64_t out_off = (uint64_t)so * sub_cap;
-      unsigned long long qbase = 0;
-      if (lane == 0) qbase = atomicAdd(&next_count[so].v, (unsigned long long)large_total);
-      qbase = __shfl(qbase, 0, 64);
-      const uint32_t my_off = __shfl(large_off, lane & ~(uint32_t)(G - 1), 64);
-      for (uint32_t j = t; j < nlarge; j += G) {
-        const unsigned long long at = qbase + my_off + j;
-        if (at < sub_cap) {
-          nxt.state[out_off + at] = nfa.fol[f0 + j];
-          nxt.sp[out_off + at] = sp;
-          nxt.ep[out_off + at] = ep;
-        } else {
-          atomicOr(&ctl->overflow, 1ull);
-        }
-      }
-    }
-    e0 = e1;
-    e1 = e2;
-    rec0 = rec1;
-  }
-  flush();
-}
-
-// One level on the whole grid: wave w reads slice w % kSub together with the other waves of that class.
-// `j` is the launch's number in its chain: it works on level ctl->level_base + j.
-template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kFThreads) void k_frontier(DevIndex ix, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
-                                                         uint64_t sub_cap, fmx_result *__restrict__ res,
-                                                         uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
-                                                         unsigned long long *__restrict__ counters) {
-  // After a queue overflow the appended count exceeds what was stored: later levels of the chain
-  // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
-  if (ctl->overflow & 1ull) return;
-  const uint32_t level = ctl->level_base + j;
-  if (level >= ctl->max_level) return;
-  const Queue &cur = (level & 1u) ? qb : qa;
-  const Queue &nxt = (level & 1u) ? qa : qb;
-  if (blockIdx.x == 0 && threadIdx.x < kSub) ctl->count[(level + 2) % 3][threadIdx.x].v = 0;
-  __shared__ uint64_t s_cf[256];
-  __shared__ uint16_t s_slot[256];
-  __shared__ Stage s_stage[kFThreads / 64];
-  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
-  __syncthreads();
-  const uint32_t w = (blockIdx.x * kFThreads + threadIdx.x) >> 6;      // this wave
-  const uint32_t nw = gridDim.x * (kFThreads / 64);
-  const uint32_t sub = w % kSub;             // the slice this wave reads
-  const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
-  uint32_t appends = 0, stepped = 0;
-  FStat fs;
-  frontier_slice<WIDE, LAYOUT>(ix, nfa, cur, nxt, level, sub_cap, res, seg_cap, ctl, s_cf, s_slot,
-                               s_stage[threadIdx.x >> 6], w, sub, w / kSub, class_waves, ctl->count[level % 3][sub].v,
-                               appends, stepped, fs);
-  const uint32_t t = threadIdx.x & (Lay<LAYOUT>::G - 1);
-  counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
-  counters_add_frontier(counters, t == 0 ? fs.reqs : 0u, t == 0 ? fs.pushes : 0u, t == 0 ? fs.emits : 0u,
-                        t == 0 ? stepped : 0u, t == 0 ? fs.reads : 0u);
-}
-
-// Closes a chain of grid launches: the next chain starts `by` levels further.
-__global__ void k_level_advance(FrontierCtl *__restrict__ ctl, uint32_t by) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->level_base += by;
-}
-
-// The long tail of a match -- levels with a handful of elements -- is bound by launches and host looks,
-// not by work.  One persistent workgroup runs those levels back to back: its 16 waves share the 64 slices,
-// a workgroup barrier (with agent-scope release/acquire fences: the next level reads what other waves of
-// this workgroup appended) separates the levels, and it hands back to the grid kernel when the frontier
-// dies, reaches max_level, or outgrows what one workgroup should handle.
-struct TailState {
-  uint32_t level;      // first level not processed
-  uint32_t reason;     // 0 frontier empty, 1 max_level reached, 2 frontier outgrew the tail kernel, 3 queue overflow
-  uint32_t pending;    // elements still alive in the kernel's LDS queue at max_level (the global counts read 0 then)
-  uint32_t pad;
-};
-constexpr int kTailThreads = 1024;
-constexpr uint64_t kTailMax = 8192;          // elements per level one workgroup keeps; it is entered below half of it
-
-template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, NfaTables nfa, Queue qa, Queue qb,
-                                                                 uint32_t level0, uint32_t max_level, uint64_t sub_cap,
-                                                                 fmx_result *__restrict__ res, uint64_t seg_cap,
-                                                                 FrontierCtl *__restrict__ ctl,
-                                                                 unsigned long long *__restrict__ counters,
-                                                                 TailState *__restrict__ ts) {
-  constexpr int G = Lay<LAYOUT>::G;
-  constexpr uint32_t kTiny = kTailThreads / G;            // elements the LDS mode holds: one per lane group
-  __shared__ uint64_t s_cf[256];
-  __shared__ uint16_t s_slot[256];
-  __shared__ Stage s_stage[kTailThreads / 64];
-  __shared__ uint32_t s_verdict, s_tcnt, s_push;
-  __shared__ uint64_t s_prefix[kSub + 1];
-  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
-  __syncthreads();
-  static_assert(kSub == 64, "one slice counter per lane below");
-  // LDS mode keeps the frontier in two small queues that live in the (then unused) staging area
-  static_assert(sizeof(s_stage) >= 2 * kTiny * 20 + 64, "the LDS queues must fit in the staging area");
-  uint8_t *raw = reinterpret_cast<uint8_t *>(&s_stage[0]);
-  uint64_t *tq_sp[2] = {reinterpret_cast<uint64_t *>(raw), reinterpret_cast<uint64_t *>(raw) + 2 * kTiny};
-  uint64_t *tq_ep[2] = {tq_sp[0] + kTiny, tq_sp[1] + kTiny};
-  uint32_t *tq_state[2] = {reinterpret_cast<uint32_t *>(tq_sp[1] + 2 * kTiny), reinterpret_cast<uint32_t *>(tq_sp[1] + 2 * kTiny) + kTiny};
-  const LaneConst lc = lane_const<G>();
-  const uint32_t t = lc.t;
-  const uint32_t w = threadIdx.x >> 6;
-  constexpr uint32_t nw = kTailThreads / 64;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t grp = threadIdx.x / G;                   // this lane group's number in the workgroup
-  uint32_t appends = 0, stepped = 0;
-  FStat fs;
-  uint32_t level = level0, reason = 1, pending = 0;
-  while (level < max_level) {
-    // lane j reads slice j's count (coherent load: other waves' atomics produced it).  Wave 0 decides for the
-    // whole workgroup -- the overflow flag can change while a level runs, and every thread must take the
-    // same way out of this loop (there is a barrier at its end)
-    const unsigned long long mine = __hip_atomic_load(&ctl->count[level % 3][lane].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (w == 0) {
-      const unsigned long long clamped = mine < sub_cap ? mine : sub_cap;
-      const unsigned long long total = wave_sum(clamped);
-      unsigned long long incl = clamped;                   // inclusive scan over the 64 lanes
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long y = __shfl_up(incl, d, 64);
-        if (lane >= (uint32_t)d) incl += y;
-      }
-      s_prefix[lane] = incl - clamped;
-      if (lane == 63) s_prefix[kSub] = incl;
-      const unsigned long long ovf = __hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lane == 0)
-        s_verdict = (ovf & 1ull) ? 3u : (total == 0 ? 0u : (total > kTailMax ? 2u : (total <= kTiny ? 5u : 4u)));
-    }
-    __syncthreads();
-    const uint32_t verdict = s_verdict;
-    if (verdict < 4u) { reason = verdict; break; }
-    const Queue &cur = (level & 1u) ? qb : qa;
-    const Queue &nxt = (level & 1u) ? qa : qb;
-    if (verdict == 4u) {
-      // ---- a level through the global queues
-      if (threadIdx.x < kSub) __hip_atomic_store(&ctl->count[(level + 2) % 3][threadIdx.x].v, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      frontier_slice<WIDE, LAYOUT, true>(ix, nfa, cur, nxt, level, sub_cap, res, seg_cap, ctl, s_cf, s_slot, s_stage[w], w, 0,
-                                         w, nw, s_prefix[kSub], appends, stepped, fs, s_prefix);
-      // level boundary.  The appends of this level were made by waves of this workgroup: draining the stores
-      // (workgroup-scope release) makes them reach L2; the acquire invalidates this CU's L1, which may still
-      // hold lines of the queue buffer from two levels ago.
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      level++;
-      continue;
-    }
-    // ---- LDS mode: at most one element per lane group.  The frontier moves into LDS and stays there, level
-    // after level, without queue traffic, counters or fences (a level is then: state record, rank blocks,
-    // three barriers), until it dies, reaches max_level, or a level's survivors no longer fit.
+    const uint32_t rgx = group_bcast<G, 3>(rq8.y);
+    // ---- results: ballot + one atomic per wave and round (they are few)
     {
-      const uint32_t total = (uint32_t)s_prefix[kSub];
-      if (grp < total && t == 0) {
-        uint32_t sl = 0;
-#pragma unroll
-        for (uint32_t step = kSub / 2; step; step >>= 1)
-          if (s_prefix[sl + step] <= grp) sl += step;
-        const uint64_t i = (uint64_t)sl * sub_cap + (grp - s_prefix[sl]);
-        tq_state[0][grp] = cur.state[i];
-        tq_sp[0][grp] = cur.sp[i];
-        tq_ep[0][grp] = cur.ep[i];
-      }
-      // the global counts of this level are consumed; nothing is appended while the frontier lives in LDS
-      if (threadIdx.x < kSub)
-        for (int sct = 0; sct < 3; sct++)
-          __hip_atomic_store(&ctl->count[sct][threadIdx.x].v, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (threadIdx.x == 0) { s_tcnt = total; s_push = 0; }
-    }
-    __syncthreads();
-    uint32_t cq = 0;                                       // which LDS queue holds the current level
-    bool spilled = false;
-    for (;;) {
-      const uint32_t tc = s_tcnt;
-      if (tc == 0) { reason = 0; break; }
-      if (level >= max_level) { reason = 1; pending = tc; break; }
-      const bool have = grp < tc;
-      uint32_t nf = 0, f0 = 0, rgx = 0;
-      uint64_t sp = 0, ep = 0;
-      uint32_t inl[kInlineFollows] = {0, 0, 0, 0};
-      bool emit = false;
-      if (have) {
-        const uint32_t state = tq_state[cq][grp];
-        sp = tq_sp[cq][grp];
-        ep = tq_ep[cq][grp];
-        const uint4 *p = reinterpret_cast<const uint4 *>(nfa.st + state);
-        const uint4 ra = p[0], rb = p[1];
-        const uint32_t c = ra.w & 0xFFu;
-        rgx = ra.z;
-        const uint16_t slot = s_slot[c];
-        const uint64_t cfc = s_cf[c];
-        if (level == 0) {
-          sp = cfc;
-          ep = (c == 255u) ? ix.n : s_cf[c + 1];
-          if (slot == kSlotNone) ep = sp;
-          else if (slot == kSlotEof) ep = sp + 1;
-        } else {
-          fs.reqs += backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
-        }
-        stepped++;
-        if (sp < ep) {
-          emit = (ra.w >> 8) != 0;
-          f0 = ra.x;
-          nf = ra.y;
-          fs.emits += emit ? 1u : 0u;
-          inl[0] = rb.x; inl[1] = rb.y; inl[2] = rb.z; inl[3] = rb.w;
-        }
-      }
-      const bool lead = t == 0;
       const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
       if (em) {
         const uint32_t so = (w + appends++) % kSub;
@@ -463,70 +268,104 @@ __global__ __launch_bounds__(kTailThreads) void k_frontier_tail(DevIndex ix, Nfa
           const unsigned long long at = rbase + __builtin_popcountll(em & ((1ull << lane) - 1ull));
           if (at < seg_cap) {
             fmx_result r;
-            r.regex = rgx; r.len = level + 1; r.sp = sp; r.ep = ep;
+            r.regex = rgx;
+            r.len = (meta & 0xFFFFu) + 1;
+            r.sp = sp;
+            r.ep = ep;
             res[(uint64_t)so * seg_cap + at] = r;
           } else {
             atomicOr(&ctl->overflow, 2ull);
           }
         }
-      }
-      // reserve room in the next LDS queue
-      uint32_t off = 0;
-      if (lead && nf) off = atomicAdd(&s_push, nf);
-      off = __shfl(off, (int)(lane & ~(uint32_t)(G - 1)), 64);
-      __syncthreads();
-      const uint32_t tp = s_push;
-      if (tp <= kTiny) {
-        for (uint32_t j = t; j < nf; j += G) {
-          const uint32_t fs = j < kInlineFollows ? (j < 2 ? (j == 0 ? inl[0] : inl[1]) : (j == 2 ? inl[2] : inl[3])) : nfa.fol[f0 + j];
-          tq_state[cq ^ 1][off + j] = fs;
-          tq_sp[cq ^ 1][off + j] = sp;
-          tq_ep[cq ^ 1][off + j] = ep;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { s_tcnt = tp; s_push = 0; }
-        cq ^= 1;
-        level++;
-        __syncthreads();
-        continue;
-      }
-      // ---- the survivors no longer fit: append them to the global queue of the next level and leave LDS mode
-      {
-        uint32_t wave_total = 0;
-        const uint32_t woff = wave_excl_scan(lead ? nf : 0u, wave_total);
-        if (wave_total) {
-          const uint32_t so = (w + appends++) % kSub;
-          const uint64_t out_off = (uint64_t)so * sub_cap;
-          unsigned long long qbase = 0;
-          if (lane == 0) qbase = atomicAdd(&ctl->count[(level + 1) % 3][so].v, (unsigned long long)wave_total);
-          qbase = __shfl(qbase, 0, 64);
-          const uint32_t my_off = __shfl(woff, (int)(lane & ~(uint32_t)(G - 1)), 64);
-          const Queue &nq = (level & 1u) ? qa : qb;
-          for (uint32_t j = t; j < nf; j += G) {
-            const unsigned long long at = qbase + my_off + j;
-            if (at < sub_cap) {
-              nq.state[out_off + at] = j < kInlineFollows ? (j < 2 ? (j == 0 ? inl[0] : inl[1]) : (j == 2 ? inl[2] : inl[3])) : nfa.fol[f0 + j];
-              nq.sp[out_off + at] = sp;
-              nq.ep[out_off + at] = ep;
-            } else {
-              atomicOr(&ctl->overflow, 1ull);
-            }
-          }
-        }
-        level++;
-        spilled = true;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        break;
+        fs.emits += (uint32_t)__builtin_popcountll(em);
       }
     }
-    if (!spilled) break;              // died or reached max_level inside LDS mode
+    // ---- the first follow stays with the lane group, the others go to the pool (short lists) or straight
+    // to the output queue (a '.' has 253)
+    const uint32_t npush = nf ? nf - 1 : 0u;
+    {
+      const uint32_t nsmall = npush <= kPoolSmall ? npush : 0u;
+      uint32_t small_total = 0;
+      const uint32_t small_off = wave_excl_scan(lead ? nsmall : 0u, small_total);
+      if (small_total) {
+        if (pn + small_total + P > kPoolCap) {
+          const uint32_t need = pn + small_total + P - kPoolCap;
+          const uint32_t half = pn < 64u ? pn : 64u;
+          spill(need > half ? need : half);
+        }
+        const uint32_t my_off = __shfl(small_off, lead_lane, 64);
+        const uint32_t fl1 = group_bcast<G, 1>(rq8.y), fl2 = group_bcast<G, 2>(rq8.x), fl3 = group_bcast<G, 2>(rq8.y);
+        const uint32_t fcs = group_bcast<G, 3>(rq8.x), f0 = group_bcast<G, 0>(rq8.x);
+        for (uint32_t q = t; q < nsmall; q += G) {
+          const uint32_t fj = q + 1;
+          const uint32_t fst = fj < kInlineFollows ? (fj == 1 ? fl1 : (fj == 2 ? fl2 : fl3)) : nfa.fol[f0 + fj];
+          const uint32_t fch = fj < kInlineFollows ? ((fcs >> (8u * fj)) & 0xFFu) : (uint32_t)nfa.fol_c[f0 + fj];
+          const uint32_t idx = (pb + pn + my_off + q) & kPoolMask;
+          pl.state[idx] = fst;
+          pl.meta[idx] = len1 | (fch << 16);
+          pl.sp[idx] = sp;
+          pl.ep[idx] = ep;
+        }
+        pn += small_total;
+        pool_sync();
+      }
+      if (__builtin_amdgcn_ballot_w64(npush > kPoolSmall)) {
+        const uint32_t nlarge = npush > kPoolSmall ? npush : 0u;
+        uint32_t large_total = 0;
+        const uint32_t large_off = wave_excl_scan(lead ? nlarge : 0u, large_total);
+        const uint32_t so = (w + appends++) % kSub;
+        const uint64_t out_off = (uint64_t)so * sub_cap;
+        unsigned long long qbase = 0;
+        if (lane == 0) qbase = atomicAdd(&next_count[so].v, (unsigned long long)large_total);
+        qbase = __shfl(qbase, 0, 64);
+        const uint32_t my_off = __shfl(large_off, lead_lane, 64);
+        const uint32_t f0 = group_bcast<G, 0>(rq8.x);
+        for (uint32_t q = t; q < nlarge; q += G) {
+          const unsigned long long at = qbase + my_off + q;
+          if (at < sub_cap) {
+            nxt.state[out_off + at] = nfa.fol[f0 + q + 1];
+            nxt.meta[out_off + at] = len1 | ((uint32_t)nfa.fol_c[f0 + q + 1] << 16);
+            nxt.sp[out_off + at] = sp;
+            nxt.ep[out_off + at] = ep;
+          } else {
+            atomicOr(&ctl->overflow, 1ull);
+          }
+        }
+        fs.writes += large_total;
+      }
+    }
+    {
+      const uint32_t fl0 = group_bcast<G, 1>(rq8.x), fc0 = group_bcast<G, 3>(rq8.x) & 0xFFu;
+      if (have) {
+        if (nf) { state = fl0; meta = len1 | (fc0 << 16); }
+        else have = false;
+      }
+    }
+    if (++rounds >= max_rounds) {
+      // ---- out of rounds: everything this wave still holds goes to the output queue -- the elements in
+      // registers, the pool, and what is left of its share of the input
+      const unsigned long long held = __builtin_amdgcn_ballot_w64(lead && have);
+      if (held) {
+        if (lead && have) {
+          const uint32_t idx = (pb + pn + (uint32_t)__builtin_popcountll(held & ((1ull << lane) - 1ull))) & kPoolMask;
+          pl.state[idx] = state; pl.meta[idx] = meta; pl.sp[idx] = sp; pl.ep[idx] = ep;
+        }
+        pn += (uint32_t)__builtin_popcountll(held);
+      }
+      spill(pn);
+      while (take_batch()) spill(pn);        // carried over, not consumed here
+      break;
+    }
   }
-  if (threadIdx.x == 0) { ts->level = level; ts->reason = reason; ts->pending = pending; ctl->level_base = level; }
-  counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
-  counters_add_frontier(counters, t == 0 ? fs.reqs : 0u, t == 0 ? fs.pushes : 0u, t == 0 ? fs.emits : 0u,
-                        t == 0 ? stepped : 0u, t == 0 ? fs.reads : 0u);
+  if (trunc) atomicOr(&ctl->truncated, 1ull);
+  counters_add(counters, lead ? 2ull * stepped : 0ull, lead ? stepped : 0u, 0);
+  counters_add_frontier(counters, fs.reqs, lane == 0 ? fs.writes : 0u, lane == 0 ? fs.emits : 0u, lead ? stepped : 0u,
+                        lane == 0 ? fs.reads : 0u);
+}
+
+// Closes a chain of launches: the next chain starts `by` passes further.
+__global__ void k_pass_advance(FrontierCtl *__restrict__ ctl, uint32_t by) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->pass_base += by;
 }
 
 // result groups the device leaves to the host (k_res_sort)
@@ -577,13 +416,12 @@ struct RegexBatch {
   fmx_result *d_res = nullptr;        // packed results
   fmx_result *d_res_seg = nullptr;    // kSub result slices the levels append to
   FrontierCtl *d_ctl = nullptr;
-  TailState *d_tail = nullptr;
   uint32_t *d_rcnt = nullptr, *d_rstart = nullptr, *d_rfill = nullptr;   // per-regex result counts / offsets
   uint32_t *d_rpart = nullptr;         // chunk totals of the offsets' scan
   BigGroups *d_big = nullptr;
   FrontierCtl *h_ctl = nullptr;        // pinned host copy the chain's last node fills
-  hipGraphExec_t chain_exec = nullptr; // one chain of grid levels + advance + counter copy, captured once
-  uint32_t chain_len = 0;
+  hipGraphExec_t chain_exec = nullptr; // one chain of launches + advance + counter copy, captured once
+  uint32_t chain_len = 0, chain_rounds = 0;
   uint32_t matches = 0;                // the chain is captured from a batch's second match on (a one-shot batch
                                        // would pay the capture and never replay it)
   ~RegexBatch() {
@@ -614,6 +452,7 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   }
   std::vector<StateRec> recs(n_states);
   std::vector<uint32_t> fol(n_fol), q_state(n_first), st_num(n_states), first_off(k + 1, 0), start_final;
+  std::vector<uint8_t> fol_c(n_fol);
   uint32_t max_fanout = 1;
   size_t base = 0, fo = 0, qo = 0;
   for (size_t r = 0; r < k; r++) {
@@ -623,13 +462,21 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
       rec.fol_off = (uint32_t)fo;
       // ReTree: `if (q.state.isLast) ret ::= ... else pqFront ++= follows` -- last states do not expand
       if (!(re.last_stops && re.st_last[s]))
-        for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) fol[fo++] = (uint32_t)base + (uint32_t)re.fol[j];
-      rec.fol_cnt = (uint32_t)fo - rec.fol_off;
+        for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) {
+          fol_c[fo] = re.st_c[(size_t)re.fol[j]];
+          fol[fo++] = (uint32_t)base + (uint32_t)re.fol[j];
+        }
+      const uint32_t cnt = (uint32_t)fo - rec.fol_off;
+      if (cnt > kMaxFollows) { set_error("a state has more than 65535 follows"); return FMX_ERR_UNSUPPORTED; }
+      rec.cnt_c_emit = cnt | ((uint32_t)re.st_c[s] << 16) | ((uint32_t)(re.st_last[s] ? 1 : 0) << 24);
       rec.regex = (uint32_t)r;
-      rec.c_emit = (uint32_t)re.st_c[s] | ((uint32_t)(re.st_last[s] ? 1 : 0) << 8);
-      for (uint32_t j = 0; j < kInlineFollows; j++) rec.f[j] = j < rec.fol_cnt ? fol[rec.fol_off + j] : 0u;
+      rec.fc = 0;
+      for (uint32_t j = 0; j < kInlineFollows; j++) {
+        rec.f[j] = j < cnt ? fol[rec.fol_off + j] : 0u;
+        if (j < cnt) rec.fc |= (uint32_t)fol_c[rec.fol_off + j] << (8 * j);
+      }
       st_num[base + s] = (uint32_t)re.st_num[s];
-      max_fanout = std::max(max_fanout, rec.fol_cnt);
+      max_fanout = std::max(max_fanout, cnt);
     }
     for (int32_t f : re.firsts) q_state[qo++] = (uint32_t)base + (uint32_t)f;
     first_off[r + 1] = (uint32_t)qo;
@@ -649,8 +496,11 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   b->all_retree = all_retree;
   StateRec *d_st = nullptr;
   uint32_t *d_fol = nullptr;
+  uint8_t *d_fol_c = nullptr;
   HIP_TRY(b->mem.alloc(&d_st, recs.size()), "hipMalloc");
   HIP_TRY(b->mem.alloc(&d_fol, fol.size()), "hipMalloc");
+  HIP_TRY(b->mem.alloc(&d_fol_c, fol_c.size() + 4), "hipMalloc");
+  if (!fol_c.empty()) HIP_TRY(hipMemcpy(d_fol_c, fol_c.data(), fol_c.size(), hipMemcpyHostToDevice), "H2D");
   HIP_TRY(b->mem.alloc(&b->d_first_state, q_state.size()), "hipMalloc");
   if (!recs.empty()) HIP_TRY(hipMemcpy(d_st, recs.data(), recs.size() * sizeof(StateRec), hipMemcpyHostToDevice), "H2D");
   if (!fol.empty()) HIP_TRY(hipMemcpy(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice), "H2D");
@@ -661,14 +511,14 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
     if (!st_num.empty()) HIP_TRY(hipMemcpy(b->d_st_num, st_num.data(), st_num.size() * 4, hipMemcpyHostToDevice), "H2D");
     HIP_TRY(hipMemcpy(b->d_first_off, first_off.data(), first_off.size() * 4, hipMemcpyHostToDevice), "H2D");
   }
-  b->nfa = NfaTables{d_st, d_fol};
+  b->nfa = NfaTables{d_st, d_fol, d_fol_c};
   *out = b.release();
   return FMX_OK;
 }
 
-// Level-0 queue: states = firsts, sp = 0, ep = n, dealt round-robin over the slices.
-__global__ void k_frontier_init(Queue q, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n,
-                                uint64_t sub_cap, uint32_t max_level, FrontierCtl *__restrict__ ctl) {
+// The start queue: states = firsts, len 0, (sp, ep) = (0, n), dealt round-robin over the slices.
+__global__ void k_frontier_init(Queue q, NfaTables nfa, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n,
+                                uint64_t sub_cap, uint32_t max_len, FrontierCtl *__restrict__ ctl) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kSub) {
     ctl->count[0][i].v = count > i ? (count - i + kSub - 1) / kSub : 0;
@@ -676,10 +526,11 @@ __global__ void k_frontier_init(Queue q, const uint32_t *__restrict__ first_stat
     ctl->count[2][i].v = 0;
     ctl->res_count[i].v = 0;
   }
-  if (i == 0) { ctl->overflow = 0; ctl->level_base = 0; ctl->max_level = max_level; }
+  if (i == 0) { ctl->overflow = 0; ctl->truncated = 0; ctl->pass_base = 0; ctl->max_len = max_len; }
   if (i < count) {
     const uint64_t at = (i % kSub) * sub_cap + i / kSub;
-    q.state[at] = first_state[i]; q.sp[at] = 0; q.ep[at] = n;
+    const uint32_t st = first_state[i];
+    q.state[at] = st; q.meta[at] = rec_c(nfa.st[st]) << 16; q.sp[at] = 0; q.ep[at] = n;
   }
 }
 
@@ -789,7 +640,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (trace) fprintf(stderr, "[fmx] regex_batch_match %-18s +%.3f ms\n", what,
                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   };
-  const uint32_t max_steps = (lim && lim->max_steps) ? lim->max_steps : 4096u;
+  const uint32_t max_steps = std::min<uint32_t>((lim && lim->max_steps) ? lim->max_steps : 4096u, kMaxLen);
   const uint64_t qcap = (lim && lim->max_frontier) ? lim->max_frontier : (1ull << 22);
   if (b->index_serial != h->serial) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
   if (per_regex_count) std::fill(per_regex_count, per_regex_count + b->k, 0u);
@@ -808,13 +659,13 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     const uint64_t seg_cap = (uint64_t)(cap ? cap : 1) / 16 + 1024;
     for (Queue *q : {&b->qa, &b->qb}) {
       HIP_TRY(b->scratch->alloc(&q->state, kSub * sub_cap), "hipMalloc(queue)");
+      HIP_TRY(b->scratch->alloc(&q->meta, kSub * sub_cap), "hipMalloc(queue)");
       HIP_TRY(b->scratch->alloc(&q->sp, kSub * sub_cap), "hipMalloc(queue)");
       HIP_TRY(b->scratch->alloc(&q->ep, kSub * sub_cap), "hipMalloc(queue)");
     }
     HIP_TRY(b->scratch->alloc(&b->d_res, cap ? cap : 1), "hipMalloc(results)");
     HIP_TRY(b->scratch->alloc(&b->d_res_seg, kSub * seg_cap), "hipMalloc(result slices)");
     HIP_TRY(b->scratch->alloc(&b->d_ctl, 1), "hipMalloc(ctl)");
-    HIP_TRY(b->scratch->alloc(&b->d_tail, 1), "hipMalloc(tail state)");
     HIP_TRY(b->scratch->alloc(&b->d_rcnt, b->k + 1), "hipMalloc(result counts)");
     HIP_TRY(b->scratch->alloc(&b->d_rstart, b->k + 1), "hipMalloc(result offsets)");
     HIP_TRY(b->scratch->alloc(&b->d_rfill, b->k + 1), "hipMalloc(result fill)");
@@ -824,7 +675,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     b->rcap = cap ? cap : 1;
   }
   // Slice capacity of the result buffer: a function of the ALLOCATED size, so that it stays what the captured
-  // level chain was recorded with when a later call passes a smaller cap (the scratch is kept then).
+  // launch chain was recorded with when a later call passes a smaller cap (the scratch is kept then).
   const uint64_t seg_cap = (uint64_t)b->rcap / 16 + 1024;
   const Queue qa = b->qa, qb = b->qb;
   fmx_result *d_res = b->d_res;
@@ -837,36 +688,44 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
 
   mark("setup");
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
-  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->d_first_state, b->n_first, h->n, sub_cap, max_steps, d_ctl);
+  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->nfa, b->d_first_state, b->n_first, h->n, sub_cap, max_steps, d_ctl);
   HIP_TRY(hipGetLastError(), "k_frontier_init");
-  // Levels are chained on the stream without host round trips; the host looks at the counters
-  // every kChain levels.  A level with an empty queue returns at once.
-  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 8u;   // levels between host looks
-  const int grid_full = h->cu_count * 6;     // what stays resident at 80 vector registers per lane
-  static const bool use_tail = !(getenv("FMX_FRONTIER_TAIL") && atoi(getenv("FMX_FRONTIER_TAIL")) == 0);   // A/B switch
+  // Launches are chained on the stream without host round trips; the host looks at the counters after every
+  // chain.  A launch whose input queue is empty returns at once.
+  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 4u;
+  // rounds a wave works before it hands its leftovers to the next launch (the load balancing step)
+  static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 64u;
+  static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : 6;
+  const int grid_full = h->cu_count * per_cu;
+  const uint32_t group_lanes = h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G;
+  const uint64_t per_wg = (uint64_t)kFThreads / group_lanes;      // elements a workgroup holds at once
   std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());
   FrontierCtl &ctl = *ctl_host;
   uint64_t n_res = 0;
-  uint32_t level = 0;
+  uint32_t pass = 0;
   uint64_t launches = 1;
   bool alive = true, truncated = false;
-  // One chain = kChain grid levels + k_level_advance + the counters' copy to pinned host memory.  Its kernel
-  // arguments do not change from chain to chain (the level comes from ctl->level_base), so it is captured
+  auto launch_pass = [&](hipStream_t s, int grid, uint32_t j, uint32_t rounds) {
+#define CALL(W, L) k_frontier<W, L><<<grid, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters)
+    FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
+  };
+  // One chain = kChain launches + k_pass_advance + the counters' copy to pinned host memory.  Its kernel
+  // arguments do not change from chain to chain (the pass comes from ctl->pass_base), so it is captured
   // into a hipGraph once per batch and replayed: one launch call per chain instead of kChain + 2.
   static const bool use_graph = !(getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) == 0);
   auto enqueue_chain = [&](hipStream_t s) -> hipError_t {
-    for (uint32_t j = 0; j < kChain; j++) {
-#define CALL(W, L) k_frontier<W, L><<<grid_full, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters)
-      FMX_LAYOUT_DISPATCH(h, CALL);
-#undef CALL
-    }
-    k_level_advance<<<1, 1, 0, s>>>(d_ctl, kChain);
+    for (uint32_t j = 0; j < kChain; j++) launch_pass(s, grid_full, j, kRounds);
+    k_pass_advance<<<1, 1, 0, s>>>(d_ctl, kChain);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(b->h_ctl, d_ctl, sizeof(FrontierCtl), hipMemcpyDeviceToHost, s);
   };
   b->matches++;
-  if (use_graph && b->matches >= 2 && (!b->chain_exec || b->chain_len != kChain)) {
+  uint64_t total = b->n_first;               // elements in the input queue of the next pass
+  const uint64_t kSmallTotal = 64 * per_wg;  // up to here a pass gets a grid of its own size and is launched directly
+  const bool want_chain = total > kSmallTotal;
+  if (use_graph && want_chain && b->matches >= 2 && (!b->chain_exec || b->chain_len != kChain || b->chain_rounds != kRounds)) {
     if (b->chain_exec) { (void)hipGraphExecDestroy(b->chain_exec); b->chain_exec = nullptr; }
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -879,50 +738,39 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (g) (void)hipGraphDestroy(g);
     if (e != hipSuccess) { (void)hipGetLastError(); b->chain_exec = nullptr; }    // fall back to plain launches
     b->chain_len = kChain;
+    b->chain_rounds = kRounds;
   }
-  // a small batch (a single regex, say) starts in the tail kernel: no grid levels, no look
-  bool grid_first = !(use_tail && b->n_first <= kTailMax / 2 && max_steps > 0);
   while (alive) {
-    uint64_t next_total = b->n_first;
-    if (grid_first) {
-      if (b->chain_exec) HIP_TRY(hipGraphLaunch(b->chain_exec, st), "hipGraphLaunch(level chain)");
+    uint32_t done = 0;
+    if (total > kSmallTotal) {
+      if (b->chain_exec) HIP_TRY(hipGraphLaunch(b->chain_exec, st), "hipGraphLaunch(launch chain)");
       else HIP_TRY(enqueue_chain(st), "k_frontier chain");
+      done = kChain;
       launches += kChain + 1;
-      HIP_TRY(hipStreamSynchronize(st), "sync(levels)");
-      std::memcpy(&ctl, b->h_ctl, sizeof ctl);
-      level = std::min<uint64_t>((uint64_t)level + kChain, max_steps);
-      if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
-      next_total = 0;
-      n_res = 0;
-      for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
-      alive = next_total != 0;
-      if (trace)
-        fprintf(stderr, "[fmx] frontier level %u: next %llu, results %llu, overflow %llu\n", level,
-                (unsigned long long)next_total, (unsigned long long)n_res, ctl.overflow);
+    } else {
+      // a small frontier (a single regex, or the tail of a batch): one launch sized to it, with rounds enough
+      // to finish most searches inside it
+      // (never fewer than kSub waves: every queue slice needs a wave that reads it)
+      const int grid = (int)std::max<uint64_t>(kSub / (kFThreads / 64), (total + per_wg - 1) / per_wg);
+      launch_pass(st, grid, 0, std::max<uint32_t>(kRounds, 256u));
+      k_pass_advance<<<1, 1, 0, st>>>(d_ctl, 1);
+      HIP_TRY(hipGetLastError(), "k_frontier");
+      HIP_TRY(hipMemcpyAsync(b->h_ctl, d_ctl, sizeof(FrontierCtl), hipMemcpyDeviceToHost, st), "D2H(ctl)");
+      done = 1;
+      launches += 2;
     }
-    grid_first = true;
-    if (alive && level < max_steps && next_total <= kTailMax / 2 && use_tail) {
-      // nearly empty frontier: one persistent workgroup runs the following levels without launches in between
-      TailState tsh{};
-#define CALL(W, L) k_frontier_tail<W, L><<<1, kTailThreads, 0, st>>>(h->dev, b->nfa, qa, qb, level, max_steps, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters, b->d_tail)
-      FMX_LAYOUT_DISPATCH(h, CALL);
-#undef CALL
-      HIP_TRY(hipGetLastError(), "k_frontier_tail");
-      launches++;
-      HIP_TRY(hipMemcpyAsync(&tsh, b->d_tail, sizeof tsh, hipMemcpyDeviceToHost, st), "D2H(tail)");
-      HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
-      HIP_TRY(hipStreamSynchronize(st), "sync(tail)");
-      if ((ctl.overflow & 1ull) || tsh.reason == 3) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
-      level = tsh.level;
-      next_total = 0;
-      n_res = 0;
-      for (uint32_t j = 0; j < kSub; j++) { next_total += ctl.count[level % 3][j].v; n_res += ctl.res_count[j].v; }
-      alive = next_total != 0 || tsh.pending != 0;
-      if (trace)
-        fprintf(stderr, "[fmx] frontier tail kernel stopped at level %u (reason %u): next %llu, results %llu\n", level,
-                tsh.reason, (unsigned long long)next_total, (unsigned long long)n_res);
-    }
-    if (alive && level >= max_steps) { truncated = true; alive = false; }
+    HIP_TRY(hipStreamSynchronize(st), "sync(passes)");
+    std::memcpy(&ctl, b->h_ctl, sizeof ctl);
+    pass += done;
+    if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
+    total = 0;
+    n_res = 0;
+    for (uint32_t j = 0; j < kSub; j++) { total += ctl.count[pass % 3][j].v; n_res += ctl.res_count[j].v; }
+    alive = total != 0;
+    truncated = ctl.truncated != 0;
+    if (trace)
+      fprintf(stderr, "[fmx] frontier after pass %u: queue %llu, results %llu, overflow %llu\n", pass,
+              (unsigned long long)total, (unsigned long long)n_res, ctl.overflow);
   }
   const bool grouped = n_res && !(ctl.overflow & 2ull) && n_res <= cap;
   if (grouped) {
@@ -1002,7 +850,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   }
   mark("results ordered");
   if (truncated) {
-    set_error("frontier still alive after max_steps levels: results hold every match of length <= max_steps");
+    set_error("some matches run past max_steps: results hold every match of length <= max_steps");
     return FMX_TRUNCATED;
   }
   return FMX_OK;

@@ -1,4 +1,4 @@
-// fmx_nfa.h -- device-side regex tables shared by the frontier kernels (fmx_frontier.hip) and the
+// fmx_nfa.h -- device-side regex tables shared by the frontier kernel (fmx_frontier.hip) and the
 // reference-order kernel (fmx_refmatch.hip).  All regexes of a batch are concatenated; state ids are global.
 #pragma once
 #include <stdint.h>
@@ -6,17 +6,24 @@
 namespace fmx {
 
 constexpr uint32_t kInlineFollows = 4;
+constexpr uint32_t kMaxFollows = 0xFFFFu;   // fol_cnt is 16 bits wide
 struct StateRec {        // 32 bytes: everything an element needs about its state, two 16-byte loads
-  uint32_t fol_off;      // first entry of its follows in `fol`
-  uint32_t fol_cnt;      // 0 for a state that emits and does not expand (ReTree isLast, retree.scala:636-641)
-  uint32_t regex;
-  uint32_t c_emit;       // byte in bits 0..7, emit flag in bit 8
+  uint32_t fol_off;      // first entry of its follows in `fol` / `fol_c`
+  uint32_t cnt_c_emit;   // fol_cnt in bits 0..15 (0 for a state that emits and does not expand: ReTree isLast,
+                         // retree.scala:636-641), the state's byte in bits 16..23, emit flag in bit 24
   uint32_t f[kInlineFollows];   // the first follows, so that short lists need no further load
+  uint32_t fc;           // the bytes of those follows (byte j = byte of state f[j]): an element that moves on to
+                         // f[j] can request its next rank blocks without waiting for f[j]'s own record
+  uint32_t regex;
 };
+__host__ __device__ inline uint32_t rec_cnt(const StateRec &r) { return r.cnt_c_emit & 0xFFFFu; }
+__host__ __device__ inline uint32_t rec_c(const StateRec &r) { return (r.cnt_c_emit >> 16) & 0xFFu; }
+__host__ __device__ inline uint32_t rec_emit(const StateRec &r) { return (r.cnt_c_emit >> 24) & 1u; }
 
 struct NfaTables {
   const StateRec *st;
   const uint32_t *fol;
+  const uint8_t *fol_c;    // byte of state fol[i], parallel to fol
 };
 
 // What ReTree._matchSA's replay needs on top: CharNode.num (the heap key) and each regex's firsts.

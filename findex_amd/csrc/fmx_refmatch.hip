@@ -132,13 +132,13 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
       uint64_t ep = ((uint64_t)__shfl(ephi, leader, 64) << 32) | __shfl(eplo, leader, 64);
       // sa.getPrevRange(q.sp, q.ep, q.state.c), :633
       const StateRec rec = rt.st[state];
-      const uint32_t c = rec.c_emit & 0xFFu;
+      const uint32_t c = rec_c(rec);
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
       backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
       stepped++;
       if (t == 0 && sp < ep) {
-        if (rec.c_emit >> 8) {                                     // isLast, :636-638
+        if (rec_emit(rec)) {                                     // isLast, :636-638
           const unsigned long long at = atomicAdd(&ctl->res_count, 1ull);
           if (at < res_cap) {
             RefResult o;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
           }
           nres++;
         } else {                                                   // :641
-          for (uint32_t f = rec.fol_off; f < rec.fol_off + rec.fol_cnt; f++) {
+          for (uint32_t f = rec.fol_off; f < rec.fol_off + rec_cnt(rec); f++) {
             HeapElem e;
             e.state = rt.fol[f]; e.num = rt.st_num[e.state]; e.len = len + 1; e.pad = 0; e.sp = sp; e.ep = ep;
             if (size0 + 1 > heap_cap) { bad = true; atomicOr(&ctl->overflow, 1ull); break; }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Workload for rocprofv3 passes: the C3 bench step (k_search4) plus a calibration launch of
+"""Workload for rocprofv3 passes: a bench step of the chosen workload (k_search4, or the regex frontier kernels
+for c4) plus a calibration launch of
 k_occ whose HBM byte count is known -- 2^24 uniformly random (c, i) rank queries over the
 77 GiB rank dictionary touch 2^24 distinct 64-byte blocks (collisions < 0.2 %), i.e. 1 GiB, plus
 the 9 bytes of (c, i) streamed in per query.  FETCH_SIZE read for k_occ calibrates the counter
@@ -26,33 +27,57 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--calib-queries", type=int, default=1 << 24)
 a = ap.parse_args()
 
-log2n, sigma, k, m, seed = bench.WORKLOADS[a.workload]
-n = 1 << log2n
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 stream = torch.cuda.current_stream().cuda_stream
-bwt, eof = bench.make_bwt(torch, n, sigma, seed, dev)
+regex = a.workload in bench.REGEX
+if regex:
+    log2n, k, seed, max_len = bench.REGEX[a.workload]
+    n, sigma = 1 << log2n, None
+    bwt, eof = bench.make_bwt(torch, n, bench.C4_ALPHABET, seed, dev)
+else:
+    log2n, sigma, k, m, seed = bench.LITERAL[a.workload]
+    n = 1 << log2n
+    bwt, eof = bench.make_bwt(torch, n, sigma, seed, dev)
 torch.cuda.synchronize()
 hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=0, stream=stream)
 del bwt
 torch.cuda.empty_cache()
-pats, off = bench.make_patterns(torch, hip, n, sigma, k, m, seed * 1000, dev, stream)
-sp = torch.empty(k, dtype=torch.int64, device=dev)
-ep = torch.empty(k, dtype=torch.int64, device=dev)
+if regex:
+    res, trees = bench.make_regexes(k, seed * 1000)
+    batch = findex_amd.ReTree.prepare_batch(hip, trees)
+    batch.match_raw(max_steps=max_len, cap=1 << 22)          # first call: allocations (the level chain is captured from the 2nd)
+    batch.match_raw(max_steps=max_len, cap=1 << 22)
+else:
+    pats, off = bench.make_patterns(torch, hip, n, sigma, k, m, seed * 1000, dev, stream)
+    sp = torch.empty(k, dtype=torch.int64, device=dev)
+    ep = torch.empty(k, dtype=torch.int64, device=dev)
 g = torch.Generator(device=dev)
 g.manual_seed(42)
 kc = a.calib_queries
-qc = torch.randint(1, sigma + 1, (kc,), generator=g, device=dev, dtype=torch.uint8)
+if regex:
+    alpha = torch.tensor([ord(c) for c in bench.C4_ALPHABET], dtype=torch.uint8, device=dev)
+    qc = alpha[torch.randint(0, alpha.numel(), (kc,), generator=g, device=dev)]
+else:
+    qc = torch.randint(1, sigma + 1, (kc,), generator=g, device=dev, dtype=torch.uint8)
 qi = torch.randint(0, n, (kc,), generator=g, device=dev, dtype=torch.int64)
 qo = torch.empty(kc, dtype=torch.int64, device=dev)
 torch.cuda.synchronize()
 hip.stats_reset()
 for _ in range(a.steps):
-    hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
+    if regex:
+        batch.match_raw(max_steps=max_len, cap=1 << 22)
+    else:
+        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
 torch.cuda.synchronize()
 st = hip.stats()
-print("k_search4: %d launches, %d rank queries and %d block requests per launch"
-      % (a.steps, st["rank_queries"] // a.steps, st["search_requests"] // a.steps))
+if regex:
+    print("frontier: %d calls; per call %d elements stepped, %d rank-line requests, %d queue reads, %d queue writes, %d results"
+          % (a.steps, st["frontier_elements"] // a.steps, st["frontier_requests"] // a.steps,
+             st["frontier_queue_reads"] // a.steps, st["frontier_queue_writes"] // a.steps, st["frontier_results"] // a.steps))
+else:
+    print("k_search4: %d launches, %d rank queries and %d block requests per launch"
+          % (a.steps, st["rank_queries"] // a.steps, st["search_requests"] // a.steps))
 for _ in range(3):
     hip.occ_batch_dev(qc.data_ptr(), qi.data_ptr(), qo.data_ptr(), kc, stream)
 torch.cuda.synchronize()

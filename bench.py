@@ -572,11 +572,11 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     if rank != 0:
         return None
     # ---- roofline of the frontier kernels (k_frontier*): bytes this design moves per call, from the device's
-    # own counters: 64 B per rank-line request, 32 B of state record per element stepped, 20 B per work-queue
-    # entry read or appended, 24 B per result written.
+    # own counters: 64 B per rank-line request, 32 B per state record loaded, 24 B per work-queue entry read or
+    # appended, 24 B per result written.
     line_bytes = 64.0 if st["layout"] == 0 else 66.0
-    alg_bytes = (s1["frontier_requests"] * line_bytes + 32.0 * s1["frontier_elements"] +
-                 20.0 * (s1["frontier_queue_reads"] + s1["frontier_queue_writes"]) + 24.0 * s1["frontier_results"])
+    alg_bytes = (s1["frontier_requests"] * line_bytes + 32.0 * s1["frontier_records"] +
+                 24.0 * (s1["frontier_queue_reads"] + s1["frontier_queue_writes"]) + 24.0 * s1["frontier_results"])
     ksec = kernel_ms * 1e-3
     achieved = alg_bytes / ksec / 1e9
     traffic = pmc_traffic(args.workload, "k_frontier")
@@ -588,8 +588,8 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         "traffic_source": ("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
                            % traffic[1]) if traffic else "no PMC profile of this workload committed",
         "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_bytes": "%d rank-line requests x %g B + %d elements x 32 B state record + (%d + %d) queue entries x 20 B "
-                             "+ %d results x 24 B" % (s1["frontier_requests"], line_bytes, s1["frontier_elements"],
+        "algorithmic_bytes": "%d rank-line requests x %g B + %d state records x 32 B + (%d + %d) queue entries x 24 B "
+                             "+ %d results x 24 B" % (s1["frontier_requests"], line_bytes, s1["frontier_records"],
                                                       s1["frontier_queue_reads"], s1["frontier_queue_writes"],
                                                       s1["frontier_results"]),
         "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,

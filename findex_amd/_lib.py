@@ -48,7 +48,8 @@ class fmx_stats_t(ctypes.Structure):
                 ("reserved", ctypes.c_uint32), ("search_requests", ctypes.c_uint64),
                 ("frontier_requests", ctypes.c_uint64), ("frontier_elements", ctypes.c_uint64),
                 ("frontier_queue_reads", ctypes.c_uint64), ("frontier_queue_writes", ctypes.c_uint64),
-                ("frontier_results", ctypes.c_uint64), ("reserved2", ctypes.c_uint64 * 3)]
+                ("frontier_results", ctypes.c_uint64), ("frontier_records", ctypes.c_uint64),
+                ("reserved2", ctypes.c_uint64 * 2)]
 
 
 # name -> (restype, argtypes); every symbol include/fmx.h declares

@@ -729,14 +729,14 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
-  unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   std::memset(out, 0, sizeof *out);
   HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   {   // the counters live in per-workgroup slots (fmx_device.h): sum them
     std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
     HIP_TRY(hipMemcpy(slots.data(), h->d_counters, kCounterBytes, hipMemcpyDeviceToHost), "D2H(counters)");
     for (uint32_t sl = 0; sl < kCounterSlots; sl++)
-      for (int j = 0; j < 8; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
+      for (int j = 0; j < 9; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
   }
   std::lock_guard<std::mutex> lk(h->mu);
   out->rank_queries = cnt[0];
@@ -754,6 +754,7 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->frontier_results = cnt[5];
   out->frontier_elements = cnt[6];
   out->frontier_queue_reads = cnt[7];
+  out->frontier_records = cnt[8];
   out->build_ms = h->build_ms;
   return FMX_OK;
 }

@@ -219,7 +219,12 @@ __device__ __forceinline__ uint64_t byte_rank_finish(const ByteRankReq &q, uint3
 __device__ __forceinline__ uint32_t byte_match_bit(const ByteRankReq &q, uint32_t c, const LaneConst &lc) {
   const uint32_t bidx = q.rem & 15u;                     // byte of this lane that holds row x
   const uint32_t comp = bidx >> 2;
-  const uint32_t word = comp < 2u ? (comp == 0u ? q.w.x : q.w.y) : (comp == 2u ? q.w.z : q.w.w);
+  // the dword that holds the byte, by 64-bit shifts (a chain of selects here is turned into an indexed load from
+  // scratch memory by the compiler)
+  const uint32_t sh = 32u * (comp & 1u);
+  const uint32_t lo = (uint32_t)((((uint64_t)q.w.y << 32) | q.w.x) >> sh);
+  const uint32_t hi = (uint32_t)((((uint64_t)q.w.w << 32) | q.w.z) >> sh);
+  const uint32_t word = (uint32_t)((((uint64_t)hi << 32) | lo) >> (16u * (comp & 2u)));
   const uint32_t byte = __builtin_amdgcn_ubfe(word, 8u * (bidx & 3u), 8u);
   return group_or<8>(((q.rem >> 4) == lc.t && byte == c) ? 1u : 0u);
 }
@@ -307,6 +312,33 @@ __device__ __forceinline__ uint32_t backward_step(const DevIndex &ix, uint32_t c
   return b2 != b1 ? 2u : 1u;
 }
 
+// The same step for an interval of exactly one row, [sp, sp + 1): it maps to [C[c] + rank(c, sp), + [BWT'[sp] == c]),
+// and BWT'[sp] == c is bit sp of c's own vector (a byte compare in the bytes layout), i.e. part of the block already
+// fetched: one request and half the popcount work.  Same result as backward_step.
+template <bool WIDE, uint32_t LAYOUT>
+__device__ __forceinline__ uint32_t single_row_step(const DevIndex &ix, uint32_t c, uint16_t slot, uint64_t cfc,
+                                                    const LaneConst &lc, uint64_t &sp, uint64_t &ep) {
+  if (slot >= kSlotEof) {
+    const uint64_t r1 = (slot == kSlotEof && sp > ix.eof) ? 1 : 0;
+    const uint64_t r2 = (slot == kSlotEof && ep > ix.eof) ? 1 : 0;
+    sp = cfc + r1;
+    ep = cfc + r2;
+    return 0;
+  }
+  if (LAYOUT == kLayoutBytes) {
+    const ByteRankReq q1 = byte_rank_issue(ix, slot, sp, lc);
+    sp = cfc + byte_rank_finish(q1, c, lc);
+    ep = sp + byte_match_bit(q1, c, lc);
+    return 2u;
+  }
+  uint32_t b1, m1;
+  split448(sp, b1, m1);
+  const uint4 w1 = load_line16(block_addr(ix, slot, b1, lc));
+  sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+  ep = sp + payload_bit(w1, m1, lc);
+  return 1u;
+}
+
 // ---- statistics counters without a hot spot.  Same-address device atomics complete at roughly 100
 // per microsecond on MI355X; a kernel whose 8192 waves all end together and each add to one shared
 // counter spends its last ~100 us per counter draining them (measured: round 1).  So the
@@ -315,7 +347,7 @@ __device__ __forceinline__ uint32_t backward_step(const DevIndex &ix, uint32_t c
 constexpr uint32_t kCounterSlots = 2048;
 constexpr uint32_t kCounterStride = 16;        // uint64 per slot: [0] rank queries, [1] backward steps, [2] search requests,
                                                // frontier kernels: [3] rank-line requests, [4] queue appends, [5] results,
-                                               // [6] elements stepped, [7] queue entries read
+                                               // [6] elements stepped, [7] queue entries read, [8] state records loaded
 constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterStride * 8;
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -341,8 +373,10 @@ __device__ __forceinline__ void counters_add(unsigned long long *__restrict__ co
 // The frontier kernels' own counters (slots 3..7), same calling rule.
 __device__ __forceinline__ void counters_add_frontier(unsigned long long *__restrict__ counters, unsigned long long reqs,
                                                       unsigned long long pushes, unsigned long long results,
-                                                      unsigned long long elems, unsigned long long reads) {
+                                                      unsigned long long elems, unsigned long long reads,
+                                                      unsigned long long recs) {
   reqs = wave_sum(reqs);
+  recs = wave_sum(recs);
   pushes = wave_sum(pushes);
   results = wave_sum(results);
   elems = wave_sum(elems);
@@ -354,6 +388,7 @@ __device__ __forceinline__ void counters_add_frontier(unsigned long long *__rest
     if (results) atomicAdd(slot + 5, results);
     if (elems) atomicAdd(slot + 6, elems);
     if (reads) atomicAdd(slot + 7, reads);
+    if (recs) atomicAdd(slot + 8, recs);
   }
 }
 

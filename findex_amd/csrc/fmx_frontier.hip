@@ -75,21 +75,28 @@ struct FrontierCtl {     // device-resident counters
 };
 
 struct FStat {           // wave-uniform sums for the frontier counters (fmx_device.h, slots 3..7)
-  uint32_t reqs = 0, writes = 0, emits = 0, reads = 0;
+  uint32_t reqs = 0, writes = 0, emits = 0, reads = 0, recs = 0;
 };
 
+// Exclusive prefix sum over the 64 lanes with DPP adds only (row shifts inside each row of 16, then the row
+// totals carried over with row_bcast:15 / row_bcast:31): six VALU instructions, no LDS crossbar round trips
+// (the __shfl_up form of round 1 cost seven dependent ds_bpermute per scan).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t x) {
+  return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+}
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
-  // inclusive Hillis-Steele over the 64 lanes, then shift
-  const uint32_t lane = __lane_id();
   uint32_t x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = __shfl_up(x, d, 64);
-    if (lane >= (uint32_t)d) x += y;
-  }
-  total = __shfl(x, 63, 64);
+  x = dpp_add<0x111, 0xF>(x);     // row_shr:1
+  x = dpp_add<0x112, 0xF>(x);     // row_shr:2
+  x = dpp_add<0x114, 0xF>(x);     // row_shr:4
+  x = dpp_add<0x118, 0xF>(x);     // row_shr:8
+  x = dpp_add<0x142, 0xA>(x);     // row_bcast:15 into rows 1 and 3
+  x = dpp_add<0x143, 0xC>(x);     // row_bcast:31 into rows 2 and 3
+  total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
   return x - v;
 }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // A wave's pool: a ring of kPoolCap entries in LDS, oldest at `pb`, `pn` entries.  Only the owning wave
 // touches it; the compiler is kept from moving LDS accesses across the hand-over points with
@@ -103,6 +110,10 @@ struct Pool {            // 24 bytes per entry, 3 KiB per wave
   uint64_t sp[kPoolCap];
   uint64_t ep[kPoolCap];
 };
+constexpr uint32_t kResStage = 32;      // results a wave collects in LDS before it reserves room for them (one atomic per flush)
+struct ResStage {
+  fmx_result r[kResStage];
+};
 __device__ __forceinline__ void pool_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -112,11 +123,10 @@ __device__ __forceinline__ void pool_sync() {
 // ctl->pass_base + j.  Wave w reads slice w % kSub together with the other waves of that class: its share
 // is the batches part, part + class_waves, ... of P = 64/G entries each.
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
-                                                         uint32_t max_rounds, uint64_t sub_cap,
-                                                         fmx_result *__restrict__ res, uint64_t seg_cap,
-                                                         FrontierCtl *__restrict__ ctl,
-                                                         unsigned long long *__restrict__ counters) {
+__device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTables &nfa, const Queue &qa, const Queue &qb, uint32_t j,
+                                              uint32_t max_rounds, uint64_t sub_cap, fmx_result *__restrict__ res,
+                                              uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
+                                              unsigned long long *__restrict__ counters) {
   constexpr int G = Lay<LAYOUT>::G;
   constexpr uint32_t P = 64 / G;             // lane groups per wave = entries per input batch
   // After a queue overflow the appended count exceeds what was stored: later passes of the chain
@@ -133,15 +143,18 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
   const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
   uint64_t cur_count = ctl->count[pass % 3][sub].v;
   if (cur_count > sub_cap) cur_count = sub_cap;
-  const bool share = (uint64_t)part * P < cur_count;
+  const bool share = (uint64_t)part * ((cur_count + class_waves - 1) / class_waves) < cur_count;
   if (!__syncthreads_or(share ? 1 : 0)) return;      // a workgroup without work leaves before staging anything
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
   __shared__ Pool s_pool[kFThreads / 64];
+  __shared__ ResStage s_res[kFThreads / 64];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
   __syncthreads();
   if (!share) return;                        // wave-uniform; no workgroup barrier below
   Pool &pl = s_pool[threadIdx.x >> 6];
+  ResStage &rs = s_res[threadIdx.x >> 6];
+  uint32_t rs_n = 0;                         // wave-uniform
   const LaneConst lc = lane_const<G>();
   const uint32_t t = lc.t, lane = __lane_id();
   const bool lead = t == 0;
@@ -150,10 +163,19 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
   PaddedCount *next_count = ctl->count[(pass + 1) % 3];
   const uint32_t max_len = ctl->max_len;
   uint32_t pb = 0, pn = 0, appends = 0, rounds = 0;     // wave-uniform
-  uint64_t a_next = part;                    // next batch of this wave's share
+  // this wave's share of the slice: one contiguous chunk, read up to 64 entries at a time
+  const uint64_t chunk = (cur_count + class_waves - 1) / class_waves;
+  uint64_t a_next = (uint64_t)part * chunk;
+  uint64_t a_end = a_next + chunk;
+  if (a_end > cur_count) a_end = cur_count;
   bool have = false;                         // the element this lane group holds
   uint32_t state = 0, meta = 0;
   uint64_t sp = 0, ep = 0;
+  // The held element's state record, 8 bytes per lane (lanes 0..3 of the group: {fol_off, cnt_c_emit}, {f0, f1},
+  // {f2, f3}, {fc, regex}): two registers, not eight; its fields are read by broadcast when they are needed.  It
+  // stays in place while the element walks a literal stretch (meta bits 24..31 = states ahead whose records need
+  // not be loaded).
+  uint2 rq8 = make_uint2(0u, 0u);
   FStat fs;
   uint32_t stepped = 0, trunc = 0;
 
@@ -179,28 +201,46 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
       }
     }
     pool_sync();
-    pb = (pb + cnt) & kPoolMask;
-    pn -= cnt;
+    pb = uni((pb + cnt) & kPoolMask);
+    pn = uni(pn - cnt);
     fs.writes += cnt;
   };
-  // The next batch of the wave's share enters the pool (wave-uniform; room: pn <= kPoolCap - P here).  It is
-  // asked for only when lane groups have run dry and the pool cannot feed them: every input entry roots a
-  // whole subtree, so this is rare next to the steps, and the other waves of the SIMD cover its latency.
+  // The next entries of the wave's share enter the pool (wave-uniform).  They are asked for only when lane
+  // groups have run dry and the pool cannot feed them: every input entry roots a whole subtree, so this is
+  // rare next to the steps, and the other waves of the SIMD cover its latency.
   auto take_batch = [&]() -> bool {
-    const uint64_t first = a_next * P;
-    if (first >= cur_count) return false;
-    const uint64_t left = cur_count - first;
-    const uint32_t cnt = left < P ? (uint32_t)left : P;
+    if (a_next >= a_end) return false;
+    const uint64_t left = a_end - a_next;
+    uint32_t room = kPoolCap - P - pn;       // the push phase wants P free entries afterwards
+    if (room > 64u) room = 64u;
+    const uint32_t cnt = left < room ? (uint32_t)left : room;
     if (lane < cnt) {
-      const uint64_t i = in_off + first + lane;
+      const uint64_t i = in_off + a_next + lane;
       const uint32_t idx = (pb + pn + lane) & kPoolMask;
       pl.state[idx] = cur.state[i]; pl.meta[idx] = cur.meta[i]; pl.sp[idx] = cur.sp[i]; pl.ep[idx] = cur.ep[i];
     }
-    pn += cnt;
+    pn = uni(pn + cnt);
     fs.reads += cnt;
-    a_next += class_waves;
+    a_next += cnt;
     pool_sync();
     return true;
+  };
+  // staged results go to the result slices: one returning atomic per flush, not per round with a result
+  auto flush_results = [&]() {
+    if (!rs_n) return;
+    pool_sync();
+    const uint32_t so = (w + appends++) % kSub;
+    unsigned long long rbase = 0;
+    if (lane == 0) rbase = atomicAdd(&ctl->res_count[so].v, (unsigned long long)rs_n);
+    rbase = __shfl(rbase, 0, 64);
+    if (lane < rs_n) {
+      const unsigned long long at = rbase + lane;
+      if (at < seg_cap) res[(uint64_t)so * seg_cap + at] = rs.r[lane];
+      else atomicOr(&ctl->overflow, 2ull);
+    }
+    pool_sync();
+    fs.emits += rs_n;
+    rs_n = 0;
   };
 
   for (;;) {
@@ -218,20 +258,23 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
             state = pl.state[idx]; meta = pl.meta[idx]; sp = pl.sp[idx]; ep = pl.ep[idx];
             have = true;
           }
-          pn -= take;
+          pn = uni(pn - take);
           pool_sync();
         }
       }
     }
     if (!__builtin_amdgcn_ballot_w64(have)) break;      // nothing held, pool empty, share consumed
     // ---- one backward step per holding lane group; the state's record is requested with the rank blocks
-    // The 32-byte record is fetched as 8 bytes per lane (lanes 0..3 of the group: {fol_off, cnt_c_emit}, {f0, f1},
-    // {f2, f3}, {fc, regex}) and its fields are read by broadcast when they are needed: two registers, not eight.
     uint32_t nf = 0, len1 = 0;
-    uint2 rq8 = make_uint2(0u, 0u);
     bool emit = false;
+    const uint32_t run = meta >> 24;          // > 0: this state is inside a literal stretch whose bytes the group holds
+    // deep in a search every interval is a single row: then the whole wave takes the one-request step (k_search4's trick)
+    const bool all_single = !__builtin_amdgcn_ballot_w64(have && (meta & 0xFFFFu) != 0 && (ep - sp) != 1);
     if (have) {
-      rq8 = reinterpret_cast<const uint2 *>(nfa.st + state)[t & 3u];
+      if (run == 0) {
+        rq8 = reinterpret_cast<const uint2 *>(nfa.st + state)[t & 3u];
+        if (lead) fs.recs++;
+      }
       const uint32_t c = (meta >> 16) & 0xFFu, len = meta & 0xFFFFu;
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
@@ -240,6 +283,9 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
         ep = (c == 255u) ? ix.n : s_cf[c + 1];
         if (slot == kSlotNone) ep = sp;
         else if (slot == kSlotEof) ep = sp + 1;
+      } else if (all_single) {
+        const uint32_t rq = single_row_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
+        if (lead) fs.reqs += rq;
       } else {
         const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
         if (lead) fs.reqs += rq;
@@ -249,35 +295,29 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
     const uint32_t cce = group_bcast<G, 0>(rq8.y);
     if (have && sp < ep) {                             // Some((sp1,ep1)), retree.scala:634
       // Glushkov tables: an isLast state emits and has no follows here (:636-641); Thompson / DFA
-      // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282)
-      emit = ((cce >> 24) & 1u) != 0;
-      nf = cce & 0xFFFFu;
+      // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282).  Inside a literal stretch the
+      // state is "single": no result, one follow.
+      emit = run == 0 && ((cce >> 24) & 1u) != 0;
+      nf = run ? 1u : (cce & 0xFFFFu);
       len1 = (meta & 0xFFFFu) + 1;
       if (nf && len1 >= max_len) { nf = 0; trunc = 1; }
     }
     const uint32_t rgx = group_bcast<G, 3>(rq8.y);
-    // ---- results: ballot + one atomic per wave and round (they are few)
+    // ---- results are staged in LDS
     {
       const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
       if (em) {
-        const uint32_t so = (w + appends++) % kSub;
-        unsigned long long rbase = 0;
-        if (lane == 0) rbase = atomicAdd(&ctl->res_count[so].v, (unsigned long long)__builtin_popcountll(em));
-        rbase = __shfl(rbase, 0, 64);
+        const uint32_t cnt = (uint32_t)__builtin_popcountll(em);
+        if (rs_n + cnt > kResStage) flush_results();
         if (lead && emit) {
-          const unsigned long long at = rbase + __builtin_popcountll(em & ((1ull << lane) - 1ull));
-          if (at < seg_cap) {
-            fmx_result r;
-            r.regex = rgx;
-            r.len = (meta & 0xFFFFu) + 1;
-            r.sp = sp;
-            r.ep = ep;
-            res[(uint64_t)so * seg_cap + at] = r;
-          } else {
-            atomicOr(&ctl->overflow, 2ull);
-          }
+          fmx_result r;
+          r.regex = rgx;
+          r.len = (meta & 0xFFFFu) + 1;
+          r.sp = sp;
+          r.ep = ep;
+          rs.r[rs_n + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = r;
         }
-        fs.emits += (uint32_t)__builtin_popcountll(em);
+        rs_n = uni(rs_n + cnt);
       }
     }
     // ---- the first follow stays with the lane group, the others go to the pool (short lists) or straight
@@ -285,9 +325,9 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
     const uint32_t npush = nf ? nf - 1 : 0u;
     {
       const uint32_t nsmall = npush <= kPoolSmall ? npush : 0u;
-      uint32_t small_total = 0;
-      const uint32_t small_off = wave_excl_scan(lead ? nsmall : 0u, small_total);
-      if (small_total) {
+      if (__builtin_amdgcn_ballot_w64(nsmall != 0)) {
+        uint32_t small_total = 0;
+        const uint32_t small_off = wave_excl_scan(lead ? nsmall : 0u, small_total);
         if (pn + small_total + P > kPoolCap) {
           const uint32_t need = pn + small_total + P - kPoolCap;
           const uint32_t half = pn < 64u ? pn : 64u;
@@ -306,7 +346,7 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
           pl.sp[idx] = sp;
           pl.ep[idx] = ep;
         }
-        pn += small_total;
+        pn = uni(pn + small_total);
         pool_sync();
       }
       if (__builtin_amdgcn_ballot_w64(npush > kPoolSmall)) {
@@ -336,9 +376,24 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
     }
     {
       const uint32_t fl0 = group_bcast<G, 1>(rq8.x), fc0 = group_bcast<G, 3>(rq8.x) & 0xFFu;
+      const uint32_t r1 = group_bcast<G, 1>(rq8.y), r2 = group_bcast<G, 2>(rq8.x), r3 = group_bcast<G, 2>(rq8.y);
       if (have) {
-        if (nf) { state = fl0; meta = len1 | (fc0 << 16); }
-        else have = false;
+        if (nf) {
+          // on a literal stretch the next state is state + 1 and its byte comes from the held record:
+          // rr[k - 1] with k = states of the stretch still ahead (the chain length when it was just entered)
+          const uint32_t k = run ? run : (nf == 1 ? (cce >> 25) & 0xFu : 0u);
+          if (k) {
+            const uint32_t word = k <= 4u ? r1 : (k <= 8u ? r2 : r3);
+            const uint32_t ch = (word >> (8u * ((k - 1u) & 3u))) & 0xFFu;
+            state = run ? state + 1u : fl0;
+            meta = len1 | (ch << 16) | ((k - 1u) << 24);
+          } else {
+            state = fl0;
+            meta = len1 | (fc0 << 16);
+          }
+        } else {
+          have = false;
+        }
       }
     }
     if (++rounds >= max_rounds) {
@@ -348,19 +403,38 @@ __global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTable
       if (held) {
         if (lead && have) {
           const uint32_t idx = (pb + pn + (uint32_t)__builtin_popcountll(held & ((1ull << lane) - 1ull))) & kPoolMask;
-          pl.state[idx] = state; pl.meta[idx] = meta; pl.sp[idx] = sp; pl.ep[idx] = ep;
+          pl.state[idx] = state; pl.meta[idx] = meta & 0x00FFFFFFu; pl.sp[idx] = sp; pl.ep[idx] = ep;   // the stretch context stays behind
         }
-        pn += (uint32_t)__builtin_popcountll(held);
+        pn = uni(pn + (uint32_t)__builtin_popcountll(held));
       }
       spill(pn);
       while (take_batch()) spill(pn);        // carried over, not consumed here
       break;
     }
   }
+  flush_results();
   if (trunc) atomicOr(&ctl->truncated, 1ull);
   counters_add(counters, lead ? 2ull * stepped : 0ull, lead ? stepped : 0u, 0);
   counters_add_frontier(counters, fs.reqs, lane == 0 ? fs.writes : 0u, lane == 0 ? fs.emits : 0u, lead ? stepped : 0u,
-                        lane == 0 ? fs.reads : 0u);
+                        lane == 0 ? fs.reads : 0u, fs.recs);
+}
+
+// One-hot layout: 80 registers keep 6 waves per SIMD resident; the bytes layout (octets, two lines per rank query)
+// needs more registers and runs 4.
+template <bool WIDE, uint32_t LAYOUT>
+__global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
+                                                            uint32_t max_rounds, uint64_t sub_cap,
+                                                            fmx_result *__restrict__ res, uint64_t seg_cap,
+                                                            FrontierCtl *__restrict__ ctl,
+                                                            unsigned long long *__restrict__ counters) {
+  frontier_pass<WIDE, LAYOUT>(ix, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
+}
+__global__ __launch_bounds__(kFThreads, 4) void k_frontier_bytes(DevIndex ix, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
+                                                                  uint32_t max_rounds, uint64_t sub_cap,
+                                                                  fmx_result *__restrict__ res, uint64_t seg_cap,
+                                                                  FrontierCtl *__restrict__ ctl,
+                                                                  unsigned long long *__restrict__ counters) {
+  frontier_pass<true, kLayoutBytes>(ix, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
 }
 
 // Closes a chain of launches: the next chain starts `by` passes further.
@@ -420,12 +494,14 @@ struct RegexBatch {
   uint32_t *d_rpart = nullptr;         // chunk totals of the offsets' scan
   BigGroups *d_big = nullptr;
   FrontierCtl *h_ctl = nullptr;        // pinned host copy the chain's last node fills
-  hipGraphExec_t chain_exec = nullptr; // one chain of launches + advance + counter copy, captured once
+  hipGraphExec_t chain_exec = nullptr; // one chain of launches + advance + counter copy, captured once (full grid)
+  hipGraphExec_t chain_small_exec = nullptr;   // the same on the small grid
   uint32_t chain_len = 0, chain_rounds = 0;
   uint32_t matches = 0;                // the chain is captured from a batch's second match on (a one-shot batch
                                        // would pay the capture and never replay it)
   ~RegexBatch() {
     if (chain_exec) (void)hipGraphExecDestroy(chain_exec);
+    if (chain_small_exec) (void)hipGraphExecDestroy(chain_small_exec);
     if (h_ctl) (void)hipHostFree(h_ctl);
   }
   uint64_t qcap = 0;
@@ -477,6 +553,25 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
       }
       st_num[base + s] = (uint32_t)re.st_num[s];
       max_fanout = std::max(max_fanout, cnt);
+    }
+    // literal stretches (fmx_nfa.h): chain lengths from the regex's last state backwards, then the bytes
+    {
+      const size_t ns = re.st_c.size();
+      auto single = [&](size_t s) {
+        const StateRec &rec = recs[base + s];
+        return rec_cnt(rec) == 1 && !rec_emit(rec) && s + 1 < ns && rec.f[0] == (uint32_t)(base + s + 1);
+      };
+      uint32_t next_chain = 0;
+      for (size_t s = ns; s-- > 0;) {
+        const uint32_t chain = single(s) ? std::min<uint32_t>(kMaxChain, 1 + next_chain) : 0;
+        next_chain = chain;
+        if (!chain) continue;
+        StateRec &rec = recs[base + s];
+        rec.cnt_c_emit |= chain << 25;
+        uint8_t rr[kMaxChain] = {0};
+        for (uint32_t j = 0; j < chain; j++) rr[chain - 1 - j] = re.st_c[s + 1 + j];
+        std::memcpy(&rec.f[1], rr, kMaxChain);
+      }
     }
     for (int32_t f : re.firsts) q_state[qo++] = (uint32_t)base + (uint32_t)f;
     first_off[r + 1] = (uint32_t)qo;
@@ -654,7 +749,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if (!b->scratch || b->qcap != qcap || b->rcap < (cap ? cap : 1)) {
     b->scratch.reset(new DevMem());
     b->qcap = 0;
-    if (b->chain_exec) { (void)hipGraphExecDestroy(b->chain_exec); b->chain_exec = nullptr; }   // it holds the old pointers
+    for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec})      // they hold the old pointers
+      if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
     if (!b->h_ctl) HIP_TRY(hipHostMalloc((void **)&b->h_ctl, sizeof(FrontierCtl), hipHostMallocDefault), "hipHostMalloc(ctl)");
     const uint64_t seg_cap = (uint64_t)(cap ? cap : 1) / 16 + 1024;
     for (Queue *q : {&b->qa, &b->qb}) {
@@ -692,11 +788,11 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   HIP_TRY(hipGetLastError(), "k_frontier_init");
   // Launches are chained on the stream without host round trips; the host looks at the counters after every
   // chain.  A launch whose input queue is empty returns at once.
-  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 4u;
+  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 10u;
   // rounds a wave works before it hands its leftovers to the next launch (the load balancing step)
-  static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 64u;
+  static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 16u;
   static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : 6;
-  const int grid_full = h->cu_count * per_cu;
+  const int grid_full = h->cu_count * (h->layout == kLayoutBytes ? std::min(per_cu, 4) : per_cu);
   const uint32_t group_lanes = h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G;
   const uint64_t per_wg = (uint64_t)kFThreads / group_lanes;      // elements a workgroup holds at once
   std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());
@@ -706,16 +802,24 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   uint64_t launches = 1;
   bool alive = true, truncated = false;
   auto launch_pass = [&](hipStream_t s, int grid, uint32_t j, uint32_t rounds) {
-#define CALL(W, L) k_frontier<W, L><<<grid, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters)
-    FMX_LAYOUT_DISPATCH(h, CALL);
-#undef CALL
+    if (h->layout == kLayoutBytes)
+      k_frontier_bytes<<<grid, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+    else if (h->n > (1ull << 32))
+      k_frontier<true, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+    else
+      k_frontier<false, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
   };
   // One chain = kChain launches + k_pass_advance + the counters' copy to pinned host memory.  Its kernel
   // arguments do not change from chain to chain (the pass comes from ctl->pass_base), so it is captured
-  // into a hipGraph once per batch and replayed: one launch call per chain instead of kChain + 2.
+  // into a hipGraph once per batch and replayed: one launch call per chain instead of kChain + 2.  Two chains
+  // are kept: the full grid for a batch's wide phase, and a small grid (64 workgroups: enough lane groups for
+  // 4096 elements) for a single regex or the thin end of a batch, whose launches cost a fraction of the
+  // full grid's when most of them find nothing to do.  A wave hands its leftovers to the next launch after
+  // kRounds rounds, so even a search that starts from one element spreads over the grid within a few launches.
   static const bool use_graph = !(getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) == 0);
-  auto enqueue_chain = [&](hipStream_t s) -> hipError_t {
-    for (uint32_t j = 0; j < kChain; j++) launch_pass(s, grid_full, j, kRounds);
+  const int grid_small = 64;
+  auto enqueue_chain = [&](hipStream_t s, int grid) -> hipError_t {
+    for (uint32_t j = 0; j < kChain; j++) launch_pass(s, grid, j, kRounds);
     k_pass_advance<<<1, 1, 0, s>>>(d_ctl, kChain);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -723,42 +827,35 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   };
   b->matches++;
   uint64_t total = b->n_first;               // elements in the input queue of the next pass
-  const uint64_t kSmallTotal = 64 * per_wg;  // up to here a pass gets a grid of its own size and is launched directly
-  const bool want_chain = total > kSmallTotal;
-  if (use_graph && want_chain && b->matches >= 2 && (!b->chain_exec || b->chain_len != kChain || b->chain_rounds != kRounds)) {
-    if (b->chain_exec) { (void)hipGraphExecDestroy(b->chain_exec); b->chain_exec = nullptr; }
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) {
-      const hipError_t e1 = enqueue_chain(st);
-      const hipError_t e2 = hipStreamEndCapture(st, &g);
-      e = e1 != hipSuccess ? e1 : e2;
-    }
-    if (e == hipSuccess) e = hipGraphInstantiate(&b->chain_exec, g, nullptr, nullptr, 0);
-    if (g) (void)hipGraphDestroy(g);
-    if (e != hipSuccess) { (void)hipGetLastError(); b->chain_exec = nullptr; }    // fall back to plain launches
+  const uint64_t kSmallTotal = (uint64_t)grid_small * per_wg;
+  if (b->chain_len != kChain || b->chain_rounds != kRounds) {
+    for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec})
+      if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
     b->chain_len = kChain;
     b->chain_rounds = kRounds;
   }
-  while (alive) {
-    uint32_t done = 0;
-    if (total > kSmallTotal) {
-      if (b->chain_exec) HIP_TRY(hipGraphLaunch(b->chain_exec, st), "hipGraphLaunch(launch chain)");
-      else HIP_TRY(enqueue_chain(st), "k_frontier chain");
-      done = kChain;
-      launches += kChain + 1;
-    } else {
-      // a small frontier (a single regex, or the tail of a batch): one launch sized to it, with rounds enough
-      // to finish most searches inside it
-      // (never fewer than kSub waves: every queue slice needs a wave that reads it)
-      const int grid = (int)std::max<uint64_t>(kSub / (kFThreads / 64), (total + per_wg - 1) / per_wg);
-      launch_pass(st, grid, 0, std::max<uint32_t>(kRounds, 256u));
-      k_pass_advance<<<1, 1, 0, st>>>(d_ctl, 1);
-      HIP_TRY(hipGetLastError(), "k_frontier");
-      HIP_TRY(hipMemcpyAsync(b->h_ctl, d_ctl, sizeof(FrontierCtl), hipMemcpyDeviceToHost, st), "D2H(ctl)");
-      done = 1;
-      launches += 2;
+  auto capture = [&](hipGraphExec_t *exec, int grid) {
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) {
+      const hipError_t e1 = enqueue_chain(st, grid);
+      const hipError_t e2 = hipStreamEndCapture(st, &g);
+      e = e1 != hipSuccess ? e1 : e2;
     }
+    if (e == hipSuccess) e = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { (void)hipGetLastError(); *exec = nullptr; }    // fall back to plain launches
+  };
+  while (alive) {
+    const bool small = total <= kSmallTotal;
+    hipGraphExec_t *exec = small ? &b->chain_small_exec : &b->chain_exec;
+    const int grid = small ? grid_small : grid_full;
+    // a chain is captured from a batch's second match on (a one-shot batch would pay the capture and never replay it)
+    if (use_graph && b->matches >= 2 && !*exec) capture(exec, grid);
+    if (*exec) HIP_TRY(hipGraphLaunch(*exec, st), "hipGraphLaunch(launch chain)");
+    else HIP_TRY(enqueue_chain(st, grid), "k_frontier chain");
+    const uint32_t done = kChain;
+    launches += kChain + 1;
     HIP_TRY(hipStreamSynchronize(st), "sync(passes)");
     std::memcpy(&ctl, b->h_ctl, sizeof ctl);
     pass += done;

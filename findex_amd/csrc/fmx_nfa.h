@@ -7,18 +7,25 @@ namespace fmx {
 
 constexpr uint32_t kInlineFollows = 4;
 constexpr uint32_t kMaxFollows = 0xFFFFu;   // fol_cnt is 16 bits wide
-struct StateRec {        // 32 bytes: everything an element needs about its state, two 16-byte loads
+constexpr uint32_t kMaxChain = 12;          // bytes of a literal stretch one record can carry
+struct StateRec {        // 32 bytes: everything an element needs about its state
   uint32_t fol_off;      // first entry of its follows in `fol` / `fol_c`
   uint32_t cnt_c_emit;   // fol_cnt in bits 0..15 (0 for a state that emits and does not expand: ReTree isLast,
-                         // retree.scala:636-641), the state's byte in bits 16..23, emit flag in bit 24
-  uint32_t f[kInlineFollows];   // the first follows, so that short lists need no further load
-  uint32_t fc;           // the bytes of those follows (byte j = byte of state f[j]): an element that moves on to
-                         // f[j] can request its next rank blocks without waiting for f[j]'s own record
+                         // retree.scala:636-641), the state's byte in bits 16..23, emit flag in bit 24, chain in 25..28
+  uint32_t f[kInlineFollows];   // the first follows, so that short lists need no further load.
+                         // LITERAL STRETCHES: a state is "single" when it does not emit and its one follow is the
+                         // next state id (s + 1) -- every character of a literal but the last.  chain = r >= 1 says
+                         // that s, s+1 .. s+r-1 are all single; then f[1..3] are not follows but 12 bytes rr[]: the
+                         // bytes of the states s+1 .. s+r, stored backwards (rr[r-1-j] = byte of state s+1+j).  An
+                         // element that has this record walks the r-1 states s+1 .. s+r-1 without loading theirs.
+  uint32_t fc;           // the bytes of f[0..3] (byte j = byte of state f[j]): an element that moves on to f[j] can
+                         // request its next rank blocks without waiting for f[j]'s own record
   uint32_t regex;
 };
 __host__ __device__ inline uint32_t rec_cnt(const StateRec &r) { return r.cnt_c_emit & 0xFFFFu; }
 __host__ __device__ inline uint32_t rec_c(const StateRec &r) { return (r.cnt_c_emit >> 16) & 0xFFu; }
 __host__ __device__ inline uint32_t rec_emit(const StateRec &r) { return (r.cnt_c_emit >> 24) & 1u; }
+__host__ __device__ inline uint32_t rec_chain(const StateRec &r) { return (r.cnt_c_emit >> 25) & 0xFu; }
 
 struct NfaTables {
   const StateRec *st;

@@ -271,7 +271,8 @@ typedef struct fmx_stats_t {
   uint64_t frontier_queue_reads;   /* elements read from the HBM work queues */
   uint64_t frontier_queue_writes;  /* elements appended to the HBM work queues */
   uint64_t frontier_results;    /* results written */
-  uint64_t reserved2[3];        /* 0 */
+  uint64_t frontier_records;    /* 32-byte state records loaded (none inside a literal stretch) */
+  uint64_t reserved2[2];        /* 0 */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 /* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */

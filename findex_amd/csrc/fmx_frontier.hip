@@ -445,10 +445,11 @@ __global__ void k_pass_advance(FrontierCtl *__restrict__ ctl, uint32_t by) {
 // result groups the device leaves to the host (k_res_sort)
 constexpr uint32_t kSmallGroup = 12;
 constexpr uint32_t kBigMax = 16384;
+constexpr uint32_t kMidGroup = 1024;   // groups up to this size are ordered by one workgroup in LDS (k_res_sort_mid)
 struct BigGroups {
-  uint32_t n;
-  uint32_t pad;
-  uint32_t ent[2 * kBigMax];     // (first result, count) of each group left unsorted
+  uint32_t n;                    // groups of more than kSmallGroup results
+  uint32_t n_host;               // of those, the ones left to the host: more than kMidGroup results, or listed past kBigMax
+  uint32_t ent[2 * kBigMax];     // (first result, count) of each such group; count 0 = ordered on the device
 };
 
 namespace {
@@ -473,6 +474,16 @@ struct DevMem {
     if (e__ != hipSuccess) return hip_fail(e__, what); \
   } while (0)
 
+// What the host needs to fetch the grouped results: how many there are and how many groups were left unsorted.
+struct GroupTotals {
+  uint32_t n_results;
+  uint32_t n_big;
+};
+__global__ void k_res_totals(const uint32_t *__restrict__ start, uint32_t k, const BigGroups *__restrict__ big,
+                             GroupTotals *__restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out->n_results = start[k]; out->n_big = big->n_host ? big->n : 0u; }
+}
+
 // A batch of compiled regexes made resident on one device: concatenated Glushkov tables plus
 // the level-0 frontier (root.firsts x (0, 0, n), retree.scala:576).  Reusable across calls.
 struct RegexBatch {
@@ -496,12 +507,16 @@ struct RegexBatch {
   FrontierCtl *h_ctl = nullptr;        // pinned host copy the chain's last node fills
   hipGraphExec_t chain_exec = nullptr; // one chain of launches + advance + counter copy, captured once (full grid)
   hipGraphExec_t chain_small_exec = nullptr;   // the same on the small grid
+  hipGraphExec_t group_exec = nullptr; // the result grouping behind a chain (count, scan, scatter, sort, totals)
+  GroupTotals *d_tot = nullptr, *h_tot = nullptr;   // device copy / pinned host copy of the grouping's totals
   uint32_t chain_len = 0, chain_rounds = 0;
   uint32_t matches = 0;                // the chain is captured from a batch's second match on (a one-shot batch
                                        // would pay the capture and never replay it)
   ~RegexBatch() {
     if (chain_exec) (void)hipGraphExecDestroy(chain_exec);
     if (chain_small_exec) (void)hipGraphExecDestroy(chain_small_exec);
+    if (group_exec) (void)hipGraphExecDestroy(group_exec);
+    if (h_tot) (void)hipHostFree(h_tot);
     if (h_ctl) (void)hipHostFree(h_ctl);
   }
   uint64_t qcap = 0;
@@ -727,6 +742,49 @@ __global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ out, 
   }
 }
 
+// The groups k_res_sort listed: one workgroup per group, bitonic sort by (len, sp, ep) in LDS (100 k regexes give a
+// few hundred such groups -- a starred class matches at every length; ordering them on the host cost 0.13 ms).
+__global__ __launch_bounds__(256) void k_res_sort_mid(fmx_result *__restrict__ out, BigGroups *__restrict__ big) {
+  __shared__ fmx_result s_r[kMidGroup];
+  const uint32_t nb = big->n < kBigMax ? big->n : kBigMax;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && big->n > kBigMax) atomicAdd(&big->n_host, big->n - kBigMax);
+  auto less = [](const fmx_result &a, const fmx_result &b) {
+    if (a.len != b.len) return a.len < b.len;
+    if (a.sp != b.sp) return a.sp < b.sp;
+    return a.ep < b.ep;
+  };
+  for (uint32_t g = blockIdx.x; g < nb; g += gridDim.x) {
+    const uint32_t lo = big->ent[2 * g], m = big->ent[2 * g + 1];
+    if (m > kMidGroup) {
+      if (threadIdx.x == 0) atomicAdd(&big->n_host, 1u);
+      continue;
+    }
+    uint32_t p2 = 1;
+    while (p2 < m) p2 <<= 1;
+    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
+      fmx_result r;
+      if (i < m) r = out[lo + i];
+      else { r.regex = 0; r.len = 0xFFFFFFFFu; r.sp = ~0ull; r.ep = ~0ull; }      // padding sorts last
+      s_r[i] = r;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= p2; size <<= 1)
+      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        for (uint32_t i = threadIdx.x; i < p2 / 2; i += blockDim.x) {
+          const uint32_t a = 2 * i - (i & (stride - 1));          // lower index of the pair
+          const uint32_t bidx = a + stride;
+          const bool up = (a & size) == 0;
+          const fmx_result x = s_r[a], y = s_r[bidx];
+          if (less(y, x) == up) { s_r[a] = y; s_r[bidx] = x; }
+        }
+        __syncthreads();
+      }
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) out[lo + i] = s_r[i];
+    if (threadIdx.x == 0) big->ent[2 * g + 1] = 0;
+    __syncthreads();
+  }
+}
+
 int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_result *out, size_t cap,
                       size_t *n_out, uint32_t *per_regex_count) {
   static const bool trace = getenv("FMX_TRACE") != nullptr;
@@ -749,8 +807,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if (!b->scratch || b->qcap != qcap || b->rcap < (cap ? cap : 1)) {
     b->scratch.reset(new DevMem());
     b->qcap = 0;
-    for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec})      // they hold the old pointers
+    for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec, &b->group_exec})      // they hold the old pointers
       if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+    if (!b->h_tot) HIP_TRY(hipHostMalloc((void **)&b->h_tot, sizeof(GroupTotals), hipHostMallocDefault), "hipHostMalloc(totals)");
     if (!b->h_ctl) HIP_TRY(hipHostMalloc((void **)&b->h_ctl, sizeof(FrontierCtl), hipHostMallocDefault), "hipHostMalloc(ctl)");
     const uint64_t seg_cap = (uint64_t)(cap ? cap : 1) / 16 + 1024;
     for (Queue *q : {&b->qa, &b->qb}) {
@@ -767,6 +826,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     HIP_TRY(b->scratch->alloc(&b->d_rfill, b->k + 1), "hipMalloc(result fill)");
     HIP_TRY(b->scratch->alloc(&b->d_rpart, (b->k + 1) / kScanChunk + 2), "hipMalloc(scan parts)");
     HIP_TRY(b->scratch->alloc(&b->d_big, 1), "hipMalloc(big groups)");
+    HIP_TRY(b->scratch->alloc(&b->d_tot, 1), "hipMalloc(totals)");
     b->qcap = qcap;
     b->rcap = cap ? cap : 1;
   }
@@ -818,9 +878,14 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // kRounds rounds, so even a search that starts from one element spreads over the grid within a few launches.
   static const bool use_graph = !(getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) == 0);
   const int grid_small = 64;
+  // the small grid's chain is short: a launch that finds nothing to do still costs ~3 us
+  const uint32_t kChainSmall = std::min<uint32_t>(kChain, 5u);
   auto enqueue_chain = [&](hipStream_t s, int grid) -> hipError_t {
-    for (uint32_t j = 0; j < kChain; j++) launch_pass(s, grid, j, kRounds);
-    k_pass_advance<<<1, 1, 0, s>>>(d_ctl, kChain);
+    // the first passes hand over early and often (the frontier is wide and must spread); the later ones find the
+    // thin, deep end of the search and work it off in long stretches
+    const uint32_t len = grid == grid_small ? kChainSmall : kChain;
+    for (uint32_t j = 0; j < len; j++) launch_pass(s, grid, j, j < (len + 1) / 2 ? kRounds : 4 * kRounds);
+    k_pass_advance<<<1, 1, 0, s>>>(d_ctl, len);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(b->h_ctl, d_ctl, sizeof(FrontierCtl), hipMemcpyDeviceToHost, s);
@@ -834,11 +899,36 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     b->chain_len = kChain;
     b->chain_rounds = kRounds;
   }
-  auto capture = [&](hipGraphExec_t *exec, int grid) {
+  // The results leave the device grouped by regex (count, scan, scatter, order small groups, totals to pinned host
+  // memory).  These launches are enqueued right behind every chain, before the host knows whether the search is
+  // over: when it is -- the usual case -- the grouped results are ready at the same synchronisation; when it is
+  // not, the grouping is simply done again behind the next chain.  All arguments are fixed for the life of the
+  // scratch, so this is a captured graph as well.
+  const size_t rcap = b->rcap;
+  auto enqueue_group = [&](hipStream_t s) -> hipError_t {
+    hipError_t e = hipMemsetAsync(b->d_rcnt, 0, (b->k + 1) * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_rfill, 0, (b->k + 1) * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_big, 0, 8, s);
+    if (e != hipSuccess) return e;
+    const dim3 rg(8, kSub);
+    k_res_count<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rcnt);
+    const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: start[k] = total
+    k_res_scan_chunks<<<nparts, kScanChunk, 0, s>>>(b->d_rcnt, n_scan, b->d_rstart, b->d_rpart);
+    k_res_scan_parts<<<1, kScanChunk, 0, s>>>(b->d_rpart, nparts);
+    k_res_scan_add<<<nparts, kScanChunk, 0, s>>>(b->d_rstart, n_scan, b->d_rpart);
+    k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)rcap);
+    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);
+    k_res_sort_mid<<<256, 256, 0, s>>>(d_res, b->d_big);
+    k_res_totals<<<1, 1, 0, s>>>(b->d_rstart, (uint32_t)b->k, b->d_big, b->d_tot);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(b->h_tot, b->d_tot, sizeof(GroupTotals), hipMemcpyDeviceToHost, s);
+  };
+  auto capture = [&](hipGraphExec_t *exec, int grid) {     // grid 0: the grouping
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) {
-      const hipError_t e1 = enqueue_chain(st, grid);
+      const hipError_t e1 = grid ? enqueue_chain(st, grid) : enqueue_group(st);
       const hipError_t e2 = hipStreamEndCapture(st, &g);
       e = e1 != hipSuccess ? e1 : e2;
     }
@@ -850,12 +940,16 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     const bool small = total <= kSmallTotal;
     hipGraphExec_t *exec = small ? &b->chain_small_exec : &b->chain_exec;
     const int grid = small ? grid_small : grid_full;
-    // a chain is captured from a batch's second match on (a one-shot batch would pay the capture and never replay it)
+    // the graphs are captured from a batch's second match on (a one-shot batch would pay the capture and never replay it)
     if (use_graph && b->matches >= 2 && !*exec) capture(exec, grid);
+    if (use_graph && b->matches >= 2 && !b->group_exec) capture(&b->group_exec, 0);
     if (*exec) HIP_TRY(hipGraphLaunch(*exec, st), "hipGraphLaunch(launch chain)");
     else HIP_TRY(enqueue_chain(st, grid), "k_frontier chain");
-    const uint32_t done = kChain;
-    launches += kChain + 1;
+    if (b->group_exec) HIP_TRY(hipGraphLaunch(b->group_exec, st), "hipGraphLaunch(result grouping)");
+    else HIP_TRY(enqueue_group(st), "result grouping kernels");
+    HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
+    const uint32_t done = small ? kChainSmall : kChain;
+    launches += done + 1 + 9;
     HIP_TRY(hipStreamSynchronize(st), "sync(passes)");
     std::memcpy(&ctl, b->h_ctl, sizeof ctl);
     pass += done;
@@ -869,34 +963,15 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       fprintf(stderr, "[fmx] frontier after pass %u: queue %llu, results %llu, overflow %llu\n", pass,
               (unsigned long long)total, (unsigned long long)n_res, ctl.overflow);
   }
-  const bool grouped = n_res && !(ctl.overflow & 2ull) && n_res <= cap;
-  if (grouped) {
-    HIP_TRY(hipMemsetAsync(b->d_rcnt, 0, (b->k + 1) * 4, st), "memset(result counts)");
-    HIP_TRY(hipMemsetAsync(b->d_rfill, 0, (b->k + 1) * 4, st), "memset(result fill)");
-    const dim3 rg(8, kSub);
-    k_res_count<<<rg, 256, 0, st>>>(d_res_seg, seg_cap, d_ctl, b->d_rcnt);
-    {
-      const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: start[k] = total
-      k_res_scan_chunks<<<nparts, kScanChunk, 0, st>>>(b->d_rcnt, n_scan, b->d_rstart, b->d_rpart);
-      k_res_scan_parts<<<1, kScanChunk, 0, st>>>(b->d_rpart, nparts);
-      k_res_scan_add<<<nparts, kScanChunk, 0, st>>>(b->d_rstart, n_scan, b->d_rpart);
-    }
-    k_res_scatter<<<rg, 256, 0, st>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)cap);
-    HIP_TRY(hipMemsetAsync(b->d_big, 0, 8, st), "memset(big groups)");
-    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, st>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);
-    HIP_TRY(hipGetLastError(), "result grouping kernels");
-    launches += 6;
-  }
-  HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
-  HIP_TRY(hipStreamSynchronize(st), "sync");
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  mark("levels done");
+  mark("passes done");
   {
     std::lock_guard<std::mutex> lk(h->mu);
     h->last_kernel_ms = ms;
     h->launches += launches;
   }
+  const uint32_t nbig = b->h_tot->n_big;
   struct { unsigned long long res_count; } tot{n_res};
   const size_t extra = b->start_final.size();
   *n_out = (size_t)tot.res_count + extra;
@@ -919,15 +994,20 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       if (a.sp != b.sp) return a.sp < b.sp;
       return a.ep < b.ep;
     };
-    uint32_t nbig = 0;
-    if (ndev) HIP_TRY(hipMemcpy(&nbig, &b->d_big->n, 4, hipMemcpyDeviceToHost), "D2H(big groups)");
     if (!extra && nbig <= kBigMax) {
       // the device ordered every group of up to kSmallGroup results; the few larger ones are listed
       if (nbig) {
         std::vector<uint32_t> ent(2 * (size_t)nbig);
         HIP_TRY(hipMemcpy(ent.data(), b->d_big->ent, ent.size() * 4, hipMemcpyDeviceToHost), "D2H(big groups)");
-        for (uint32_t g = 0; g < nbig; g++) std::sort(out + ent[2 * g], out + ent[2 * g] + ent[2 * g + 1], by_key);
+        for (uint32_t g = 0; g < nbig; g++)
+          if (ent[2 * g + 1]) std::sort(out + ent[2 * g], out + ent[2 * g] + ent[2 * g + 1], by_key);
+        if (trace) {
+          size_t tot_big = 0;
+          for (uint32_t g = 0; g < nbig; g++) tot_big += ent[2 * g + 1];
+          fprintf(stderr, "[fmx] %u large result groups (%zu results) ordered on the host\n", nbig, tot_big);
+        }
       }
+      mark("large groups");
       if (per_regex_count && ndev)
         HIP_TRY(hipMemcpy(per_regex_count, b->d_rcnt, b->k * 4, hipMemcpyDeviceToHost), "D2H(result counts)");
     } else {

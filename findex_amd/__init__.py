@@ -25,4 +25,10 @@ def set_layout(name):
     _lib.check(_lib.load().fmx_config_set(b"layout", name.encode()))
 
 
-__all__ = ["set_layout", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "FmxError", "MatchError", "Re2PostSyntax"]
+def set_checkpoints(name):
+    """fmx_config_set("checkpoints", ...): "auto" | "superblock" (bytes layout, indexes opened afterwards)."""
+    from . import _lib
+    _lib.check(_lib.load().fmx_config_set(b"checkpoints", name.encode()))
+
+
+__all__ = ["set_layout", "set_checkpoints", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "FmxError", "MatchError", "Re2PostSyntax"]

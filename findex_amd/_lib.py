@@ -80,6 +80,8 @@ SYMBOLS = {
     "fmx_lf_walk_batch": (_i32, [_vp, _vp, _sz, _u32, _vp, _vp]),
     "fmx_lf_walk_batch_dev": (_i32, [_vp, _vp, _sz, _u32, _vp, _vp, _vp]),
     "fmx_psi_batch": (_i32, [_vp, _vp, _vp, _sz]),
+    "fmx_psi_batch_dev": (_i32, [_vp, _vp, _vp, _sz, _vp]),
+    "fmx_next_substr_batch_dev": (_i32, [_vp, _vp, _sz, _u32, _vp, _vp, _vp]),
     "fmx_next_substr": (_i32, [_vp, _u64, _u32, _vp, _P(_u32)]),
     "fmx_prev_substr": (_i32, [_vp, _u64, _u32, _vp]),
     "fmx_next_substr_batch": (_i32, [_vp, _vp, _sz, _u32, _vp, _vp]),

@@ -28,6 +28,8 @@ int hip_fail(hipError_t e, const char *what) {
 static std::atomic<int> g_layout_pref{-1};       // fmx_config_set may race with fmx_open* on other threads
 int layout_preference() { return g_layout_pref.load(std::memory_order_relaxed); }
 static std::atomic<uint64_t> g_serial{0};
+static std::atomic<int> g_force_superblocks{0};
+bool force_superblocks() { return g_force_superblocks.load(std::memory_order_relaxed) != 0; }
 
 static int arg_fail(const char *msg) {
   g_err = msg;
@@ -241,6 +243,9 @@ static void destroy(Index *h) {
   if (h->d_cf) (void)hipFree(h->d_cf);
   if (h->d_slot) (void)hipFree(h->d_slot);
   if (h->d_counters) (void)hipFree(h->d_counters);
+  if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
+  if (h->d_sel_off) (void)hipFree(h->d_sel_off);
+  if (h->d_sel_shift) (void)hipFree(h->d_sel_shift);
   for (CallCtx *c : h->ctx_pool) free_ctx(c);
   delete h;
 }
@@ -391,6 +396,12 @@ int fmx_config_set(const char *key, const char *value) {
     else return arg_fail("layout must be auto, onehot or bytes");
     return FMX_OK;
   }
+  if (std::strcmp(key, "checkpoints") == 0) {
+    if (std::strcmp(value, "auto") == 0) g_force_superblocks.store(0);
+    else if (std::strcmp(value, "superblock") == 0) g_force_superblocks.store(1);
+    else return arg_fail("checkpoints must be auto or superblock");
+    return FMX_OK;
+  }
   return arg_fail("unknown configuration key");
 }
 
@@ -491,6 +502,23 @@ int fmx_lf_walk_batch_dev(const fmx_index *idx, const void *d_rows, size_t k, ui
   int rc = use_device(H(idx));
   if (rc) return rc;
   HIP_TRY(launch_lf_walk(H(idx), d_rows, k, len, d_out_bytes, d_end_rows, (hipStream_t)stream), "k_lf_walk");
+  return FMX_OK;
+}
+
+int fmx_psi_batch_dev(const fmx_index *idx, const void *d_rows, void *d_out, size_t k, void *stream) {
+  if (!idx || (k && (!d_rows || !d_out))) return arg_fail("null argument");
+  int rc = use_device(H(idx));
+  if (rc) return rc;
+  HIP_TRY(launch_psi(H(idx), d_rows, d_out, k, (hipStream_t)stream), "k_psi");
+  return FMX_OK;
+}
+
+int fmx_next_substr_batch_dev(const fmx_index *idx, const void *d_rows, size_t k, uint32_t len, void *d_out,
+                              void *d_out_len, void *stream) {
+  if (!idx || (k && (!d_rows || !d_out_len || (len && !d_out)))) return arg_fail("null argument");
+  int rc = use_device(H(idx));
+  if (rc) return rc;
+  HIP_TRY(launch_next_substr(H(idx), d_rows, k, len, d_out, d_out_len, (hipStream_t)stream), "k_next_substr");
   return FMX_OK;
 }
 
@@ -743,7 +771,7 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->backward_steps = cnt[1];
   out->launches = h->launches;
   out->last_kernel_ms = h->last_kernel_ms;
-  out->index_bytes = h->index_bytes;
+  out->index_bytes = h->index_bytes + h->sel_bytes;
   out->n_blocks = h->nblocks;
   out->n_symbols = h->nslots;
   out->block_bytes = h->layout == kLayoutBytes ? kByteBlock + 4 : kBlockBytes;

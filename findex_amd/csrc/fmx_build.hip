@@ -14,6 +14,7 @@
 #include "fmx_device.h"
 #include "fmx_host.h"
 
+#include <algorithm>
 #include <string>
 
 namespace fmx {
@@ -140,11 +141,15 @@ __global__ __launch_bounds__(kBuildThreads) void k_fill_bytes(const uint8_t *__r
                                                                const uint16_t *__restrict__ sym_of,
                                                                const uint64_t *__restrict__ base /* [nsb][256] */,
                                                                uint32_t *__restrict__ chk, uint64_t *__restrict__ sup) {
-  __shared__ uint32_t run[256];       // per slot: count since the superblock start
+  __shared__ uint32_t run[256];       // per slot: count since the superblock start (sup != nullptr) or since row 0
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_slot[c] = slot_of[c]; run[c] = 0; }
-  for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x)
-    sup[(uint64_t)blockIdx.x * nslots + s] = base[(uint64_t)blockIdx.x * 256 + sym_of[s]];
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < nslots; s += blockDim.x) {
+    const uint64_t before = base[(uint64_t)blockIdx.x * 256 + sym_of[s]];
+    if (sup) sup[(uint64_t)blockIdx.x * nslots + s] = before;
+    else run[s] = (uint32_t)before;   // absolute checkpoints: every count fits 32 bits
+  }
   __syncthreads();
   const uint64_t b0 = (uint64_t)blockIdx.x << kSuperShift;
   uint64_t b1 = b0 + (1ull << kSuperShift);
@@ -237,7 +242,10 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
       if (tot[c]) { sym_of[h->nslots] = (uint16_t)c; h->slot[c] = (uint16_t)h->nslots++; }
       else h->slot[c] = kSlotNone;
     }
-    const uint64_t bv_bytes = bytes_layout ? (uint64_t)h->nslots * (h->nblocks * 4 + nsuper * 8)
+    uint64_t max_count = 0;
+    for (int c = 1; c < 256; c++) max_count = std::max<uint64_t>(max_count, tot[c]);
+    const bool abs_chk = bytes_layout && max_count < (1ull << 32) && !force_superblocks();      // absolute 32-bit checkpoints, no superblocks
+    const uint64_t bv_bytes = bytes_layout ? (uint64_t)h->nslots * (h->nblocks * 4 + (abs_chk ? 0 : nsuper * 8))
                                            : (uint64_t)h->nslots * h->nblocks * kBD * 4;
     size_t free_b = 0, total_b = 0;
     FMX_TRY(hipMemGetInfo(&free_b, &total_b), "hipMemGetInfo");
@@ -249,7 +257,7 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
     }
     if (bytes_layout) {
       FMX_TRY(hipMalloc(&h->d_chk, (uint64_t)h->nslots * h->nblocks * 4 + 16), "hipMalloc(checkpoints)");
-      FMX_TRY(hipMalloc(&h->d_sup, (uint64_t)h->nslots * nsuper * 8 + 16), "hipMalloc(superblocks)");
+      if (!abs_chk) FMX_TRY(hipMalloc(&h->d_sup, (uint64_t)h->nslots * nsuper * 8 + 16), "hipMalloc(superblocks)");
     } else {
       FMX_TRY(hipMalloc(&h->d_bv, bv_bytes ? bv_bytes : 16), "hipMalloc(rank dictionary)");
     }

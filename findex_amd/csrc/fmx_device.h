@@ -40,10 +40,13 @@ constexpr uint64_t kOneHotMaxN = 1ull << 37;   // split448 is exact for position
 // Second layout, for indexes whose one-hot vectors (sigma * n / 7 bytes) do not fit in HBM
 // (BASELINE config C5: n = 2^34, sigma = 128 -> 314 GB): the BWT bytes themselves in 128-byte
 // blocks (slot eof holds 0, which no real symbol has) + per-block checkpoints
-//     chk[blk][slot]  uint32  occurrences of the symbol in its superblock before this block
+//     chk[blk][slot]  uint32  occurrences of the symbol before this block -- absolute when every symbol occurs
+//                             fewer than 2^32 times (C5: n = 2^34, sigma = 128 -> ~2^27 each), else since the
+//                             start of the block's superblock, with
 //     sup[sb][slot]   uint64  occurrences before superblock sb (2^15 blocks = 2^22 positions)
-// rank = sup + chk + #{bytes of the block below the boundary that equal c}: two HBM lines per rank
-// query (the block and the checkpoint; sup stays cache-resident), 132 B algorithmic as SURVEY 8d.
+// rank = [sup +] chk + #{bytes of the block below the boundary that equal c}: two HBM lines per rank
+// query (the block and the checkpoint), 132 B algorithmic as SURVEY 8d; the superblock form adds a third
+// (cache-resident) request.
 // A query is served by 8 lanes (an "octet"): 16 of the block's 128 bytes per lane.
 constexpr uint32_t kLayoutOneHot = 0;
 constexpr uint32_t kLayoutBytes = 1;
@@ -206,7 +209,9 @@ __device__ __forceinline__ ByteRankReq byte_rank_issue(const DevIndex &ix, uint1
   q.rem = (uint32_t)x & 127u;
   q.w = load_line16((uint64_t)(uintptr_t)ix.bwt + blk * kByteBlock + lc.t * 16u);
   q.chk = lc.t == 0 ? ix.chk[blk * ix.nslots + slot] : 0u;
-  q.sup = ix.sup[(blk >> kSuperShift) * ix.nslots + slot];
+  // When every symbol occurs fewer than 2^32 times the checkpoints are absolute counts and there are no
+  // superblocks (ix.sup == nullptr): two requests per rank query -- the block and its checkpoint -- not three.
+  q.sup = ix.sup ? ix.sup[(blk >> kSuperShift) * ix.nslots + slot] : 0ull;
   return q;
 }
 

@@ -49,6 +49,11 @@ struct Index {
   // host-call bookkeeping
   mutable std::mutex mu;
   mutable std::vector<CallCtx *> ctx_pool;      // idle call contexts (guarded by mu)
+  // select directory for Psi (fmx_select.hip), built on first use
+  mutable std::mutex sel_mu;
+  mutable bool sel_ready = false;
+  mutable void *d_sel_dir = nullptr, *d_sel_off = nullptr, *d_sel_shift = nullptr;
+  mutable uint64_t sel_bytes = 0;
   mutable uint64_t launches = 0;
   mutable double last_kernel_ms = 0.0;
 };
@@ -67,13 +72,14 @@ struct CtxLease {            // scope guard around ctx_acquire / ctx_release
   CtxLease(const CtxLease &) = delete;
   CtxLease &operator=(const CtxLease &) = delete;
 };
+bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP
 
 // fmx_build.hip
 int build_index(Index *h, hipStream_t st, const int64_t *given_counts);   // returns an FMX_* status
 
-// fmx_kernels.hip
+// fmx_kernels.hip (launch_psi, launch_next_substr: fmx_select.hip)
 hipError_t launch_occ(const Index *h, const void *d_c, const void *d_i, void *d_out, uint64_t k, hipStream_t st);
 hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep, const void *d_c, void *d_sp1,
                              void *d_ep1, uint64_t k, hipStream_t st);

@@ -1,6 +1,6 @@
 // fmx_kernels.hip -- query kernels over the rank dictionary (gfx950, wave64).
 //
-// K2 occ_batch, K3 literal backward search, K4 prev_range_batch, LF / Psi walks.
+// K2 occ_batch, K3 literal backward search (generic form), K4 prev_range_batch, LF walks.
 // All are HBM-bound integer work: one 64-byte block per rank query, fetched whole by a quad of
 // lanes (an octet and two lines in the bytes layout; fmx_device.h); C[] and the symbol->slot map
 // are staged in LDS per workgroup.  "group" below = the lanes that serve one query.
@@ -253,82 +253,7 @@ __global__ __launch_bounds__(kThreads) void k_fm_fill(DevIndex ix, uint64_t p0, 
   }
 }
 
-// ---------------------------------------------------------------- Psi (getNextI = fm[row])
-// fm[row] is the BWT position of the (row - cf(c))-th occurrence of the symbol c whose bucket
-// holds `row` (FMCreator, bwtmerger.scala:424-533): a select on c's bit-vector.  One lane per
-// query: binary search over block headers, then a scan of the block.  Not on the hot path.
-__device__ uint64_t psi_one(const DevIndex &ix, const uint64_t *cf, const uint16_t *slot, uint64_t row) {
-  if (row == 0) return ix.eof;                 // bucket 0 = the EOF row
-  int lo = 1, hi = 255;                        // last c with cf[c] <= row (cf is non-decreasing)
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (cf[mid] <= row) lo = mid; else hi = mid - 1;
-  }
-  // symbols without occurrences share their start with the next present symbol, so the LAST c
-  // with cf[c] <= row is the one that owns the row
-  const int c = lo;
-  const uint16_t s = slot[c];
-  if (s >= kSlotEof) return ix.n;              // unreachable for row < n
-  const uint64_t j = row - cf[c];              // 0-based occurrence wanted
-  if (ix.layout == kLayoutBytes) {
-    auto before = [&](uint64_t blk) { return ix.sup[(blk >> kSuperShift) * ix.nslots + s] + ix.chk[blk * ix.nslots + s]; };
-    uint64_t a = 0, b = ix.nblocks - 1;        // last block with count-before <= j
-    while (a < b) {
-      uint64_t mid = (a + b + 1) >> 1;
-      if (before(mid) <= j) a = mid; else b = mid - 1;
-    }
-    uint64_t need = j - before(a);
-    for (uint32_t q = 0; q < kByteBlock; q++)
-      if (ix.bwt[a * kByteBlock + q] == (uint8_t)c) {
-        if (need == 0) return a * kByteBlock + q;
-        need--;
-      }
-    return ix.n;                               // unreachable for row < n
-  }
-  const uint64_t *hdr = reinterpret_cast<const uint64_t *>(ix.bv + (uint64_t)s * ix.nblocks * (kBlockBytes / 16));
-  uint64_t a = 0, b = ix.nblocks - 1;          // last block with header <= j
-  while (a < b) {
-    uint64_t mid = (a + b + 1) >> 1;
-    if (hdr[mid * (kBlockBytes / 8)] <= j) a = mid; else b = mid - 1;
-  }
-  uint64_t need = j - hdr[a * (kBlockBytes / 8)];
-  const uint32_t *w = reinterpret_cast<const uint32_t *>(hdr + a * (kBlockBytes / 8)) + 2;
-  for (uint32_t d = 0; d < kBlockPayloadDwords; d++) {
-    uint32_t v = w[d];
-    uint32_t pc = __builtin_popcount(v);
-    if (need < pc) {
-      for (uint32_t z = 0; z < need; z++) v &= v - 1;       // drop `need` lowest set bits
-      return a * kBlockBits + d * 32 + (uint32_t)__builtin_ctz(v);
-    }
-    need -= pc;
-  }
-  return ix.n;   // unreachable for row < n
-}
-
-__global__ __launch_bounds__(kThreads) void k_psi(DevIndex ix, const uint64_t *__restrict__ rows,
-                                                   uint64_t *__restrict__ out, uint64_t k) {
-  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < k; q += (uint64_t)gridDim.x * blockDim.x)
-    out[q] = psi_one(ix, ix.cf, ix.slot, rows[q] < ix.n ? rows[q] : ix.n - 1);
-}
-
-// NaiveFMSearcher.nextSubstr (bwtmerger.scala:394-405) for k independent (sp) starts: walk Psi,
-// stop after a 0 byte; bytes are written in walk order (the host reverses, :404).
-__global__ __launch_bounds__(kThreads) void k_next_substr(DevIndex ix, const uint64_t *__restrict__ sps, uint64_t k,
-                                                           uint32_t len, uint8_t *__restrict__ out,
-                                                           uint32_t *__restrict__ out_len) {
-  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < k; q += (uint64_t)gridDim.x * blockDim.x) {
-    uint64_t cp = psi_one(ix, ix.cf, ix.slot, sps[q]);
-    uint32_t w = 0;
-    bool eof = false;
-    for (uint32_t s = 0; s < len && !eof; s++) {
-      const uint32_t b = cp == ix.eof ? 0u : ix.bwt[cp];
-      eof = b == 0;
-      out[q * len + w++] = (uint8_t)b;
-      cp = psi_one(ix, ix.cf, ix.slot, cp);
-    }
-    out_len[q] = w;
-  }
-}
+// Psi (getNextI) and nextSubstr: fmx_select.hip.
 
 // ---------------------------------------------------------------- launchers
 // Counts fit 32 bits iff n <= 2^32; the one-hot kernels then reduce the block header with the popcounts.
@@ -389,20 +314,6 @@ hipError_t launch_fm_fill(const Index *h, void *d_fm, hipStream_t st) {
   k_fm_fill<W, L><<<grid_for(h, h->n, kThreads / Lay<L>::G), kThreads, 0, st>>>(h->dev, (uint64_t)0, h->n, (uint32_t *)d_fm)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
-  return hipGetLastError();
-}
-
-hipError_t launch_psi(const Index *h, const void *d_rows, void *d_out, uint64_t k, hipStream_t st) {
-  if (!k) return hipSuccess;
-  k_psi<<<grid_for(h, k, kThreads), kThreads, 0, st>>>(h->dev, (const uint64_t *)d_rows, (uint64_t *)d_out, k);
-  return hipGetLastError();
-}
-
-hipError_t launch_next_substr(const Index *h, const void *d_sps, uint64_t k, uint32_t len, void *d_out,
-                              void *d_out_len, hipStream_t st) {
-  if (!k) return hipSuccess;
-  k_next_substr<<<grid_for(h, k, kThreads), kThreads, 0, st>>>(h->dev, (const uint64_t *)d_sps, k, len,
-                                                                 (uint8_t *)d_out, (uint32_t *)d_out_len);
   return hipGetLastError();
 }
 

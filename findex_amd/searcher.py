@@ -241,6 +241,13 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_lf_walk_batch_dev(self._h, _dp(d_rows), int(k), int(length), _dp(d_out_bytes),
                                                  _dp(d_end_rows), _dp(stream)))
 
+    def psi_batch_dev(self, d_rows, d_out, k, stream=0):
+        _lib.check(self._L.fmx_psi_batch_dev(self._h, _dp(d_rows), _dp(d_out), int(k), _dp(stream)))
+
+    def next_substr_batch_dev(self, d_rows, k, length, d_out, d_out_len, stream=0):
+        _lib.check(self._L.fmx_next_substr_batch_dev(self._h, _dp(d_rows), int(k), int(length), _dp(d_out),
+                                                     _dp(d_out_len), _dp(stream)))
+
     # ---- statistics
     def stats(self):
         s = _lib.fmx_stats_t()

@@ -62,7 +62,9 @@ const char *fmx_last_error(void);
 int fmx_abi_version(void);
 /* Process-wide options.  key "layout": "auto" (default: one-hot bit-vectors, one 64-byte block per
  * rank query, when sigma*n/7 bytes fit in free HBM and n < 2^37; else BWT bytes + checkpoints, two
- * lines per rank query), "onehot", "bytes".  Affects indexes opened afterwards. */
+ * lines per rank query), "onehot", "bytes".  key "checkpoints": "auto" (default: the bytes layout keeps absolute
+ * 32-bit checkpoints whenever every symbol occurs fewer than 2^32 times) or "superblock" (always the relative
+ * checkpoints + 64-bit superblock counts that larger counts need; for tests).  Affects indexes opened afterwards. */
 int fmx_config_set(const char *key, const char *value);
 /* Number of HIP devices visible (0 and FMX_OK when there is none). */
 int fmx_device_count(int *count);
@@ -145,6 +147,13 @@ int fmx_lf_walk_batch_dev(const fmx_index *idx, const void *d_rows, size_t k, ui
  * fmx_next_substr: the reference's nextSubstr(sp,len): walk Psi, stop after a 0 byte, reversed;
  * out needs len bytes, *out_len = bytes written. */
 int fmx_psi_batch(const fmx_index *idx, const uint64_t *rows, uint64_t *out, size_t k);
+int fmx_psi_batch_dev(const fmx_index *idx, const void *d_rows, void *d_out, size_t k, void *stream);
+/* Device form of the batched nextSubstr: d_out is k*len bytes in WALK order (the reference's `ret` before its
+ * final .reverse, bwtmerger.scala:404), d_out_len[q] (uint32) = bytes of walk q written. */
+int fmx_next_substr_batch_dev(const fmx_index *idx, const void *d_rows, size_t k, uint32_t len, void *d_out,
+                              void *d_out_len, void *stream);
+/* The first Psi / nextSubstr call on a handle builds a select directory on the device (at most ~n bytes; it is
+ * counted in fmx_stats_t.index_bytes from then on). */
 int fmx_next_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *out, uint32_t *out_len);
 /* the same for k rows at once (rendering a result list): out is k*len bytes, row q's string at q*len, out_len[q]
  * bytes of it written. */

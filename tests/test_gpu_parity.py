@@ -646,10 +646,14 @@ def test_dfa_engine(testdata):
 
 # ---------------------------------------------------------------- second layout: BWT bytes + checkpoints
 @pytest.fixture
-def bytes_layout():
+def bytes_layout(request):
+    """The compact layout, in both of its checkpoint forms: absolute 32-bit counts (whenever every symbol occurs
+    fewer than 2^32 times) and counts relative to 64-bit superblock totals (forced here; larger counts need it)."""
     findex_amd.set_layout("bytes")
+    findex_amd.set_checkpoints(getattr(request, "param", "auto"))
     yield
     findex_amd.set_layout("auto")
+    findex_amd.set_checkpoints("auto")
 
 
 def test_bytes_layout_fixtures(testdata, bytes_layout, tmp_path):
@@ -683,6 +687,7 @@ def test_bytes_layout_fixtures(testdata, bytes_layout, tmp_path):
             assert [r.key() for r in g] == orc.match_tables(R.ReTree(R.re2post(re)).tables(), 16, 50)[0], re
 
 
+@pytest.mark.parametrize("bytes_layout", ["auto", "superblock"], indirect=True)
 @pytest.mark.parametrize("n,lo,hi", [(1, 1, 1), (127, 1, 4), (128, 1, 4), (129, 1, 4), (4_194_304 + 5, 1, 128),
                                      (300_007, 1, 255)])
 def test_bytes_layout_synthetic(n, lo, hi, bytes_layout):

@@ -64,6 +64,7 @@ SYMBOLS = {
     "fmx_open": (_i32, [_cp, _cp, _i32, _i32, _P(_vp)]),
     "fmx_open_mem": (_i32, [_vp, _u64, _u64, _vp, _i32, _P(_vp)]),
     "fmx_open_dev": (_i32, [_vp, _u64, _u64, _vp, _i32, _vp, _P(_vp)]),
+    "fmx_open_block": (_i32, [_vp, _u64, _vp, _u64, _i32, _P(_vp)]),
     "fmx_close": (_i32, [_vp]),
     "fmx_n": (_i32, [_vp, _P(_u64)]),
     "fmx_eof": (_i32, [_vp, _P(_u64)]),
@@ -98,6 +99,10 @@ SYMBOLS = {
     "fmx_regex_batch_create": (_i32, [_vp, _vp, _sz, _P(_vp)]),
     "fmx_regex_batch_free": (_i32, [_vp]),
     "fmx_regex_batch_match": (_i32, [_vp, _vp, _vp, _vp, _sz, _P(_sz), _vp]),
+    "fmx_regex_batch_create_multi": (_i32, [_vp, _sz, _vp, _sz, _P(_vp)]),
+    "fmx_regex_batch_free_multi": (_i32, [_vp]),
+    "fmx_regex_batch_match_multi": (_i32, [_vp, _vp, _vp, _sz, _P(_sz), _vp]),
+    "fmx_gather": (_i32, [_vp, _sz, _vp, _vp, _sz, _vp]),
     "fmx_stats": (_i32, [_vp, _P(fmx_stats_t)]),
     "fmx_stats_reset": (_i32, [_vp]),
     "fmx_last_kernel_ms": (_i32, [_vp, _P(ctypes.c_double)]),

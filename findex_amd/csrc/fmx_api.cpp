@@ -251,8 +251,14 @@ static void destroy(Index *h) {
 }
 
 // Common tail of the three open flavours: `src` is host or device memory holding n BWT bytes.
+struct BlockSpec {       // fmx_open_block: NaiveBWTSearcher's constructor arguments beside the BWT
+  const int64_t *bs;
+  int first, skipped;    // BWT bytes at position 0 (-1 when that is the skipped row) and at the skipped row
+};
+
 static int open_common(const void *src, bool src_on_device, FILE *src_file, uint64_t n, uint64_t eof,
-                       const int64_t *counts, int device, hipStream_t user_stream, fmx_index **out) {
+                       const int64_t *counts, int device, hipStream_t user_stream, fmx_index **out,
+                       const BlockSpec *block = nullptr) {
   if (!out) return arg_fail("out is null");
   *out = nullptr;
   if (!src && !src_file && n) return arg_fail("bwt is null");
@@ -266,6 +272,12 @@ static int open_common(const void *src, bool src_on_device, FILE *src_file, uint
   Index *h = new (std::nothrow) Index();
   if (!h) { g_err = "out of host memory"; return FMX_ERR_NOMEM; }
   h->serial = ++g_serial;
+  if (block) {
+    h->block_mode = true;
+    std::memcpy(h->block_bs, block->bs, sizeof h->block_bs);
+    h->block_first = block->first;
+    h->block_skipped = block->skipped;
+  }
   h->device = device;
   h->n = n;
   h->eof = eof;
@@ -437,6 +449,19 @@ int fmx_open_dev(const void *d_bwt, uint64_t n, uint64_t eof, const int64_t *cou
   return open_common(d_bwt, true, nullptr, n, eof, counts_or_null, device, (hipStream_t)stream, out);
 }
 
+// NaiveBWTSearcher(bwt, bucketStarts, rk0), findex.scala:459-506: the searcher BWTMerger2.calcGaps uses over one
+// block's BWT.  The skipped row plays the part of the EOF slot; everything else that differs from NaiveFMSearcher
+// is settled when the dictionary is built (build_index, block mode).
+int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[256], uint64_t rk0, int device,
+                   fmx_index **out) {
+  if (!bwt || !bucket_starts) return arg_fail("null argument");
+  if (n < 1 || rk0 >= n) return arg_fail("need n >= 1 and rk0 < n");
+  for (int c = 0; c < 256; c++)
+    if (bucket_starts[c] < 0 || (uint64_t)bucket_starts[c] > n) return arg_fail("bucket start out of range");
+  BlockSpec spec{bucket_starts, rk0 == 0 ? -1 : (int)bwt[0], (int)bwt[rk0]};
+  return open_common(bwt, false, nullptr, n, rk0, nullptr, device, nullptr, out, &spec);
+}
+
 int fmx_close(fmx_index *idx) {
   destroy(H(idx));
   return FMX_OK;
@@ -596,6 +621,37 @@ int fmx_search_batch_multi(fmx_index *const *idxs, size_t n_idx, const uint8_t *
   for (size_t r = 0; r < n_idx; r++)
     if (rc[r] != FMX_OK) { g_err = msg[r]; return rc[r]; }
   return FMX_OK;
+}
+
+int fmx_gather(fmx_index *const *idxs, size_t n_idx, const void *const *d_src, const size_t *cnt, size_t elem,
+               void *dst) {
+  if (!idxs || !n_idx || !d_src || !cnt || !elem || !dst) return arg_fail("null argument");
+  std::vector<CallCtx *> ctx(n_idx, nullptr);
+  size_t at = 0;
+  int rc = FMX_OK;
+  for (size_t r = 0; r < n_idx && rc == FMX_OK; r++) {
+    if (!idxs[r]) { rc = arg_fail("null index handle"); break; }
+    const Index *h = H(idxs[r]);
+    if (cnt[r]) {
+      if (!d_src[r]) { rc = arg_fail("null slice pointer"); break; }
+      if ((rc = use_device(h)) != FMX_OK) break;
+      ctx[r] = ctx_acquire(h);
+      if (!ctx[r]) { rc = FMX_ERR_HIP; break; }
+      const hipError_t e = hipMemcpyAsync(static_cast<uint8_t *>(dst) + at * elem, d_src[r], cnt[r] * elem,
+                                          hipMemcpyDeviceToHost, ctx[r]->stream);
+      if (e != hipSuccess) rc = hip_fail(e, "D2H(gather)");
+    }
+    at += cnt[r];
+  }
+  for (size_t r = 0; r < n_idx; r++) {
+    if (!ctx[r]) continue;
+    const Index *h = H(idxs[r]);
+    (void)hipSetDevice(h->device);
+    const hipError_t e = hipStreamSynchronize(ctx[r]->stream);
+    if (e != hipSuccess && rc == FMX_OK) rc = hip_fail(e, "hipStreamSynchronize(gather)");
+    ctx_release(h, ctx[r]);
+  }
+  return rc;
 }
 
 int fmx_prev_range_batch(const fmx_index *idx, const uint64_t *sp, const uint64_t *ep, const uint8_t *c,

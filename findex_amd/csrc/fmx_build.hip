@@ -221,7 +221,7 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
       rc = 6 /* FMX_ERR_UNSUPPORTED */;
       break;
     }
-    if (given_counts) {
+    if (given_counts && !h->block_mode) {
       bool ok = given_counts[0] == 0;
       for (int c = 1; c < 256 && ok; c++) ok = (uint64_t)given_counts[c] == tot[c];
       if (!ok) {
@@ -241,6 +241,26 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
       run += tot[c];
       if (tot[c]) { sym_of[h->nslots] = (uint16_t)c; h->slot[c] = (uint16_t)h->nslots++; }
       else h->slot[c] = kSlotNone;
+    }
+    if (h->block_mode) {
+      // NaiveBWTSearcher (findex.scala:459-506): cf = the caller's bucket starts (:478); occ counts the symbol in
+      // bwt[0..key] without row rk0 -- the rank dictionary with that row as its "EOF" slot -- for every symbol,
+      // 0 included (no byte 0 here, so 0 everywhere).  Its binary search returns (iend - istart) when it ends on the
+      // bucket's last slot and reads 0 there (:500-502, meant for the hole the skipped row leaves): a bucket
+      // without a hole whose ONLY entry is position 0 reads the same, so such a symbol -- the block's first byte,
+      // if it occurs nowhere else and is not the skipped row's byte -- answers 0 for every key.
+      for (int c = 0; c < 256; c++) h->cf[c] = (uint64_t)h->block_bs[c];
+      h->slot[0] = kSlotNone;
+      const int c0 = h->block_first;
+      if (c0 > 0 && tot[c0] == 1 && h->block_skipped != c0 && h->slot[c0] < kSlotEof) {
+        // drop its vector: compact the slot numbering
+        const uint16_t dead = h->slot[c0];
+        for (int c = 1; c < 256; c++)
+          if (h->slot[c] < kSlotEof && h->slot[c] > dead) h->slot[c]--;
+        for (uint32_t sl = dead; sl + 1 < h->nslots; sl++) sym_of[sl] = sym_of[sl + 1];
+        h->nslots--;
+        h->slot[c0] = kSlotNone;
+      }
     }
     uint64_t max_count = 0;
     for (int c = 1; c < 256; c++) max_count = std::max<uint64_t>(max_count, tot[c]);

@@ -31,6 +31,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "fmx_device.h"
@@ -1158,6 +1160,108 @@ int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *b, const fmx_li
   }
   if (lim && lim->mode != FMX_MATCH_FRONTIER) { set_error("unknown fmx_limits.mode"); return FMX_ERR_ARG; }
   return regex_batch_match(h, rb, lim, out, cap, n_out, per_regex_count);
+}
+
+// ---- one process, several GPUs: the batch is cut into contiguous slices of about equal ESTIMATED
+// frontier work, slice r is made resident on idxs[r]'s device, slices are matched from one host thread each and
+// their result lists -- each already in canonical order, regex ids ascending across slices -- are concatenated.
+struct RegexBatchMulti {
+  size_t k = 0;
+  std::vector<const Index *> idx;
+  std::vector<RegexBatch *> part;
+  std::vector<size_t> cut;       // n_idx + 1 slice bounds
+  ~RegexBatchMulti() {
+    for (size_t r = 0; r < part.size(); r++)
+      if (part[r]) { (void)hipSetDevice(part[r]->device); delete part[r]; }
+  }
+};
+
+// What a regex is expected to cost: its start elements, its states (each is stepped at least once per path through
+// it) and its follow entries (every one is a push); a starred class shows up as many follows.
+static double regex_work_estimate(const Regex &re) {
+  return 4.0 * (double)re.firsts.size() + (double)re.st_c.size() + (double)re.fol.size();
+}
+
+int fmx_regex_batch_create_multi(fmx_index *const *idxs, size_t n_idx, fmx_regex *const *res, size_t k,
+                                 fmx_regex_batch_multi **out) {
+  if (!idxs || !n_idx || !out || (k && !res)) { set_error("null argument"); return FMX_ERR_ARG; }
+  *out = nullptr;
+  for (size_t r = 0; r < n_idx; r++) {
+    if (!idxs[r]) { set_error("null index handle"); return FMX_ERR_ARG; }
+    const Index *a = reinterpret_cast<const Index *>(idxs[r]), *b0 = reinterpret_cast<const Index *>(idxs[0]);
+    if (a->n != b0->n || a->eof != b0->eof) { set_error("the handles are not replicas of one index"); return FMX_ERR_ARG; }
+  }
+  for (size_t r = 0; r < k; r++)
+    if (!res[r]) { set_error("null regex handle"); return FMX_ERR_ARG; }
+  std::unique_ptr<RegexBatchMulti> m(new RegexBatchMulti());
+  m->k = k;
+  std::vector<double> cum(k + 1, 0.0);
+  for (size_t r = 0; r < k; r++) cum[r + 1] = cum[r] + regex_work_estimate(*reinterpret_cast<const Regex *>(res[r]));
+  m->cut.assign(n_idx + 1, k);
+  m->cut[0] = 0;
+  for (size_t r = 1; r < n_idx; r++) {
+    const double want = cum[k] * (double)r / (double)n_idx;
+    size_t c = (size_t)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+    if (c > k) c = k;
+    m->cut[r] = std::max(c, m->cut[r - 1]);
+  }
+  for (size_t r = 0; r < n_idx; r++) {
+    m->idx.push_back(reinterpret_cast<const Index *>(idxs[r]));
+    m->part.push_back(nullptr);
+    const size_t a = m->cut[r], b = m->cut[r + 1];
+    int rc = regex_batch_create(m->idx[r], reinterpret_cast<const Regex *const *>(res) + a, b - a, &m->part[r]);
+    if (rc != FMX_OK) return rc;
+  }
+  *out = reinterpret_cast<fmx_regex_batch_multi *>(m.release());
+  return FMX_OK;
+}
+
+int fmx_regex_batch_free_multi(fmx_regex_batch_multi *mb) {
+  delete reinterpret_cast<RegexBatchMulti *>(mb);
+  return FMX_OK;
+}
+
+int fmx_regex_batch_match_multi(fmx_regex_batch_multi *mb, const fmx_limits *lim, fmx_result *out, size_t cap,
+                                size_t *n_out, uint32_t *per_regex_count) {
+  if (!mb || !n_out || (cap && !out)) { set_error("null argument"); return FMX_ERR_ARG; }
+  RegexBatchMulti *m = reinterpret_cast<RegexBatchMulti *>(mb);
+  if (lim && lim->mode != FMX_MATCH_FRONTIER) { set_error("the multi-device form runs the frontier mode"); return FMX_ERR_UNSUPPORTED; }
+  const size_t np = m->part.size();
+  std::vector<std::vector<fmx_result>> got(np);
+  std::vector<size_t> cnt(np, 0);
+  std::vector<int> rc(np, FMX_OK);
+  std::vector<std::string> msg(np);
+  std::vector<std::thread> th;
+  for (size_t r = 0; r < np; r++) {
+    if (m->cut[r] == m->cut[r + 1]) continue;
+    th.emplace_back([&, r]() {
+      // every slice may fill the caller's whole capacity; its own buffer grows to what it needs
+      got[r].resize(cap ? cap : 1);
+      uint32_t *per = per_regex_count ? per_regex_count + m->cut[r] : nullptr;
+      rc[r] = regex_batch_match(m->idx[r], m->part[r], lim, got[r].data(), cap, &cnt[r], per);
+      if (rc[r] != FMX_OK) msg[r] = fmx_last_error();
+    });
+  }
+  for (std::thread &t : th) t.join();
+  size_t total = 0;
+  bool truncated = false;
+  for (size_t r = 0; r < np; r++) {
+    if (rc[r] == FMX_TRUNCATED) { truncated = true; msg[np - 1] = msg[r]; }
+    else if (rc[r] != FMX_OK) { set_error(msg[r]); *n_out = cnt[r]; return rc[r]; }
+    total += cnt[r];
+  }
+  *n_out = total;
+  if (total > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
+  size_t at = 0;
+  for (size_t r = 0; r < np; r++) {
+    for (size_t j = 0; j < cnt[r]; j++) {
+      out[at] = got[r][j];
+      out[at].regex += (uint32_t)m->cut[r];
+      at++;
+    }
+  }
+  if (truncated) { set_error("some matches run past max_steps: results hold every match of length <= max_steps"); return FMX_TRUNCATED; }
+  return FMX_OK;
 }
 
 int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k, const fmx_limits *lim,

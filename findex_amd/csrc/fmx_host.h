@@ -35,6 +35,12 @@ struct Index {
   uint64_t cf[256] = {0};
   uint16_t slot[256] = {0};
   // device memory owned by the handle
+  // NaiveBWTSearcher form (fmx_open_block, findex.scala:459-506): bucket starts come from the caller, symbol 0 is an
+  // ordinary (absent) symbol, and the block's first byte decides one quirk (build_index)
+  bool block_mode = false;
+  int64_t block_bs[256] = {0};
+  int block_first = -1;         // BWT byte at position 0 (-1: position 0 is the skipped row)
+  int block_skipped = -1;       // BWT byte at the skipped row rk0
   uint32_t layout = 0;          // kLayoutOneHot | kLayoutBytes
   void *d_bv = nullptr;
   void *d_chk = nullptr;        // bytes layout: checkpoints

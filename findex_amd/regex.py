@@ -270,3 +270,36 @@ class RegexBatch:
                                                       per.ctypes.data_as(ctypes.c_void_p)))
         self.truncated = rc == _lib.FMX_TRUNCATED
         return out[: n_out.value], per[: self.k]
+
+
+class RegexBatchMulti:
+    """fmx_regex_batch_create_multi / _match_multi: one process, one replica handle per GPU, the regex batch cut by
+    estimated frontier work; same results as RegexBatch on one handle."""
+
+    def __init__(self, searchers, trees):
+        self._L = _lib.load()
+        self.searchers = list(searchers)
+        self.k = len(trees)
+        self._trees = list(trees)
+        idxs = (ctypes.c_void_p * len(self.searchers))(*[s.handle for s in self.searchers])
+        arr = (ctypes.c_void_p * max(self.k, 1))(*[t._h for t in trees])
+        self._h = ctypes.c_void_p()
+        _lib.check(self._L.fmx_regex_batch_create_multi(idxs, len(self.searchers), arr, self.k, ctypes.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.fmx_regex_batch_free_multi(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22):
+        lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_FRONTIER, int(max_frontier), 1024, 1000)
+        out = np.empty(cap, dtype=RESULT_DTYPE)
+        per = np.zeros(max(self.k, 1), dtype=np.uint32)
+        n_out = ctypes.c_size_t()
+        rc = _lib.check(self._L.fmx_regex_batch_match_multi(self._h, ctypes.byref(lim), out.ctypes.data_as(ctypes.c_void_p),
+                                                            cap, ctypes.byref(n_out), per.ctypes.data_as(ctypes.c_void_p)))
+        self.truncated = rc == _lib.FMX_TRUNCATED
+        return out[: n_out.value], per[: self.k]

@@ -72,6 +72,19 @@ class HipFMSearcher:
                                   ctypes.byref(h)))
         return cls(_handle=h)
 
+    @classmethod
+    def from_block(cls, bwt, bucketStarts, rk0, device=0):
+        """`new NaiveBWTSearcher(bwt, bucketStarts, rk0)` (findex.scala:459-506): one merge block's BWT, the caller's
+        bucket starts, row rk0 skipped."""
+        L = _lib.load()
+        bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+        bs = np.ascontiguousarray(bucketStarts, dtype=np.int64)
+        if bs.size != 256:
+            raise ValueError("bucketStarts must have 256 entries")
+        h = ctypes.c_void_p()
+        _lib.check(L.fmx_open_block(_ptr(bwt), bwt.size, _ptr(bs), int(rk0), int(device), ctypes.byref(h)))
+        return cls(_handle=h)
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.fmx_close(self._h)

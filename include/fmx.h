@@ -87,6 +87,15 @@ int fmx_open_mem(const uint8_t *bwt, uint64_t n, uint64_t eof, const int64_t cou
                  fmx_index **out);
 int fmx_open_dev(const void *d_bwt, uint64_t n, uint64_t eof, const int64_t *counts_or_null, int device,
                  void *stream, fmx_index **out);
+/* fmx_open_block : class NaiveBWTSearcher(bwt, bucketStarts, rk0), findex.scala:459-506 -- the searcher
+ *                  BWTMerger2.calcGaps (bwtmerger.scala:981-1023) uses over one block's raw BWT.  cf(c) is the
+ *                  caller's bucket_starts[c]; occ(c, key) = occurrences of byte c in bwt[0..key] without row rk0
+ *                  (c is taken & 0xff by the byte-typed batch entry points, like :480), including the reference's
+ *                  last-slot rule (:500-502): a symbol whose only occurrence is position 0 answers 0.  The block
+ *                  must not contain byte 0 (FMX_ERR_UNSUPPORTED; the merger's input is 0-free).  The handle
+ *                  serves every entry point (search, getPrevRange ... are inherited from SuffixAlgo there too). */
+int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[256], uint64_t rk0, int device,
+                   fmx_index **out);
 int fmx_close(fmx_index *idx);
 
 /* ---- scalars: SuffixAlgo.n / cf, findex.scala:10-12; NaiveFMSearcher.cf bwtmerger.scala:346-352 */
@@ -253,6 +262,27 @@ int fmx_regex_batch_create(const fmx_index *idx, fmx_regex *const *res, size_t k
 int fmx_regex_batch_free(fmx_regex_batch *batch);
 int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *batch, const fmx_limits *lim, fmx_result *out,
                           size_t cap, size_t *n_out, uint32_t *per_regex_count);
+
+/* One process, several GPUs (the single-process form of SURVEY.md 8e for regexes; one process per GPU uses
+ * findex_amd/distributed.py and an RCCL gather instead): the batch is cut into contiguous slices of about equal
+ * estimated frontier work (start elements, states and follow entries of each regex), slice r is made resident on
+ * idxs[r]'s device (every handle a replica of one index), the slices are matched concurrently from one host thread
+ * each with no device-to-device traffic, and the result lists are concatenated: same output as
+ * fmx_regex_batch_match on one handle (frontier mode only). */
+typedef struct fmx_regex_batch_multi fmx_regex_batch_multi;
+int fmx_regex_batch_create_multi(fmx_index *const *idxs, size_t n_idx, fmx_regex *const *res, size_t k,
+                                 fmx_regex_batch_multi **out);
+int fmx_regex_batch_free_multi(fmx_regex_batch_multi *mb);
+int fmx_regex_batch_match_multi(fmx_regex_batch_multi *mb, const fmx_limits *lim, fmx_result *out, size_t cap,
+                                size_t *n_out, uint32_t *per_regex_count);
+
+/* Gathers per-device result slices into one host array (the host-side counterpart of the RCCL all-gather): slice r
+ * is cnt[r] elements of `elem` bytes at DEVICE pointer d_src[r] on idxs[r]'s device and lands at
+ * dst + (cnt[0] + .. + cnt[r-1]) * elem.  The copies of all devices run concurrently and the call returns when all
+ * have landed.  For callers that keep their batches on the devices (fmx_*_dev entry points) and search slices on
+ * several handles themselves. */
+int fmx_gather(fmx_index *const *idxs, size_t n_idx, const void *const *d_src, const size_t *cnt, size_t elem,
+               void *dst);
 
 /* ---- statistics (since open or the last reset; device counters are read with a sync).
  * rank_queries counts occ(c,i) evaluations in the REFERENCE's terms: two per backward step (findex.scala:26-27,

@@ -87,6 +87,8 @@ def lib():
     L.orc_match_sa.restype = i64
     L.orc_match_sa.argtypes = [vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.c_int32, i64, i64,
                                vp, vp, vp, i64, P(i64), P(i64)]
+    L.orc_lf_chain.restype = i64
+    L.orc_lf_chain.argtypes = [vp, i64, i64]
     L.orc_histogram.restype = None
     L.orc_histogram.argtypes = [vp, u64, u64, i32, vp]
     L.orc_match_sa_batch.restype = i64
@@ -266,6 +268,10 @@ class NaiveFMSearcher:
         if k < 0:
             raise IndexOutOfBounds(sp)
         return bytes(out[:k])
+
+    def lf_chain(self, row, steps):
+        """`steps` dependent LF steps from `row` -> the row reached (one core, in C)."""
+        return int(self._L.orc_lf_chain(self._h, int(row), int(steps)))
 
     def fm(self):
         """The inverted list (= .fm payload) as a uint32 view copy."""

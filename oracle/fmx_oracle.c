@@ -402,6 +402,17 @@ int64_t orc_prev_substr(const orc_index *ix, int64_t sp, int64_t len, uint8_t *o
 /* Plain loops over the functions above; `threads` > 1 uses OpenMP when built
  * with -fopenmp (bench.py's cpu_baseline leg). */
 
+/* One dependent chain of `steps` rank steps, curRank = cf(c) + occ(c, curRank - 1), the shape of BWTMerger2.calcGaps'
+ * inner loop (F/bwtmerger.scala:992-999; there c comes from the already-merged text, here from the BWT itself, i.e. an
+ * LF walk).  Timed by tools/calcgaps_chain.py beside the same chain on the GPU. */
+int64_t orc_lf_chain(const orc_index *ix, int64_t row, int64_t steps) {
+  for (int64_t s = 0; s < steps; s++) {
+    const int c = bwt_read(ix, (uint64_t)row);
+    row = (int64_t)ix->bs[c] + orc_occ(ix, c, row - 1);
+  }
+  return row;
+}
+
 int orc_occ_batch(const orc_index *ix, const uint8_t *c, const int64_t *i, int64_t *out, uint64_t k) {
   for (uint64_t q = 0; q < k; q++) out[q] = orc_occ(ix, c[q], i[q]);
   return ORC_OK;

@@ -127,6 +127,50 @@ def test_reference_kats_through_the_product(testdata):
     assert [hip.getPrevI(i) for i in (3, 9, 10, 4, 5, 0)] == [9, 10, 4, 5, 0, 1]
 
 
+def test_naive_bwt_searcher_through_the_product(golden):
+    """NaiveBWTSearcher (findex.scala:459-506) through the C ABI -- the 22 known answers of
+    T/Indexer.scala:703-725,737-742 (the 0xff symbol and the EOF hole among them), then every (c, key) of random
+    blocks against the oracle's restatement, the reference's last-slot rule (:500-502) included."""
+    import json
+    from oracle.naive_bwt import NaiveBWTSearcher
+    kat = json.load(open(os.path.join(golden, "naive_bwt_searcher_kat.json")))
+    n_kat = 0
+    for name in ("case1", "case2"):
+        k = kat[name]
+        bwt = np.array(k["bwt"], dtype=np.int64).astype(np.uint8)
+        hip = findex_amd.HipFMSearcher.from_block(bwt, k["bs"], k["rk0"])
+        assert hip.n == bwt.size and hip.eof == k["rk0"]
+        for c, key, want in k["occ"]:
+            assert hip.occ(c & 0xFF, key) == want, (name, c, key)
+            n_kat += 1
+        for c in (97, 100, 106, 122, 255):
+            assert hip.cf(c) == k["bs"][c]
+    assert n_kat == 22
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        n = int(rng.integers(1, 700))
+        bwt = rng.integers(1, 7 if trial % 2 else 256, n).astype(np.uint8)
+        rk0 = int(rng.integers(0, n))
+        if trial == 3 and n > 3:          # the last-slot rule: the first byte occurs nowhere else
+            bwt[0] = 250
+            bwt[1:][bwt[1:] == 250] = 1
+            rk0 = n - 1
+        cnt = np.bincount(bwt, minlength=256)
+        cnt[bwt[rk0]] -= 1
+        cnt[bwt[rk0]] += 1                # the bucket starts come from the block's text: the skipped row's byte is in it
+        bs = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+        hip = findex_amd.HipFMSearcher.from_block(bwt, bs, rk0)
+        ref = NaiveBWTSearcher(bwt, bs, rk0)
+        cs = np.repeat(np.arange(256, dtype=np.uint8), 6)
+        keys = rng.integers(-1, n, cs.size).astype(np.int64)
+        got = hip.occ_batch(cs, keys)
+        want = [ref.occ(int(c), int(key)) if key >= 0 else 0 for c, key in zip(cs, keys)]
+        assert got.tolist() == want, trial
+        for c in {int(bwt[0]), int(bwt[rk0]), 1, 255}:     # full columns for the interesting symbols
+            ks = np.arange(n, dtype=np.int64)
+            assert hip.occ_batch(np.full(n, c, dtype=np.uint8), ks).tolist() == [ref.occ(c, int(key)) for key in ks], (trial, c)
+
+
 def test_extract_is_next_and_prev_substr(testdata):
     hip, orc = pair_from_files(testdata, "test1024.cmp", False)
     for row in (0, 1, 48, 462, 517, hip.n - 1):
@@ -336,6 +380,55 @@ def test_search_batch_multi_replicas():
     other = findex_amd.HipFMSearcher.from_mem(bwt[:1000], 5, np.bincount(np.delete(bwt[:1000], 5), minlength=256).astype(np.int64))
     with pytest.raises(findex_amd.FmxError):
         findex_amd.HipFMSearcher.search_batch_multi([hips[0], other], buf, off)
+
+
+def test_regex_batch_multi_replicas_and_gather(testdata):
+    """fmx_regex_batch_match_multi over three replica handles (all on device 0 here; one per GPU in production): the
+    batch is cut by estimated frontier work, slices are matched from three host threads, the concatenated result
+    list equals the single-handle one.  fmx_gather then collects device-resident slices of three handles into one
+    host array."""
+    import ctypes
+    from findex_amd import _lib
+    from findex_amd.regex import RegexBatchMulti
+    hips = [pair_from_files(testdata, "words", True)[0] for _ in range(3)]
+    res = REGEXES + ["co(m|n)+e", "s[aeiou]+t", "abc", "zz?y"]          # light and heavy ones mixed
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re)) for re in res]
+    want, wper = findex_amd.ReTree.prepare_batch(hips[0], trees).match_raw(cap=1 << 20)
+    multi = RegexBatchMulti(hips, trees)
+    for _ in range(2):
+        got, gper = multi.match_raw(cap=1 << 20)
+        assert got.size == want.size and all(np.array_equal(got[f], want[f]) for f in ("regex", "len", "sp", "ep"))
+        assert np.array_equal(gper, wper)
+    one = RegexBatchMulti(hips, trees[:1])                              # fewer regexes than handles
+    got, _ = one.match_raw()
+    assert np.array_equal(got["sp"], want["sp"][want["regex"] == 0])
+    with pytest.raises(findex_amd.FmxError) as e:                       # too small a result buffer is reported
+        multi.match_raw(cap=8)
+    assert e.value.code == 9
+    # fmx_gather: (sp, ep) slices left on the device by three handles' searches
+    torch = _torch()
+    orc = oracle.NaiveFMSearcher(os.path.join(testdata, "words.bwt"), bigEndian=True)
+    rng = np.random.default_rng(8)
+    buf, off = pack_patterns(lf_walk_patterns(orc, rng, 900, 6, 0.2, alphabet=list(range(97, 123))))
+    wsp, _, _ = orc.search_batch(buf, off)
+    cuts = [0, 100, 100, 900]                                           # an empty slice in the middle
+    d_pat = torch.from_numpy(buf).cuda()
+    outs, ptrs = [], []
+    for r in range(3):
+        a, b = cuts[r], cuts[r + 1]
+        d_off = torch.from_numpy(off[a:b + 1].astype(np.int64)).cuda()
+        sp = torch.empty(max(b - a, 1), dtype=torch.int64, device="cuda")
+        ep = torch.empty_like(sp)
+        hips[r].search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), sp.data_ptr(), ep.data_ptr(), b - a)
+        outs.append((sp, ep, d_off))
+        ptrs.append(sp.data_ptr())
+    torch.cuda.synchronize()
+    dst = np.zeros(900, dtype=np.uint64)
+    idxs = (ctypes.c_void_p * 3)(*[h.handle for h in hips])
+    srcs = (ctypes.c_void_p * 3)(*ptrs)
+    cnt = (ctypes.c_size_t * 3)(100, 0, 800)
+    _lib.check(_lib.load().fmx_gather(idxs, 3, srcs, cnt, 8, dst.ctypes.data_as(ctypes.c_void_p)))
+    assert np.array_equal(dst, wsp)
 
 
 def test_counts_must_describe_bwt():

@@ -927,8 +927,12 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     return hipMemcpyAsync(b->h_tot, b->d_tot, sizeof(GroupTotals), hipMemcpyDeviceToHost, s);
   };
   auto capture = [&](hipGraphExec_t *exec, int grid) {     // grid 0: the grouping
+    // one capture at a time in the process: concurrent captures from several host threads (the multi-device entry
+    // point matches its slices in parallel) invalidated each other on ROCm 7.2
+    static std::mutex capture_mu;
+    std::lock_guard<std::mutex> lk(capture_mu);
     hipGraph_t g = nullptr;
-    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
     if (e == hipSuccess) {
       const hipError_t e1 = grid ? enqueue_chain(st, grid) : enqueue_group(st);
       const hipError_t e2 = hipStreamEndCapture(st, &g);

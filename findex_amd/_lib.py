@@ -61,6 +61,8 @@ SYMBOLS = {
     "fmx_abi_version": (_i32, []),
     "fmx_config_set": (_i32, [_cp, _cp]),
     "fmx_device_count": (_i32, [_P(_i32)]),
+    "fmx_host_alloc": (_i32, [_sz, _P(_vp)]),
+    "fmx_host_free": (_i32, [_vp]),
     "fmx_open": (_i32, [_cp, _cp, _i32, _i32, _P(_vp)]),
     "fmx_open_mem": (_i32, [_vp, _u64, _u64, _vp, _i32, _P(_vp)]),
     "fmx_open_dev": (_i32, [_vp, _u64, _u64, _vp, _i32, _vp, _P(_vp)]),

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -66,6 +67,7 @@ static void free_ctx(CallCtx *c) {
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  for (hipEvent_t e : c->chunk_ev) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -138,6 +140,19 @@ class Call {
     *out = c_->pin;
     return hipSuccess;
   }
+  hipStream_t stream() const { return c_->stream; }
+  hipError_t chunk_events(size_t n, hipEvent_t **out) {      // n events that live with the context
+    while (c_->chunk_ev.size() < n) {
+      hipEvent_t e = nullptr;
+      const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      if (rc != hipSuccess) return rc;
+      c_->chunk_ev.push_back(e);
+    }
+    *out = c_->chunk_ev.data();
+    return hipSuccess;
+  }
+  hipEvent_t ev_a() const { return c_->ev_a; }
+  hipEvent_t ev_b() const { return c_->ev_b; }
   // Runs `enqueue` on the context's stream and records the device time between the two events.
   template <class F>
   int timed(F enqueue) {
@@ -417,6 +432,17 @@ int fmx_config_set(const char *key, const char *value) {
   return arg_fail("unknown configuration key");
 }
 
+int fmx_host_alloc(size_t bytes, void **out) {
+  if (!out) return arg_fail("out is null");
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault), "hipHostMalloc");
+  return FMX_OK;
+}
+int fmx_host_free(void *p) {
+  if (p) HIP_TRY(hipHostFree(p), "hipHostFree");
+  return FMX_OK;
+}
+
 int fmx_device_count(int *count) {
   if (!count) return arg_fail("count is null");
   int n = 0;
@@ -578,11 +604,94 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
     for (size_t q = 0; q <= k; q++) roff[q] = off[q] - lo;
     offp = roff.data();
   }
-  const HostIn ins[] = {{total ? pat + lo : nullptr, (size_t)total}, {offp, (k + 1) * 8}};
-  const HostOut outs[] = {{sp, k * 8}, {ep, k * 8}};
-  return run_io(h, ins, 2, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
-    return launch_search(h, di[0], di[1], dout[0], dout[1], k, st);
-  });
+  // Small batches: one copy each way through run_io.  Large batches in page-locked caller memory (fmx_host_alloc,
+  // or the caller's own hipHostMalloc / registered pages) are pipelined: the batch is cut into chunks of patterns,
+  // chunk j's bytes and offsets go up, are searched and come back on stream j % 2, so the copies of one chunk run
+  // beside the kernel of another and both directions of the link are busy.  Offsets stay absolute: every chunk is
+  // copied to its own place of one device image of the batch.
+  constexpr size_t kPipelineMin = 128u << 10;     // patterns
+  if (k < kPipelineMin) {
+    const HostIn ins[] = {{total ? pat + lo : nullptr, (size_t)total}, {offp, (k + 1) * 8}};
+    const HostOut outs[] = {{sp, k * 8}, {ep, k * 8}};
+    return run_io(h, ins, 2, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
+      return launch_search(h, di[0], di[1], dout[0], dout[1], k, st);
+    });
+  }
+  Call c0(h), c1(h);
+  if ((rc = c0.init()) != FMX_OK || (rc = c1.init()) != FMX_OK) return rc;
+  DevBuf d_pat, d_off, d_sp, d_ep;
+  HIP_TRY(c0.alloc(d_pat, (size_t)total + 16), "hipMalloc");
+  HIP_TRY(c0.alloc(d_off, (k + 1) * 8), "hipMalloc");
+  HIP_TRY(c0.alloc(d_sp, k * 8), "hipMalloc");
+  HIP_TRY(c0.alloc(d_ep, k * 8), "hipMalloc");
+  auto pinned = [](const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+  };
+  if (!(pinned(sp) && pinned(ep) && pinned(offp) && (!total || pinned(pat + lo)))) {
+    // Pageable caller memory: "asynchronous" copies of it are staged piecewise by the runtime and block the calling
+    // thread (measured: 8 chunks, 0.37 ms each, nothing overlapped), while one synchronous copy per array runs at
+    // link speed.  So: whole arrays up, one kernel, whole arrays down.
+    if (total) HIP_TRY(hipMemcpy(d_pat.p, pat + lo, (size_t)total, hipMemcpyHostToDevice), "H2D(patterns)");
+    HIP_TRY(hipMemcpy(d_off.p, offp, (k + 1) * 8, hipMemcpyHostToDevice), "H2D(offsets)");
+    rc = c0.timed([&](hipStream_t st, EventPair &ev) {
+      HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
+      HIP_TRY(launch_search(h, d_pat.p, d_off.p, d_sp.p, d_ep.p, k, st), "k_search");
+      HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
+      return (int)FMX_OK;
+    });
+    if (rc != FMX_OK) return rc;
+    HIP_TRY(hipMemcpy(sp, d_sp.p, k * 8, hipMemcpyDeviceToHost), "D2H(sp)");
+    HIP_TRY(hipMemcpy(ep, d_ep.p, k * 8, hipMemcpyDeviceToHost), "D2H(ep)");
+    return FMX_OK;
+  }
+  const size_t nchunk = 8;
+  static const bool trace = getenv("FMX_TRACE") != nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what, size_t j) {
+    if (trace) fprintf(stderr, "[fmx] search_batch %s %zu +%.3f ms\n", what, j,
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  };
+  // stream `up` carries the chunks' uploads in order, one event after each; stream `run` waits for chunk j's event,
+  // searches it and sends its intervals back: uploads of later chunks run beside the kernels and downloads of
+  // earlier ones
+  hipStream_t up = c1.stream(), run = c0.stream();
+  hipEvent_t *cev = nullptr;
+  HIP_TRY(c0.chunk_events(nchunk, &cev), "hipEventCreate");
+  HIP_TRY(hipEventRecord(c0.ev_a(), run), "hipEventRecord");
+  HIP_TRY(hipStreamWaitEvent(up, c0.ev_a(), 0), "hipStreamWaitEvent");      // the buffers' previous users are done
+  for (size_t j = 0; j < nchunk; j++) {
+    const size_t a = k * j / nchunk, b = k * (j + 1) / nchunk;
+    const uint64_t b0 = offp[a], b1 = offp[b];
+    if (b1 > b0)
+      HIP_TRY(hipMemcpyAsync((uint8_t *)d_pat.p + b0, pat + lo + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, up), "H2D(patterns)");
+    // chunk j needs offsets a .. b: entry b is also the next chunk's first, copied by both (same value)
+    HIP_TRY(hipMemcpyAsync((uint64_t *)d_off.p + a, offp + a, (b - a + 1) * 8, hipMemcpyHostToDevice, up), "H2D(offsets)");
+    HIP_TRY(hipEventRecord(cev[j], up), "hipEventRecord");
+  }
+  mark("uploads enqueued", nchunk);
+  for (size_t j = 0; j < nchunk; j++) {
+    const size_t a = k * j / nchunk, b = k * (j + 1) / nchunk;
+    HIP_TRY(hipStreamWaitEvent(run, cev[j], 0), "hipStreamWaitEvent");
+    if (a == b) continue;
+    HIP_TRY(launch_search(h, d_pat.p, (const uint64_t *)d_off.p + a, (uint64_t *)d_sp.p + a, (uint64_t *)d_ep.p + a, b - a, run),
+            "k_search");
+    HIP_TRY(hipMemcpyAsync(sp + a, (uint64_t *)d_sp.p + a, (b - a) * 8, hipMemcpyDeviceToHost, run), "D2H(sp)");
+    HIP_TRY(hipMemcpyAsync(ep + a, (uint64_t *)d_ep.p + a, (b - a) * 8, hipMemcpyDeviceToHost, run), "D2H(ep)");
+    mark("chunk enqueued", j);
+  }
+  HIP_TRY(hipEventRecord(c0.ev_b(), run), "hipEventRecord");
+  hipStream_t sts[1] = {run};
+  HIP_TRY(hipStreamSynchronize(sts[0]), "hipStreamSynchronize");
+  mark("synchronized", 0);
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c0.ev_a(), c0.ev_b()) == hipSuccess) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->last_kernel_ms = ms;            // for a pipelined call: the whole device side, copies included
+    h->launches += nchunk;
+  }
+  return FMX_OK;
 }
 
 int fmx_search_batch_multi(fmx_index *const *idxs, size_t n_idx, const uint8_t *pat, const uint64_t *off,

@@ -20,6 +20,7 @@ struct CallCtx {
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   void *buf[kBufs] = {nullptr};
   size_t cap[kBufs] = {0};
+  std::vector<hipEvent_t> chunk_ev;   // per-chunk events of the pipelined batch search (created on first use)
   void *pin = nullptr;            // pinned host staging for small calls (operands packed into one copy each way)
   size_t pin_cap = 0;
   size_t total() const { size_t t = 0; for (size_t c : cap) t += c; return t; }

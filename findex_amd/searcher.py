@@ -21,6 +21,29 @@ def _dp(x):
     return ctypes.c_void_p(int(x) if x else 0)
 
 
+class PinnedArray:
+    """A numpy view of page-locked host memory from fmx_host_alloc (freed with the object): batch buffers that the
+    host-pointer entry points move by DMA at link speed."""
+
+    def __init__(self, shape, dtype):
+        self._L = _lib.load()
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        self._p = ctypes.c_void_p()
+        _lib.check(self._L.fmx_host_alloc(max(n, 1) * self.dtype.itemsize, ctypes.byref(self._p)))
+        buf = (ctypes.c_uint8 * (max(n, 1) * self.dtype.itemsize)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=n).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._p:
+                self.array = None
+                self._L.fmx_host_free(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
 class HipFMSearcher:
     """`new NaiveFMSearcher(filename, bigEndian)`: opens X.bwt and X.aux next to `filename` and
     builds the rank dictionary in HBM (the reference's X.fm is not needed).
@@ -200,7 +223,8 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_occ_batch(self._h, _ptr(c), _ptr(i), _ptr(out), c.size))
         return out
 
-    def search_batch(self, pat, off):
+    def search_batch(self, pat, off, out=None):
+        """out = (sp, ep) uint64 arrays to fill (e.g. PinnedArray views), else new ones."""
         pat = np.ascontiguousarray(pat, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         k = off.size - 1
@@ -208,8 +232,13 @@ class HipFMSearcher:
             raise ValueError("off needs k+1 entries")
         if k and int(off[-1]) > pat.size:
             raise ValueError("offsets run past the pattern buffer")
-        sp = np.zeros(k, dtype=np.uint64)
-        ep = np.zeros(k, dtype=np.uint64)
+        if out is not None:
+            sp, ep = out
+            if sp.size != k or ep.size != k or sp.dtype != np.uint64 or ep.dtype != np.uint64:
+                raise ValueError("out arrays must be uint64 of length k")
+        else:
+            sp = np.zeros(k, dtype=np.uint64)
+            ep = np.zeros(k, dtype=np.uint64)
         _lib.check(self._L.fmx_search_batch(self._h, _ptr(pat), _ptr(off), _ptr(sp), _ptr(ep), k))
         return sp, ep
 

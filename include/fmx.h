@@ -66,6 +66,11 @@ int fmx_abi_version(void);
  * 32-bit checkpoints whenever every symbol occurs fewer than 2^32 times) or "superblock" (always the relative
  * checkpoints + 64-bit superblock counts that larger counts need; for tests).  Affects indexes opened afterwards. */
 int fmx_config_set(const char *key, const char *value);
+/* Page-locked host memory for batch buffers (hipHostMalloc): the host-pointer entry points move such buffers
+ * by DMA at link speed; pageable memory works everywhere too, through the runtime's staging copies.  A JNI adapter
+ * wraps these in direct ByteBuffers. */
+int fmx_host_alloc(size_t bytes, void **out);
+int fmx_host_free(void *p);
 /* Number of HIP devices visible (0 and FMX_OK when there is none). */
 int fmx_device_count(int *count);
 
@@ -116,7 +121,9 @@ int fmx_occ_batch_dev(const fmx_index *idx, const void *d_c, const void *d_i, vo
  * sp[q], ep[q] receive the loop's final values: a hit iff sp < ep, a miss has sp == ep.
  * An empty pattern yields (0, n).  The host form validates the offsets (non-decreasing); the device form
  * cannot look at them: d_off must hold k+1 non-decreasing offsets into the d_pat buffer, or the kernel reads
- * outside it. */
+ * outside it.  A host-pointer batch of 128k patterns or more whose four buffers are page-locked (fmx_host_alloc) is
+ * pipelined in chunks over two streams (copies of one chunk beside the kernel of another);
+ * fmx_stats_t.last_kernel_ms is then the whole device side of the call. */
 int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
                      size_t k);
 int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep,

@@ -322,6 +322,36 @@ def test_many_patterns_ragged_lengths():
     assert hits > 50_000
 
 
+def test_pipelined_host_batch_pageable_and_pinned():
+    """Host-pointer batches of 128k patterns or more are cut into chunks over two streams (fmx_api.cpp): ragged
+    lengths with empty patterns at chunk borders, offsets that do not start at 0, pageable and page-locked
+    (fmx_host_alloc) buffers -- every interval must equal the oracle's."""
+    from findex_amd.searcher import PinnedArray
+    bwt, eof, counts = synth_bwt(400_000, 1, 6, 77)
+    hip, orc = pair_from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(21)
+    k = 300_001
+    lens = rng.integers(0, 14, k)
+    lens[[0, k // 8, k // 8 + 1, k // 2, k - 1]] = 0
+    off = np.concatenate([[5], 5 + np.cumsum(lens)]).astype(np.uint64)       # the first 5 bytes belong to no pattern
+    buf = rng.integers(1, 7, int(off[-1])).astype(np.uint8)
+    # make a good share of them hits: overwrite with LF-walk text
+    walk, _ = hip.lf_walk_batch(rng.integers(0, hip.n, 20000).astype(np.uint64), 13)
+    for j in range(0, k, 15):
+        L = int(lens[j])
+        buf[int(off[j]):int(off[j]) + L] = walk[(j // 15) % 20000, :L][::-1]
+    wsp, wep, _ = orc.search_batch(buf, off)
+    sp, ep = hip.search_batch(buf, off)
+    assert np.array_equal(sp, wsp) and np.array_equal(ep, wep)
+    assert int((wsp < wep).sum()) > k // 20
+    pb, po = PinnedArray(buf.shape, np.uint8), PinnedArray(off.shape, np.uint64)
+    psp, pep = PinnedArray((k,), np.uint64), PinnedArray((k,), np.uint64)
+    pb.array[:] = buf
+    po.array[:] = off
+    hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
+    assert np.array_equal(psp.array, wsp) and np.array_equal(pep.array, wep)
+
+
 def test_concurrent_calls_on_one_handle():
     """An index handle is immutable after open: host-pointer calls from several threads (each borrows its own
     call context from the handle's pool) must give the single-threaded answers -- small and large batches,

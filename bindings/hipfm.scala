@@ -1,0 +1,202 @@
+// hipfm.scala -- the reference-side adapter: findex's search engines on libfmx.so (MI355X).
+//
+// Drop this file into src/main/scala/org/fmindex/ next to findex.scala and load libfmx_jni.so (bindings/fmx_jni.c)
+// and libfmx.so.  It adds, and changes nothing else:
+//   class HipFMSearcher(filename, bigEndian)  extends SuffixWalkingAlgo   -- drop-in for NaiveFMSearcher
+//                                                                            (bwtmerger.scala:335-421)
+//   class HipBWTSearcher(bwt, bucketStarts, rk0) extends SuffixAlgo       -- drop-in for NaiveBWTSearcher
+//                                                                            (findex.scala:459-506)
+//   object HipRegex                                                       -- ReTree.matchSA (re2/retree.scala:570-653)
+//                                                                            for one regex or a batch, on the device
+// Every engine of the reference takes `sa: SuffixWalkingAlgo` and touches only sa.n, sa.getPrevRange and
+// sa.nextSubstr (re2/retree.scala:576,633; re2/re2.scala:13,461,473,530; dfa.scala:234,248,263), so
+// `ReTree(post).matchSA(new HipFMSearcher(f))` already runs unchanged -- one kernel launch per getPrevRange, correct
+// but slow.  The fast forms are the batch methods below and HipRegex, which hand whole batches to the device.
+//
+// Positions are Int like the trait (the reference is 32-bit, findex.scala:10-13): valid for n < 2^31.  The Long
+// variants (searchBatchLong ...) serve larger indexes.  Written for Scala 2.10 like the reference
+// (project/Build.scala:12); never compiled in the image this library was built in (no JVM there).
+package org.fmindex
+
+import java.nio.{ByteBuffer, ByteOrder}
+import org.fmindex.re2.SAResult
+
+object HipFM {
+  System.loadLibrary("fmx_jni")
+  @native def open0(bwt: String, aux: String, bigEndian: Boolean, device: Int): Long
+  @native def openBlock0(bwt: Array[Byte], bucketStarts: Array[Long], rk0: Long, device: Int): Long
+  @native def close0(h: Long): Unit
+  @native def n0(h: Long): Long
+  @native def eof0(h: Long): Long
+  @native def cf0(h: Long, c: Int): Long
+  @native def occBatch0(h: Long, c: Array[Byte], i: Array[Long], out: Array[Long]): Unit
+  @native def searchBatch0(h: Long, pat: Array[Byte], off: Array[Long], out: Array[Long]): Unit
+  @native def searchBatchDirect0(h: Long, pat: ByteBuffer, off: ByteBuffer, out: ByteBuffer, k: Long): Unit
+  @native def prevRangeBatch0(h: Long, sp: Array[Long], ep: Array[Long], c: Array[Byte], out: Array[Long]): Unit
+  @native def intervalPrevRange0(h: Long, sp: Long, ep: Long, cstart: Int, cend: Int, out: Array[Long]): Int
+  @native def nextSubstr0(h: Long, sp: Long, len: Int): Array[Byte]
+  @native def prevSubstr0(h: Long, sp: Long, len: Int): Array[Byte]
+  @native def nextSubstrBatch0(h: Long, rows: Array[Long], len: Int, out: Array[Byte], outLen: Array[Int]): Unit
+  @native def writeFm0(h: Long, path: String): Unit
+  @native def hostAlloc0(bytes: Long): ByteBuffer
+  @native def hostFree0(buf: ByteBuffer): Unit
+  @native def regexCompile0(latin1: Array[Byte], lineOnly: Boolean): Long
+  @native def regexFree0(r: Long): Unit
+  @native def regexBatchCreate0(h: Long, regexes: Array[Long]): Long
+  @native def regexBatchFree0(b: Long): Unit
+  @native def regexBatchMatch0(h: Long, batch: Long, limits: Array[Int], maxFrontier: Long, out: Array[Long],
+                               perRegex: Array[Int], status: Array[Int]): Long
+  @native def stats0(h: Long, counters: Array[Long], ms: Array[Double]): Unit
+
+  val MATCH_FRONTIER = 0      // every match, breadth of the whole batch at once (the throughput path)
+  val MATCH_REFERENCE = 1     // ReTree._matchSA's own queue order and limits (re2/retree.scala:618-653)
+
+  def latin1(s: String): Array[Byte] = s.map(_.toByte).toArray
+  def fromLatin1(b: Array[Byte]): String = new String(b.map(x => (x & 0xff).toChar))
+}
+
+/** The SuffixAlgo part shared by both searchers: everything is answered by the device through the handle `h`. */
+trait HipSuffixAlgo extends SuffixAlgo {
+  import HipFM._
+  protected def h: Long
+  lazy val n: Int = n0(h).toInt
+  def nLong: Long = n0(h)
+  def cf(c: Int): Int = cf0(h, c).toInt
+  def occ(c: Int, i: Int): Int = occBatch(Array(c.toByte), Array(i.toLong))(0).toInt
+
+  /** occ for many (c, i) pairs in one launch. */
+  def occBatch(c: Array[Byte], i: Array[Long]): Array[Long] = {
+    val out = new Array[Long](c.length); occBatch0(h, c, i, out); out
+  }
+
+  override def search(in: Array[Byte]): Option[(Int, Int)] = searchBatch(Array(in))(0)
+
+  /** SuffixAlgo.search (findex.scala:15-31) for a batch: one launch.  A miss comes back as sp == ep and maps to
+    * None like the reference's `if (sp < ep) Some(..) else None` (:30).  Bytes >= 0x80 are legal here (the
+    * reference throws ArrayIndexOutOfBounds on its signed Byte index, :21,26). */
+  def searchBatch(pats: Array[Array[Byte]]): Array[Option[(Int, Int)]] =
+    searchBatchLong(pats).map { case (sp, ep) => if (sp < ep) Some((sp.toInt, ep.toInt)) else None }
+
+  def searchBatchLong(pats: Array[Array[Byte]]): Array[(Long, Long)] = {
+    val k = pats.length
+    val off = new Array[Long](k + 1)
+    var q = 0
+    while (q < k) { off(q + 1) = off(q) + pats(q).length; q += 1 }
+    val flat = new Array[Byte](off(k).toInt)
+    q = 0
+    while (q < k) { System.arraycopy(pats(q), 0, flat, off(q).toInt, pats(q).length); q += 1 }
+    val out = new Array[Long](2 * k)
+    searchBatch0(h, flat, off, out)
+    Array.tabulate(k)(j => (out(j), out(k + j)))
+  }
+
+  override def getPrevRange(sp: Int, ep: Int, c: Int): Option[(Int, Int)] = {
+    val o = new Array[Long](2)
+    prevRangeBatch0(h, Array(sp.toLong), Array(ep.toLong), Array(c.toByte), o)
+    if (o(0) < o(1)) Some((o(0).toInt, o(1).toInt)) else None
+  }
+
+  /** getPrevRange for many (sp, ep, c) at once: (sp1, ep1) per triple, empty when sp1 >= ep1. */
+  def prevRangeBatch(sp: Array[Long], ep: Array[Long], c: Array[Byte]): Array[(Long, Long)] = {
+    val k = c.length
+    val o = new Array[Long](2 * k)
+    prevRangeBatch0(h, sp, ep, c, o)
+    Array.tabulate(k)(j => (o(j), o(k + j)))
+  }
+
+  override def getIntervalPrevRange(sp: Int, ep: Int, cstart: Int, cend: Int): List[(Int, Int)] = {
+    val o = new Array[Long](2 * math.max(cend - cstart + 1, 1))
+    val k = intervalPrevRange0(h, sp, ep, cstart, cend, o)        // already in the reference's descending-c order (:47)
+    List.tabulate(k)(j => (o(2 * j).toInt, o(2 * j + 1).toInt))
+  }
+
+  def close(): Unit = close0(h)
+  override def finalize(): Unit = close0(h)
+}
+
+/** Same constructor arguments and sibling-file rule as NaiveFMSearcher (bwtmerger.scala:335-338, 17-36); X.fm is not
+  * read (its content is a function of X.bwt and X.aux; `writeFm` produces it for the reference's own tools). */
+class HipFMSearcher(filename: String, bigEndian: Boolean = true, device: Int = 0)
+    extends SuffixWalkingAlgo with HipSuffixAlgo {
+  import HipFM._
+  protected val h: Long =
+    open0(BWTTempStorage.genBWTFilename(filename), BWTTempStorage.genAuxFilename(filename), bigEndian, device)
+  val K = 256
+  lazy val eof: Long = eof0(h)
+  def handle: Long = h
+
+  def nextSubstr(sp: Int, len: Int): String = fromLatin1(nextSubstr0(h, sp, len))
+  def prevSubstr(sp: Int, len: Int): String = fromLatin1(prevSubstr0(h, sp, len))
+  def getPrevI(i: Int): Int = { val (a, _) = prevRangeBatch(Array(i.toLong), Array(i + 1L), Array(bwtRead(i)))(0); a.toInt }
+  def bwtRead(i: Int): Byte = prevSubstr0(h, i, 1)(0)          // BWTLoader.read: 0 at the EOF slot (bwtmerger.scala:155-162)
+
+  /** nextSubstr for many rows in one launch: what rendering a result list needs (SAResult.toString, re2.scala:11-15). */
+  def nextSubstrBatch(rows: Array[Long], len: Int): Array[String] = {
+    val out = new Array[Byte](rows.length * len)
+    val lens = new Array[Int](rows.length)
+    nextSubstrBatch0(h, rows, len, out, lens)
+    Array.tabulate(rows.length)(q => fromLatin1(out.slice(q * len, q * len + lens(q))))
+  }
+
+  /** FMCreator.create (bwtmerger.scala:424-533) from the device structure. */
+  def writeFm(path: String): Unit = writeFm0(h, path)
+
+  /** A batch in page-locked direct buffers (little-endian): the library moves it by DMA, pipelined against the
+    * search.  `pat` = pattern bytes, `off` = k+1 longs, `out` receives sp[0..k) then ep[0..k) as longs. */
+  def searchBatchDirect(pat: ByteBuffer, off: ByteBuffer, out: ByteBuffer, k: Long): Unit =
+    searchBatchDirect0(h, pat, off, out, k)
+}
+
+object HipFMSearcher {
+  /** A page-locked direct buffer for batches (free with HipFM.hostFree0 when done). */
+  def pinned(bytes: Long): ByteBuffer = HipFM.hostAlloc0(bytes).order(ByteOrder.LITTLE_ENDIAN)
+}
+
+/** NaiveBWTSearcher(bwt, bucketStarts, rk0) (findex.scala:459-506): the searcher BWTMerger2.calcGaps uses. */
+class HipBWTSearcher(bwt: Array[Byte], bucketStarts: Array[Long], rk0: Int, device: Int = 0) extends HipSuffixAlgo {
+  protected val h: Long = HipFM.openBlock0(bwt, bucketStarts, rk0, device)
+  val K = bucketStarts.length
+  override def occ(c: Int, key: Int): Int = super.occ(c & 0xff, key)        // `val ci = c & 0xff`, :480
+}
+
+/** ReTree.matchSA on the device.  A regex string is parsed by the library with the reference's own grammar and tree
+  * (REParser.re2post re2/re2.scala:50-185, ReTree.apply re2/retree.scala:156-370): "re2post syntax" and
+  * scala.MatchError surface as Exceptions with those messages. */
+object HipRegex {
+  import HipFM._
+
+  /** `ReTree(REParser.re2post(re)).matchSA(sa, maxBranching = .., maxIterations = ..)`: the reference's own queue
+    * order and limits replayed on the device; the same list in the same order (newest first). */
+  def matchSA(sa: HipFMSearcher, re: String, lineOnly: Boolean = false, maxBranching: Int = 1024,
+              maxIterations: Int = 1000): List[SAResult] =
+    matchBatch(sa, Array(re), lineOnly, MATCH_REFERENCE, 0, maxBranching, maxIterations)(0)
+
+  /** Every match of every regex (the result multiset of matchSA whenever its limits do not bind), per regex sorted
+    * by (len, sp, ep).  maxSteps bounds the match length (0 = 4096). */
+  def matchAll(sa: HipFMSearcher, res: Array[String], lineOnly: Boolean = false, maxSteps: Int = 0): Array[List[SAResult]] =
+    matchBatch(sa, res, lineOnly, MATCH_FRONTIER, maxSteps, 1024, 1000)
+
+  def matchBatch(sa: HipFMSearcher, res: Array[String], lineOnly: Boolean, mode: Int, maxSteps: Int, maxBranching: Int,
+                 maxIterations: Int, cap: Int = 1 << 20, maxFrontier: Long = 0): Array[List[SAResult]] = {
+    val handles = res.map(r => regexCompile0(latin1(r), lineOnly))
+    val batch = regexBatchCreate0(sa.handle, handles)
+    try {
+      val out = new Array[Long](3 * cap)
+      val per = new Array[Int](res.length)
+      val status = new Array[Int](1)
+      val got = regexBatchMatch0(sa.handle, batch, Array(maxSteps, mode, maxBranching, maxIterations), maxFrontier, out,
+                                 per, status).toInt
+      val lists = Array.fill(res.length)(List[SAResult]())
+      var j = got - 1
+      while (j >= 0) {                                   // prepend from the end: each list keeps the library's order
+        val rx = (out(3 * j) >>> 32).toInt
+        lists(rx) ::= SAResult(sa, (out(3 * j) & 0xffffffffL).toInt, out(3 * j + 1).toInt, out(3 * j + 2).toInt)
+        j -= 1
+      }
+      lists
+    } finally {
+      regexBatchFree0(batch)
+      handles.foreach(regexFree0)
+    }
+  }
+}

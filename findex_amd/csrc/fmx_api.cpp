@@ -30,6 +30,8 @@ static std::atomic<int> g_layout_pref{-1};       // fmx_config_set may race with
 int layout_preference() { return g_layout_pref.load(std::memory_order_relaxed); }
 static std::atomic<uint64_t> g_serial{0};
 static std::atomic<int> g_force_superblocks{0};
+static std::atomic<int> g_validate{0};
+bool validate_device_operands() { return g_validate.load(std::memory_order_relaxed) != 0; }
 bool force_superblocks() { return g_force_superblocks.load(std::memory_order_relaxed) != 0; }
 
 static int arg_fail(const char *msg) {
@@ -423,6 +425,10 @@ int fmx_config_set(const char *key, const char *value) {
     else return arg_fail("layout must be auto, onehot or bytes");
     return FMX_OK;
   }
+  if (std::strcmp(key, "validate") == 0) {
+    g_validate.store(std::strcmp(value, "0") != 0);
+    return FMX_OK;
+  }
   if (std::strcmp(key, "checkpoints") == 0) {
     if (std::strcmp(value, "auto") == 0) g_force_superblocks.store(0);
     else if (std::strcmp(value, "superblock") == 0) g_force_superblocks.store(1);
@@ -534,6 +540,11 @@ int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_
   if (!idx || (k && (!d_off || !d_sp || !d_ep))) return arg_fail("null argument");
   int rc = use_device(H(idx));
   if (rc) return rc;
+  if (k && validate_device_operands()) {
+    bool ok = true;
+    HIP_TRY(check_offsets(H(idx), d_off, k, (hipStream_t)stream, &ok), "k_check_offsets");
+    if (!ok) return arg_fail("pattern offsets must be non-decreasing");
+  }
   HIP_TRY(launch_search(H(idx), d_pat, d_off, d_sp, d_ep, k, (hipStream_t)stream), "k_search");
   return FMX_OK;
 }

@@ -92,6 +92,8 @@ hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep,
                              void *d_ep1, uint64_t k, hipStream_t st);
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
                          hipStream_t st);
+// fmx_config_set("validate", "1"): is d_off[0..k] non-decreasing?  Synchronises the stream.
+hipError_t check_offsets(const Index *h, const void *d_off, uint64_t k, hipStream_t st, bool *ok);
 hipError_t launch_lf_walk(const Index *h, const void *d_rows, uint64_t k, uint32_t len, void *d_out, void *d_end,
                           hipStream_t st);
 hipError_t launch_fm_fill(const Index *h, void *d_fm, hipStream_t st);

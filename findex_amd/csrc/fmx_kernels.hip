@@ -255,6 +255,30 @@ __global__ __launch_bounds__(kThreads) void k_fm_fill(DevIndex ix, uint64_t p0, 
 
 // Psi (getNextI) and nextSubstr: fmx_select.hip.
 
+// ---------------------------------------------------------------- operand check for the device-pointer search
+__global__ __launch_bounds__(kThreads) void k_check_offsets(const uint64_t *__restrict__ off, uint64_t k,
+                                                             unsigned int *__restrict__ bad) {
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < k; q += (uint64_t)gridDim.x * blockDim.x)
+    if (off[q + 1] < off[q]) atomicOr(bad, 1u);
+}
+
+hipError_t check_offsets(const Index *h, const void *d_off, uint64_t k, hipStream_t st, bool *ok) {
+  unsigned int *d_bad = nullptr, bad = 0;
+  hipError_t e = hipMallocAsync((void **)&d_bad, sizeof bad, st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d_bad, 0, sizeof bad, st);
+  if (e == hipSuccess) {
+    uint64_t want = (k + kThreads - 1) / kThreads, cap = (uint64_t)h->cu_count * 8;
+    k_check_offsets<<<(int)(want < cap ? want : cap), kThreads, 0, st>>>((const uint64_t *)d_off, k, d_bad);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFreeAsync(d_bad, st);
+  *ok = bad == 0;
+  return e;
+}
+
 // ---------------------------------------------------------------- launchers
 // Counts fit 32 bits iff n <= 2^32; the one-hot kernels then reduce the block header with the popcounts.
 static inline int grid_for(const Index *h, uint64_t k, int per_block) {

@@ -62,7 +62,9 @@ const char *fmx_last_error(void);
 int fmx_abi_version(void);
 /* Process-wide options.  key "layout": "auto" (default: one-hot bit-vectors, one 64-byte block per
  * rank query, when sigma*n/7 bytes fit in free HBM and n < 2^37; else BWT bytes + checkpoints, two
- * lines per rank query), "onehot", "bytes".  key "checkpoints": "auto" (default: the bytes layout keeps absolute
+ * lines per rank query), "onehot", "bytes".  key "validate": "0" (default) / "1": the device-pointer search entry
+ * point then checks on the device that d_off is non-decreasing and fails with FMX_ERR_ARG otherwise (one more small
+ * kernel and a synchronisation per call: a debugging aid; the host-pointer form always checks).  key "checkpoints": "auto" (default: the bytes layout keeps absolute
  * 32-bit checkpoints whenever every symbol occurs fewer than 2^32 times) or "superblock" (always the relative
  * checkpoints + 64-bit superblock counts that larger counts need; for tests).  Affects indexes opened afterwards. */
 int fmx_config_set(const char *key, const char *value);
@@ -216,9 +218,16 @@ enum {
  * fmx_dfa_compile : DFA.compileBuckets + DFA.matchSA (dfa.scala:190-213,231-289) over a caller-built
  *                   transition table moves[nstates][nchars] (-1 = none), finish[nstates]: as in the
  *                   reference only single-character actions expand (runs of equal targets are "buckets",
- *                   which StatePoint.expand ignores, :247-251).  The reference's 500-pop cap is not
- *                   emulated (results are equal whenever it does not bind).
- * Both return an fmx_regex handle for fmx_regex_match_batch / fmx_regex_batch_* in frontier mode. */
+ *                   which StatePoint.expand ignores, :247-251).
+ * Both return an fmx_regex handle for fmx_regex_match_batch / fmx_regex_batch_* in frontier mode: every match.
+ * The reference's cuts for these two engines -- REParser.matchSA's maxIterations (re2.scala:612) and DFA.matchSA's
+ * 500 iterations (dfa.scala:268) -- stop the search after a number of POPS, and the pop order is not defined by the
+ * reference's source: the NFA engine seeds its queue from an immutable Set of state objects hashed by identity and
+ * takes equal-length elements in heap-layout order, the DFA engine takes `head` of an immutable HashSet.  Two
+ * orders the source allows return different results once a cut binds (and the same multiset while it does not):
+ * tests/test_oracle_engines.py::test_order_dependent_cuts_are_not_reproducible_without_the_jvm.  So there is no
+ * reference-order mode for them; FMX_MATCH_REFERENCE exists for ReTree, whose order IS defined by its source
+ * (CharNode.num and Scala's binary heap). */
 int fmx_nfa_compile(const char *src, int line_only, int src_is_postfix, fmx_regex **out);
 int fmx_dfa_compile(const int32_t *moves, uint32_t nstates, uint32_t nchars, const uint8_t *finish,
                     fmx_regex **out);

@@ -122,14 +122,20 @@ def createNFA(postfix):
     return e0[0]
 
 
-def nfa_matchSA(nfa, sa, maxIterations=0, maxLength=0):
+def nfa_matchSA(nfa, sa, maxIterations=0, maxLength=0, tie="first"):
     """REParser.matchSA, re2.scala:568-693 -> list of (len, sp, ep) (order not meaningful).
-    StatePoint = (len, state, [intervals]); the queue pops the largest len (:446)."""
+    StatePoint = (len, state, [intervals]); the queue pops the largest len (:446).  Which of several elements
+    of equal len comes out is not defined by the reference's source: the start states come from an immutable
+    Set of objects hashed by identity (`liststates`, :570-578) and the queue breaks ties by its internal layout.
+    `tie` picks one legal order ("first" / "last" element of maximal len): with maxIterations = 0 the result
+    multiset does not depend on it, with a binding maxIterations it does (tests/test_oracle_engines.py)."""
     front = [(0, s, [(0, sa.n)]) for s in nfa.outStates()]
     results = []
     i = 0
     while front and (maxIterations == 0 or i < maxIterations):
-        k = max(range(len(front)), key=lambda j: front[j][0])
+        top = max(f[0] for f in front)
+        cand = [j for j in range(len(front)) if front[j][0] == top]
+        k = cand[0] if tie == "first" else cand[-1]
         ln, state, intervals = front.pop(k)
         if isinstance(state, ConstState):
             chars = [state.c]
@@ -186,14 +192,16 @@ class DFA:
     def _action(state, c1, c2):                       # DFAAction.create, :177-185
         return ("char", state, c1) if c1 == c2 else ("bucket", state, c1, c2)
 
-    def matchSA(self, sa):
-        """dfa.scala:261-289 -> list of (len, sp, ep)."""
+    def matchSA(self, sa, cap=500, take="first"):
+        """dfa.scala:261-289 -> list of (len, sp, ep).  The reference's frontier is an immutable Set whose
+        head/tail order is the hash trie's (no contract); `take` picks a legal order ("first" = oldest, "last" =
+        newest).  Results do not depend on it unless the 500-iteration cap (:268) binds."""
         front = [(0, 0, 0, sa.n)]                     # StatePoint(state, len, sp, ep); a Set there
         visited = set()
         results = []
         i = 0
-        while front and i < 500:
-            st = front.pop(0)
+        while front and i < cap:
+            st = front.pop(0 if take == "first" else -1)
             visited.add(st)
             state, ln, sp, ep = st
             new = []

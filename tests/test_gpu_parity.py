@@ -461,6 +461,31 @@ def test_regex_batch_multi_replicas_and_gather(testdata):
     assert np.array_equal(dst, wsp)
 
 
+def test_device_offsets_validation_knob():
+    """fmx_config_set("validate", "1"): the device-pointer search checks d_off on the device."""
+    import ctypes
+    from findex_amd import _lib
+    torch = _torch()
+    bwt, eof, counts = synth_bwt(50_000, 1, 6, 3)
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    pat = torch.randint(1, 7, (4000,), dtype=torch.uint8, device="cuda")
+    good = torch.arange(0, 4001, 4, dtype=torch.int64, device="cuda")
+    bad = good.clone()
+    bad[500] = 1
+    sp = torch.empty(1000, dtype=torch.int64, device="cuda")
+    ep = torch.empty_like(sp)
+    L = _lib.load()
+    _lib.check(L.fmx_config_set(b"validate", b"1"))
+    try:
+        hip.search_batch_dev(pat.data_ptr(), good.data_ptr(), sp.data_ptr(), ep.data_ptr(), 1000)
+        with pytest.raises(findex_amd.FmxError) as e:
+            hip.search_batch_dev(pat.data_ptr(), bad.data_ptr(), sp.data_ptr(), ep.data_ptr(), 1000)
+        assert e.value.code == 3
+    finally:
+        _lib.check(L.fmx_config_set(b"validate", b"0"))
+    torch.cuda.synchronize()
+
+
 def test_counts_must_describe_bwt():
     bwt, eof, counts = synth_bwt(5000, 1, 4, 1)
     bad = counts.copy()

@@ -31,4 +31,10 @@ def set_checkpoints(name):
     _lib.check(_lib.load().fmx_config_set(b"checkpoints", name.encode()))
 
 
-__all__ = ["set_layout", "set_checkpoints", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "FmxError", "MatchError", "Re2PostSyntax"]
+def set_ktab(name):
+    """fmx_config_set("ktab", ...): "auto" | "off" (handles that have not searched yet)."""
+    from . import _lib
+    _lib.check(_lib.load().fmx_config_set(b"ktab", name.encode()))
+
+
+__all__ = ["set_layout", "set_checkpoints", "set_ktab", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "FmxError", "MatchError", "Re2PostSyntax"]

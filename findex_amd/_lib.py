@@ -49,7 +49,7 @@ class fmx_stats_t(ctypes.Structure):
                 ("frontier_requests", ctypes.c_uint64), ("frontier_elements", ctypes.c_uint64),
                 ("frontier_queue_reads", ctypes.c_uint64), ("frontier_queue_writes", ctypes.c_uint64),
                 ("frontier_results", ctypes.c_uint64), ("frontier_records", ctypes.c_uint64),
-                ("reserved2", ctypes.c_uint64 * 2)]
+                ("ktab_lookups", ctypes.c_uint64), ("ktab_k", ctypes.c_uint32), ("reserved3", ctypes.c_uint32)]
 
 
 # name -> (restype, argtypes); every symbol include/fmx.h declares

@@ -31,6 +31,8 @@ int layout_preference() { return g_layout_pref.load(std::memory_order_relaxed); 
 static std::atomic<uint64_t> g_serial{0};
 static std::atomic<int> g_force_superblocks{0};
 static std::atomic<int> g_validate{0};
+static std::atomic<int> g_ktab{1};
+bool ktab_enabled() { return g_ktab.load(std::memory_order_relaxed) != 0; }
 bool validate_device_operands() { return g_validate.load(std::memory_order_relaxed) != 0; }
 bool force_superblocks() { return g_force_superblocks.load(std::memory_order_relaxed) != 0; }
 
@@ -83,7 +85,9 @@ CallCtx *ctx_acquire(const Index *h) {
   if (!c) c = new (std::nothrow) CallCtx();
   if (!c) { g_err = "out of host memory"; return nullptr; }
   hipError_t e = hipSuccess;
-  if (!c->stream) e = hipStreamCreate(&c->stream);
+  // non-blocking: no implicit ties to the legacy stream (another host thread may be capturing a graph, or torch may
+  // be working on stream 0)
+  if (!c->stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess && !c->ev_a) e = hipEventCreate(&c->ev_a);
   if (e == hipSuccess && !c->ev_b) e = hipEventCreate(&c->ev_b);
   if (e != hipSuccess) { (void)hip_fail(e, "hipStreamCreate/hipEventCreate"); free_ctx(c); return nullptr; }
@@ -260,6 +264,8 @@ static void destroy(Index *h) {
   if (h->d_cf) (void)hipFree(h->d_cf);
   if (h->d_slot) (void)hipFree(h->d_slot);
   if (h->d_counters) (void)hipFree(h->d_counters);
+  if (h->d_ktab) (void)hipFree(h->d_ktab);
+  if (h->d_kt_dense) (void)hipFree(h->d_kt_dense);
   if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
   if (h->d_sel_off) (void)hipFree(h->d_sel_off);
   if (h->d_sel_shift) (void)hipFree(h->d_sel_shift);
@@ -423,6 +429,12 @@ int fmx_config_set(const char *key, const char *value) {
     else if (std::strcmp(value, "onehot") == 0) g_layout_pref.store((int)kLayoutOneHot);
     else if (std::strcmp(value, "bytes") == 0) g_layout_pref.store((int)kLayoutBytes);
     else return arg_fail("layout must be auto, onehot or bytes");
+    return FMX_OK;
+  }
+  if (std::strcmp(key, "ktab") == 0) {
+    if (std::strcmp(value, "auto") == 0) g_ktab.store(1);
+    else if (std::strcmp(value, "off") == 0) g_ktab.store(0);
+    else return arg_fail("ktab must be auto or off");
     return FMX_OK;
   }
   if (std::strcmp(key, "validate") == 0) {
@@ -933,21 +945,21 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
-  unsigned long long cnt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   std::memset(out, 0, sizeof *out);
   HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   {   // the counters live in per-workgroup slots (fmx_device.h): sum them
     std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
     HIP_TRY(hipMemcpy(slots.data(), h->d_counters, kCounterBytes, hipMemcpyDeviceToHost), "D2H(counters)");
     for (uint32_t sl = 0; sl < kCounterSlots; sl++)
-      for (int j = 0; j < 9; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
+      for (int j = 0; j < 10; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
   }
   std::lock_guard<std::mutex> lk(h->mu);
   out->rank_queries = cnt[0];
   out->backward_steps = cnt[1];
   out->launches = h->launches;
   out->last_kernel_ms = h->last_kernel_ms;
-  out->index_bytes = h->index_bytes + h->sel_bytes;
+  out->index_bytes = h->index_bytes + h->sel_bytes + h->kt_bytes;
   out->n_blocks = h->nblocks;
   out->n_symbols = h->nslots;
   out->block_bytes = h->layout == kLayoutBytes ? kByteBlock + 4 : kBlockBytes;
@@ -959,6 +971,8 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->frontier_elements = cnt[6];
   out->frontier_queue_reads = cnt[7];
   out->frontier_records = cnt[8];
+  out->ktab_lookups = cnt[9];
+  out->ktab_k = h->kt.k;
   out->build_ms = h->build_ms;
   return FMX_OK;
 }

@@ -531,6 +531,13 @@ struct RegexBatch {
   bool all_retree = true;
 };
 
+// Copies go through the caller's own (non-blocking) stream and wait for it: a plain hipMemcpy runs on the legacy
+// stream, which implicitly waits for every blocking stream -- an error while another host thread is capturing a graph.
+static hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+  return e == hipSuccess ? hipStreamSynchronize(st) : e;
+}
+
 int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexBatch **out) {
   // sizes first, then one pass that fills pre-sized arrays (100 k regexes: 1.3 M states, 2 M follows)
   size_t n_states = 0, n_fol = 0, n_first = 0;
@@ -597,6 +604,9 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
     base += re.st_c.size();
   }
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+  CtxLease lease(h);
+  if (!lease.c) return FMX_ERR_HIP;
+  hipStream_t st = lease.c->stream;
   std::unique_ptr<RegexBatch> b(new RegexBatch());
   b->device = h->device;
   b->k = k;
@@ -612,16 +622,16 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   HIP_TRY(b->mem.alloc(&d_st, recs.size()), "hipMalloc");
   HIP_TRY(b->mem.alloc(&d_fol, fol.size()), "hipMalloc");
   HIP_TRY(b->mem.alloc(&d_fol_c, fol_c.size() + 4), "hipMalloc");
-  if (!fol_c.empty()) HIP_TRY(hipMemcpy(d_fol_c, fol_c.data(), fol_c.size(), hipMemcpyHostToDevice), "H2D");
+  if (!fol_c.empty()) HIP_TRY(copy_sync(d_fol_c, fol_c.data(), fol_c.size(), hipMemcpyHostToDevice, st), "H2D");
   HIP_TRY(b->mem.alloc(&b->d_first_state, q_state.size()), "hipMalloc");
-  if (!recs.empty()) HIP_TRY(hipMemcpy(d_st, recs.data(), recs.size() * sizeof(StateRec), hipMemcpyHostToDevice), "H2D");
-  if (!fol.empty()) HIP_TRY(hipMemcpy(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice), "H2D");
-  if (!q_state.empty()) HIP_TRY(hipMemcpy(b->d_first_state, q_state.data(), q_state.size() * 4, hipMemcpyHostToDevice), "H2D");
+  if (!recs.empty()) HIP_TRY(copy_sync(d_st, recs.data(), recs.size() * sizeof(StateRec), hipMemcpyHostToDevice, st), "H2D");
+  if (!fol.empty()) HIP_TRY(copy_sync(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+  if (!q_state.empty()) HIP_TRY(copy_sync(b->d_first_state, q_state.data(), q_state.size() * 4, hipMemcpyHostToDevice, st), "H2D");
   if (all_retree) {
     HIP_TRY(b->mem.alloc(&b->d_st_num, st_num.size()), "hipMalloc");
     HIP_TRY(b->mem.alloc(&b->d_first_off, first_off.size()), "hipMalloc");
-    if (!st_num.empty()) HIP_TRY(hipMemcpy(b->d_st_num, st_num.data(), st_num.size() * 4, hipMemcpyHostToDevice), "H2D");
-    HIP_TRY(hipMemcpy(b->d_first_off, first_off.data(), first_off.size() * 4, hipMemcpyHostToDevice), "H2D");
+    if (!st_num.empty()) HIP_TRY(copy_sync(b->d_st_num, st_num.data(), st_num.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+    HIP_TRY(copy_sync(b->d_first_off, first_off.data(), first_off.size() * 4, hipMemcpyHostToDevice, st), "H2D");
   }
   b->nfa = NfaTables{d_st, d_fol, d_fol_c};
   *out = b.release();
@@ -983,7 +993,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   *n_out = (size_t)tot.res_count + extra;
   if ((ctl.overflow & 2ull) || tot.res_count + extra > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
   if (tot.res_count)
-    HIP_TRY(hipMemcpy(out, d_res, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost), "D2H(results)");
+    HIP_TRY(copy_sync(out, d_res, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost, st), "D2H(results)");
   mark("results copied");
   for (size_t j = 0; j < extra; j++) {           // dfa.scala:270-273 with the start StatePoint(0,0,0,n)
     fmx_result &o = out[tot.res_count + j];
@@ -1004,7 +1014,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       // the device ordered every group of up to kSmallGroup results; the few larger ones are listed
       if (nbig) {
         std::vector<uint32_t> ent(2 * (size_t)nbig);
-        HIP_TRY(hipMemcpy(ent.data(), b->d_big->ent, ent.size() * 4, hipMemcpyDeviceToHost), "D2H(big groups)");
+        HIP_TRY(copy_sync(ent.data(), b->d_big->ent, ent.size() * 4, hipMemcpyDeviceToHost, st), "D2H(big groups)");
         for (uint32_t g = 0; g < nbig; g++)
           if (ent[2 * g + 1]) std::sort(out + ent[2 * g], out + ent[2 * g] + ent[2 * g + 1], by_key);
         if (trace) {
@@ -1015,7 +1025,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       }
       mark("large groups");
       if (per_regex_count && ndev)
-        HIP_TRY(hipMemcpy(per_regex_count, b->d_rcnt, b->k * 4, hipMemcpyDeviceToHost), "D2H(result counts)");
+        HIP_TRY(copy_sync(per_regex_count, b->d_rcnt, b->k * 4, hipMemcpyDeviceToHost, st), "D2H(result counts)");
     } else {
       // host-made results to merge in (or too many large groups to list): bucket everything by regex id
       std::vector<uint32_t> cnt(b->k + 1, 0);

@@ -26,6 +26,14 @@ struct CallCtx {
   size_t total() const { size_t t = 0; for (size_t c : cap) t += c; return t; }
 };
 
+// The k-mer jump table of an index (fmx_ktab.hip): level[j] holds the intervals of all (j+1)-mers, tab = the last.
+struct KTab {
+  const uint4 *tab = nullptr;
+  const uint4 *level[16] = {nullptr};
+  const uint8_t *dense = nullptr;   // [256] byte -> dense symbol id, 0xFF for bytes without a bit-vector
+  uint32_t k = 0, sigma = 0;
+};
+
 struct Index {
   uint64_t serial = 0;          // unique per open in this process: what a resident regex batch remembers of its index
   int device = 0;
@@ -56,6 +64,12 @@ struct Index {
   // host-call bookkeeping
   mutable std::mutex mu;
   mutable std::vector<CallCtx *> ctx_pool;      // idle call contexts (guarded by mu)
+  // k-mer jump table (fmx_ktab.hip), built on first use
+  mutable std::mutex kt_mu;
+  mutable bool kt_ready = false;
+  mutable KTab kt;
+  mutable void *d_ktab = nullptr, *d_kt_dense = nullptr;
+  mutable uint64_t kt_bytes = 0;
   // select directory for Psi (fmx_select.hip), built on first use
   mutable std::mutex sel_mu;
   mutable bool sel_ready = false;
@@ -79,6 +93,8 @@ struct CtxLease {            // scope guard around ctx_acquire / ctx_release
   CtxLease(const CtxLease &) = delete;
   CtxLease &operator=(const CtxLease &) = delete;
 };
+bool ktab_enabled();                            // fmx_config_set("ktab", "auto" | "off")
+hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out);     // fmx_ktab.hip
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP

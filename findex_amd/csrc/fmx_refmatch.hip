@@ -217,7 +217,8 @@ int regex_match_reference(const Index *h, const RefTables &rt, size_t k, uint32_
   HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
   HIP_TRY(hipStreamSynchronize(st), "sync(k_match_ref)");
   RefCtl ctl{};
-  HIP_TRY(hipMemcpy(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost), "D2H(ctl)");
+  HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
+  HIP_TRY(hipStreamSynchronize(st), "sync(ctl)");
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
   {
@@ -228,10 +229,14 @@ int regex_match_reference(const Index *h, const RefTables &rt, size_t k, uint32_
   if (ctl.overflow & 1ull) { set_error("reference-order heap overflow (internal bound)"); return FMX_ERR_OVERFLOW; }
   *n_out = (size_t)ctl.res_count;
   if (ctl.res_count > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
-  if (front_left) HIP_TRY(hipMemcpy(front_left, d_left, k * 4, hipMemcpyDeviceToHost), "D2H(front_left)");
+  if (front_left) {
+    HIP_TRY(hipMemcpyAsync(front_left, d_left, k * 4, hipMemcpyDeviceToHost, st), "D2H(front_left)");
+    HIP_TRY(hipStreamSynchronize(st), "sync(front_left)");
+  }
   if (ctl.res_count) {
     std::vector<RefResult> tmp((size_t)ctl.res_count);
-    HIP_TRY(hipMemcpy(tmp.data(), d_res, tmp.size() * sizeof(RefResult), hipMemcpyDeviceToHost), "D2H(results)");
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d_res, tmp.size() * sizeof(RefResult), hipMemcpyDeviceToHost, st), "D2H(results)");
+    HIP_TRY(hipStreamSynchronize(st), "sync(results)");
     // per regex, newest first: the order of the reference's prepended list (:638)
     std::sort(tmp.begin(), tmp.end(), [](const RefResult &a, const RefResult &b) {
       if (a.regex != b.regex) return a.regex < b.regex;

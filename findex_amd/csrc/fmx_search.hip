@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 }
 
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_t *__restrict__ pat,
+__global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, KTab kt, const uint8_t *__restrict__ pat,
                                                         const uint64_t *__restrict__ off,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
                                                         uint32_t k, unsigned long long *__restrict__ counters) {
@@ -82,7 +82,9 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_
   // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
   // slot + 2 (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
   __shared__ uint4 s_tab[256];
+  __shared__ uint8_t s_dense[256];       // byte -> dense symbol id of the k-mer table (0xFF: not in it)
   for (int c = threadIdx.x; c < 256; c += blockDim.x) {
+    s_dense[c] = kt.k ? kt.dense[c] : (uint8_t)0xFF;
     const uint64_t cf = ix.cf[c];
     const uint16_t s = ix.slot[c];
     uint64_t vb = 0;
@@ -112,39 +114,83 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_
       len = (uint32_t)(e - b);
     }
   };
+  // `tail` = the pattern's last 16 bytes (bytes pat[end-16 .. end): what the first steps consume and what the k-mer
+  // table is indexed with); patterns that end inside the buffer's first 16 bytes get their last 4 only
+  auto load_tail = [&](uint64_t e, uint32_t len) -> uint4 {
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (len) {
+      if (e >= 16) __builtin_memcpy(&q, pat + e - 16, 16);
+      else q.w = __builtin_bswap32(fetch4(pat, e));          // byte 15 = pat[e-1] as in the 16-byte form
+    }
+    return q;
+  };
   uint64_t end0, end1, end2;
-  uint32_t len0, len1, len2, tail0;
+  uint32_t len0, len1, len2;
+  uint4 tail0;
   load_off(wave, end0, len0);
-  tail0 = len0 ? fetch4(pat, end0) : 0u;
+  tail0 = load_tail(end0, len0);
   load_off((uint64_t)wave + nwaves, end1, len1);
+  uint32_t ktl = 0;                 // k-mer table lookups (counters[9])
   for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
     const uint32_t pid = batch * P + grp;
     const bool act = pid < k;
     const uint64_t *own = off + (act ? pid : 0u);
     const uint64_t end = end0;
     const uint32_t len = act ? len0 : 0u;
-    uint32_t ch = tail0;                                      // chunk 0
-    uint32_t nx = pat_chunk(pat, own, end, len, 1);           // chunk 1, wanted from step 4 on
-    const uint32_t tail1 = len1 ? fetch4(pat, end1) : 0u;     // the next batch's chunk 0
+    const uint4 tailq = tail0;
+    const uint4 tail1 = load_tail(end1, len1);                // the next batch's tail
     load_off((uint64_t)batch + 2ull * nwaves, end2, len2);
     uint64_t sp = 0, ep = ix.n;
     // symbols without a vector: absent (x = 0) or the EOF symbol (x = 1)
     auto special = [&](uint64_t cfc, uint64_t vb, uint64_t x) { return cfc + ((vb == 1 && x > ix.eof) ? 1u : 0u); };
-    // ---- step 0: rank(c, 0) = 0 and rank(c, n) = the symbol's count -- the interval is the symbol's
-    // whole bucket [C[c], C[c+1]), no block needed
-    if (len > 0) {
-      const uint32_t c = ch & 0xFFu;
-      const uint4 e = s_tab[c];
-      const uint4 e2 = s_tab[(c + 1) & 0xFFu];
-      const uint64_t cfc = ((uint64_t)e.y << 32) | e.x;
-      const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
-      const uint64_t nxt = c == 255u ? ix.n : (((uint64_t)e2.y << 32) | e2.x);
-      sp = vb > 1 ? cfc : special(cfc, vb, 0);
-      ep = vb > 1 ? nxt : special(cfc, vb, ix.n);
-      steps++;
+    uint32_t ch, nx, it0;
+    // ---- the first K steps from the k-mer table (fmx_ktab.hip): one 16-byte lookup.  Taken when every pattern of
+    // the wave's batch has K characters, all of them in the table's alphabet, and ends past the buffer's first 16
+    // bytes; else the batch starts with the plain step 0 below.
+    uint32_t code = 0;
+    bool elig = kt.k != 0 && len >= kt.k && end >= 16;
+    if (elig) {
+      const uint64_t hi = ((uint64_t)tailq.w << 32) | tailq.z, lo = ((uint64_t)tailq.y << 32) | tailq.x;
+      for (uint32_t j = 0; j < kt.k; j++) {
+        const uint32_t b = (uint32_t)((j < 8 ? hi >> (8u * (7u - j)) : lo >> (8u * (15u - j))) & 0xFFu);
+        const uint32_t d = s_dense[b];
+        elig = elig && d != 0xFFu;
+        code = code * kt.sigma + d;
+      }
     }
-    ch >>= 8;
-    for (uint32_t it = 1;; it++) {                             // `it` is wave-uniform
+    if (kt.k && !__builtin_amdgcn_ballot_w64(act && !elig)) {
+      if (act) {
+        const uint4 ent = kt.tab[code];
+        ch = pat_chunk(pat, own, end, len, kt.k >> 2) >> (8u * (kt.k & 3u));
+        nx = pat_chunk(pat, own, end, len, (kt.k >> 2) + 1);
+        sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
+        ep = ((uint64_t)ent.w << 32) | ent.z;
+        steps += ent.y >> 24;           // the reference's loop ran this many steps on these characters
+        ktl++;
+      } else {
+        ch = 0; nx = 0;
+      }
+      it0 = kt.k;
+    } else {
+      ch = __builtin_bswap32(tailq.w);                         // chunk 0
+      nx = pat_chunk(pat, own, end, len, 1);                   // chunk 1, wanted from step 4 on
+      // ---- step 0: rank(c, 0) = 0 and rank(c, n) = the symbol's count -- the interval is the symbol's
+      // whole bucket [C[c], C[c+1]), no block needed
+      if (len > 0) {
+        const uint32_t c = ch & 0xFFu;
+        const uint4 e = s_tab[c];
+        const uint4 e2 = s_tab[(c + 1) & 0xFFu];
+        const uint64_t cfc = ((uint64_t)e.y << 32) | e.x;
+        const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
+        const uint64_t nxt = c == 255u ? ix.n : (((uint64_t)e2.y << 32) | e2.x);
+        sp = vb > 1 ? cfc : special(cfc, vb, 0);
+        ep = vb > 1 ? nxt : special(cfc, vb, ix.n);
+        steps++;
+      }
+      ch >>= 8;
+      it0 = 1;
+    }
+    for (uint32_t it = it0;; it++) {                           // `it` is wave-uniform
       const bool stepping = it < len && sp < ep;
       if (!__builtin_amdgcn_ballot_w64(stepping)) break;
       const bool wide_iv = stepping && (ep - sp) != 1;
@@ -219,6 +265,11 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint8_
     end1 = end2; len1 = len2;
   }
   counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
+  {
+    const unsigned long long lookups = wave_sum(t == 0 ? (unsigned long long)ktl : 0ull);
+    if ((threadIdx.x & 63u) == 0 && lookups)
+      atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 9, lookups);
+  }
 }
 
 // generic kernel (fmx_kernels.hip)
@@ -251,7 +302,10 @@ static hipError_t launch_v4(const Index *h, const uint8_t *pat, const uint64_t *
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search4<WIDE, LAYOUT><<<grid, kSThreads, 0, st>>>(h->dev, pat, off, sp, ep, k, h->d_counters);
+  KTab kt;
+  const hipError_t e = ktab_get(h, st, &kt);
+  if (e != hipSuccess) return e;
+  k_search4<WIDE, LAYOUT><<<grid, kSThreads, 0, st>>>(h->dev, kt, pat, off, sp, ep, k, h->d_counters);
   return hipGetLastError();
 }
 

@@ -62,7 +62,9 @@ const char *fmx_last_error(void);
 int fmx_abi_version(void);
 /* Process-wide options.  key "layout": "auto" (default: one-hot bit-vectors, one 64-byte block per
  * rank query, when sigma*n/7 bytes fit in free HBM and n < 2^37; else BWT bytes + checkpoints, two
- * lines per rank query), "onehot", "bytes".  key "validate": "0" (default) / "1": the device-pointer search entry
+ * lines per rank query), "onehot", "bytes".  key "ktab": "auto" (default) / "off": the k-mer jump table that
+ * answers a search's first K backward steps with one lookup (built on a handle's first search; K is chosen from n
+ * and the alphabet: fmx_stats_t.ktab_k).  key "validate": "0" (default) / "1": the device-pointer search entry
  * point then checks on the device that d_off is non-decreasing and fails with FMX_ERR_ARG otherwise (one more small
  * kernel and a synchronisation per call: a debugging aid; the host-pointer form always checks).  key "checkpoints": "auto" (default: the bytes layout keeps absolute
  * 32-bit checkpoints whenever every symbol occurs fewer than 2^32 times) or "superblock" (always the relative
@@ -327,7 +329,9 @@ typedef struct fmx_stats_t {
   uint64_t frontier_queue_writes;  /* elements appended to the HBM work queues */
   uint64_t frontier_results;    /* results written */
   uint64_t frontier_records;    /* 32-byte state records loaded (none inside a literal stretch) */
-  uint64_t reserved2[2];        /* 0 */
+  uint64_t ktab_lookups;        /* 16-byte k-mer table entries fetched (each stands for up to ktab_k backward steps) */
+  uint32_t ktab_k;              /* K of the k-mer jump table (0: none, or not built yet) */
+  uint32_t reserved3;           /* 0 */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 /* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */

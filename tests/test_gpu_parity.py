@@ -322,6 +322,33 @@ def test_many_patterns_ragged_lengths():
     assert hits > 50_000
 
 
+def test_kmer_table_on_and_off_agree():
+    """The k-mer jump table (fmx_ktab.hip) answers a search's first K steps with one lookup; with it and without it
+    every (sp, ep) -- misses with the reference's values at the failing step included -- and the executed-step
+    counter must equal the oracle's.  Patterns shorter than K, patterns with bytes outside the alphabet and a
+    pattern inside the buffer's first 16 bytes take the stepwise start."""
+    bwt, eof, counts = synth_bwt(300_000, 1, 5, 19)
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(4)
+    pats = [b"\x01\x02", b"\x03"]                                   # first in the buffer: end < 16
+    for m in (1, 2, 5, 6, 7, 9, 13, 30):
+        pats += lf_walk_patterns(orc, rng, 400, m, 0.3, alphabet=[1, 2, 3, 4, 5])
+    pats += [bytes([1, 2, 9, 1, 2, 3, 4, 5, 1]), bytes([0, 1, 2, 3, 4, 5, 1, 2]), b""] * 20      # foreign bytes inside / outside the k-mer
+    pats = pats[:2] + [pats[2 + i] for i in rng.permutation(len(pats) - 2)]
+    ks = []
+    for mode in ("off", "auto"):
+        findex_amd.set_ktab(mode)
+        try:
+            hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+            check_search(hip, orc, pats)
+            ks.append(hip.stats()["ktab_k"])
+            if mode == "auto":
+                assert hip.stats()["ktab_lookups"] > 0
+        finally:
+            findex_amd.set_ktab("auto")
+    assert ks[0] == 0 and ks[1] >= 5                                 # 5^6 = 15625 <= n/8
+
+
 def test_pipelined_host_batch_pageable_and_pinned():
     """Host-pointer batches of 128k patterns or more are cut into chunks over two streams (fmx_api.cpp): ragged
     lengths with empty patterns at chunk borders, offsets that do not start at 0, pageable and page-locked

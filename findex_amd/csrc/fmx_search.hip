@@ -71,8 +71,13 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
   return __builtin_bswap32(d) >> (8u * (4u - (back ? back : 4u)));
 }
 
-template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, KTab kt, const uint8_t *__restrict__ pat,
+// KT = characters the k-mer jump table (fmx_ktab.hip) answers with one lookup at the start of a search: 0 (no table),
+// 4, 8 or 12 -- a compile-time constant, so that the step loop below starts at a constant step number and is
+// compiled exactly as without the table, and the pattern pipeline prefetches exactly the KT tail bytes the table
+// is indexed with (4 at sigma = 128: nothing more than before).
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
+__global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
+                                                        uint32_t ksigma, const uint8_t *__restrict__ pat,
                                                         const uint64_t *__restrict__ off,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
                                                         uint32_t k, unsigned long long *__restrict__ counters) {
@@ -82,9 +87,10 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, KTab kt, con
   // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
   // slot + 2 (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
   __shared__ uint4 s_tab[256];
-  __shared__ uint8_t s_dense[256];       // byte -> dense symbol id of the k-mer table (0xFF: not in it)
+  __shared__ uint8_t s_dense[KT ? 256 : 4];      // byte -> dense symbol id of the k-mer table (0xFF: not in it)
+  __shared__ uint16_t s_slot[KT ? 256 : 4];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) {
-    s_dense[c] = kt.k ? kt.dense[c] : (uint8_t)0xFF;
+    if (KT) { s_dense[c] = kdense[c]; s_slot[c] = ix.slot[c]; }
     const uint64_t cf = ix.cf[c];
     const uint16_t s = ix.slot[c];
     uint64_t vb = 0;
@@ -114,66 +120,38 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, KTab kt, con
       len = (uint32_t)(e - b);
     }
   };
-  // `tail` = the pattern's last 16 bytes (bytes pat[end-16 .. end): what the first steps consume and what the k-mer
-  // table is indexed with); patterns that end inside the buffer's first 16 bytes get their last 4 only
-  auto load_tail = [&](uint64_t e, uint32_t len) -> uint4 {
-    uint4 q = make_uint4(0u, 0u, 0u, 0u);
-    if (len) {
-      if (e >= 16) __builtin_memcpy(&q, pat + e - 16, 16);
-      else q.w = __builtin_bswap32(fetch4(pat, e));          // byte 15 = pat[e-1] as in the 16-byte form
-    }
+  // the tail of a pattern: its first NT chunks (chunk i = the four bytes the search consumes at steps 4i .. 4i+3,
+  // first one in byte lane 0); NT = 1 without the table, KT / 4 with it
+  constexpr uint32_t NT = KT ? KT / 4 : 1;
+  struct Tail { uint32_t c[NT]; };
+  auto load_tail = [&](uint64_t e, uint32_t len) {
+    Tail q;
+#pragma unroll
+    for (uint32_t i = 0; i < NT; i++) q.c[i] = len > 4u * i ? fetch4(pat, e - 4ull * i) : 0u;
     return q;
   };
   uint64_t end0, end1, end2;
   uint32_t len0, len1, len2;
-  uint4 tail0;
+  Tail tail0;
+  uint32_t ktl = 0;                 // k-mer table lookups (counters[9])
   load_off(wave, end0, len0);
   tail0 = load_tail(end0, len0);
   load_off((uint64_t)wave + nwaves, end1, len1);
-  uint32_t ktl = 0;                 // k-mer table lookups (counters[9])
   for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
     const uint32_t pid = batch * P + grp;
     const bool act = pid < k;
     const uint64_t *own = off + (act ? pid : 0u);
     const uint64_t end = end0;
     const uint32_t len = act ? len0 : 0u;
-    const uint4 tailq = tail0;
-    const uint4 tail1 = load_tail(end1, len1);                // the next batch's tail
+    const Tail tailq = tail0;
+    uint32_t ch = tailq.c[0];                                 // chunk 0
+    uint32_t nx = pat_chunk(pat, own, end, len, KT ? KT / 4 + 1 : 1);       // the chunk after the current one
+    const Tail tail1 = load_tail(end1, len1);                 // the next batch's tail
     load_off((uint64_t)batch + 2ull * nwaves, end2, len2);
     uint64_t sp = 0, ep = ix.n;
     // symbols without a vector: absent (x = 0) or the EOF symbol (x = 1)
     auto special = [&](uint64_t cfc, uint64_t vb, uint64_t x) { return cfc + ((vb == 1 && x > ix.eof) ? 1u : 0u); };
-    uint32_t ch, nx, it0;
-    // ---- the first K steps from the k-mer table (fmx_ktab.hip): one 16-byte lookup.  Taken when every pattern of
-    // the wave's batch has K characters, all of them in the table's alphabet, and ends past the buffer's first 16
-    // bytes; else the batch starts with the plain step 0 below.
-    uint32_t code = 0;
-    bool elig = kt.k != 0 && len >= kt.k && end >= 16;
-    if (elig) {
-      const uint64_t hi = ((uint64_t)tailq.w << 32) | tailq.z, lo = ((uint64_t)tailq.y << 32) | tailq.x;
-      for (uint32_t j = 0; j < kt.k; j++) {
-        const uint32_t b = (uint32_t)((j < 8 ? hi >> (8u * (7u - j)) : lo >> (8u * (15u - j))) & 0xFFu);
-        const uint32_t d = s_dense[b];
-        elig = elig && d != 0xFFu;
-        code = code * kt.sigma + d;
-      }
-    }
-    if (kt.k && !__builtin_amdgcn_ballot_w64(act && !elig)) {
-      if (act) {
-        const uint4 ent = kt.tab[code];
-        ch = pat_chunk(pat, own, end, len, kt.k >> 2) >> (8u * (kt.k & 3u));
-        nx = pat_chunk(pat, own, end, len, (kt.k >> 2) + 1);
-        sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
-        ep = ((uint64_t)ent.w << 32) | ent.z;
-        steps += ent.y >> 24;           // the reference's loop ran this many steps on these characters
-        ktl++;
-      } else {
-        ch = 0; nx = 0;
-      }
-      it0 = kt.k;
-    } else {
-      ch = __builtin_bswap32(tailq.w);                         // chunk 0
-      nx = pat_chunk(pat, own, end, len, 1);                   // chunk 1, wanted from step 4 on
+    if (KT == 0) {
       // ---- step 0: rank(c, 0) = 0 and rank(c, n) = the symbol's count -- the interval is the symbol's
       // whole bucket [C[c], C[c+1]), no block needed
       if (len > 0) {
@@ -188,9 +166,41 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, KTab kt, con
         steps++;
       }
       ch >>= 8;
-      it0 = 1;
+    } else {
+      // ---- the first KT steps from the k-mer table: T[code] = (sp, ep, steps) after the KT characters of `code`
+      // (for a k-mer that does not occur: the reference loop's values at its first empty step and the steps it
+      // took).  A pattern shorter than KT, or with a byte that has no bit-vector among its last KT, walks those
+      // steps the plain way below.
+      uint32_t code = 0;
+      bool elig = act && len >= KT;
+#pragma unroll
+      for (uint32_t j = 0; j < KT; j++) {
+        const uint32_t d = s_dense[(tailq.c[j >> 2] >> (8u * (j & 3u))) & 0xFFu];
+        elig = elig && d != 0xFFu;
+        code = code * ksigma + d;
+      }
+      if (elig) {
+        const uint4 ent = ktab[code];
+        sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
+        ep = ((uint64_t)ent.w << 32) | ent.z;
+        steps += ent.y >> 24;           // the reference's loop ran this many steps on these characters
+        ktl++;
+      }
+      if (__builtin_amdgcn_ballot_w64(act && !elig)) {
+        for (uint32_t j = 0; j < KT; j++) {
+          const bool stepping = act && !elig && j < len && sp < ep;
+          if (!__builtin_amdgcn_ballot_w64(stepping)) break;
+          if (stepping) {
+            const uint32_t c = (tailq.c[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+            const uint4 e = s_tab[c];
+            reqs += backward_step<WIDE, LAYOUT>(ix, c, s_slot[c], ((uint64_t)e.y << 32) | e.x, lc, sp, ep);
+            steps++;
+          }
+        }
+      }
+      ch = pat_chunk(pat, own, end, len, KT / 4);              // the chunk step KT starts
     }
-    for (uint32_t it = it0;; it++) {                           // `it` is wave-uniform
+    for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
       const bool stepping = it < len && sp < ep;
       if (!__builtin_amdgcn_ballot_w64(stepping)) break;
       const bool wide_iv = stepping && (ep - sp) != 1;
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, KTab kt, con
     end1 = end2; len1 = len2;
   }
   counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
-  {
+  if (KT) {
     const unsigned long long lookups = wave_sum(t == 0 ? (unsigned long long)ktl : 0ull);
     if ((threadIdx.x & 63u) == 0 && lookups)
       atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 9, lookups);
@@ -294,19 +304,30 @@ static int blocks_per_cu(K kernel) {
   return nb > 8 ? 8 : nb;
 }
 
-template <bool WIDE, uint32_t LAYOUT>
-static hipError_t launch_v4(const Index *h, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
-                            uint32_t k, hipStream_t st) {
-  static const int per_cu = blocks_per_cu(k_search4<WIDE, LAYOUT>);
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
+static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
+                             uint32_t k, hipStream_t st) {
+  static const int per_cu = blocks_per_cu(k_search4<WIDE, LAYOUT, KT>);
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
+  k_search4<WIDE, LAYOUT, KT><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, pat, off, sp, ep, k,
+                                                          h->d_counters);
+  return hipGetLastError();
+}
+
+template <bool WIDE, uint32_t LAYOUT>
+static hipError_t launch_v4(const Index *h, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
+                            uint32_t k, hipStream_t st) {
   KTab kt;
   const hipError_t e = ktab_get(h, st, &kt);
   if (e != hipSuccess) return e;
-  k_search4<WIDE, LAYOUT><<<grid, kSThreads, 0, st>>>(h->dev, kt, pat, off, sp, ep, k, h->d_counters);
-  return hipGetLastError();
+  // the search uses the table's levels in steps of four characters (all levels are kept: fmx_ktab.hip)
+  if (kt.k >= 12) return launch_v4k<WIDE, LAYOUT, 12>(h, kt, pat, off, sp, ep, k, st);
+  if (kt.k >= 8) return launch_v4k<WIDE, LAYOUT, 8>(h, kt, pat, off, sp, ep, k, st);
+  if (kt.k >= 4) return launch_v4k<WIDE, LAYOUT, 4>(h, kt, pat, off, sp, ep, k, st);
+  return launch_v4k<WIDE, LAYOUT, 0>(h, kt, pat, off, sp, ep, k, st);
 }
 
 // One launch per call: no scratch, nothing to own per stream, so concurrent calls on one handle need no lock.

@@ -335,15 +335,20 @@ def test_kmer_table_on_and_off_agree():
         pats += lf_walk_patterns(orc, rng, 400, m, 0.3, alphabet=[1, 2, 3, 4, 5])
     pats += [bytes([1, 2, 9, 1, 2, 3, 4, 5, 1]), bytes([0, 1, 2, 3, 4, 5, 1, 2]), b""] * 20      # foreign bytes inside / outside the k-mer
     pats = pats[:2] + [pats[2 + i] for i in rng.permutation(len(pats) - 2)]
+    long_only = []
+    for m in (7, 8, 9, 13, 30):                                      # hits and misses at every depth, all >= K characters
+        long_only += lf_walk_patterns(orc, rng, 1500, m, 0.5, alphabet=[1, 2, 3, 4, 5])
+    long_only = [long_only[i] for i in rng.permutation(len(long_only))]
     ks = []
     for mode in ("off", "auto"):
         findex_amd.set_ktab(mode)
         try:
             hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
-            check_search(hip, orc, pats)
+            check_search(hip, orc, pats)                         # mixed: most waves hold an ineligible pattern
+            check_search(hip, orc, long_only)                    # every wave takes the table
             ks.append(hip.stats()["ktab_k"])
             if mode == "auto":
-                assert hip.stats()["ktab_lookups"] > 0
+                assert hip.stats()["ktab_lookups"] >= len(long_only) - 64
         finally:
             findex_amd.set_ktab("auto")
     assert ks[0] == 0 and ks[1] >= 5                                 # 5^6 = 15625 <= n/8

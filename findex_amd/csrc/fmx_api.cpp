@@ -266,6 +266,7 @@ static void destroy(Index *h) {
   if (h->d_counters) (void)hipFree(h->d_counters);
   if (h->d_ktab) (void)hipFree(h->d_ktab);
   if (h->d_kt_dense) (void)hipFree(h->d_kt_dense);
+  if (h->d_kt_levels) (void)hipFree(h->d_kt_levels);
   if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
   if (h->d_sel_off) (void)hipFree(h->d_sel_off);
   if (h->d_sel_shift) (void)hipFree(h->d_sel_shift);

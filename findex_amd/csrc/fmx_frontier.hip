@@ -77,7 +77,7 @@ struct FrontierCtl {     // device-resident counters
 };
 
 struct FStat {           // wave-uniform sums for the frontier counters (fmx_device.h, slots 3..7)
-  uint32_t reqs = 0, writes = 0, emits = 0, reads = 0, recs = 0;
+  uint32_t reqs = 0, writes = 0, emits = 0, reads = 0, recs = 0, ktl = 0;
 };
 
 // Exclusive prefix sum over the 64 lanes with DPP adds only (row shifts inside each row of 16, then the row
@@ -125,7 +125,7 @@ __device__ __forceinline__ void pool_sync() {
 // ctl->pass_base + j.  Wave w reads slice w % kSub together with the other waves of that class: its share
 // is the batches part, part + class_waves, ... of P = 64/G entries each.
 template <bool WIDE, uint32_t LAYOUT>
-__device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTables &nfa, const Queue &qa, const Queue &qb, uint32_t j,
+__device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt, const NfaTables &nfa, const Queue &qa, const Queue &qb, uint32_t j,
                                               uint32_t max_rounds, uint64_t sub_cap, fmx_result *__restrict__ res,
                                               uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
                                               unsigned long long *__restrict__ counters) {
@@ -151,7 +151,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTable
   __shared__ uint16_t s_slot[256];
   __shared__ Pool s_pool[kFThreads / 64];
   __shared__ ResStage s_res[kFThreads / 64];
+  __shared__ const uint4 *s_lvl[16];         // the k-mer table's levels (picked by an element's length at run time)
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  if (threadIdx.x < 16) s_lvl[threadIdx.x] = kt.k ? kt.level_dev[threadIdx.x] : nullptr;
   __syncthreads();
   if (!share) return;                        // wave-uniform; no workgroup barrier below
   Pool &pl = s_pool[threadIdx.x >> 6];
@@ -270,8 +272,14 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTable
     uint32_t nf = 0, len1 = 0;
     bool emit = false;
     const uint32_t run = meta >> 24;          // > 0: this state is inside a literal stretch whose bytes the group holds
+    // An element shorter than the k-mer table's K (fmx_ktab.hip) carries its k-mer code instead of an interval
+    // (ep == 0 marks it, sp = the code): its step is a lookup in the next level of the table -- one 16-byte entry,
+    // usually cache resident, instead of two rank blocks -- and the start elements need no C[] special case.
+    const bool cm = have && kt.k != 0 && ep == 0;
     // deep in a search every interval is a single row: then the whole wave takes the one-request step (k_search4's trick)
-    const bool all_single = !__builtin_amdgcn_ballot_w64(have && (meta & 0xFFFFu) != 0 && (ep - sp) != 1);
+    const bool all_single = !__builtin_amdgcn_ballot_w64(have && !cm && (meta & 0xFFFFu) != 0 && (ep - sp) != 1);
+    uint32_t ncode = 0;                      // codes fit 32 bits: the table has at most 2^32 entries per level
+    bool from_tab = false;
     if (have) {
       if (run == 0) {
         rq8 = reinterpret_cast<const uint2 *>(nfa.st + state)[t & 3u];
@@ -280,17 +288,41 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTable
       const uint32_t c = (meta >> 16) & 0xFFu, len = meta & 0xFFFFu;
       const uint16_t slot = s_slot[c];
       const uint64_t cfc = s_cf[c];
-      if (len == 0) {       // every start element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
-        sp = cfc;
-        ep = (c == 255u) ? ix.n : s_cf[c + 1];
-        if (slot == kSlotNone) ep = sp;
-        else if (slot == kSlotEof) ep = sp + 1;
-      } else if (all_single) {
-        const uint32_t rq = single_row_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
-        if (lead) fs.reqs += rq;
-      } else {
-        const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
-        if (lead) fs.reqs += rq;
+      bool ranked = !cm;
+      if (cm) {
+        if (slot < kSlotEof) {                        // the table's symbols are numbered like the bit-vector slots
+          ncode = (uint32_t)sp * kt.sigma + slot;
+          const uint4 ent = s_lvl[len][ncode];
+          sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
+          ep = ((uint64_t)ent.w << 32) | ent.z;
+          from_tab = true;
+          if (lead) fs.ktl++;
+        } else if (slot == kSlotNone) {               // a byte that does not occur: the interval is empty
+          sp = 0;
+          ep = 0;
+        } else {                                      // the EOF symbol: leave the table, step on the interval itself
+          if (len == 0) { sp = 0; ep = ix.n; }
+          else {
+            const uint4 ent = s_lvl[len - 1][sp];
+            sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
+            ep = ((uint64_t)ent.w << 32) | ent.z;
+          }
+          ranked = true;
+        }
+      }
+      if (ranked) {
+        if (len == 0) {     // every start element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
+          sp = cfc;
+          ep = (c == 255u) ? ix.n : s_cf[c + 1];
+          if (slot == kSlotNone) ep = sp;
+          else if (slot == kSlotEof) ep = sp + 1;
+        } else if (all_single && !cm) {
+          const uint32_t rq = single_row_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
+          if (lead) fs.reqs += rq;
+        } else {
+          const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
+          if (lead) fs.reqs += rq;
+        }
       }
       stepped++;
     }
@@ -305,6 +337,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTable
       if (nf && len1 >= max_len) { nf = 0; trunc = 1; }
     }
     const uint32_t rgx = group_bcast<G, 3>(rq8.y);
+    // what the element and its follows carry on: the code while they are still inside the table, else the interval
+    const bool keep_code = from_tab && len1 < kt.k;
+    const uint64_t ssp = keep_code ? (uint64_t)ncode : sp, sep = keep_code ? 0ull : ep;
     // ---- results are staged in LDS
     {
       const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
@@ -345,8 +380,8 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTable
           const uint32_t idx = (pb + pn + my_off + q) & kPoolMask;
           pl.state[idx] = fst;
           pl.meta[idx] = len1 | (fch << 16);
-          pl.sp[idx] = sp;
-          pl.ep[idx] = ep;
+          pl.sp[idx] = ssp;
+          pl.ep[idx] = sep;
         }
         pn = uni(pn + small_total);
         pool_sync();
@@ -367,8 +402,8 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTable
           if (at < sub_cap) {
             nxt.state[out_off + at] = nfa.fol[f0 + q + 1];
             nxt.meta[out_off + at] = len1 | ((uint32_t)nfa.fol_c[f0 + q + 1] << 16);
-            nxt.sp[out_off + at] = sp;
-            nxt.ep[out_off + at] = ep;
+            nxt.sp[out_off + at] = ssp;
+            nxt.ep[out_off + at] = sep;
           } else {
             atomicOr(&ctl->overflow, 1ull);
           }
@@ -381,6 +416,8 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTable
       const uint32_t r1 = group_bcast<G, 1>(rq8.y), r2 = group_bcast<G, 2>(rq8.x), r3 = group_bcast<G, 2>(rq8.y);
       if (have) {
         if (nf) {
+          sp = ssp;
+          ep = sep;
           // on a literal stretch the next state is state + 1 and its byte comes from the held record:
           // rr[k - 1] with k = states of the stretch still ahead (the chain length when it was just entered)
           const uint32_t k = run ? run : (nf == 1 ? (cce >> 25) & 0xFu : 0u);
@@ -419,24 +456,28 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const NfaTable
   counters_add(counters, lead ? 2ull * stepped : 0ull, lead ? stepped : 0u, 0);
   counters_add_frontier(counters, fs.reqs, lane == 0 ? fs.writes : 0u, lane == 0 ? fs.emits : 0u, lead ? stepped : 0u,
                         lane == 0 ? fs.reads : 0u, fs.recs);
+  {
+    const unsigned long long lookups = wave_sum((unsigned long long)fs.ktl);
+    if (lane == 0 && lookups) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 9, lookups);
+  }
 }
 
 // One-hot layout: 80 registers keep 6 waves per SIMD resident; the bytes layout (octets, two lines per rank query)
 // needs more registers and runs 4.
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kFThreads, 6) void k_frontier(DevIndex ix, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
+__global__ __launch_bounds__(kFThreads, 5) void k_frontier(DevIndex ix, KTab kt, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
                                                             uint32_t max_rounds, uint64_t sub_cap,
                                                             fmx_result *__restrict__ res, uint64_t seg_cap,
                                                             FrontierCtl *__restrict__ ctl,
                                                             unsigned long long *__restrict__ counters) {
-  frontier_pass<WIDE, LAYOUT>(ix, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
+  frontier_pass<WIDE, LAYOUT>(ix, kt, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
 }
-__global__ __launch_bounds__(kFThreads, 4) void k_frontier_bytes(DevIndex ix, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
+__global__ __launch_bounds__(kFThreads, 4) void k_frontier_bytes(DevIndex ix, KTab kt, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
                                                                   uint32_t max_rounds, uint64_t sub_cap,
                                                                   fmx_result *__restrict__ res, uint64_t seg_cap,
                                                                   FrontierCtl *__restrict__ ctl,
                                                                   unsigned long long *__restrict__ counters) {
-  frontier_pass<true, kLayoutBytes>(ix, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
+  frontier_pass<true, kLayoutBytes>(ix, kt, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
 }
 
 // Closes a chain of launches: the next chain starts `by` passes further.
@@ -639,7 +680,7 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
 }
 
 // The start queue: states = firsts, len 0, (sp, ep) = (0, n), dealt round-robin over the slices.
-__global__ void k_frontier_init(Queue q, NfaTables nfa, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n,
+__global__ void k_frontier_init(Queue q, NfaTables nfa, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n /* 0: the start elements carry the empty k-mer code */,
                                 uint64_t sub_cap, uint32_t max_len, FrontierCtl *__restrict__ ctl) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < kSub) {
@@ -854,16 +895,18 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   hipStream_t st = lease.c->stream;
   hipEvent_t e0 = lease.c->ev_a, e1 = lease.c->ev_b;
 
+  KTab kt;
+  HIP_TRY(ktab_get(h, st, &kt), "k-mer table");
   mark("setup");
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
-  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->nfa, b->d_first_state, b->n_first, h->n, sub_cap, max_steps, d_ctl);
+  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->nfa, b->d_first_state, b->n_first, kt.k ? 0 : h->n, sub_cap, max_steps, d_ctl);
   HIP_TRY(hipGetLastError(), "k_frontier_init");
   // Launches are chained on the stream without host round trips; the host looks at the counters after every
   // chain.  A launch whose input queue is empty returns at once.
   static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 10u;
   // rounds a wave works before it hands its leftovers to the next launch (the load balancing step)
   static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 16u;
-  static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : 6;
+  static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : 5;
   const int grid_full = h->cu_count * (h->layout == kLayoutBytes ? std::min(per_cu, 4) : per_cu);
   const uint32_t group_lanes = h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G;
   const uint64_t per_wg = (uint64_t)kFThreads / group_lanes;      // elements a workgroup holds at once
@@ -875,11 +918,11 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   bool alive = true, truncated = false;
   auto launch_pass = [&](hipStream_t s, int grid, uint32_t j, uint32_t rounds) {
     if (h->layout == kLayoutBytes)
-      k_frontier_bytes<<<grid, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier_bytes<<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
     else if (h->n > (1ull << 32))
-      k_frontier<true, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier<true, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
     else
-      k_frontier<false, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier<false, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
   };
   // One chain = kChain launches + k_pass_advance + the counters' copy to pinned host memory.  Its kernel
   // arguments do not change from chain to chain (the pass comes from ctl->pass_base), so it is captured

@@ -30,6 +30,8 @@ struct CallCtx {
 struct KTab {
   const uint4 *tab = nullptr;
   const uint4 *level[16] = {nullptr};
+  const uint4 *const *level_dev = nullptr;   // the same 16 pointers in device memory (kernels that pick a level at run time
+                                             // stage them in LDS: indexing the by-value array would go through scratch)
   const uint8_t *dense = nullptr;   // [256] byte -> dense symbol id, 0xFF for bytes without a bit-vector
   uint32_t k = 0, sigma = 0;
 };
@@ -68,7 +70,7 @@ struct Index {
   mutable std::mutex kt_mu;
   mutable bool kt_ready = false;
   mutable KTab kt;
-  mutable void *d_ktab = nullptr, *d_kt_dense = nullptr;
+  mutable void *d_ktab = nullptr, *d_kt_dense = nullptr, *d_kt_levels = nullptr;
   mutable uint64_t kt_bytes = 0;
   // select directory for Psi (fmx_select.hip), built on first use
   mutable std::mutex sel_mu;

@@ -73,7 +73,7 @@ static hipError_t build_ktab(const Index *h, hipStream_t st) {
   uint64_t entries = 1, all = 0;
   for (;;) {
     const uint64_t nxt = entries * sigma;
-    if (k >= 16 || nxt > h->n / 8 || (all + nxt) * 16 > max_bytes) break;
+    if (k >= 16 || nxt > h->n / 8 || nxt > (1ull << 32) || (all + nxt) * 16 > max_bytes) break;
     if (forced > 0 && k >= (uint32_t)forced) break;
     entries = nxt;
     all += nxt;
@@ -109,16 +109,22 @@ static hipError_t build_ktab(const Index *h, hipStream_t st) {
     off += n_next;
     n_prev = n_next;
   }
+  void *d_levels = nullptr;
+  if (e == hipSuccess) e = hipMalloc(&d_levels, sizeof h->kt.level);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_levels, h->kt.level, sizeof h->kt.level, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);      // `dense` / `sym_of` go out of scope
   if (d_sym) (void)hipFree(d_sym);
   if (e != hipSuccess) {
     if (d_all) (void)hipFree(d_all);
     if (d_dense) (void)hipFree(d_dense);
+    if (d_levels) (void)hipFree(d_levels);
     h->kt.k = 0;
     return e;
   }
   h->d_ktab = d_all;
   h->d_kt_dense = d_dense;
+  h->d_kt_levels = d_levels;
+  h->kt.level_dev = static_cast<const uint4 *const *>(d_levels);
   h->kt.k = k;
   h->kt.tab = h->kt.level[k - 1];
   h->kt.dense = static_cast<const uint8_t *>(d_dense);

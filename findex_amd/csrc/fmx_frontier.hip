@@ -906,8 +906,10 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 10u;
   // rounds a wave works before it hands its leftovers to the next launch (the load balancing step)
   static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 16u;
-  static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : 5;
-  const int grid_full = h->cu_count * (h->layout == kLayoutBytes ? std::min(per_cu, 4) : per_cu);
+  // workgroups per CU in the full grid: twice what is resident at once (5 per CU at 96 registers), so that the
+  // dispatcher fills the slots of waves whose share ran out early (measured on C4: 5 -> 0.72 ms, 10 -> 0.67, 20 -> 0.71)
+  static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : 10;
+  const int grid_full = h->cu_count * per_cu;
   const uint32_t group_lanes = h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G;
   const uint64_t per_wg = (uint64_t)kFThreads / group_lanes;      // elements a workgroup holds at once
   std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());

@@ -260,14 +260,18 @@ def pmc_traffic(workload, kernel):
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters.csv" % workload))):
-        vals, per_kib = {}, None
+        vals, per_kib, calls, disp = {}, None, None, None
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel"]:
                 vals[r["Counter"]] = float(r["Mean"])
+                disp = float(r["Dispatches"])
             if r["Counter"] == "FETCH_BYTES_PER_KIB":
                 per_kib = float(r["Mean"])
+            if r["Counter"] == "CALLS":
+                calls = float(r["Mean"])
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and per_kib:
-            best = (int(vals["FETCH_SIZE"] * per_kib + vals["WRITE_SIZE"] * 1024), os.path.basename(f))
+            per_launch = calls is None and 1.0 or disp / calls      # a regex call = several dispatches of the kernel
+            best = (int((vals["FETCH_SIZE"] * per_kib + vals["WRITE_SIZE"] * 1024) * per_launch), os.path.basename(f))
     return best
 
 
@@ -376,6 +380,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     s1 = hip.stats()
     ranks_per_step = int(s1["rank_queries"])
     requests_per_step = int(s1["search_requests"])
+    lookups_per_step = int(s1["ktab_lookups"])
     hits = int((sp < ep).sum().item())
     sp0, ep0 = sp.clone(), ep.clone()
     for _ in range(max(0, args.warmup - 1)):
@@ -423,7 +428,8 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     onehot = st["layout"] == 0
     line_bytes = 64.0 if onehot else 66.0        # bytes layout: a 128-B block and its 4-B checkpoint, one request each
     operand_bytes = k * m + 8 * (k + 1) + 16 * k
-    alg_bytes = requests_per_step * line_bytes + operand_bytes
+    alg_bytes = requests_per_step * line_bytes + 16.0 * lookups_per_step + operand_bytes
+    all_requests = requests_per_step + lookups_per_step      # every one a dependent random request
     ksec = kernel_ms * 1e-3
     achieved = alg_bytes / ksec / 1e9
     resident = "hbm" if st["index_bytes"] > INFINITY_CACHE_BYTES else "infinity-cache"
@@ -435,11 +441,12 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "traffic_source": ("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
                            % traffic[1]) if traffic else "no PMC profile of this workload committed",
         "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_bytes": "%d rank-line requests x %g B + %d operand bytes (patterns, offsets, intervals)"
-                             % (requests_per_step, line_bytes, operand_bytes),
+        "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d operand bytes (patterns, "
+                             "offsets, intervals)" % (requests_per_step, line_bytes, lookups_per_step, operand_bytes),
         "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
-        "requests_per_launch": requests_per_step, "rank_queries_per_launch": ranks_per_step,
-        "rank_queries_per_request": ranks_per_step / max(requests_per_step, 1),
+        "requests_per_launch": all_requests, "rank_line_requests": requests_per_step, "ktab_lookups": lookups_per_step,
+        "ktab_k": int(s1["ktab_k"]), "rank_queries_per_launch": ranks_per_step,
+        "rank_queries_per_request": ranks_per_step / max(all_requests, 1),
         # SURVEY 8d's own pricing (its structure fetches 128/132 B per rank query; this layout does not): reported
         # for comparison only, it is not a fraction of anything
         "survey_equiv_GBps": ranks_per_step * survey_bytes_per_rank(sigma) / ksec / 1e9,
@@ -447,7 +454,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     }
     if resident == "hbm":
         # the limit that binds this access pattern: distinct dependent memory requests per second
-        roof["requests_G_per_s"] = requests_per_step / ksec / 1e9
+        roof["requests_G_per_s"] = all_requests / ksec / 1e9
         roof["request_ceiling_G_per_s"] = REQUEST_CEILING_G_PER_S
         roof["request_frac"] = roof["requests_G_per_s"] / REQUEST_CEILING_G_PER_S
     else:
@@ -575,7 +582,7 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     # own counters: 64 B per rank-line request, 32 B per state record loaded, 24 B per work-queue entry read or
     # appended, 24 B per result written.
     line_bytes = 64.0 if st["layout"] == 0 else 66.0
-    alg_bytes = (s1["frontier_requests"] * line_bytes + 32.0 * s1["frontier_records"] +
+    alg_bytes = (s1["frontier_requests"] * line_bytes + 16.0 * s1["ktab_lookups"] + 32.0 * s1["frontier_records"] +
                  24.0 * (s1["frontier_queue_reads"] + s1["frontier_queue_writes"]) + 24.0 * s1["frontier_results"])
     ksec = kernel_ms * 1e-3
     achieved = alg_bytes / ksec / 1e9
@@ -588,15 +595,19 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         "traffic_source": ("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
                            % traffic[1]) if traffic else "no PMC profile of this workload committed",
         "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_bytes": "%d rank-line requests x %g B + %d state records x 32 B + (%d + %d) queue entries x 24 B "
-                             "+ %d results x 24 B" % (s1["frontier_requests"], line_bytes, s1["frontier_records"],
+        "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d state records x 32 B + "
+                             "(%d + %d) queue entries x 24 B + %d results x 24 B"
+                             % (s1["frontier_requests"], line_bytes, s1["ktab_lookups"], s1["frontier_records"],
                                                       s1["frontier_queue_reads"], s1["frontier_queue_writes"],
                                                       s1["frontier_results"]),
         "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
-        "requests_per_launch": int(s1["frontier_requests"]), "rank_queries_per_launch": ranks_per_step,
-        "requests_G_per_s": s1["frontier_requests"] / ksec / 1e9,
+        "requests_per_launch": int(s1["frontier_requests"] + s1["ktab_lookups"] + s1["frontier_records"]),
+        "rank_line_requests": int(s1["frontier_requests"]), "ktab_lookups": int(s1["ktab_lookups"]),
+        "state_records": int(s1["frontier_records"]), "ktab_k": int(s1["ktab_k"]),
+        "rank_queries_per_launch": ranks_per_step,
+        "requests_G_per_s": (s1["frontier_requests"] + s1["ktab_lookups"] + s1["frontier_records"]) / ksec / 1e9,
         "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S,
-        "request_frac": s1["frontier_requests"] / ksec / 1e9 / REQUEST_CEILING_G_PER_S,
+        "request_frac": (s1["frontier_requests"] + s1["ktab_lookups"] + s1["frontier_records"]) / ksec / 1e9 / REQUEST_CEILING_G_PER_S,
         "device_rank_queries_G_per_s": ranks_per_step / ksec / 1e9,
     }
     out = {

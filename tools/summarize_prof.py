@@ -63,8 +63,15 @@ occ_key = next((k for k, c in agg if c == "FETCH_SIZE" and "k_occ" in k), None)
 bytes_per_kib = 1024.0            # uncalibrated: FETCH_SIZE taken at face value
 if calib_bytes and occ_key:
     bytes_per_kib = calib_bytes / mean(occ_key, "FETCH_SIZE")
+calls = None          # regex workloads: one fmx_regex_batch_match = several k_frontier dispatches
+for f in glob.glob(os.path.join(src, "*.log")):
+    m = re.search(r"frontier: (\d+) calls;", open(f, errors="replace").read())
+    if m:
+        calls = int(m.group(1)) + 2          # prof_workload.py makes two untimed calls first
 with open(dst + "_counters.csv", "a", newline="") as fo:
     csv.writer(fo).writerow(["(calibration)", "FETCH_BYTES_PER_KIB", 1, "%.6g" % bytes_per_kib])
+    if calls:
+        csv.writer(fo).writerow(["(workload)", "CALLS", 1, calls])
 
 
 with open(dst + "_summary.md", "w") as fo:

@@ -262,14 +262,16 @@ class RegexBatch:
         reference's list order."""
         lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_REFERENCE if mode == "reference" else _lib.FMX_MATCH_FRONTIER,
                               int(max_frontier), int(maxBranching), int(maxIterations))
-        out = np.empty(cap, dtype=RESULT_DTYPE)
+        if getattr(self, "_out", None) is None or self._out.size < cap:
+            self._out = np.empty(cap, dtype=RESULT_DTYPE)      # kept between calls: fresh pages fault on every copy-in
+        out = self._out
         per = np.zeros(max(self.k, 1), dtype=np.uint32)
         n_out = ctypes.c_size_t()
         rc = _lib.check(self._L.fmx_regex_batch_match(self.sa.handle, self._h, ctypes.byref(lim),
                                                       out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n_out),
                                                       per.ctypes.data_as(ctypes.c_void_p)))
         self.truncated = rc == _lib.FMX_TRUNCATED
-        return out[: n_out.value], per[: self.k]
+        return out[: n_out.value].copy(), per[: self.k]
 
 
 class RegexBatchMulti:

@@ -43,7 +43,11 @@
 
 namespace fmx {
 
-constexpr int kFThreads = 256;
+#ifndef FMX_FTHREADS
+#define FMX_FTHREADS 256
+#endif
+constexpr int kFThreads = FMX_FTHREADS;      // threads of a frontier workgroup
+constexpr int kFScale = 256 / kFThreads;     // grids are stated in units of 256 threads
 
 struct Queue {           // SoA work queue in HBM
   uint32_t *state;       // global state id
@@ -117,6 +121,12 @@ constexpr uint32_t kResStage = 32;      // results a wave collects in LDS before
 struct ResStage {
   fmx_result r[kResStage];
 };
+#ifdef FMX_WAVELOG
+// Diagnostic build only (tools/wave_timeline.py): per launch and wave {start, first round, end, rounds} in the
+// constant 100 MHz clock, so that the occupancy of the wave slots over a launch can be drawn.
+constexpr uint32_t kLogPasses = 16, kLogWaves = 1u << 15;
+__device__ unsigned long long g_wavelog[kLogPasses][kLogWaves][4];
+#endif
 __device__ __forceinline__ void pool_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -134,6 +144,10 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
   constexpr uint32_t P = 64 / G;             // lane groups per wave = entries per input batch
   // After a queue overflow the appended count exceeds what was stored: later passes of the chain
   // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
+#ifdef FMX_WAVELOG
+  const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long wl_t1 = 0;
+#endif
   if (ctl->overflow & 1ull) return;
   const uint32_t pass = ctl->pass_base + j;
   const Queue &cur = (pass & 1u) ? qb : qa;
@@ -248,6 +262,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     rs_n = 0;
   };
 
+#ifdef FMX_WAVELOG
+  wl_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (;;) {
     // ---- lane groups without an element take the newest pool entries
     {
@@ -453,6 +470,12 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     }
   }
   flush_results();
+#ifdef FMX_WAVELOG
+  if (lane == 0 && pass < kLogPasses && w < kLogWaves) {
+    unsigned long long *e = g_wavelog[pass][w];
+    e[0] = wl_t0; e[1] = wl_t1; e[2] = __builtin_amdgcn_s_memrealtime(); e[3] = rounds | (wave_sum(lead ? (unsigned long long)stepped : 0ull) << 32);
+  }
+#endif
   if (trunc) atomicOr(&ctl->truncated, 1ull);
   counters_add(counters, lead ? 2ull * stepped : 0ull, lead ? stepped : 0u, 0);
   counters_add_frontier(counters, fs.reqs, lane == 0 ? fs.writes : 0u, lane == 0 ? fs.emits : 0u, lead ? stepped : 0u,
@@ -910,7 +933,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // workgroups per CU in the full grid: twice what is resident at once (5 per CU at 96 registers), so that the
   // dispatcher fills the slots of waves whose share ran out early (measured on C4: 5 -> 0.72 ms, 10 -> 0.67, 20 -> 0.71)
   static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : 10;
-  const int grid_full = h->cu_count * per_cu;
+  const int grid_full = h->cu_count * per_cu * kFScale;
   const uint32_t group_lanes = h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G;
   const uint64_t per_wg = (uint64_t)kFThreads / group_lanes;      // elements a workgroup holds at once
   std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());
@@ -935,14 +958,21 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // full grid's when most of them find nothing to do.  A wave hands its leftovers to the next launch after
   // kRounds rounds, so even a search that starts from one element spreads over the grid within a few launches.
   static const bool use_graph = !(getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) == 0);
-  const int grid_small = 64;
+  // experiments: rounds per launch of a chain as a comma list (the last entry repeats)
+  static const std::vector<uint32_t> plan = [] {
+    std::vector<uint32_t> v;
+    if (const char *e = getenv("FMX_FRONTIER_PLAN"))
+      for (const char *p = e; *p;) { v.push_back((uint32_t)std::max(1l, strtol(p, const_cast<char **>(&p), 10))); if (*p == ',') p++; else break; }
+    return v;
+  }();
+  const int grid_small = 64 * kFScale;
   // the small grid's chain is short: a launch that finds nothing to do still costs ~3 us
   const uint32_t kChainSmall = std::min<uint32_t>(kChain, 5u);
   auto enqueue_chain = [&](hipStream_t s, int grid) -> hipError_t {
     // the first passes hand over early and often (the frontier is wide and must spread); the later ones find the
     // thin, deep end of the search and work it off in long stretches
     const uint32_t len = grid == grid_small ? kChainSmall : kChain;
-    for (uint32_t j = 0; j < len; j++) launch_pass(s, grid, j, j < (len + 1) / 2 ? kRounds : 4 * kRounds);
+    for (uint32_t j = 0; j < len; j++) launch_pass(s, grid, j, plan.empty() ? (j < (len + 1) / 2 ? kRounds : 4 * kRounds) : plan[std::min<size_t>(j, plan.size() - 1)]);
     k_pass_advance<<<1, 1, 0, s>>>(d_ctl, len);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1100,6 +1130,16 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
 using namespace fmx;
 
 extern "C" {
+#ifdef FMX_WAVELOG
+int fmx_debug_wavelog(void *out, size_t bytes, int clear) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wavelog), std::min(bytes, sizeof g_wavelog)) != hipSuccess) return FMX_ERR_HIP;
+  if (clear) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wavelog)) != hipSuccess || hipMemset(p, 0, sizeof g_wavelog) != hipSuccess) return FMX_ERR_HIP;
+  }
+  return FMX_OK;
+}
+#endif
 
 int fmx_regex_compile(const char *re, int line_only, fmx_regex **out) {
   if (!re || !out) { set_error("null argument"); return FMX_ERR_ARG; }

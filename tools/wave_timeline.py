@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Occupancy of the wave slots over the launches of one C4 match (diagnostic build -DFMX_WAVELOG):
+    tools/build_variant.sh wl -DFMX_WAVELOG && FMX_LIB=findex_amd/lib/variants/libfmx_wl.so python tools/wave_timeline.py
+Prints, per launch: waves that had a share, their rounds (mean / max), start-up and run times, and how many waves were
+resident at tenths of the launch's span."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench, findex_amd
+from findex_amd import _lib
+wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
+log2n, k, seed, max_len = bench.REGEX[wl]
+n = 1 << log2n
+dev = torch.device("cuda", 0)
+bwt, eof = bench.make_bwt(torch, n, bench.C4_ALPHABET, seed, dev); torch.cuda.synchronize()
+hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None)
+del bwt
+res, trees = bench.make_regexes(k, seed * 1000)
+from findex_amd.regex import RegexBatch
+rb = RegexBatch(hip, trees)
+for _ in range(4):
+    rb.match_raw(max_steps=max_len)
+L = _lib.load()
+L.fmx_debug_wavelog.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+L.fmx_debug_wavelog(None, 0, 1)
+rb.match_raw(max_steps=max_len)
+log = np.zeros((16, 1 << 15, 4), dtype=np.uint64)
+assert L.fmx_debug_wavelog(log.ctypes.data_as(ctypes.c_void_p), log.nbytes, 0) == 0
+print("kernel ms of the logged call: %.3f" % hip.last_kernel_ms())
+T = 0.01   # us per tick (100 MHz)
+g0 = None
+for p in range(16):
+    e = log[p]
+    m = e[:, 2] != 0
+    if not m.any():
+        continue
+    t0, t1, t2 = e[m, 0].astype(np.int64), e[m, 1].astype(np.int64), e[m, 2].astype(np.int64)
+    rounds = (e[m, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    steps = (e[m, 3] >> np.uint64(32)).astype(np.int64)
+    lo, hi = t0.min(), t2.max()
+    if g0 is None:
+        g0 = lo
+    span = (hi - lo) * T
+    busy = ((t2 - t0) * T).sum()
+    print("pass %2d: start %7.1f us span %6.1f us | %5d waves, rounds mean %.1f max %d, steps %d | start-up %.1f us, in rounds %.1f us mean (%.2f us/round), resident wave-time %.0f us = %.0f%% of 5120 slots"
+          % (p, (lo - g0) * T, span, m.sum(), rounds.mean(), rounds.max(), steps.sum(), ((t1 - t0) * T).mean(), ((t2 - t1) * T).mean(),
+             ((t2 - t1) * T).sum() / max(1, rounds.sum()), busy, 100 * busy / (5120 * span)))
+    occ = []
+    for q in range(10):
+        t = lo + (hi - lo) * (q + 0.5) / 10
+        occ.append(int(((t0 <= t) & (t2 > t)).sum()))
+    print("         resident waves at tenths of the span:", occ)

@@ -24,7 +24,10 @@ for _ in range(4):
 L = _lib.load()
 L.fmx_debug_wavelog.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 L.fmx_debug_wavelog(None, 0, 1)
+hip.stats_reset()
 rb.match_raw(max_steps=max_len)
+st = hip.stats()
+print({k: v for k, v in st.items() if k.startswith("frontier") or k in ("launches", "backward_steps", "ktab_lookups")})
 log = np.zeros((16, 1 << 15, 4), dtype=np.uint64)
 assert L.fmx_debug_wavelog(log.ctypes.data_as(ctypes.c_void_p), log.nbytes, 0) == 0
 print("kernel ms of the logged call: %.3f" % hip.last_kernel_ms())

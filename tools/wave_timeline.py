@@ -32,6 +32,7 @@ log = np.zeros((16, 1 << 15, 4), dtype=np.uint64)
 assert L.fmx_debug_wavelog(log.ctypes.data_as(ctypes.c_void_p), log.nbytes, 0) == 0
 print("kernel ms of the logged call: %.3f" % hip.last_kernel_ms())
 T = 0.01   # us per tick (100 MHz)
+SLOTS = int(os.environ.get("SLOTS", "4096"))
 g0 = None
 for p in range(16):
     e = log[p]
@@ -46,11 +47,16 @@ for p in range(16):
         g0 = lo
     span = (hi - lo) * T
     busy = ((t2 - t0) * T).sum()
-    print("pass %2d: start %7.1f us span %6.1f us | %5d waves, rounds mean %.1f max %d, steps %d | start-up %.1f us, in rounds %.1f us mean (%.2f us/round), resident wave-time %.0f us = %.0f%% of 5120 slots"
+    print("pass %2d: start %7.1f us span %6.1f us | %5d waves, rounds mean %.1f max %d, steps %d | start-up %.1f us, in rounds %.1f us mean (%.2f us/round), resident wave-time %.0f us = %.0f%% of %d slots"
           % (p, (lo - g0) * T, span, m.sum(), rounds.mean(), rounds.max(), steps.sum(), ((t1 - t0) * T).mean(), ((t2 - t1) * T).mean(),
-             ((t2 - t1) * T).sum() / max(1, rounds.sum()), busy, 100 * busy / (5120 * span)))
+             ((t2 - t1) * T).sum() / max(1, rounds.sum()), busy, 100 * busy / (SLOTS * span), SLOTS))
     occ = []
     for q in range(10):
         t = lo + (hi - lo) * (q + 0.5) / 10
         occ.append(int(((t0 <= t) & (t2 > t)).sum()))
     print("         resident waves at tenths of the span:", occ)
+    late = np.argsort(t2)[-6:]
+    print("         last waves to end (start us, first round us, end us, rounds, steps):",
+          [(round((t0[i] - lo) * T, 1), round((t1[i] - lo) * T, 1), round((t2[i] - lo) * T, 1), int(rounds[i]), int(steps[i])) for i in late])
+    hist = np.bincount(np.minimum(rounds, 20), minlength=21)
+    print("         waves by rounds (0..20+):", hist.tolist())

@@ -540,7 +540,7 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     from findex_amd.distributed import gather_results
 
     def step():
-        r, per_regex = batch.match_raw(max_steps=max_len, cap=cap)
+        r, per_regex = batch.match_raw(max_steps=max_len, cap=cap, copy=False)     # views of the batch's pinned buffers
         if use_dist:        # the path's one exchange: every rank receives every rank's result list
             gather_results(r, device)
         return r, per_regex

@@ -504,9 +504,22 @@ __global__ __launch_bounds__(kFThreads, 4) void k_frontier_bytes(DevIndex ix, KT
   frontier_pass<true, kLayoutBytes>(ix, kt, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
 }
 
-// Closes a chain of launches: the next chain starts `by` passes further.
-__global__ void k_pass_advance(FrontierCtl *__restrict__ ctl, uint32_t by) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->pass_base += by;
+// What the host reads after a chain of launches: 32 bytes, not the 40 KB of counters.
+struct FrontierSummary {
+  unsigned long long queued;       // entries in the next launch's input queue
+  unsigned long long results;
+  unsigned long long overflow;
+  unsigned long long truncated;
+};
+// Closes a chain of launches (one wave, lane = slice): the next chain starts `by` passes further.
+__global__ __launch_bounds__(64) void k_pass_advance(FrontierCtl *__restrict__ ctl, uint32_t by, FrontierSummary *__restrict__ sum) {
+  const uint32_t pass = ctl->pass_base + by;
+  const unsigned long long queued = wave_sum(ctl->count[pass % 3][threadIdx.x].v);
+  const unsigned long long results = wave_sum(ctl->res_count[threadIdx.x].v);
+  if (threadIdx.x == 0) {
+    ctl->pass_base = pass;
+    sum->queued = queued; sum->results = results; sum->overflow = ctl->overflow; sum->truncated = ctl->truncated;
+  }
 }
 
 // result groups the device leaves to the host (k_res_sort)
@@ -551,6 +564,28 @@ __global__ void k_res_totals(const uint32_t *__restrict__ start, uint32_t k, con
   if (blockIdx.x == 0 && threadIdx.x == 0) { out->n_results = start[k]; out->n_big = big->n_host ? big->n : 0u; }
 }
 
+// Where the grouped results go when the caller's buffers are page-locked (fmx_host_alloc): the device writes them
+// there itself, behind the grouping and before the host's one synchronisation.  The struct lives in pinned host
+// memory; the host fills it before it starts the launches (null pointers: the host copies after the synchronisation).
+struct ExportDst {
+  fmx_result *out;
+  unsigned long long cap;
+  uint32_t *per;
+};
+__global__ __launch_bounds__(256) void k_res_export(const fmx_result *__restrict__ res, const uint32_t *__restrict__ start, uint32_t k,
+                                                     const uint32_t *__restrict__ rcnt, const ExportDst *__restrict__ dst) {
+  const ExportDst d = *dst;
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+  if (d.out) {
+    const uint64_t n = start[k] < d.cap ? start[k] : d.cap;
+    const uint2 *src = reinterpret_cast<const uint2 *>(res);       // 24-byte results as three 8-byte words
+    uint2 *out = reinterpret_cast<uint2 *>(d.out);
+    for (uint64_t i = tid; i < 3 * n; i += nth) out[i] = src[i];
+  }
+  if (d.per)
+    for (uint64_t i = tid; i < k; i += nth) d.per[i] = rcnt[i];
+}
+
 // A batch of compiled regexes made resident on one device: concatenated Glushkov tables plus
 // the level-0 frontier (root.firsts x (0, 0, n), retree.scala:576).  Reusable across calls.
 struct RegexBatch {
@@ -571,10 +606,10 @@ struct RegexBatch {
   uint32_t *d_rcnt = nullptr, *d_rstart = nullptr, *d_rfill = nullptr;   // per-regex result counts / offsets
   uint32_t *d_rpart = nullptr;         // chunk totals of the offsets' scan
   BigGroups *d_big = nullptr;
-  FrontierCtl *h_ctl = nullptr;        // pinned host copy the chain's last node fills
+  FrontierSummary *d_sum = nullptr, *h_sum = nullptr;   // what a chain reports / its pinned host copy
+  ExportDst *h_dst = nullptr;          // pinned: where k_res_export writes (set per call)
   hipGraphExec_t chain_exec = nullptr; // one chain of launches + advance + counter copy, captured once (full grid)
   hipGraphExec_t chain_small_exec = nullptr;   // the same on the small grid
-  hipGraphExec_t group_exec = nullptr; // the result grouping behind a chain (count, scan, scatter, sort, totals)
   GroupTotals *d_tot = nullptr, *h_tot = nullptr;   // device copy / pinned host copy of the grouping's totals
   uint32_t chain_len = 0, chain_rounds = 0;
   uint32_t matches = 0;                // the chain is captured from a batch's second match on (a one-shot batch
@@ -582,9 +617,9 @@ struct RegexBatch {
   ~RegexBatch() {
     if (chain_exec) (void)hipGraphExecDestroy(chain_exec);
     if (chain_small_exec) (void)hipGraphExecDestroy(chain_small_exec);
-    if (group_exec) (void)hipGraphExecDestroy(group_exec);
     if (h_tot) (void)hipHostFree(h_tot);
-    if (h_ctl) (void)hipHostFree(h_ctl);
+    if (h_sum) (void)hipHostFree(h_sum);
+    if (h_dst) (void)hipHostFree(h_dst);
   }
   uint64_t qcap = 0;
   size_t rcap = 0;
@@ -884,10 +919,11 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if (!b->scratch || b->qcap != qcap || b->rcap < (cap ? cap : 1)) {
     b->scratch.reset(new DevMem());
     b->qcap = 0;
-    for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec, &b->group_exec})      // they hold the old pointers
+    for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec})      // they hold the old pointers
       if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
     if (!b->h_tot) HIP_TRY(hipHostMalloc((void **)&b->h_tot, sizeof(GroupTotals), hipHostMallocDefault), "hipHostMalloc(totals)");
-    if (!b->h_ctl) HIP_TRY(hipHostMalloc((void **)&b->h_ctl, sizeof(FrontierCtl), hipHostMallocDefault), "hipHostMalloc(ctl)");
+    if (!b->h_sum) HIP_TRY(hipHostMalloc((void **)&b->h_sum, sizeof(FrontierSummary), hipHostMallocDefault), "hipHostMalloc(summary)");
+    if (!b->h_dst) HIP_TRY(hipHostMalloc((void **)&b->h_dst, sizeof(ExportDst), hipHostMallocDefault), "hipHostMalloc(export)");
     const uint64_t seg_cap = (uint64_t)(cap ? cap : 1) / 16 + 1024;
     for (Queue *q : {&b->qa, &b->qb}) {
       HIP_TRY(b->scratch->alloc(&q->state, kSub * sub_cap), "hipMalloc(queue)");
@@ -898,11 +934,16 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     HIP_TRY(b->scratch->alloc(&b->d_res, cap ? cap : 1), "hipMalloc(results)");
     HIP_TRY(b->scratch->alloc(&b->d_res_seg, kSub * seg_cap), "hipMalloc(result slices)");
     HIP_TRY(b->scratch->alloc(&b->d_ctl, 1), "hipMalloc(ctl)");
-    HIP_TRY(b->scratch->alloc(&b->d_rcnt, b->k + 1), "hipMalloc(result counts)");
+    {   // counts, fill cursors and the big-group list in one block: one memset clears what a grouping starts from
+      uint32_t *blk = nullptr;
+      HIP_TRY(b->scratch->alloc(&blk, 2 * (b->k + 1) + (sizeof(BigGroups) + 3) / 4), "hipMalloc(result counts)");
+      b->d_rcnt = blk;
+      b->d_rfill = blk + (b->k + 1);
+      b->d_big = reinterpret_cast<BigGroups *>(blk + 2 * (b->k + 1));
+    }
+    HIP_TRY(b->scratch->alloc(&b->d_sum, 1), "hipMalloc(summary)");
     HIP_TRY(b->scratch->alloc(&b->d_rstart, b->k + 1), "hipMalloc(result offsets)");
-    HIP_TRY(b->scratch->alloc(&b->d_rfill, b->k + 1), "hipMalloc(result fill)");
     HIP_TRY(b->scratch->alloc(&b->d_rpart, (b->k + 1) / kScanChunk + 2), "hipMalloc(scan parts)");
-    HIP_TRY(b->scratch->alloc(&b->d_big, 1), "hipMalloc(big groups)");
     HIP_TRY(b->scratch->alloc(&b->d_tot, 1), "hipMalloc(totals)");
     b->qcap = qcap;
     b->rcap = cap ? cap : 1;
@@ -936,8 +977,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   const int grid_full = h->cu_count * per_cu * kFScale;
   const uint32_t group_lanes = h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G;
   const uint64_t per_wg = (uint64_t)kFThreads / group_lanes;      // elements a workgroup holds at once
-  std::unique_ptr<FrontierCtl> ctl_host(new FrontierCtl());
-  FrontierCtl &ctl = *ctl_host;
+  FrontierSummary sum{};
   uint64_t n_res = 0;
   uint32_t pass = 0;
   uint64_t launches = 1;
@@ -973,11 +1013,22 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     // thin, deep end of the search and work it off in long stretches
     const uint32_t len = grid == grid_small ? kChainSmall : kChain;
     for (uint32_t j = 0; j < len; j++) launch_pass(s, grid, j, plan.empty() ? (j < (len + 1) / 2 ? kRounds : 4 * kRounds) : plan[std::min<size_t>(j, plan.size() - 1)]);
-    k_pass_advance<<<1, 1, 0, s>>>(d_ctl, len);
+    k_pass_advance<<<1, 64, 0, s>>>(d_ctl, len, b->d_sum);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return hipMemcpyAsync(b->h_ctl, d_ctl, sizeof(FrontierCtl), hipMemcpyDeviceToHost, s);
+    return hipMemcpyAsync(b->h_sum, b->d_sum, sizeof(FrontierSummary), hipMemcpyDeviceToHost, s);
   };
+  // page-locked caller buffers are written by the device itself (k_res_export, the last launch of the grouping)
+  auto pinned = [](const void *p) {
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+  };
+  const bool export_out = cap && pinned(out) && pinned(out + (cap - 1));
+  const bool export_per = per_regex_count && b->k && pinned(per_regex_count) && pinned(per_regex_count + (b->k - 1));
+  b->h_dst->out = export_out ? out : nullptr;
+  b->h_dst->cap = cap;
+  b->h_dst->per = export_per ? per_regex_count : nullptr;
   b->matches++;
   uint64_t total = b->n_first;               // elements in the input queue of the next pass
   const uint64_t kSmallTotal = (uint64_t)grid_small * per_wg;
@@ -994,9 +1045,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // scratch, so this is a captured graph as well.
   const size_t rcap = b->rcap;
   auto enqueue_group = [&](hipStream_t s) -> hipError_t {
-    hipError_t e = hipMemsetAsync(b->d_rcnt, 0, (b->k + 1) * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(b->d_rfill, 0, (b->k + 1) * 4, s);
-    if (e == hipSuccess) e = hipMemsetAsync(b->d_big, 0, 8, s);
+    hipError_t e = hipMemsetAsync(b->d_rcnt, 0, 2 * (b->k + 1) * 4 + 8, s);      // counts, fill cursors, BigGroups{n, n_host}
     if (e != hipSuccess) return e;
     const dim3 rg(8, kSub);
     k_res_count<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rcnt);
@@ -1008,11 +1057,12 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);
     k_res_sort_mid<<<256, 256, 0, s>>>(d_res, b->d_big);
     k_res_totals<<<1, 1, 0, s>>>(b->d_rstart, (uint32_t)b->k, b->d_big, b->d_tot);
+    k_res_export<<<128, 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_rcnt, b->h_dst);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(b->h_tot, b->d_tot, sizeof(GroupTotals), hipMemcpyDeviceToHost, s);
   };
-  auto capture = [&](hipGraphExec_t *exec, int grid) {     // grid 0: the grouping
+  auto capture = [&](hipGraphExec_t *exec, int grid) {     // one graph: the chain of launches, then the grouping
     // one capture at a time in the process: concurrent captures from several host threads (the multi-device entry
     // point matches its slices in parallel) invalidated each other on ROCm 7.2
     static std::mutex capture_mu;
@@ -1020,7 +1070,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
     if (e == hipSuccess) {
-      const hipError_t e1 = grid ? enqueue_chain(st, grid) : enqueue_group(st);
+      hipError_t e1 = enqueue_chain(st, grid);
+      if (e1 == hipSuccess) e1 = enqueue_group(st);
       const hipError_t e2 = hipStreamEndCapture(st, &g);
       e = e1 != hipSuccess ? e1 : e2;
     }
@@ -1034,26 +1085,25 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     const int grid = small ? grid_small : grid_full;
     // the graphs are captured from a batch's second match on (a one-shot batch would pay the capture and never replay it)
     if (use_graph && b->matches >= 2 && !*exec) capture(exec, grid);
-    if (use_graph && b->matches >= 2 && !b->group_exec) capture(&b->group_exec, 0);
-    if (*exec) HIP_TRY(hipGraphLaunch(*exec, st), "hipGraphLaunch(launch chain)");
-    else HIP_TRY(enqueue_chain(st, grid), "k_frontier chain");
-    if (b->group_exec) HIP_TRY(hipGraphLaunch(b->group_exec, st), "hipGraphLaunch(result grouping)");
-    else HIP_TRY(enqueue_group(st), "result grouping kernels");
+    if (*exec) HIP_TRY(hipGraphLaunch(*exec, st), "hipGraphLaunch(launch chain + grouping)");
+    else {
+      HIP_TRY(enqueue_chain(st, grid), "k_frontier chain");
+      HIP_TRY(enqueue_group(st), "result grouping kernels");
+    }
     HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
     const uint32_t done = small ? kChainSmall : kChain;
-    launches += done + 1 + 9;
+    launches += done + 1 + 10;
     HIP_TRY(hipStreamSynchronize(st), "sync(passes)");
-    std::memcpy(&ctl, b->h_ctl, sizeof ctl);
+    sum = *b->h_sum;
     pass += done;
-    if (ctl.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
-    total = 0;
-    n_res = 0;
-    for (uint32_t j = 0; j < kSub; j++) { total += ctl.count[pass % 3][j].v; n_res += ctl.res_count[j].v; }
+    if (sum.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
+    total = sum.queued;
+    n_res = sum.results;
     alive = total != 0;
-    truncated = ctl.truncated != 0;
+    truncated = sum.truncated != 0;
     if (trace)
       fprintf(stderr, "[fmx] frontier after pass %u: queue %llu, results %llu, overflow %llu\n", pass,
-              (unsigned long long)total, (unsigned long long)n_res, ctl.overflow);
+              (unsigned long long)total, (unsigned long long)n_res, sum.overflow);
   }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
@@ -1067,8 +1117,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   struct { unsigned long long res_count; } tot{n_res};
   const size_t extra = b->start_final.size();
   *n_out = (size_t)tot.res_count + extra;
-  if ((ctl.overflow & 2ull) || tot.res_count + extra > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
-  if (tot.res_count)
+  if ((sum.overflow & 2ull) || tot.res_count + extra > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
+  if (tot.res_count && !export_out)
     HIP_TRY(copy_sync(out, d_res, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost, st), "D2H(results)");
   mark("results copied");
   for (size_t j = 0; j < extra; j++) {           // dfa.scala:270-273 with the start StatePoint(0,0,0,n)
@@ -1100,7 +1150,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
         }
       }
       mark("large groups");
-      if (per_regex_count && ndev)
+      if (per_regex_count && ndev && !export_per)
         HIP_TRY(copy_sync(per_regex_count, b->d_rcnt, b->k * 4, hipMemcpyDeviceToHost, st), "D2H(result counts)");
     } else {
       // host-made results to merge in (or too many large groups to list): bucket everything by regex id
@@ -1272,7 +1322,8 @@ struct RegexBatchMulti {
   std::vector<size_t> cut;       // n_idx + 1 slice bounds
   // per-slice result buffers, kept between calls and never value-initialised (a fresh zeroed 100 MB vector per
   // slice and call cost 25 ms)
-  std::vector<std::unique_ptr<fmx_result[]>> buf;
+  struct PinnedFree { void operator()(fmx_result *p) const { if (p) (void)hipHostFree(p); } };
+  std::vector<std::unique_ptr<fmx_result[], PinnedFree>> buf;      // page-locked: the device writes a slice's results itself
   std::vector<size_t> buf_cap;
   ~RegexBatchMulti() {
     for (size_t r = 0; r < part.size(); r++)
@@ -1335,8 +1386,14 @@ int fmx_regex_batch_match_multi(fmx_regex_batch_multi *mb, const fmx_limits *lim
   m->buf_cap.resize(np, 0);
   for (size_t r = 0; r < np; r++)
     if (m->cut[r] != m->cut[r + 1] && m->buf_cap[r] < (cap ? cap : 1)) {
-      m->buf[r].reset(new (std::nothrow) fmx_result[cap ? cap : 1]);
-      if (!m->buf[r]) { set_error("out of host memory"); return FMX_ERR_NOMEM; }
+      void *p = nullptr;
+      m->buf[r].reset();
+      if (hipSetDevice(m->idx[r]->device) != hipSuccess || hipHostMalloc(&p, (cap ? cap : 1) * sizeof(fmx_result), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("out of page-locked host memory");
+        return FMX_ERR_NOMEM;
+      }
+      m->buf[r].reset(static_cast<fmx_result *>(p));
       m->buf_cap[r] = cap ? cap : 1;
     }
   std::vector<size_t> cnt(np, 0);

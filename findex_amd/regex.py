@@ -256,22 +256,28 @@ class RegexBatch:
         except Exception:
             pass
 
-    def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22, mode="frontier", maxBranching=1024, maxIterations=1000):
+    def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22, mode="frontier", maxBranching=1024, maxIterations=1000,
+                  copy=True):
         """-> (results as a structured array, per-regex counts).  mode="frontier": every match, sorted by
         (regex, len, sp, ep); mode="reference": ReTree._matchSA's own queue and limits, per regex in the
-        reference's list order."""
+        reference's list order.  The library writes into page-locked buffers the batch keeps between calls
+        (fmx_host_alloc: the device copies straight into them); copy=False returns views of those buffers, valid
+        until the next match on this batch -- the serving loop's form: a fresh 1.2 MB array per call costs more in
+        page faults than the copy itself."""
+        from .searcher import PinnedArray
         lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_REFERENCE if mode == "reference" else _lib.FMX_MATCH_FRONTIER,
                               int(max_frontier), int(maxBranching), int(maxIterations))
-        if getattr(self, "_out", None) is None or self._out.size < cap:
-            self._out = np.empty(cap, dtype=RESULT_DTYPE)      # kept between calls: fresh pages fault on every copy-in
-        out = self._out
-        per = np.zeros(max(self.k, 1), dtype=np.uint32)
+        if getattr(self, "_out", None) is None or self._out.array.size < cap:
+            self._out = PinnedArray((cap,), RESULT_DTYPE)
+            self._per = PinnedArray((max(self.k, 1),), np.uint32)
+            self._out_p = self._out.array.ctypes.data_as(ctypes.c_void_p)
+            self._per_p = self._per.array.ctypes.data_as(ctypes.c_void_p)
         n_out = ctypes.c_size_t()
-        rc = _lib.check(self._L.fmx_regex_batch_match(self.sa.handle, self._h, ctypes.byref(lim),
-                                                      out.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n_out),
-                                                      per.ctypes.data_as(ctypes.c_void_p)))
+        rc = _lib.check(self._L.fmx_regex_batch_match(self.sa.handle, self._h, ctypes.byref(lim), self._out_p, cap,
+                                                      ctypes.byref(n_out), self._per_p))
         self.truncated = rc == _lib.FMX_TRUNCATED
-        return out[: n_out.value].copy(), per[: self.k]
+        out, per = self._out.array[: n_out.value], self._per.array[: self.k]
+        return (out.copy(), per.copy()) if copy else (out, per)
 
 
 class RegexBatchMulti:

@@ -616,8 +616,17 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc || !k) return rc;
-  for (size_t q = 0; q < k; q++)
-    if (off[q + 1] < off[q]) return arg_fail("pattern offsets must be non-decreasing");
+  // Offsets must be non-decreasing (a kernel would read a "negative" pattern as 2^64 bytes).  Walking a million of
+  // them on the host takes 0.37 ms -- a quarter of a large call -- so large batches are checked where it is free:
+  // chunk by chunk on the host while the uploads run (page-locked buffers), or by a kernel on the uploaded copy.
+  constexpr size_t kPipelineMin = 128u << 10;     // patterns
+  auto monotonic = [&](size_t a, size_t b) {      // off[a] <= off[a+1] <= .. <= off[b]
+    unsigned bad = 0;
+    for (size_t q = a; q < b; q++) bad |= off[q + 1] < off[q];
+    return bad == 0;
+  };
+  if (k < kPipelineMin && !monotonic(0, k)) return arg_fail("pattern offsets must be non-decreasing");
+  if (off[k] < off[0]) return arg_fail("pattern offsets must be non-decreasing");
   const uint64_t lo = off[0], total = off[k] - off[0];
   if (total && !pat) return arg_fail("pat is null");
   // offsets are rebased so that only the bytes in use travel
@@ -633,7 +642,6 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
   // chunk j's bytes and offsets go up, are searched and come back on stream j % 2, so the copies of one chunk run
   // beside the kernel of another and both directions of the link are busy.  Offsets stay absolute: every chunk is
   // copied to its own place of one device image of the batch.
-  constexpr size_t kPipelineMin = 128u << 10;     // patterns
   if (k < kPipelineMin) {
     const HostIn ins[] = {{total ? pat + lo : nullptr, (size_t)total}, {offp, (k + 1) * 8}};
     const HostOut outs[] = {{sp, k * 8}, {ep, k * 8}};
@@ -659,6 +667,9 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
     // link speed.  So: whole arrays up, one kernel, whole arrays down.
     if (total) HIP_TRY(hipMemcpy(d_pat.p, pat + lo, (size_t)total, hipMemcpyHostToDevice), "H2D(patterns)");
     HIP_TRY(hipMemcpy(d_off.p, offp, (k + 1) * 8, hipMemcpyHostToDevice), "H2D(offsets)");
+    bool ok = true;
+    HIP_TRY(check_offsets(h, d_off.p, k, c0.stream(), &ok), "k_check_offsets");
+    if (!ok) return arg_fail("pattern offsets must be non-decreasing");
     rc = c0.timed([&](hipStream_t st, EventPair &ev) {
       HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
       HIP_TRY(launch_search(h, d_pat.p, d_off.p, d_sp.p, d_ep.p, k, st), "k_search");
@@ -681,6 +692,9 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
   // searches it and sends its intervals back: uploads of later chunks run beside the kernels and downloads of
   // earlier ones
   hipStream_t up = c1.stream(), run = c0.stream();
+  for (size_t j = 0; j <= nchunk; j++)            // the chunks' byte ranges come from these: checked before any copy
+    if (offp[k * j / nchunk] > total || (j && offp[k * j / nchunk] < offp[k * (j - 1) / nchunk]))
+      return arg_fail("pattern offsets must be non-decreasing");
   hipEvent_t *cev = nullptr;
   HIP_TRY(c0.chunk_events(nchunk, &cev), "hipEventCreate");
   HIP_TRY(hipEventRecord(c0.ev_a(), run), "hipEventRecord");
@@ -699,6 +713,11 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
     const size_t a = k * j / nchunk, b = k * (j + 1) / nchunk;
     HIP_TRY(hipStreamWaitEvent(run, cev[j], 0), "hipStreamWaitEvent");
     if (a == b) continue;
+    if (!monotonic(a, b)) {                        // while the uploads are under way
+      (void)hipStreamSynchronize(up);
+      (void)hipStreamSynchronize(run);
+      return arg_fail("pattern offsets must be non-decreasing");
+    }
     HIP_TRY(launch_search(h, d_pat.p, (const uint64_t *)d_off.p + a, (uint64_t *)d_sp.p + a, (uint64_t *)d_ep.p + a, b - a, run),
             "k_search");
     HIP_TRY(hipMemcpyAsync(sp + a, (uint64_t *)d_sp.p + a, (b - a) * 8, hipMemcpyDeviceToHost, run), "D2H(sp)");

@@ -382,6 +382,22 @@ def test_pipelined_host_batch_pageable_and_pinned():
     po.array[:] = off
     hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
     assert np.array_equal(psp.array, wsp) and np.array_equal(pep.array, wep)
+    # a decreasing offset is refused on both paths (large batches are checked beside / behind their uploads, not by a
+    # walk over the offsets before anything starts), and the handle stays usable
+    for q in (k // 3, k // 8):                   # inside a chunk; at a chunk's border
+        bad = off.copy()
+        bad[q] = bad[q + 1] + 1
+        with pytest.raises(findex_amd.FmxError) as e:
+            hip.search_batch(buf, bad)
+        assert e.value.code == 3
+        po.array[:] = bad
+        with pytest.raises(findex_amd.FmxError) as e:
+            hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
+        assert e.value.code == 3
+    po.array[:] = off
+    psp.array[:] = 0
+    hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
+    assert np.array_equal(psp.array, wsp) and np.array_equal(pep.array, wep)
 
 
 def test_concurrent_calls_on_one_handle():

@@ -49,37 +49,63 @@ namespace fmx {
 constexpr int kFThreads = FMX_FTHREADS;      // threads of a frontier workgroup
 constexpr int kFScale = 256 / kFThreads;     // grids are stated in units of 256 threads
 
-struct Queue {           // SoA work queue in HBM
-  uint32_t *state;       // global state id
-  uint32_t *meta;        // len in bits 0..15, the state's byte in bits 16..23
-  uint64_t *sp;
-  uint64_t *ep;
+// The work queue in HBM.  An entry is three 8-byte GRANULES, each written by one aligned agent-scope (write-through)
+// store and carrying the tag of its buffer's current generation in its top 16 bits -- the data is its own "ready"
+// flag (cdna_hip_programming.md, Guideline 16, form R2), so a wave may take entries that another wave appended
+// earlier IN THE SAME LAUNCH: it re-reads a granule until the tag matches.
+//   g0 = tag:16 | byte:8 | sp:40        g1 = tag:16 | 0:8 | ep:40        g2 = tag:16 | len:16 | state:32
+struct FlowQueue {
+  unsigned long long *g0, *g1, *g2;    // kSub slices x 2 buffers x sub_cap entries each
 };
 constexpr uint32_t kMaxLen = 0xFFFFu;
+constexpr uint64_t kMaxRows = 1ull << 40;     // sp / ep fields of a granule
 
-// The queues and the result buffer are cut into kSub slices with one tail counter each, every counter
-// on its own 128-byte line: a single tail cannot take the appends of a whole launch (same-address device
-// atomics complete at ~100 per microsecond).  A wave appends to slice (wave + number of its earlier
-// appends) % kSub, so slices stay balanced even when one wave produces everything; in the next launch
-// slice j is dealt to the waves with id % kSub == j.
+// The queue and the result buffer are cut into kSub slices with their own counters, every slice on its own
+// 128-byte line: a single tail cannot take the appends of a whole launch (same-address device atomics complete at
+// ~100 per microsecond).  A wave appends to slice (wave + number of its earlier appends) % kSub, so slices stay
+// balanced even when one wave produces everything.
+// Every slice has TWO linear buffers.  Appends go to buffer `wsel`; takers empty the other one first.  Between
+// launches (k_frontier_advance) a buffer that has been emptied is rewound -- tail = head = 0, next tag -- and
+// becomes the slice's write buffer, so the memory a search needs follows the frontier's width, not its total work.
 constexpr uint32_t kSub = 64;
+struct alignas(128) SliceCtl {
+  unsigned long long tail[2];      // entries appended (agent-scope atomic adds)
+  unsigned long long head[2];      // entries taken (atomic add on the buffer that is not written; CAS on the other)
+  uint32_t tag[2];                 // generation tag of each buffer: 1..65535, 0 = never written
+  uint32_t wsel;                   // the buffer this launch appends to
+  uint32_t pad_[21];
+};
 struct alignas(128) PaddedCount {
   unsigned long long v;
   unsigned long long pad[15];
 };
+__host__ __device__ inline uint32_t next_tag(uint32_t t) { return t % 0xFFFFu + 1u; }
 
 struct FrontierCtl {     // device-resident counters
-  // Pass p reads count[p % 3], appends to count[(p+1) % 3] and clears count[(p+2) % 3] (its
-  // predecessor's input), so a chain of launches needs no host round trip in between.
-  PaddedCount count[3][kSub];
+  SliceCtl q[kSub];
   PaddedCount res_count[kSub];
-  unsigned long long overflow;     // bit 0: queue, bit 1: results
+  unsigned long long overflow;     // bit 0: queue, bit 1: results, bit 2: an appended entry never became readable
   unsigned long long truncated;    // some element was not expanded because its follows would have len >= max_len
-  // The pass the next launch works on is pass_base + its launch number, so that a chain of launches
-  // can be replayed as one hipGraph with fixed kernel arguments.
-  uint32_t pass_base;
   uint32_t max_len;
+  uint32_t pad_;
+  unsigned long long left;         // entries queued when the launch began (k_frontier_reset / k_frontier_advance): 0 = nothing to do
 };
+struct FrontierSummary { // what the host reads after a chain of launches (k_frontier_advance)
+  unsigned long long left;         // entries still queued
+  unsigned long long results;
+  unsigned long long overflow;
+  unsigned long long truncated;
+};
+
+// Agent-scope relaxed accesses to words other workgroups write during the launch: global_load / global_store with
+// sc1 (they bypass the CU's L1 and are written through; plain accesses could be served from a stale line).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+  return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 struct FStat {           // wave-uniform sums for the frontier counters (fmx_device.h, slots 3..7)
   uint32_t reqs = 0, writes = 0, emits = 0, reads = 0, recs = 0, ktl = 0;
@@ -104,23 +130,11 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
   return x - v;
 }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+  return ((unsigned long long)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
 
-// A wave's pool: a ring of kPoolCap entries in LDS, oldest at `pb`, `pn` entries.  Only the owning wave
-// touches it; the compiler is kept from moving LDS accesses across the hand-over points with
-// wavefront-scope fences (LDS operations of one wave execute in program order).
-constexpr uint32_t kPoolCap = 128;
-constexpr uint32_t kPoolMask = kPoolCap - 1;
 constexpr uint32_t kPoolSmall = 6;      // follow lists with up to this many pushed entries go through the pool
-struct Pool {            // 24 bytes per entry, 3 KiB per wave
-  uint32_t state[kPoolCap];
-  uint32_t meta[kPoolCap];
-  uint64_t sp[kPoolCap];
-  uint64_t ep[kPoolCap];
-};
-constexpr uint32_t kResStage = 32;      // results a wave collects in LDS before it reserves room for them (one atomic per flush)
-struct ResStage {
-  fmx_result r[kResStage];
-};
 #ifdef FMX_WAVELOG
 // Diagnostic build only (tools/wave_timeline.py): per launch and wave {start, first round, end, rounds} in the
 // constant 100 MHz clock, so that the occupancy of the wave slots over a launch can be drawn.
@@ -132,117 +146,218 @@ __device__ __forceinline__ void pool_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// One launch = one pass over the input queue.  `j` is the launch's number in its chain: it works on pass
-// ctl->pass_base + j.  Wave w reads slice w % kSub together with the other waves of that class: its share
-// is the batches part, part + class_waves, ... of P = 64/G entries each.
+// One launch.  Every wave works until it finds nothing more to take (or its round budget ends): it takes entries
+// from the queue, follows them, keeps what they branch into in its pool, and hands pool entries beyond kPoolKeep
+// back to the queue, where waves that have run dry find them during the same launch.  No wave ever waits for
+// another one: a wave that finds the queue empty a few polls in a row simply ends, and whatever is appended after
+// that is the next launch's input.
+#ifndef FMX_FWAVES
+#define FMX_FWAVES 3
+#endif
+#ifndef FMX_FBATCH
+#define FMX_FBATCH 2
+#endif
+#ifndef FMX_POOL_KEEP
+#define FMX_POOL_KEEP 192
+#endif
+#ifndef FMX_GRAB
+#define FMX_GRAB 64
+#endif
+constexpr uint32_t kPoolKeep = FMX_POOL_KEEP;   // pool entries a wave keeps for itself; the older ones go to the queue
+constexpr uint32_t kGrab = FMX_GRAB;            // entries taken from the queue at a time
+#ifndef FMX_IDLE_LOOKS
+#define FMX_IDLE_LOOKS 3
+#endif
+constexpr uint32_t kIdleLooks = FMX_IDLE_LOOKS; // looks that find nothing before a wave without work ends
+constexpr uint32_t kTagLimit = 60000;          // host-side bound on a buffer's generation tag before everything is zeroed
+constexpr uint32_t kTagSpins = 1u << 16;        // re-reads of a reserved entry before the wave gives up (an error)
+constexpr uint32_t kPool64 = 256, kPool64Mask = kPool64 - 1;
+struct Pool64 {          // 24 bytes per entry, 6 KiB per wave
+  uint32_t state[kPool64];
+  uint32_t meta[kPool64];
+  uint64_t sp[kPool64];
+  uint64_t ep[kPool64];
+};
+constexpr uint32_t kRes64 = 64;
+struct ResStage64 {
+  fmx_result r[kRes64];
+};
+struct Xchg {            // a round's intervals on their way to the lane groups and back, by element (= lane) number
+  uint64_t sp[64];
+  uint64_t ep[64];
+  uint32_t key[64];      // slot | byte << 16, 0xFFFFFFFF: this element has no rank query this round
+};
+constexpr uint32_t kNoQuery = 0xFFFFFFFFu;
+
 template <bool WIDE, uint32_t LAYOUT>
-__device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt, const NfaTables &nfa, const Queue &qa, const Queue &qb, uint32_t j,
+__device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt, const NfaTables &nfa, const FlowQueue &fq, uint32_t j,
                                               uint32_t max_rounds, uint64_t sub_cap, fmx_result *__restrict__ res,
                                               uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
                                               unsigned long long *__restrict__ counters) {
   constexpr int G = Lay<LAYOUT>::G;
-  constexpr uint32_t P = 64 / G;             // lane groups per wave = entries per input batch
-  // After a queue overflow the appended count exceeds what was stored: later passes of the chain
-  // must not run (they would read past the queue); the host reports FMX_ERR_OVERFLOW.
+  constexpr uint32_t EPS = 64 / G;           // elements per sub-round
+  constexpr int B = LAYOUT == kLayoutBytes ? 2 : FMX_FBATCH;     // sub-rounds whose lines are requested before any is consumed
 #ifdef FMX_WAVELOG
   const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long wl_t1 = 0;
 #endif
-  if (ctl->overflow & 1ull) return;
-  const uint32_t pass = ctl->pass_base + j;
-  const Queue &cur = (pass & 1u) ? qb : qa;
-  const Queue &nxt = (pass & 1u) ? qa : qb;
-  if (blockIdx.x == 0 && threadIdx.x < kSub) ctl->count[(pass + 2) % 3][threadIdx.x].v = 0;
-  const uint32_t w = (blockIdx.x * kFThreads + threadIdx.x) >> 6;      // this wave
-  const uint32_t nw = gridDim.x * (kFThreads / 64);
-  const uint32_t sub = w % kSub;             // the slice this wave reads
-  const uint32_t part = w / kSub;
-  const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
-  uint64_t cur_count = ctl->count[pass % 3][sub].v;
-  if (cur_count > sub_cap) cur_count = sub_cap;
-  const bool share = (uint64_t)part * ((cur_count + class_waves - 1) / class_waves) < cur_count;
-  if (!__syncthreads_or(share ? 1 : 0)) return;      // a workgroup without work leaves before staging anything
+  const uint32_t lane = __lane_id();
+  const uint32_t w = uni((blockIdx.x * kFThreads + threadIdx.x) >> 6);      // this wave (kept in scalar registers)
+  // After a queue overflow entries are missing: later launches of the chain do nothing (the host reports it).
+  if (ctl->left == 0 || (ctl->overflow & 1ull)) return;      // uniform over the grid
+  // which buffer of a slice is written, and the buffers' tags, do not change during a launch
+  __shared__ uint32_t s_wsel[kSub], s_tags[kSub];            // tags: tag[0] | tag[1] << 16
+  if (threadIdx.x < kSub) {
+    const SliceCtl &q = ctl->q[threadIdx.x];
+    s_wsel[threadIdx.x] = q.wsel;
+    s_tags[threadIdx.x] = q.tag[0] | (q.tag[1] << 16);
+  }
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
-  __shared__ Pool s_pool[kFThreads / 64];
-  __shared__ ResStage s_res[kFThreads / 64];
+  __shared__ Pool64 s_pool[kFThreads / 64];
+  __shared__ ResStage64 s_res[kFThreads / 64];
+  __shared__ Xchg s_xc[kFThreads / 64];
   __shared__ const uint4 *s_lvl[16];         // the k-mer table's levels (picked by an element's length at run time)
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
   if (threadIdx.x < 16) s_lvl[threadIdx.x] = kt.k ? kt.level_dev[threadIdx.x] : nullptr;
   __syncthreads();
-  if (!share) return;                        // wave-uniform; no workgroup barrier below
-  Pool &pl = s_pool[threadIdx.x >> 6];
-  ResStage &rs = s_res[threadIdx.x >> 6];
+  Pool64 &pl = s_pool[threadIdx.x >> 6];
+  ResStage64 &rs = s_res[threadIdx.x >> 6];
+  Xchg &xc = s_xc[threadIdx.x >> 6];
   uint32_t rs_n = 0;                         // wave-uniform
   const LaneConst lc = lane_const<G>();
-  const uint32_t t = lc.t, lane = __lane_id();
-  const bool lead = t == 0;
-  const uint32_t lead_lane = lane & ~(uint32_t)(G - 1);
-  const uint64_t in_off = (uint64_t)sub * sub_cap;
-  PaddedCount *next_count = ctl->count[(pass + 1) % 3];
+  const uint32_t grp = lane / G;             // this lane's group: it serves element r * EPS + grp in sub-round r
   const uint32_t max_len = ctl->max_len;
-  uint32_t pb = 0, pn = 0, appends = 0, rounds = 0;     // wave-uniform
-  // this wave's share of the slice: one contiguous chunk, read up to 64 entries at a time
-  const uint64_t chunk = (cur_count + class_waves - 1) / class_waves;
-  uint64_t a_next = (uint64_t)part * chunk;
-  uint64_t a_end = a_next + chunk;
-  if (a_end > cur_count) a_end = cur_count;
-  bool have = false;                         // the element this lane group holds
+  uint32_t pb = 0, pn = 0, appends = 0, grabs = 0, rounds = 0, idle_looks = 0;     // wave-uniform
+  // This wave's share of what the launch found queued: slice w % kSub's buffer that is not written now is dealt out
+  // evenly to the waves of that class, one contiguous chunk each, read without atomics (nobody else touches it).
+  const uint32_t nw = gridDim.x * (kFThreads / 64);
+  const uint32_t sub = w % kSub, part = w / kSub;
+  const uint32_t class_waves = (nw - sub + kSub - 1) / kSub;
+  const uint32_t in_buf = 1u - s_wsel[sub];
+  const uint64_t in_off = ((uint64_t)sub * 2 + in_buf) * sub_cap;
+  uint64_t a_next, a_end;
+  {
+    const SliceCtl &q = ctl->q[sub];
+    const uint64_t hd = q.head[in_buf], tl = q.tail[in_buf] < sub_cap ? q.tail[in_buf] : sub_cap;
+    const uint64_t cnt = tl > hd ? tl - hd : 0, chunk = (cnt + class_waves - 1) / class_waves;
+    a_next = hd + (uint64_t)part * chunk;
+    a_end = a_next + chunk < tl ? a_next + chunk : tl;
+    if (a_next > a_end) a_next = a_end;
+    a_next = uni64(a_next);
+    a_end = uni64(a_end);
+  }
+  bool have = false;                         // the element this lane holds
   uint32_t state = 0, meta = 0;
   uint64_t sp = 0, ep = 0;
-  // The held element's state record, 8 bytes per lane (lanes 0..3 of the group: {fol_off, cnt_c_emit}, {f0, f1},
-  // {f2, f3}, {fc, regex}): two registers, not eight; its fields are read by broadcast when they are needed.  It
-  // stays in place while the element walks a literal stretch (meta bits 24..31 = states ahead whose records need
-  // not be loaded).
-  uint2 rq8 = make_uint2(0u, 0u);
-  FStat fs;
-  uint32_t stepped = 0, trunc = 0;
+  // the held element's state record; it stays while the element walks a literal stretch (meta bits 24..31)
+  uint4 ra = make_uint4(0, 0, 0, 0);         // fol_off, cnt_c_emit, f[0], f[1]
+  uint4 rb = make_uint4(0, 0, 0, 0);         // f[2], f[3], fc, regex
+  uint32_t n_reqs = 0, n_recs = 0, n_ktl = 0, n_writes = 0, n_emits = 0, n_reads = 0, stepped = 0, trunc = 0;
 
-  // the `cnt` oldest pool entries go to the output queue
+  // room for `cnt` entries in some slice's write buffer: slice, buffer, tag and first index (wave-uniform)
+  struct Slot { uint64_t first; uint32_t tag; unsigned long long at; };
+  auto reserve = [&](uint32_t cnt) -> Slot {
+    const uint32_t so = (w + appends++) % kSub;
+    const uint32_t buf = s_wsel[so];
+    Slot s;
+    s.tag = (s_tags[so] >> (16u * buf)) & 0xFFFFu;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&ctl->q[so].tail[buf], (unsigned long long)cnt);
+    s.at = __shfl(base, 0, 64);
+    s.first = ((uint64_t)so * 2 + buf) * sub_cap;
+    return s;
+  };
+  auto put = [&](const Slot &s, unsigned long long at, uint32_t st, uint32_t mt, uint64_t esp, uint64_t eep) {
+    if (at < sub_cap) {
+      const unsigned long long tg = (unsigned long long)s.tag << 48;
+      const uint64_t i = s.first + at;
+      st_agent(fq.g0 + i, tg | ((unsigned long long)((mt >> 16) & 0xFFu) << 40) | esp);
+      st_agent(fq.g1 + i, tg | eep);
+      st_agent(fq.g2 + i, tg | ((unsigned long long)(mt & 0xFFFFu) << 32) | st);
+    } else {
+      atomicOr(&ctl->overflow, 1ull);
+    }
+  };
+  // the `cnt` oldest pool entries go to the queue
   auto spill = [&](uint32_t cnt) {
     if (!cnt) return;
     pool_sync();
-    const uint32_t so = (w + appends++) % kSub;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&next_count[so].v, (unsigned long long)cnt);
-    base = __shfl(base, 0, 64);
-    const uint64_t out_off = (uint64_t)so * sub_cap;
+    const Slot s = reserve(cnt);
     for (uint32_t i = lane; i < cnt; i += 64) {
-      const uint32_t idx = (pb + i) & kPoolMask;
-      const unsigned long long at = base + i;
-      if (at < sub_cap) {
-        nxt.state[out_off + at] = pl.state[idx];
-        nxt.meta[out_off + at] = pl.meta[idx];
-        nxt.sp[out_off + at] = pl.sp[idx];
-        nxt.ep[out_off + at] = pl.ep[idx];
-      } else {
-        atomicOr(&ctl->overflow, 1ull);
-      }
+      const uint32_t idx = (pb + i) & kPool64Mask;
+      put(s, s.at + i, pl.state[idx], pl.meta[idx], pl.sp[idx], pl.ep[idx]);
     }
     pool_sync();
-    pb = uni((pb + cnt) & kPoolMask);
+    pb = uni((pb + cnt) & kPool64Mask);
     pn = uni(pn - cnt);
-    fs.writes += cnt;
+    n_writes += cnt;
   };
-  // The next entries of the wave's share enter the pool (wave-uniform).  They are asked for only when lane
-  // groups have run dry and the pool cannot feed them: every input entry roots a whole subtree, so this is
-  // rare next to the steps, and the other waves of the SIMD cover its latency.
+  auto to_pool = [&](uint32_t cnt, unsigned long long e0, unsigned long long e1, unsigned long long e2) {
+    if (lane < cnt) {
+      const uint32_t idx = (pb + pn + lane) & kPool64Mask;
+      pl.state[idx] = (uint32_t)e2;
+      pl.meta[idx] = (uint32_t)((e2 >> 32) & 0xFFFFu) | ((uint32_t)((e0 >> 40) & 0xFFu) << 16);
+      pl.sp[idx] = e0 & (kMaxRows - 1);
+      pl.ep[idx] = e1 & (kMaxRows - 1);
+    }
+    pn = uni(pn + cnt);
+    n_reads += cnt;
+    pool_sync();
+  };
+  // The next entries of the wave's share enter the pool (wave-uniform).  They were written before this launch began.
   auto take_batch = [&]() -> bool {
     if (a_next >= a_end) return false;
     const uint64_t left = a_end - a_next;
-    uint32_t room = kPoolCap - P - pn;       // the push phase wants P free entries afterwards
+    uint32_t room = kPool64 - 64u - pn;      // the push phase wants 64 free entries afterwards
     if (room > 64u) room = 64u;
     const uint32_t cnt = left < room ? (uint32_t)left : room;
-    if (lane < cnt) {
-      const uint64_t i = in_off + a_next + lane;
-      const uint32_t idx = (pb + pn + lane) & kPoolMask;
-      pl.state[idx] = cur.state[i]; pl.meta[idx] = cur.meta[i]; pl.sp[idx] = cur.sp[i]; pl.ep[idx] = cur.ep[i];
-    }
-    pn = uni(pn + cnt);
-    fs.reads += cnt;
+    unsigned long long e0 = 0, e1 = 0, e2 = 0;
+    if (lane < cnt) { const uint64_t i = in_off + a_next + lane; e0 = fq.g0[i]; e1 = fq.g1[i]; e2 = fq.g2[i]; }
     a_next += cnt;
-    pool_sync();
+    to_pool(cnt, e0, e1, e2);
     return true;
+  };
+  // A wave with nothing left looks for entries that other waves appended during THIS launch (wave-uniform; returns
+  // how many it took): four slices per look, one round trip -- lanes 0..3 read the written buffer's tail and head of
+  // one slice each -- then a compare-and-swap on the first head that has something below its tail, and the reserved
+  // entries are re-read until they carry the buffer's tag (the wave that reserved them writes them at once).
+  auto steal = [&]() -> uint32_t {
+    const uint32_t s4 = (w + 4u * grabs++) & 63u;
+    unsigned long long tail_w = 0, head_w = 0;
+    if (lane < 4) {
+      const uint32_t sl = (s4 + lane) & 63u;
+      SliceCtl *const q = ctl->q + sl;
+      const uint32_t ws = s_wsel[sl];
+      tail_w = ld_agent(&q->tail[ws]);
+      head_w = ld_agent(&q->head[ws]);
+      if (tail_w > sub_cap) tail_w = sub_cap;          // appends past the capacity were dropped (overflow is flagged)
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(tail_w > head_w);
+    if (!m) return 0;
+    const uint32_t src = (uint32_t)__builtin_ctzll(m);
+    const uint32_t s = (s4 + src) & 63u, ws = s_wsel[s];
+    tail_w = __shfl(tail_w, (int)src, 64);
+    head_w = __shfl(head_w, (int)src, 64);
+    const uint32_t cnt = tail_w - head_w < kGrab ? (uint32_t)(tail_w - head_w) : kGrab;
+    unsigned long long old = 0;
+    if (lane == 0) old = atomicCAS(&ctl->q[s].head[ws], head_w, head_w + cnt);
+    if (uni64(old) != head_w) return 0;                // another wave was faster
+    const unsigned long long tag = (s_tags[s] >> (16u * ws)) & 0xFFFFu;
+    const uint64_t i = ((uint64_t)s * 2 + ws) * sub_cap + head_w + lane;
+    unsigned long long e0 = 0, e1 = 0, e2 = 0;
+    bool ok = true;
+    for (uint32_t spins = 0;; spins++) {
+      if (lane < cnt) {
+        e0 = ld_agent(fq.g0 + i); e1 = ld_agent(fq.g1 + i); e2 = ld_agent(fq.g2 + i);
+        ok = (e0 >> 48) == tag && (e1 >> 48) == tag && (e2 >> 48) == tag;
+      }
+      if (!__builtin_amdgcn_ballot_w64(!ok)) break;
+      if (spins >= kTagSpins) { atomicOr(&ctl->overflow, 4ull); return 0; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    to_pool(cnt, e0, e1, e2);
+    return cnt;
   };
   // staged results go to the result slices: one returning atomic per flush, not per round with a result
   auto flush_results = [&]() {
@@ -258,7 +373,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       else atomicOr(&ctl->overflow, 2ull);
     }
     pool_sync();
-    fs.emits += rs_n;
+    n_emits += rs_n;
     rs_n = 0;
   };
 
@@ -266,17 +381,18 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
   wl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
   for (;;) {
-    // ---- lane groups without an element take the newest pool entries
+    // ---- lanes without an element take the newest pool entries; a pool that cannot feed them is refilled from the
+    // wave's share, and a wave with nothing left at all looks for entries appended during this launch
     {
-      const unsigned long long idle = __builtin_amdgcn_ballot_w64(lead && !have);
+      const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
       if (idle) {
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (pn < n_idle) take_batch();
+        if (pn < n_idle && !take_batch() && pn == 0 && n_idle == 64u) steal();
         if (pn) {
           const uint32_t take = n_idle < pn ? n_idle : pn;
-          const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lead_lane) - 1ull));
+          const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
           if (!have && rank < take) {
-            const uint32_t idx = (pb + pn - 1 - rank) & kPoolMask;
+            const uint32_t idx = (pb + pn - 1 - rank) & kPool64Mask;
             state = pl.state[idx]; meta = pl.meta[idx]; sp = pl.sp[idx]; ep = pl.ep[idx];
             have = true;
           }
@@ -285,89 +401,140 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         }
       }
     }
-    if (!__builtin_amdgcn_ballot_w64(have)) break;      // nothing held, pool empty, share consumed
-    // ---- one backward step per holding lane group; the state's record is requested with the rank blocks
-    uint32_t nf = 0, len1 = 0;
-    bool emit = false;
-    const uint32_t run = meta >> 24;          // > 0: this state is inside a literal stretch whose bytes the group holds
-    // An element shorter than the k-mer table's K (fmx_ktab.hip) carries its k-mer code instead of an interval
-    // (ep == 0 marks it, sp = the code): its step is a lookup in the next level of the table -- one 16-byte entry,
-    // usually cache resident, instead of two rank blocks -- and the start elements need no C[] special case.
-    const bool cm = have && kt.k != 0 && ep == 0;
-    // deep in a search every interval is a single row: then the whole wave takes the one-request step (k_search4's trick)
-    const bool all_single = !__builtin_amdgcn_ballot_w64(have && !cm && (meta & 0xFFFFu) != 0 && (ep - sp) != 1);
-    uint32_t ncode = 0;                      // codes fit 32 bits: the table has at most 2^32 entries per level
+    if (!__builtin_amdgcn_ballot_w64(have)) {      // nothing held, pool empty, share used up, nothing found
+      if (++idle_looks > kIdleLooks) break;
+      for (uint32_t z = 0; z < (1u << (idle_looks < 3u ? idle_looks : 3u)); z++) __builtin_amdgcn_s_sleep(16);      // 1, 2, 4 .. x ~0.5 us: another wave may be about to hand work over
+      continue;
+    }
+    idle_looks = 0;
+    // ---- every element's state record and its step's lines are requested together
+    const uint32_t run = meta >> 24;          // > 0: inside a literal stretch whose bytes the held record carries
+    const uint32_t c = (meta >> 16) & 0xFFu, len = meta & 0xFFFFu;
+    const uint16_t slot = s_slot[c];
+    const uint64_t cfc = s_cf[c];
+    if (have && run == 0) {
+      const uint4 *rp = reinterpret_cast<const uint4 *>(nfa.st + state);
+      ra = rp[0];
+      rb = rp[1];
+      n_recs++;
+    }
+    // An element shorter than the k-mer table's K carries its k-mer code instead of an interval (ep == 0 marks it,
+    // sp = the code): its step is a lookup in the next level of the table.
+    bool cm = have && kt.k != 0 && ep == 0;
+    uint32_t ncode = 0;
     bool from_tab = false;
-    if (have) {
-      if (run == 0) {
-        rq8 = reinterpret_cast<const uint2 *>(nfa.st + state)[t & 3u];
-        if (lead) fs.recs++;
+    uint4 ent = make_uint4(0, 0, 0, 0);
+    if (cm) {
+      if (slot < kSlotEof) {
+        ncode = (uint32_t)sp * kt.sigma + slot;
+        ent = s_lvl[len][ncode];
+        from_tab = true;
+        n_ktl++;
+      } else if (slot == kSlotNone) {
+        sp = 0; ep = 0;                                 // a byte that does not occur: the interval is empty
+      } else {                                          // the EOF symbol: leave the table, step on the interval itself
+        if (len == 0) { sp = 0; ep = ix.n; }
+        else {
+          const uint4 e0 = s_lvl[len - 1][sp];
+          sp = (((uint64_t)e0.y << 32) | e0.x) & ((1ull << 56) - 1);
+          ep = ((uint64_t)e0.w << 32) | e0.z;
+        }
+        cm = false;
       }
-      const uint32_t c = (meta >> 16) & 0xFFu, len = meta & 0xFFFFu;
-      const uint16_t slot = s_slot[c];
-      const uint64_t cfc = s_cf[c];
-      bool ranked = !cm;
-      if (cm) {
-        if (slot < kSlotEof) {                        // the table's symbols are numbered like the bit-vector slots
-          ncode = (uint32_t)sp * kt.sigma + slot;
-          const uint4 ent = s_lvl[len][ncode];
-          sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
-          ep = ((uint64_t)ent.w << 32) | ent.z;
-          from_tab = true;
-          if (lead) fs.ktl++;
-        } else if (slot == kSlotNone) {               // a byte that does not occur: the interval is empty
-          sp = 0;
-          ep = 0;
-        } else {                                      // the EOF symbol: leave the table, step on the interval itself
-          if (len == 0) { sp = 0; ep = ix.n; }
-          else {
-            const uint4 ent = s_lvl[len - 1][sp];
-            sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
-            ep = ((uint64_t)ent.w << 32) | ent.z;
+    }
+    const bool ranked = have && !cm;
+    // a rank query is needed unless the symbol is absent / EOF or the element is a start element
+    const bool query = ranked && len != 0 && slot < kSlotEof;
+    xc.sp[lane] = sp;
+    xc.ep[lane] = ep;
+    xc.key[lane] = query ? ((uint32_t)slot | (c << 16)) : kNoQuery;
+    pool_sync();
+#pragma unroll
+    for (int r0 = 0; r0 < G; r0 += B) {
+      // B sub-rounds: all their lines are requested before the first is consumed
+      RankReq q1[B], q2[B];
+      uint32_t key[B];
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
+        key[b] = xc.key[e];
+        q1[b].kind = 0; q2[b].kind = 0;
+        if (key[b] != kNoQuery) {
+          const uint64_t esp = xc.sp[e], eep = xc.ep[e];
+          const uint16_t es = (uint16_t)(key[b] & 0xFFFFu);
+          q1[b] = rank_issue<LAYOUT>(ix, es, esp, lc);
+          const bool same = LAYOUT == kLayoutBytes ? (eep >> 7) == (esp >> 7) : false;
+          if (LAYOUT == kLayoutBytes) {
+            if (same) { q2[b] = q1[b]; q2[b].rem = (uint32_t)eep & 127u; }
+            else q2[b] = rank_issue<LAYOUT>(ix, es, eep, lc);
+            if (lc.t == 0) n_reqs += same ? 2u : 4u;
+          } else {
+            uint32_t b1, m1, b2, m2;
+            split448(esp, b1, m1);
+            split448(eep, b2, m2);
+            q2[b] = q1[b];
+            q2[b].rem = m2;
+            if (b2 != b1) q2[b].w = load_line16(block_addr(ix, es, b2, lc));
+            if (lc.t == 0) n_reqs += b2 != b1 ? 2u : 1u;
           }
-          ranked = true;
         }
       }
-      if (ranked) {
-        if (len == 0) {     // every start element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        if (key[b] != kNoQuery) {
+          const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
+          const uint32_t ec = key[b] >> 16;
+          const uint64_t r1 = rank_complete<WIDE, LAYOUT>(q1[b], ec, lc);
+          const uint64_t r2 = rank_complete<WIDE, LAYOUT>(q2[b], ec, lc);
+          if (lc.t == 0) { xc.sp[e] = r1; xc.ep[e] = r2; }
+        }
+      }
+    }
+    pool_sync();
+    if (have) {
+      if (from_tab) {
+        sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
+        ep = ((uint64_t)ent.w << 32) | ent.z;
+      } else if (ranked) {
+        if (len == 0) {       // every start element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
           sp = cfc;
           ep = (c == 255u) ? ix.n : s_cf[c + 1];
           if (slot == kSlotNone) ep = sp;
           else if (slot == kSlotEof) ep = sp + 1;
-        } else if (all_single && !cm) {
-          const uint32_t rq = single_row_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
-          if (lead) fs.reqs += rq;
+        } else if (slot >= kSlotEof) {                  // absent symbol, or the EOF symbol 0
+          const uint64_t r1 = (slot == kSlotEof && sp > ix.eof) ? 1 : 0;
+          const uint64_t r2 = (slot == kSlotEof && ep > ix.eof) ? 1 : 0;
+          sp = cfc + r1;
+          ep = cfc + r2;
         } else {
-          const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, c, slot, cfc, lc, sp, ep);
-          if (lead) fs.reqs += rq;
+          sp = cfc + xc.sp[lane];
+          ep = cfc + xc.ep[lane];
         }
       }
       stepped++;
     }
-    const uint32_t cce = group_bcast<G, 0>(rq8.y);
+    const uint32_t cce = ra.y;
+    uint32_t nf = 0, len1 = 0;
+    bool emit = false;
     if (have && sp < ep) {                             // Some((sp1,ep1)), retree.scala:634
-      // Glushkov tables: an isLast state emits and has no follows here (:636-641); Thompson / DFA
-      // tables may both emit and push (re2.scala:639-649, dfa.scala:270-282).  Inside a literal stretch the
-      // state is "single": no result, one follow.
       emit = run == 0 && ((cce >> 24) & 1u) != 0;
       nf = run ? 1u : (cce & 0xFFFFu);
-      len1 = (meta & 0xFFFFu) + 1;
+      len1 = len + 1;
       if (nf && len1 >= max_len) { nf = 0; trunc = 1; }
     }
-    const uint32_t rgx = group_bcast<G, 3>(rq8.y);
     // what the element and its follows carry on: the code while they are still inside the table, else the interval
     const bool keep_code = from_tab && len1 < kt.k;
     const uint64_t ssp = keep_code ? (uint64_t)ncode : sp, sep = keep_code ? 0ull : ep;
     // ---- results are staged in LDS
     {
-      const unsigned long long em = __builtin_amdgcn_ballot_w64(lead && emit);
+      const unsigned long long em = __builtin_amdgcn_ballot_w64(emit);
       if (em) {
         const uint32_t cnt = (uint32_t)__builtin_popcountll(em);
-        if (rs_n + cnt > kResStage) flush_results();
-        if (lead && emit) {
+        if (rs_n + cnt > kRes64) flush_results();
+        if (emit) {
           fmx_result r;
-          r.regex = rgx;
-          r.len = (meta & 0xFFFFu) + 1;
+          r.regex = rb.w;
+          r.len = len + 1;
           r.sp = sp;
           r.ep = ep;
           rs.r[rs_n + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = r;
@@ -375,27 +542,31 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         rs_n = uni(rs_n + cnt);
       }
     }
-    // ---- the first follow stays with the lane group, the others go to the pool (short lists) or straight
-    // to the output queue (a '.' has 253)
+    // ---- the first follow stays with the lane, the others go to the pool (short lists) or straight to the
+    // output queue (a '.' has 253)
     const uint32_t npush = nf ? nf - 1 : 0u;
     {
-      const uint32_t nsmall = npush <= kPoolSmall ? npush : 0u;
+      uint32_t nsmall = npush <= kPoolSmall ? npush : 0u;
+      bool demoted = false;
       if (__builtin_amdgcn_ballot_w64(nsmall != 0)) {
         uint32_t small_total = 0;
-        const uint32_t small_off = wave_excl_scan(lead ? nsmall : 0u, small_total);
-        if (pn + small_total + P > kPoolCap) {
-          const uint32_t need = pn + small_total + P - kPoolCap;
-          const uint32_t half = pn < 64u ? pn : 64u;
-          spill(need > half ? need : half);
+        uint32_t my_off = wave_excl_scan(nsmall, small_total);
+        if (small_total > 128u) {      // more than the pool can take in one round: lists of 3 and more go the long way
+          demoted = nsmall > 2u;
+          if (demoted) nsmall = 0;
+          my_off = wave_excl_scan(nsmall, small_total);
         }
-        const uint32_t my_off = __shfl(small_off, lead_lane, 64);
-        const uint32_t fl1 = group_bcast<G, 1>(rq8.y), fl2 = group_bcast<G, 2>(rq8.x), fl3 = group_bcast<G, 2>(rq8.y);
-        const uint32_t fcs = group_bcast<G, 3>(rq8.x), f0 = group_bcast<G, 0>(rq8.x);
-        for (uint32_t q = t; q < nsmall; q += G) {
+        if (pn + small_total + 64u > kPool64) {
+          const uint32_t need = pn + small_total + 64u - kPool64;
+          const uint32_t half = pn < 64u ? pn : 128u;
+          const uint32_t out = need > half ? need : half;
+          spill(out < pn ? out : pn);
+        }
+        for (uint32_t q = 0; q < nsmall; q++) {
           const uint32_t fj = q + 1;
-          const uint32_t fst = fj < kInlineFollows ? (fj == 1 ? fl1 : (fj == 2 ? fl2 : fl3)) : nfa.fol[f0 + fj];
-          const uint32_t fch = fj < kInlineFollows ? ((fcs >> (8u * fj)) & 0xFFu) : (uint32_t)nfa.fol_c[f0 + fj];
-          const uint32_t idx = (pb + pn + my_off + q) & kPoolMask;
+          const uint32_t fst = fj < kInlineFollows ? (fj == 1 ? ra.w : (fj == 2 ? rb.x : rb.y)) : nfa.fol[ra.x + fj];
+          const uint32_t fch = fj < kInlineFollows ? ((rb.z >> (8u * fj)) & 0xFFu) : (uint32_t)nfa.fol_c[ra.x + fj];
+          const uint32_t idx = (pb + pn + my_off + q) & kPool64Mask;
           pl.state[idx] = fst;
           pl.meta[idx] = len1 | (fch << 16);
           pl.sp[idx] = ssp;
@@ -403,123 +574,105 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         }
         pn = uni(pn + small_total);
         pool_sync();
+        // what the wave cannot work off soon goes to the queue, oldest (shallowest) first: waves that ran dry take it
+        // what the wave cannot work off soon goes to the queue, oldest (shallowest) first: waves that ran dry take it
+        if (pn > kPoolKeep) spill(pn - kPoolKeep / 2 < 64u ? pn - kPoolKeep / 2 : 64u);
       }
-      if (__builtin_amdgcn_ballot_w64(npush > kPoolSmall)) {
-        const uint32_t nlarge = npush > kPoolSmall ? npush : 0u;
-        uint32_t large_total = 0;
-        const uint32_t large_off = wave_excl_scan(lead ? nlarge : 0u, large_total);
-        const uint32_t so = (w + appends++) % kSub;
-        const uint64_t out_off = (uint64_t)so * sub_cap;
-        unsigned long long qbase = 0;
-        if (lane == 0) qbase = atomicAdd(&next_count[so].v, (unsigned long long)large_total);
-        qbase = __shfl(qbase, 0, 64);
-        const uint32_t my_off = __shfl(large_off, lead_lane, 64);
-        const uint32_t f0 = group_bcast<G, 0>(rq8.x);
-        for (uint32_t q = t; q < nlarge; q += G) {
-          const unsigned long long at = qbase + my_off + q;
-          if (at < sub_cap) {
-            nxt.state[out_off + at] = nfa.fol[f0 + q + 1];
-            nxt.meta[out_off + at] = len1 | ((uint32_t)nfa.fol_c[f0 + q + 1] << 16);
-            nxt.sp[out_off + at] = ssp;
-            nxt.ep[out_off + at] = sep;
-          } else {
-            atomicOr(&ctl->overflow, 1ull);
-          }
-        }
-        fs.writes += large_total;
+      unsigned long long big = __builtin_amdgcn_ballot_w64(npush > kPoolSmall || demoted);
+      while (big) {                                     // one long list at a time, written by the whole wave
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)npush, src);
+        const uint32_t fo = (uint32_t)__builtin_amdgcn_readlane((int)ra.x, src);
+        const uint32_t l1 = (uint32_t)__builtin_amdgcn_readlane((int)len1, src);
+        const uint64_t xsp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(ssp >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ssp, src);
+        const uint64_t xep = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(sep >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)sep, src);
+        const Slot sl = reserve(nl);
+        for (uint32_t q = lane; q < nl; q += 64)
+          put(sl, sl.at + q, nfa.fol[fo + q + 1], l1 | ((uint32_t)nfa.fol_c[fo + q + 1] << 16), xsp, xep);
+        n_writes += nl;
       }
     }
-    {
-      const uint32_t fl0 = group_bcast<G, 1>(rq8.x), fc0 = group_bcast<G, 3>(rq8.x) & 0xFFu;
-      const uint32_t r1 = group_bcast<G, 1>(rq8.y), r2 = group_bcast<G, 2>(rq8.x), r3 = group_bcast<G, 2>(rq8.y);
-      if (have) {
-        if (nf) {
-          sp = ssp;
-          ep = sep;
-          // on a literal stretch the next state is state + 1 and its byte comes from the held record:
-          // rr[k - 1] with k = states of the stretch still ahead (the chain length when it was just entered)
-          const uint32_t k = run ? run : (nf == 1 ? (cce >> 25) & 0xFu : 0u);
-          if (k) {
-            const uint32_t word = k <= 4u ? r1 : (k <= 8u ? r2 : r3);
-            const uint32_t ch = (word >> (8u * ((k - 1u) & 3u))) & 0xFFu;
-            state = run ? state + 1u : fl0;
-            meta = len1 | (ch << 16) | ((k - 1u) << 24);
-          } else {
-            state = fl0;
-            meta = len1 | (fc0 << 16);
-          }
+    if (have) {
+      if (nf) {
+        sp = ssp;
+        ep = sep;
+        // on a literal stretch the next state is state + 1 and its byte comes from the held record:
+        // rr[k - 1] with k = states of the stretch still ahead (the chain length when it was just entered)
+        const uint32_t k = run ? run : (nf == 1 ? (cce >> 25) & 0xFu : 0u);
+        if (k) {
+          const uint32_t word = k <= 4u ? ra.w : (k <= 8u ? rb.x : rb.y);
+          const uint32_t ch = (word >> (8u * ((k - 1u) & 3u))) & 0xFFu;
+          state = run ? state + 1u : ra.z;
+          meta = len1 | (ch << 16) | ((k - 1u) << 24);
         } else {
-          have = false;
+          state = ra.z;
+          meta = len1 | ((rb.z & 0xFFu) << 16);
         }
+      } else {
+        have = false;
       }
     }
     if (++rounds >= max_rounds) {
-      // ---- out of rounds: everything this wave still holds goes to the output queue -- the elements in
-      // registers, the pool, and what is left of its share of the input
-      const unsigned long long held = __builtin_amdgcn_ballot_w64(lead && have);
+      // ---- out of rounds: everything this wave still holds goes to the output queue
+      const unsigned long long held = __builtin_amdgcn_ballot_w64(have);
       if (held) {
-        if (lead && have) {
-          const uint32_t idx = (pb + pn + (uint32_t)__builtin_popcountll(held & ((1ull << lane) - 1ull))) & kPoolMask;
+        if (have) {
+          const uint32_t idx = (pb + pn + (uint32_t)__builtin_popcountll(held & ((1ull << lane) - 1ull))) & kPool64Mask;
           pl.state[idx] = state; pl.meta[idx] = meta & 0x00FFFFFFu; pl.sp[idx] = sp; pl.ep[idx] = ep;   // the stretch context stays behind
         }
         pn = uni(pn + (uint32_t)__builtin_popcountll(held));
       }
-      spill(pn);
+      while (pn) spill(pn < 64u ? pn : 64u);
       while (take_batch()) spill(pn);        // carried over, not consumed here
       break;
     }
   }
   flush_results();
 #ifdef FMX_WAVELOG
-  if (lane == 0 && pass < kLogPasses && w < kLogWaves) {
-    unsigned long long *e = g_wavelog[pass][w];
-    e[0] = wl_t0; e[1] = wl_t1; e[2] = __builtin_amdgcn_s_memrealtime(); e[3] = rounds | (wave_sum(lead ? (unsigned long long)stepped : 0ull) << 32);
+  {
+    const unsigned long long st_all = wave_sum((unsigned long long)stepped);
+    if (lane == 0 && j < kLogPasses && w < kLogWaves) {
+      unsigned long long *e = g_wavelog[j][w];
+      e[0] = wl_t0; e[1] = wl_t1; e[2] = __builtin_amdgcn_s_memrealtime(); e[3] = rounds | (st_all << 32);
+    }
   }
 #endif
   if (trunc) atomicOr(&ctl->truncated, 1ull);
-  counters_add(counters, lead ? 2ull * stepped : 0ull, lead ? stepped : 0u, 0);
-  counters_add_frontier(counters, fs.reqs, lane == 0 ? fs.writes : 0u, lane == 0 ? fs.emits : 0u, lead ? stepped : 0u,
-                        lane == 0 ? fs.reads : 0u, fs.recs);
+  counters_add(counters, 2ull * stepped, stepped, 0);
+  counters_add_frontier(counters, n_reqs, lane == 0 ? n_writes : 0u, lane == 0 ? n_emits : 0u, stepped,
+                        lane == 0 ? n_reads : 0u, n_recs);
   {
-    const unsigned long long lookups = wave_sum((unsigned long long)fs.ktl);
+    const unsigned long long lookups = wave_sum((unsigned long long)n_ktl);
     if (lane == 0 && lookups) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 9, lookups);
   }
 }
 
-// One-hot layout: 80 registers keep 6 waves per SIMD resident; the bytes layout (octets, two lines per rank query)
-// needs more registers and runs 4.
+// 128 registers: 4 waves per SIMD = 256 elements in flight per SIMD.  `j` = the launch's number in its chain (diagnostics).
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kFThreads, 5) void k_frontier(DevIndex ix, KTab kt, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
+__global__ __launch_bounds__(kFThreads, FMX_FWAVES) void k_frontier(DevIndex ix, KTab kt, NfaTables nfa, FlowQueue fq, uint32_t j,
                                                             uint32_t max_rounds, uint64_t sub_cap,
                                                             fmx_result *__restrict__ res, uint64_t seg_cap,
                                                             FrontierCtl *__restrict__ ctl,
                                                             unsigned long long *__restrict__ counters) {
-  frontier_pass<WIDE, LAYOUT>(ix, kt, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
-}
-__global__ __launch_bounds__(kFThreads, 4) void k_frontier_bytes(DevIndex ix, KTab kt, NfaTables nfa, Queue qa, Queue qb, uint32_t j,
-                                                                  uint32_t max_rounds, uint64_t sub_cap,
-                                                                  fmx_result *__restrict__ res, uint64_t seg_cap,
-                                                                  FrontierCtl *__restrict__ ctl,
-                                                                  unsigned long long *__restrict__ counters) {
-  frontier_pass<true, kLayoutBytes>(ix, kt, nfa, qa, qb, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
+  frontier_pass<WIDE, LAYOUT>(ix, kt, nfa, fq, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
 }
 
-// What the host reads after a chain of launches: 32 bytes, not the 40 KB of counters.
-struct FrontierSummary {
-  unsigned long long queued;       // entries in the next launch's input queue
-  unsigned long long results;
-  unsigned long long overflow;
-  unsigned long long truncated;
-};
-// Closes a chain of launches (one wave, lane = slice): the next chain starts `by` passes further.
-__global__ __launch_bounds__(64) void k_pass_advance(FrontierCtl *__restrict__ ctl, uint32_t by, FrontierSummary *__restrict__ sum) {
-  const uint32_t pass = ctl->pass_base + by;
-  const unsigned long long queued = wave_sum(ctl->count[pass % 3][threadIdx.x].v);
-  const unsigned long long results = wave_sum(ctl->res_count[threadIdx.x].v);
-  if (threadIdx.x == 0) {
-    ctl->pass_base = pass;
-    sum->queued = queued; sum->results = results; sum->overflow = ctl->overflow; sum->truncated = ctl->truncated;
-  }
+// Between launches (one wave, lane = slice): a buffer that has been emptied is rewound under its next tag; when that
+// is the buffer the slice was emptying and the written one holds entries, the two swap roles.  Also sums up what
+// the host wants to know after a chain.
+__global__ __launch_bounds__(64) void k_frontier_advance(FrontierCtl *__restrict__ ctl, uint64_t sub_cap, FrontierSummary *__restrict__ sum) {
+  SliceCtl &q = ctl->q[threadIdx.x];
+  const uint32_t wr = q.wsel, ot = 1u - wr;
+  // the launch has worked off (or carried over) everything in the buffer it was not writing
+  const unsigned long long lo = 0;
+  const unsigned long long tl = q.tail[wr] < sub_cap ? q.tail[wr] : sub_cap;
+  const unsigned long long lw = tl > q.head[wr] ? tl - q.head[wr] : 0ull;
+  if (q.tail[ot] | q.head[ot]) { q.tail[ot] = 0; q.head[ot] = 0; q.tag[ot] = next_tag(q.tag[ot]); }
+  if (lw) q.wsel = ot;
+  else if (q.tail[wr] | q.head[wr]) { q.tail[wr] = 0; q.head[wr] = 0; q.tag[wr] = next_tag(q.tag[wr]); }
+  const unsigned long long left = wave_sum(lo + lw), results = wave_sum(ctl->res_count[threadIdx.x].v);
+  if (threadIdx.x == 0) { ctl->left = left; sum->left = left; sum->results = results; sum->overflow = ctl->overflow; sum->truncated = ctl->truncated; }
 }
 
 // result groups the device leaves to the host (k_res_sort)
@@ -599,7 +752,8 @@ struct RegexBatch {
   DevMem mem;
   // scratch reused across matches of this batch (one match at a time per batch object)
   std::unique_ptr<DevMem> scratch;
-  Queue qa{}, qb{};
+  FlowQueue fq{};
+  uint32_t tag_bound = 0;              // upper bound of the buffers' generation tags (they wrap at 65535: the queue is zeroed before)
   fmx_result *d_res = nullptr;        // packed results
   fmx_result *d_res_seg = nullptr;    // kSub result slices the levels append to
   FrontierCtl *d_ctl = nullptr;
@@ -738,21 +892,30 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   return FMX_OK;
 }
 
-// The start queue: states = firsts, len 0, (sp, ep) = (0, n), dealt round-robin over the slices.
-__global__ void k_frontier_init(Queue q, NfaTables nfa, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n /* 0: the start elements carry the empty k-mer code */,
-                                uint64_t sub_cap, uint32_t max_len, FrontierCtl *__restrict__ ctl) {
+// A call starts from rewound buffers under fresh tags (one wave, lane = slice): buffer 0 of every slice receives
+// the slice's share of the start elements, buffer 1 is the first one written.
+__global__ __launch_bounds__(64) void k_frontier_reset(FrontierCtl *__restrict__ ctl, uint64_t count, uint32_t max_len) {
+  const uint32_t i = threadIdx.x;
+  SliceCtl &q = ctl->q[i];
+  q.tail[0] = count > i ? (count - i + kSub - 1) / kSub : 0;
+  q.tail[1] = 0; q.head[0] = 0; q.head[1] = 0;
+  q.tag[0] = next_tag(q.tag[0]); q.tag[1] = next_tag(q.tag[1]);
+  q.wsel = 1;
+  ctl->res_count[i].v = 0;
+  if (i == 0) { ctl->overflow = 0; ctl->truncated = 0; ctl->max_len = max_len; ctl->left = count; }
+}
+// The start elements: states = firsts, len 0, (sp, ep) = (0, n), dealt round-robin over the slices.
+__global__ void k_frontier_init(FlowQueue fq, NfaTables nfa, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n /* 0: the start elements carry the empty k-mer code */,
+                                uint64_t sub_cap, const FrontierCtl *__restrict__ ctl) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < kSub) {
-    ctl->count[0][i].v = count > i ? (count - i + kSub - 1) / kSub : 0;
-    ctl->count[1][i].v = 0;
-    ctl->count[2][i].v = 0;
-    ctl->res_count[i].v = 0;
-  }
-  if (i == 0) { ctl->overflow = 0; ctl->truncated = 0; ctl->pass_base = 0; ctl->max_len = max_len; }
   if (i < count) {
-    const uint64_t at = (i % kSub) * sub_cap + i / kSub;
+    const uint32_t s = (uint32_t)(i % kSub);
+    const uint64_t at = ((uint64_t)s * 2) * sub_cap + i / kSub;
     const uint32_t st = first_state[i];
-    q.state[at] = st; q.meta[at] = rec_c(nfa.st[st]) << 16; q.sp[at] = 0; q.ep[at] = n;
+    const unsigned long long tg = (unsigned long long)ctl->q[s].tag[0] << 48;
+    fq.g0[at] = tg | ((unsigned long long)rec_c(nfa.st[st]) << 40);     // sp = 0
+    fq.g1[at] = tg | n;
+    fq.g2[at] = tg | st;                                                  // len = 0
   }
 }
 
@@ -925,15 +1088,14 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (!b->h_sum) HIP_TRY(hipHostMalloc((void **)&b->h_sum, sizeof(FrontierSummary), hipHostMallocDefault), "hipHostMalloc(summary)");
     if (!b->h_dst) HIP_TRY(hipHostMalloc((void **)&b->h_dst, sizeof(ExportDst), hipHostMallocDefault), "hipHostMalloc(export)");
     const uint64_t seg_cap = (uint64_t)(cap ? cap : 1) / 16 + 1024;
-    for (Queue *q : {&b->qa, &b->qb}) {
-      HIP_TRY(b->scratch->alloc(&q->state, kSub * sub_cap), "hipMalloc(queue)");
-      HIP_TRY(b->scratch->alloc(&q->meta, kSub * sub_cap), "hipMalloc(queue)");
-      HIP_TRY(b->scratch->alloc(&q->sp, kSub * sub_cap), "hipMalloc(queue)");
-      HIP_TRY(b->scratch->alloc(&q->ep, kSub * sub_cap), "hipMalloc(queue)");
+    for (unsigned long long **g : {&b->fq.g0, &b->fq.g1, &b->fq.g2}) {
+      HIP_TRY(b->scratch->alloc(g, 2 * kSub * sub_cap), "hipMalloc(queue)");
     }
+    HIP_TRY(b->scratch->alloc(&b->d_sum, 1), "hipMalloc(summary)");
     HIP_TRY(b->scratch->alloc(&b->d_res, cap ? cap : 1), "hipMalloc(results)");
     HIP_TRY(b->scratch->alloc(&b->d_res_seg, kSub * seg_cap), "hipMalloc(result slices)");
     HIP_TRY(b->scratch->alloc(&b->d_ctl, 1), "hipMalloc(ctl)");
+    b->tag_bound = kTagLimit;          // new memory: zeroed below (tag 0 = never written)
     {   // counts, fill cursors and the big-group list in one block: one memset clears what a grouping starts from
       uint32_t *blk = nullptr;
       HIP_TRY(b->scratch->alloc(&blk, 2 * (b->k + 1) + (sizeof(BigGroups) + 3) / 4), "hipMalloc(result counts)");
@@ -941,7 +1103,6 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       b->d_rfill = blk + (b->k + 1);
       b->d_big = reinterpret_cast<BigGroups *>(blk + 2 * (b->k + 1));
     }
-    HIP_TRY(b->scratch->alloc(&b->d_sum, 1), "hipMalloc(summary)");
     HIP_TRY(b->scratch->alloc(&b->d_rstart, b->k + 1), "hipMalloc(result offsets)");
     HIP_TRY(b->scratch->alloc(&b->d_rpart, (b->k + 1) / kScanChunk + 2), "hipMalloc(scan parts)");
     HIP_TRY(b->scratch->alloc(&b->d_tot, 1), "hipMalloc(totals)");
@@ -951,7 +1112,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // Slice capacity of the result buffer: a function of the ALLOCATED size, so that it stays what the captured
   // launch chain was recorded with when a later call passes a smaller cap (the scratch is kept then).
   const uint64_t seg_cap = (uint64_t)b->rcap / 16 + 1024;
-  const Queue qa = b->qa, qb = b->qb;
+  const FlowQueue fq = b->fq;
   fmx_result *d_res = b->d_res;
   fmx_result *d_res_seg = b->d_res_seg;
   FrontierCtl *d_ctl = b->d_ctl;
@@ -962,21 +1123,33 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
 
   KTab kt;
   HIP_TRY(ktab_get(h, st, &kt), "k-mer table");
+  // Generation tags are 16 bits wide; a buffer's tag advances at most once per launch.  Long before a tag can come
+  // round to a value that an old entry still carries, the queue and the tags are zeroed (a 100 MB memset every few
+  // thousand calls).
+  if (b->tag_bound >= kTagLimit) {
+    for (unsigned long long *g : {fq.g0, fq.g1, fq.g2}) HIP_TRY(hipMemsetAsync(g, 0, 2 * kSub * sub_cap * 8, st), "hipMemset(queue)");
+    HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(FrontierCtl), st), "hipMemset(ctl)");
+    b->tag_bound = 0;
+  }
+  b->tag_bound++;
   mark("setup");
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
-  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(qa, b->nfa, b->d_first_state, b->n_first, kt.k ? 0 : h->n, sub_cap, max_steps, d_ctl);
+  k_frontier_reset<<<1, 64, 0, st>>>(d_ctl, b->n_first, max_steps);
+  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(fq, b->nfa, b->d_first_state, b->n_first, kt.k ? 0 : h->n, sub_cap, d_ctl);
   HIP_TRY(hipGetLastError(), "k_frontier_init");
-  // Launches are chained on the stream without host round trips; the host looks at the counters after every
-  // chain.  A launch whose input queue is empty returns at once.
-  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 10u;
-  // rounds a wave works before it hands its leftovers to the next launch (the load balancing step)
-  static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 16u;
-  // workgroups per CU in the full grid: twice what is resident at once (5 per CU at 96 registers), so that the
-  // dispatcher fills the slots of waves whose share ran out early (measured on C4: 5 -> 0.72 ms, 10 -> 0.67, 20 -> 0.71)
-  static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : 10;
+  // Launches are chained on the stream without host round trips; the host looks at the summary after every
+  // chain.  A launch that finds the queue empty returns at once.
+  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 3u;
+  // rounds a wave works at most in one launch (what it still holds then goes to the queue): the bound that makes
+  // every wave end.  C4 is done in one launch of ~50 rounds per wave (the longest wave: 113); measured 64 / 96 / 128 /
+  // 256: 0.565 / 0.548 / 0.527 / 0.534 ms
+  static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 64u;
+  // workgroups per CU in the full grid: what is resident at once (FMX_FWAVES waves per SIMD) -- a launch lasts as
+  // long as the search does, so a second generation of workgroups would find nothing (measured 3 / 4 / 6: 0.567 /
+  // 0.712 / 0.664 ms)
+  static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : FMX_FWAVES;
   const int grid_full = h->cu_count * per_cu * kFScale;
-  const uint32_t group_lanes = h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G;
-  const uint64_t per_wg = (uint64_t)kFThreads / group_lanes;      // elements a workgroup holds at once
+  const uint64_t per_wg = (uint64_t)kFThreads;                    // elements a workgroup holds at once
   FrontierSummary sum{};
   uint64_t n_res = 0;
   uint32_t pass = 0;
@@ -984,19 +1157,17 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   bool alive = true, truncated = false;
   auto launch_pass = [&](hipStream_t s, int grid, uint32_t j, uint32_t rounds) {
     if (h->layout == kLayoutBytes)
-      k_frontier_bytes<<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier<true, kLayoutBytes><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
     else if (h->n > (1ull << 32))
-      k_frontier<true, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier<true, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
     else
-      k_frontier<false, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, qa, qb, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier<false, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
   };
-  // One chain = kChain launches + k_pass_advance + the counters' copy to pinned host memory.  Its kernel
-  // arguments do not change from chain to chain (the pass comes from ctl->pass_base), so it is captured
-  // into a hipGraph once per batch and replayed: one launch call per chain instead of kChain + 2.  Two chains
-  // are kept: the full grid for a batch's wide phase, and a small grid (64 workgroups: enough lane groups for
-  // 4096 elements) for a single regex or the thin end of a batch, whose launches cost a fraction of the
-  // full grid's when most of them find nothing to do.  A wave hands its leftovers to the next launch after
-  // kRounds rounds, so even a search that starts from one element spreads over the grid within a few launches.
+  // One chain = kChain x (launch + k_frontier_advance) + the summary's copy to pinned host memory.  Its kernel
+  // arguments do not change from chain to chain, so it is captured into a hipGraph once per batch and replayed:
+  // one launch call per chain.  Two chains are kept: the full grid for a batch's wide phase, and a small grid
+  // (64 workgroups: enough lane groups for 4096 elements) for a single regex or the thin end of a batch, whose
+  // launches cost a fraction of the full grid's when most of them find nothing to do.
   static const bool use_graph = !(getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) == 0);
   // experiments: rounds per launch of a chain as a comma list (the last entry repeats)
   static const std::vector<uint32_t> plan = [] {
@@ -1007,13 +1178,17 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   }();
   const int grid_small = 64 * kFScale;
   // the small grid's chain is short: a launch that finds nothing to do still costs ~3 us
-  const uint32_t kChainSmall = std::min<uint32_t>(kChain, 5u);
+  // The small grid serves a single regex or the thin end of a batch: there a search is a few elements that grow
+  // into a tree, and what spreads it over the waves is the hand-over at the end of a launch -- short launches, more
+  // of them (a[ab]*c on 2 M rows: 302 us per call with 128-round launches, 250 with 32; a 24-character literal: 87 / 95 us)
+  static const uint32_t kChainSmall = getenv("FMX_FRONTIER_CHAIN_SMALL") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN_SMALL"))) : 4u;
+  static const uint32_t kRoundsSmall = getenv("FMX_FRONTIER_ROUNDS_SMALL") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS_SMALL"))) : 32u;
   auto enqueue_chain = [&](hipStream_t s, int grid) -> hipError_t {
-    // the first passes hand over early and often (the frontier is wide and must spread); the later ones find the
-    // thin, deep end of the search and work it off in long stretches
     const uint32_t len = grid == grid_small ? kChainSmall : kChain;
-    for (uint32_t j = 0; j < len; j++) launch_pass(s, grid, j, plan.empty() ? (j < (len + 1) / 2 ? kRounds : 4 * kRounds) : plan[std::min<size_t>(j, plan.size() - 1)]);
-    k_pass_advance<<<1, 64, 0, s>>>(d_ctl, len, b->d_sum);
+    for (uint32_t j = 0; j < len; j++) {
+      launch_pass(s, grid, j, grid == grid_small ? kRoundsSmall : (plan.empty() ? kRounds : plan[std::min<size_t>(j, plan.size() - 1)]));
+      k_frontier_advance<<<1, 64, 0, s>>>(d_ctl, sub_cap, b->d_sum);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return hipMemcpyAsync(b->h_sum, b->d_sum, sizeof(FrontierSummary), hipMemcpyDeviceToHost, s);
@@ -1092,17 +1267,19 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     }
     HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
     const uint32_t done = small ? kChainSmall : kChain;
-    launches += done + 1 + 10;
+    launches += 2 * done + 10;
+    b->tag_bound += done;
     HIP_TRY(hipStreamSynchronize(st), "sync(passes)");
     sum = *b->h_sum;
     pass += done;
+    if (sum.overflow & 4ull) { set_error("frontier work queue: an appended entry never became readable"); return FMX_ERR_HIP; }
     if (sum.overflow & 1ull) { set_error("frontier work queue overflow (raise fmx_limits.max_frontier)"); return FMX_ERR_OVERFLOW; }
-    total = sum.queued;
+    total = sum.left;
     n_res = sum.results;
     alive = total != 0;
     truncated = sum.truncated != 0;
     if (trace)
-      fprintf(stderr, "[fmx] frontier after pass %u: queue %llu, results %llu, overflow %llu\n", pass,
+      fprintf(stderr, "[fmx] frontier after launch %u: queue %llu, results %llu, overflow %llu\n", pass,
               (unsigned long long)total, (unsigned long long)n_res, sum.overflow);
   }
   float ms = 0;

@@ -1095,7 +1095,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     HIP_TRY(b->scratch->alloc(&b->d_res, cap ? cap : 1), "hipMalloc(results)");
     HIP_TRY(b->scratch->alloc(&b->d_res_seg, kSub * seg_cap), "hipMalloc(result slices)");
     HIP_TRY(b->scratch->alloc(&b->d_ctl, 1), "hipMalloc(ctl)");
-    b->tag_bound = kTagLimit;          // new memory: zeroed below (tag 0 = never written)
+    b->tag_bound = ~0u;                // new memory: zeroed below (tag 0 = never written)
     {   // counts, fill cursors and the big-group list in one block: one memset clears what a grouping starts from
       uint32_t *blk = nullptr;
       HIP_TRY(b->scratch->alloc(&blk, 2 * (b->k + 1) + (sizeof(BigGroups) + 3) / 4), "hipMalloc(result counts)");
@@ -1126,7 +1126,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // Generation tags are 16 bits wide; a buffer's tag advances at most once per launch.  Long before a tag can come
   // round to a value that an old entry still carries, the queue and the tags are zeroed (a 100 MB memset every few
   // thousand calls).
-  if (b->tag_bound >= kTagLimit) {
+  // (FMX_FRONTIER_TAG_LIMIT: a test makes the tags wrap within a few calls)
+  static const uint32_t tag_limit = getenv("FMX_FRONTIER_TAG_LIMIT") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_TAG_LIMIT"))) : kTagLimit;
+  if (b->tag_bound >= tag_limit) {
     for (unsigned long long *g : {fq.g0, fq.g1, fq.g2}) HIP_TRY(hipMemsetAsync(g, 0, 2 * kSub * sub_cap * 8, st), "hipMemset(queue)");
     HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(FrontierCtl), st), "hipMemset(ctl)");
     b->tag_bound = 0;

@@ -757,10 +757,9 @@ def test_regex_resident_batch_shrinking_cap_and_foreign_index(testdata):
 
 def test_regex_long_tail_levels():
     """Frontiers that stay small for many levels, grow, and die slowly (n = 2M over 4 letters: "ab[a-c]*d"
-    holds min(3^k, 125k * 0.75^k) elements at level k + 2, i.e. ~700 at the first host look, ~9.4k at level
-    11, ~900 at level 19, dead near level 45).  The persistent tail kernel takes over at the first look
-    (<= 4096 elements), hands back to the grid kernel when the frontier outgrows it (> 8192), and takes over
-    again for the dying tail.  Every match must equal the oracle's."""
+    holds min(3^k, 125k * 0.75^k) elements at level k + 2, i.e. ~9.4k at level 11, ~900 at level 19, dead near
+    level 45): a search that starts in one wave, spills its pool into the work queue, is dealt out again by the
+    next launches on the small grid and moves to the full grid and back.  Every match must equal the oracle's."""
     bwt, eof, counts = synth_bwt(2_000_000, 97, 100, 12)            # 4 letters: a..d
     hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
     for re in ("ab[a-c]*d", "a[ab]*c", "dcba[ab]*d"):
@@ -768,6 +767,45 @@ def test_regex_long_tail_levels():
         got = findex_amd.ReTree(findex_amd.REParser.re2post(re)).matchAll(hip, max_steps=60, max_frontier=1 << 22)
         assert sorted(r.key() for r in got) == want, re
         assert len(want) > 100, re
+
+
+_QUEUE_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+import findex_amd
+from findex_amd.regex import RegexBatch
+from helpers import synth_bwt
+from test_gpu_parity import oracle_results_capped
+bwt, eof, counts = synth_bwt(600_000, 97, 100, 5)            # 4 letters: a..d
+hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+res = ["ab[a-c]*d", "a[ab]*c", "dcba[ab]*d", "b(a|cd)[ad]*b"] + ["abcd"[i % 4] + "abcd"[(i // 4) % 4] + "c[ab]?d" for i in range(60)]
+trees = [findex_amd.ReTree(findex_amd.REParser.re2post(r)) for r in res]
+batch = RegexBatch(hip, trees)
+want = sorted((i, ) + k for i, r in enumerate(res) for k in oracle_results_capped(bwt, eof, counts, r, 40))
+for call in range(40):
+    out, per = batch.match_raw(max_steps=40, cap=1 << 20)
+    got = sorted(zip(out["regex"].tolist(), out["len"].tolist(), out["sp"].tolist(), out["ep"].tolist()))
+    assert got == want, call
+    assert per.tolist() == np.bincount(out["regex"], minlength=len(res)).tolist()
+st = hip.stats()
+assert st["frontier_queue_writes"] > 40 * 1000, st         # entries did go through the queue
+print("ok", len(want), st["frontier_queue_writes"] // 40)
+"""
+
+
+def test_regex_queue_tags_wrap_and_launches_hand_over():
+    """The work queue's entries carry 16-bit generation tags and the queue is zeroed before a tag can come round
+    (fmx_frontier.hip): with the limit at 5 instead of 60000, 4-round launches and chains of 2, forty calls on one
+    resident batch rewind and swap the buffers hundreds of times and cross the zeroing every other call -- each
+    call's results must equal the oracle's.  (A child process: the knobs are read once per process.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FMX_FRONTIER_TAG_LIMIT="5", FMX_FRONTIER_ROUNDS="4", FMX_FRONTIER_ROUNDS_SMALL="4",
+               FMX_FRONTIER_CHAIN="2", FMX_FRONTIER_CHAIN_SMALL="2")
+    r = subprocess.run([sys.executable, "-c", _QUEUE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
 
 
 # ---------------------------------------------------------------- the reference's other two engines

@@ -558,7 +558,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         }
         if (pn + small_total + 64u > kPool64) {
           const uint32_t need = pn + small_total + 64u - kPool64;
-          const uint32_t half = pn < 64u ? pn : 128u;
+          const uint32_t half = pn < 64u ? pn : 64u;
           const uint32_t out = need > half ? need : half;
           spill(out < pn ? out : pn);
         }
@@ -1141,11 +1141,11 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   HIP_TRY(hipGetLastError(), "k_frontier_init");
   // Launches are chained on the stream without host round trips; the host looks at the summary after every
   // chain.  A launch that finds the queue empty returns at once.
-  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 3u;
+  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 2u;
   // rounds a wave works at most in one launch (what it still holds then goes to the queue): the bound that makes
   // every wave end.  C4 is done in one launch of ~50 rounds per wave (the longest wave: 113); measured 64 / 96 / 128 /
   // 256: 0.565 / 0.548 / 0.527 / 0.534 ms
-  static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 64u;
+  static const uint32_t kRounds = getenv("FMX_FRONTIER_ROUNDS") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS"))) : 128u;
   // workgroups per CU in the full grid: what is resident at once (FMX_FWAVES waves per SIMD) -- a launch lasts as
   // long as the search does, so a second generation of workgroups would find nothing (measured 3 / 4 / 6: 0.567 /
   // 0.712 / 0.664 ms)

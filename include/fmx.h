@@ -235,16 +235,19 @@ int fmx_dfa_compile(const int32_t *moves, uint32_t nstates, uint32_t nchars, con
                     fmx_regex **out);
 
 typedef struct fmx_limits {
-  /* mode = FMX_MATCH_FRONTIER.  The frontier kernel expands every regex's frontier breadth-first, so
-   * its results equal the reference's (as a multiset) whenever the reference's limits do not bind:
+  /* mode = FMX_MATCH_FRONTIER.  The frontier kernel steps every element of every regex's frontier (in the order
+   * that suits the device: elements are independent), so its results equal the reference's (as a multiset) whenever
+   * the reference's limits do not bind:
    * max_steps   = longest match explored (levels); 0 = default 4096.  When the frontier is still alive
    *               there, the call returns FMX_TRUNCATED with every match of length <= max_steps.  (On
    *               the BWT of a real text a frontier always dies -- no match is longer than the text --
    *               but on a synthetic "BWT" that is just a random string, LF has short cycles and x* can
    *               run forever.)
-   * max_frontier= capacity of the device work queue in elements, 0 = default (1<<22): at least this many
-   *               elements fit per level (the queue is cut into 64 slices with some headroom each);
-   *               FMX_ERR_OVERFLOW when a level outgrows it.
+   * max_frontier= capacity of the device work queue in elements, 0 = default (1<<22): what the waves cannot
+   *               hold in their own pools is queued in HBM (64 slices of two buffers each, about
+   *               max_frontier / 50 entries per buffer); FMX_ERR_OVERFLOW when a buffer fills up.
+   * Results and per-regex counts are written by the device itself when `out` / `per_regex_count` are
+   * page-locked memory (fmx_host_alloc); pageable buffers are filled by a copy after the search.
    * mode = FMX_MATCH_REFERENCE.  ReTree._matchSA exactly (re2/retree.scala:618-653): the priority queue
    * of Scala 2.10 replayed per regex, loop while queue non-empty && queue.length < max_branching &&
    * (max_iterations == 0 || i < max_iterations), i from 1.  Results come back per regex in the

@@ -223,6 +223,36 @@ JNIEXPORT void JNICALL FN(writeFm0)(JNIEnv *e, jobject self, jlong h, jstring pa
   rethrow(e, rc);
 }
 
+/* The same into direct ByteBuffers: out = cap fmx_result records of 24 bytes (u32 regex, u32 len, u64 sp, u64 ep,
+ * native byte order), perRegex = k u32 counts or null.  With buffers from hostAlloc0 the device writes the grouped
+ * results and the counts into them itself, behind the search and before the call's one synchronisation
+ * (k_res_export): nothing is copied or converted on the host -- the form a serving loop uses on a resident batch. */
+JNIEXPORT jlong JNICALL FN(regexBatchMatchDirect0)(JNIEnv *e, jobject self, jlong h, jlong batch, jintArray limits,
+                                                   jlong maxFrontier, jobject out, jobject perRegex, jintArray status) {
+  jint lim4[4] = {0, 0, 1024, 1000};
+  (*e)->GetIntArrayRegion(e, limits, 0, 4, lim4);
+  fmx_limits lim;
+  lim.max_steps = (uint32_t)lim4[0];
+  lim.mode = (uint32_t)lim4[1];
+  lim.max_frontier = (uint64_t)maxFrontier;
+  lim.max_branching = (uint32_t)lim4[2];
+  lim.max_iterations = (uint32_t)lim4[3];
+  fmx_result *res = (*e)->GetDirectBufferAddress(e, out);
+  uint32_t *per = perRegex ? (*e)->GetDirectBufferAddress(e, perRegex) : 0;
+  if (!res || (perRegex && !per)) {
+    rethrow(e, FMX_ERR_ARG);
+    return 0;
+  }
+  size_t cap = (size_t)((*e)->GetDirectBufferCapacity(e, out) / (jlong)sizeof(fmx_result)), got = 0;
+  int rc = fmx_regex_batch_match(H(h), (fmx_regex_batch *)(intptr_t)batch, &lim, res, cap, &got, per);
+  if ((rc == FMX_OK || rc == FMX_TRUNCATED) && status) {
+    jint st = rc == FMX_TRUNCATED ? 1 : 0;
+    (*e)->SetIntArrayRegion(e, status, 0, 1, &st);
+  }
+  rethrow(e, rc);
+  return (jlong)got;
+}
+
 /* ---- page-locked batch buffers as direct ByteBuffers */
 JNIEXPORT jobject JNICALL FN(hostAlloc0)(JNIEnv *e, jobject self, jlong bytes) {
   void *p = 0;

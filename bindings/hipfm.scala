@@ -46,6 +46,8 @@ object HipFM {
   @native def regexBatchFree0(b: Long): Unit
   @native def regexBatchMatch0(h: Long, batch: Long, limits: Array[Int], maxFrontier: Long, out: Array[Long],
                                perRegex: Array[Int], status: Array[Int]): Long
+  @native def regexBatchMatchDirect0(h: Long, batch: Long, limits: Array[Int], maxFrontier: Long, out: ByteBuffer,
+                                     perRegex: ByteBuffer, status: Array[Int]): Long
   @native def stats0(h: Long, counters: Array[Long], ms: Array[Double]): Unit
 
   val MATCH_FRONTIER = 0      // every match, breadth of the whole batch at once (the throughput path)
@@ -198,5 +200,47 @@ object HipRegex {
       regexBatchFree0(batch)
       handles.foreach(regexFree0)
     }
+  }
+}
+
+/** A batch of regexes kept resident on the device and matched many times (the serving shape of ReTree.matchSA over
+  * many regexes).  Results land in page-locked direct buffers that the device writes itself: 24-byte records
+  * (regex: Int, len: Int, sp: Long, ep: Long, little-endian), grouped by regex and sorted by (len, sp, ep), plus one
+  * count per regex.  The buffers are reused by every call: read them before the next `matchRaw`. */
+class HipRegexBatch(sa: HipFMSearcher, res: Array[String], lineOnly: Boolean = false, cap: Int = 1 << 22) {
+  import HipFM._
+  private val handles = res.map(r => regexCompile0(latin1(r), lineOnly))
+  private val batch = regexBatchCreate0(sa.handle, handles)
+  val results: ByteBuffer = HipFMSearcher.pinned(24L * cap)
+  val perRegex: ByteBuffer = HipFMSearcher.pinned(4L * math.max(res.length, 1))
+  private val status = new Array[Int](1)
+  var truncated = false
+
+  /** Every match of every regex up to maxSteps characters (0 = 4096); returns the number of records in `results`. */
+  def matchRaw(maxSteps: Int = 0, maxFrontier: Long = 0): Int = {
+    val got = regexBatchMatchDirect0(sa.handle, batch, Array(maxSteps, MATCH_FRONTIER, 1024, 1000), maxFrontier, results,
+                                     perRegex, status).toInt
+    truncated = status(0) != 0
+    got
+  }
+
+  /** The same as lists of SAResult per regex (ReTree.matchSA's result type). */
+  def matchAll(maxSteps: Int = 0): Array[List[SAResult]] = {
+    val got = matchRaw(maxSteps)
+    val lists = Array.fill(res.length)(List[SAResult]())
+    var j = got - 1
+    while (j >= 0) {                                     // prepend from the end: each list keeps the library's order
+      val at = 24 * j
+      lists(results.getInt(at)) ::= SAResult(sa, results.getInt(at + 4), results.getLong(at + 8).toInt, results.getLong(at + 16).toInt)
+      j -= 1
+    }
+    lists
+  }
+
+  def close(): Unit = {
+    regexBatchFree0(batch)
+    handles.foreach(regexFree0)
+    hostFree0(results)
+    hostFree0(perRegex)
   }
 }

@@ -152,11 +152,15 @@ __device__ __forceinline__ void pool_sync() {
 // another one: a wave that finds the queue empty a few polls in a row simply ends, and whatever is appended after
 // that is the next launch's input.
 #ifndef FMX_FWAVES
-#define FMX_FWAVES 3
+#define FMX_FWAVES 4
 #endif
 #ifndef FMX_FBATCH
-#define FMX_FBATCH 2
+#define FMX_FBATCH 4
 #endif
+#ifndef FMX_TAKE_OLDEST
+#define FMX_TAKE_OLDEST 32
+#endif
+constexpr uint32_t kTakeOldest = FMX_TAKE_OLDEST;   // pool sizes up to which idle lanes take the oldest entries
 #ifndef FMX_POOL_KEEP
 #define FMX_POOL_KEEP 192
 #endif
@@ -391,11 +395,16 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         if (pn) {
           const uint32_t take = n_idle < pn ? n_idle : pn;
           const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+          // A small pool is emptied from its OLD end: the oldest entries are the shallowest, i.e. the ones with the
+          // longest way still to go, and a wave's last rounds are the launch's critical path.  A large pool is emptied
+          // from its new end (depth first), which keeps it from growing.
+          const bool oldest = pn <= kTakeOldest;
           if (!have && rank < take) {
-            const uint32_t idx = (pb + pn - 1 - rank) & kPool64Mask;
+            const uint32_t idx = (oldest ? pb + rank : pb + pn - 1 - rank) & kPool64Mask;
             state = pl.state[idx]; meta = pl.meta[idx]; sp = pl.sp[idx]; ep = pl.ep[idx];
             have = true;
           }
+          if (oldest) pb = uni((pb + take) & kPool64Mask);
           pn = uni(pn - take);
           pool_sync();
         }
@@ -449,44 +458,114 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     xc.ep[lane] = ep;
     xc.key[lane] = query ? ((uint32_t)slot | (c << 16)) : kNoQuery;
     pool_sync();
-#pragma unroll
-    for (int r0 = 0; r0 < G; r0 += B) {
-      // B sub-rounds: all their lines are requested before the first is consumed
-      RankReq q1[B], q2[B];
-      uint32_t key[B];
-#pragma unroll
-      for (int b = 0; b < B; b++) {
-        const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
-        key[b] = xc.key[e];
-        q1[b].kind = 0; q2[b].kind = 0;
-        if (key[b] != kNoQuery) {
-          const uint64_t esp = xc.sp[e], eep = xc.ep[e];
-          const uint16_t es = (uint16_t)(key[b] & 0xFFFFu);
-          q1[b] = rank_issue<LAYOUT>(ix, es, esp, lc);
-          const bool same = LAYOUT == kLayoutBytes ? (eep >> 7) == (esp >> 7) : false;
-          if (LAYOUT == kLayoutBytes) {
-            if (same) { q2[b] = q1[b]; q2[b].rem = (uint32_t)eep & 127u; }
-            else q2[b] = rank_issue<LAYOUT>(ix, es, eep, lc);
-            if (lc.t == 0) n_reqs += same ? 2u : 4u;
-          } else {
-            uint32_t b1, m1, b2, m2;
-            split448(esp, b1, m1);
-            split448(eep, b2, m2);
-            q2[b] = q1[b];
-            q2[b].rem = m2;
-            if (b2 != b1) q2[b].w = load_line16(block_addr(ix, es, b2, lc));
-            if (lc.t == 0) n_reqs += b2 != b1 ? 2u : 1u;
+    if constexpr (LAYOUT == kLayoutBytes) {
+  #pragma unroll
+      for (int r0 = 0; r0 < G; r0 += B) {
+        // B sub-rounds: all their lines are requested before the first is consumed
+        RankReq q1[B], q2[B];
+        uint32_t key[B];
+  #pragma unroll
+        for (int b = 0; b < B; b++) {
+          const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
+          key[b] = xc.key[e];
+          q1[b].kind = 0; q2[b].kind = 0;
+          if (key[b] != kNoQuery) {
+            const uint64_t esp = xc.sp[e], eep = xc.ep[e];
+            const uint16_t es = (uint16_t)(key[b] & 0xFFFFu);
+            q1[b] = rank_issue<LAYOUT>(ix, es, esp, lc);
+            const bool same = LAYOUT == kLayoutBytes ? (eep >> 7) == (esp >> 7) : false;
+            if (LAYOUT == kLayoutBytes) {
+              if (same) { q2[b] = q1[b]; q2[b].rem = (uint32_t)eep & 127u; }
+              else q2[b] = rank_issue<LAYOUT>(ix, es, eep, lc);
+              if (lc.t == 0) n_reqs += same ? 2u : 4u;
+            } else {
+              uint32_t b1, m1, b2, m2;
+              split448(esp, b1, m1);
+              split448(eep, b2, m2);
+              q2[b] = q1[b];
+              q2[b].rem = m2;
+              if (b2 != b1) q2[b].w = load_line16(block_addr(ix, es, b2, lc));
+              if (lc.t == 0) n_reqs += b2 != b1 ? 2u : 1u;
+            }
+          }
+        }
+  #pragma unroll
+        for (int b = 0; b < B; b++) {
+          if (key[b] != kNoQuery) {
+            const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
+            const uint32_t ec = key[b] >> 16;
+            const uint64_t r1 = rank_complete<WIDE, LAYOUT>(q1[b], ec, lc);
+            const uint64_t r2 = rank_complete<WIDE, LAYOUT>(q2[b], ec, lc);
+            if (lc.t == 0) { xc.sp[e] = r1; xc.ep[e] = r2; }
           }
         }
       }
+    } else {
+      // One-hot layout.  An interval that has been narrowed by a few steps lies inside one 448-position block, so the
+      // common case is ONE line per element: B sub-rounds request their sp-block together (5 registers each: the
+      // line and the two in-block boundaries), both ranks come from it, and the few elements whose ep falls into
+      // another block are finished in a second trip afterwards (their ep stays in the exchange area meanwhile).
+      constexpr uint32_t kTwo = 1u << 30, kActive = 1u << 31, kPending = 1u << 31;
+      bool any_two = false;
 #pragma unroll
-      for (int b = 0; b < B; b++) {
-        if (key[b] != kNoQuery) {
+      for (int r0 = 0; r0 < G; r0 += B) {
+        uint4 w[B];
+        uint32_t m[B];      // m1 | m2 << 9 | kTwo | kActive
+#pragma unroll
+        for (int b = 0; b < B; b++) {
           const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
-          const uint32_t ec = key[b] >> 16;
-          const uint64_t r1 = rank_complete<WIDE, LAYOUT>(q1[b], ec, lc);
-          const uint64_t r2 = rank_complete<WIDE, LAYOUT>(q2[b], ec, lc);
-          if (lc.t == 0) { xc.sp[e] = r1; xc.ep[e] = r2; }
+          const uint32_t key = xc.key[e];
+          m[b] = 0;
+          w[b] = make_uint4(0, 0, 0, 0);
+          if (key != kNoQuery) {
+            const uint64_t esp = xc.sp[e], eep = xc.ep[e];
+            uint32_t b1, m1, b2, m2;
+            split448(esp, b1, m1);
+            split448(eep, b2, m2);
+            w[b] = load_line16(block_addr(ix, key & 0xFFFFu, b1, lc));
+            m[b] = m1 | (m2 << 9) | kActive | (b2 != b1 ? kTwo : 0u);
+            if (lc.t == 0) n_reqs += b2 != b1 ? 2u : 1u;
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          if (m[b] & kActive) {
+            const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
+            const bool two = (m[b] & kTwo) != 0;
+            const uint64_t r1 = rank_finish<WIDE>(w[b], m[b] & 0x1FFu, lc);
+            const uint64_t r2 = rank_finish<WIDE>(w[b], (m[b] >> 9) & 0x1FFu, lc);
+            if (lc.t == 0) {
+              xc.sp[e] = r1;
+              if (two) xc.key[e] |= kPending;      // ep's own block is still to be read
+              else xc.ep[e] = r2;
+            }
+            any_two |= two;
+          }
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(any_two)) {
+        pool_sync();
+        uint4 w2[G];
+        uint32_t m2s[G];
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+          const uint32_t e = (uint32_t)r * EPS + grp;
+          const uint32_t key = xc.key[e];
+          m2s[r] = 0xFFFFFFFFu;
+          w2[r] = make_uint4(0, 0, 0, 0);
+          if (key != kNoQuery && (key & kPending)) {
+            uint32_t b2, m2;
+            split448(xc.ep[e], b2, m2);
+            w2[r] = load_line16(block_addr(ix, key & 0xFFFFu, b2, lc));
+            m2s[r] = m2;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+          if (m2s[r] != 0xFFFFFFFFu) {
+            const uint64_t r2 = rank_finish<WIDE>(w2[r], m2s[r], lc);
+            if (lc.t == 0) xc.ep[(uint32_t)r * EPS + grp] = r2;
+          }
         }
       }
     }

@@ -786,16 +786,12 @@ struct DevMem {
     if (e__ != hipSuccess) return hip_fail(e__, what); \
   } while (0)
 
-// What the host needs to fetch the grouped results: how many there are and how many groups were left unsorted.
+// What the host needs to fetch the grouped results: how many there are and how many groups were left unsorted
+// (written to pinned host memory by the grouping's last kernel, k_res_export).
 struct GroupTotals {
   uint32_t n_results;
   uint32_t n_big;
 };
-__global__ void k_res_totals(const uint32_t *__restrict__ start, uint32_t k, const BigGroups *__restrict__ big,
-                             GroupTotals *__restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { out->n_results = start[k]; out->n_big = big->n_host ? big->n : 0u; }
-}
-
 // Where the grouped results go when the caller's buffers are page-locked (fmx_host_alloc): the device writes them
 // there itself, behind the grouping and before the host's one synchronisation.  The struct lives in pinned host
 // memory; the host fills it before it starts the launches (null pointers: the host copies after the synchronisation).
@@ -805,7 +801,9 @@ struct ExportDst {
   uint32_t *per;
 };
 __global__ __launch_bounds__(256) void k_res_export(const fmx_result *__restrict__ res, const uint32_t *__restrict__ start, uint32_t k,
-                                                     const uint32_t *__restrict__ rcnt, const ExportDst *__restrict__ dst) {
+                                                     const uint32_t *__restrict__ rcnt, const BigGroups *__restrict__ big,
+                                                     const ExportDst *__restrict__ dst, GroupTotals *__restrict__ tot /* pinned host */) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { tot->n_results = start[k]; tot->n_big = big->n_host ? big->n : 0u; }
   const ExportDst d = *dst;
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
   if (d.out) {
@@ -843,7 +841,7 @@ struct RegexBatch {
   ExportDst *h_dst = nullptr;          // pinned: where k_res_export writes (set per call)
   hipGraphExec_t chain_exec = nullptr; // one chain of launches + advance + counter copy, captured once (full grid)
   hipGraphExec_t chain_small_exec = nullptr;   // the same on the small grid
-  GroupTotals *d_tot = nullptr, *h_tot = nullptr;   // device copy / pinned host copy of the grouping's totals
+  GroupTotals *h_tot = nullptr;        // pinned: the grouping's totals, written by k_res_export
   uint32_t chain_len = 0, chain_rounds = 0;
   uint32_t matches = 0;                // the chain is captured from a batch's second match on (a one-shot batch
                                        // would pay the capture and never replay it)
@@ -1039,22 +1037,20 @@ __global__ __launch_bounds__(kScanChunk) void k_res_scan_chunks(const uint32_t *
   if (threadIdx.x == 0) part[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(kScanChunk) void k_res_scan_parts(uint32_t *__restrict__ part, uint32_t nparts) {
-  __shared__ uint32_t s_wave[16];
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < nparts; base += kScanChunk) {        // one trip up to a million regexes
-    const uint32_t i = base + threadIdx.x;
-    uint32_t total = 0;
-    const uint32_t ex = block_excl_scan_1024(i < nparts ? part[i] : 0u, s_wave, total);
-    if (i < nparts) part[i] = carry + ex;
-    carry += total;
-  }
-}
-
+// Every workgroup adds up the totals of the chunks before its own (a hundred values for 100 k regexes) and adds
+// that to its chunk's sums: no separate launch for the scan of the chunk totals.
 __global__ __launch_bounds__(kScanChunk) void k_res_scan_add(uint32_t *__restrict__ start, uint32_t n,
                                                              const uint32_t *__restrict__ part) {
+  __shared__ unsigned long long s_sum[kScanChunk / 64];
+  unsigned long long mine = 0;
+  for (uint32_t q = threadIdx.x; q < blockIdx.x; q += kScanChunk) mine += part[q];
+  mine = wave_sum(mine);
+  if ((threadIdx.x & 63u) == 0) s_sum[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t j = 0; j < kScanChunk / 64; j++) before += (uint32_t)s_sum[j];
   const uint32_t i = blockIdx.x * kScanChunk + threadIdx.x;
-  if (i < n) start[i] += part[blockIdx.x];
+  if (i < n) start[i] += before;
 }
 
 __global__ __launch_bounds__(256) void k_res_scatter(const fmx_result *__restrict__ seg, uint64_t seg_cap,
@@ -1071,28 +1067,44 @@ __global__ __launch_bounds__(256) void k_res_scatter(const fmx_result *__restric
 }
 
 // Orders each regex's group by (len, sp, ep): one thread per regex, insertion sort for the usual handful of
-// results; larger groups are listed for the host.
+// results; larger groups are listed for k_res_sort_mid / the host.  The results of a workgroup's 256 regexes are one
+// contiguous stretch of `out`: when it fits (it nearly always does) it is sorted in LDS -- an insertion sort is a
+// chain of dependent accesses, 0.1 us each in LDS against 0.5 in L2.
+constexpr uint32_t kSortStage = 768;      // results (18 KB)
 __global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ out, const uint32_t *__restrict__ start, uint32_t k,
                                                    BigGroups *__restrict__ big) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= k) return;
-  const uint32_t lo = start[r], m = start[r + 1] - lo;
-  if (m < 2) return;
-  if (m > kSmallGroup) {
-    const uint32_t at = atomicAdd(&big->n, 1u);
-    if (at < kBigMax) { big->ent[2 * at] = lo; big->ent[2 * at + 1] = m; }
-    return;
+  __shared__ fmx_result s_r[kSortStage];
+  const uint32_t r0 = blockIdx.x * blockDim.x, r = r0 + threadIdx.x;
+  const uint32_t r_end = r0 + blockDim.x < k ? r0 + blockDim.x : k;
+  const uint32_t base = start[r0], span = start[r_end] - base;      // uniform over the workgroup
+  const bool staged = span <= kSortStage;
+  if (staged) {
+    for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) s_r[i] = out[base + i];
+    __syncthreads();
   }
   auto less = [](const fmx_result &a, const fmx_result &b) {
     if (a.len != b.len) return a.len < b.len;
     if (a.sp != b.sp) return a.sp < b.sp;
     return a.ep < b.ep;
   };
-  for (uint32_t i = 1; i < m; i++) {
-    const fmx_result x = out[lo + i];
-    uint32_t j = i;
-    while (j > 0 && less(x, out[lo + j - 1])) { out[lo + j] = out[lo + j - 1]; j--; }
-    out[lo + j] = x;
+  if (r < k) {
+    const uint32_t lo = start[r], m = start[r + 1] - lo;
+    if (m > kSmallGroup) {
+      const uint32_t at = atomicAdd(&big->n, 1u);
+      if (at < kBigMax) { big->ent[2 * at] = lo; big->ent[2 * at + 1] = m; }
+    } else if (m >= 2) {
+      fmx_result *g = staged ? s_r + (lo - base) : out + lo;
+      for (uint32_t i = 1; i < m; i++) {
+        const fmx_result x = g[i];
+        uint32_t j = i;
+        while (j > 0 && less(x, g[j - 1])) { g[j] = g[j - 1]; j--; }
+        g[j] = x;
+      }
+    }
+  }
+  if (staged) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) out[base + i] = s_r[i];
   }
 }
 
@@ -1184,7 +1196,6 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     }
     HIP_TRY(b->scratch->alloc(&b->d_rstart, b->k + 1), "hipMalloc(result offsets)");
     HIP_TRY(b->scratch->alloc(&b->d_rpart, (b->k + 1) / kScanChunk + 2), "hipMalloc(scan parts)");
-    HIP_TRY(b->scratch->alloc(&b->d_tot, 1), "hipMalloc(totals)");
     b->qcap = qcap;
     b->rcap = cap ? cap : 1;
   }
@@ -1307,16 +1318,12 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     k_res_count<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rcnt);
     const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: start[k] = total
     k_res_scan_chunks<<<nparts, kScanChunk, 0, s>>>(b->d_rcnt, n_scan, b->d_rstart, b->d_rpart);
-    k_res_scan_parts<<<1, kScanChunk, 0, s>>>(b->d_rpart, nparts);
     k_res_scan_add<<<nparts, kScanChunk, 0, s>>>(b->d_rstart, n_scan, b->d_rpart);
     k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)rcap);
     k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);
     k_res_sort_mid<<<256, 256, 0, s>>>(d_res, b->d_big);
-    k_res_totals<<<1, 1, 0, s>>>(b->d_rstart, (uint32_t)b->k, b->d_big, b->d_tot);
-    k_res_export<<<128, 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_rcnt, b->h_dst);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return hipMemcpyAsync(b->h_tot, b->d_tot, sizeof(GroupTotals), hipMemcpyDeviceToHost, s);
+    k_res_export<<<128, 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst, b->h_tot);
+    return hipGetLastError();
   };
   auto capture = [&](hipGraphExec_t *exec, int grid) {     // one graph: the chain of launches, then the grouping
     // one capture at a time in the process: concurrent captures from several host threads (the multi-device entry
@@ -1348,7 +1355,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     }
     HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
     const uint32_t done = small ? kChainSmall : kChain;
-    launches += 2 * done + 10;
+    launches += 2 * done + 8;
     b->tag_bound += done;
     HIP_TRY(hipStreamSynchronize(st), "sync(passes)");
     sum = *b->h_sum;

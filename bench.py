@@ -588,8 +588,8 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     achieved = alg_bytes / ksec / 1e9
     traffic = pmc_traffic(args.workload, "k_frontier")
     roof = {
-        "bound": "hbm", "kernel": "k_frontier* (all device work of one fmx_regex_batch_match: HIP events around the "
-                                   "level launches, host looks between them included)",
+        "bound": "hbm", "kernel": "k_frontier* (all device work of one fmx_regex_batch_match: HIP events around reset, start "
+                                   "elements, the launch chain, result grouping and export)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic[0] if traffic else None,
         "traffic_source": ("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"

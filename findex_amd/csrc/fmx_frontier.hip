@@ -459,44 +459,58 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     xc.key[lane] = query ? ((uint32_t)slot | (c << 16)) : kNoQuery;
     pool_sync();
     if constexpr (LAYOUT == kLayoutBytes) {
-  #pragma unroll
-      for (int r0 = 0; r0 < G; r0 += B) {
-        // B sub-rounds: all their lines are requested before the first is consumed
-        RankReq q1[B], q2[B];
-        uint32_t key[B];
-  #pragma unroll
-        for (int b = 0; b < B; b++) {
+      // Bytes layout: a rank query is the 128-position block (16 bytes per lane of the octet) plus its checkpoint.
+      // As below, sp and ep of a narrowed interval lie in one block: one request pair per element, both ranks from
+      // it, a second trip for the elements whose ep lies in the next block.
+      constexpr uint32_t kTwo = 1u << 30, kPending = 1u << 31;
+      constexpr int BB = 2;
+      bool any_two = false;
+#pragma unroll
+      for (int r0 = 0; r0 < G; r0 += BB) {
+        ByteRankReq q[BB];
+        uint32_t key[BB], m[BB];      // m: ep's in-block offset | kTwo
+#pragma unroll
+        for (int b = 0; b < BB; b++) {
           const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
           key[b] = xc.key[e];
-          q1[b].kind = 0; q2[b].kind = 0;
+          m[b] = 0;
+          q[b].w = make_uint4(0, 0, 0, 0); q[b].chk = 0; q[b].sup = 0; q[b].rem = 0;
           if (key[b] != kNoQuery) {
             const uint64_t esp = xc.sp[e], eep = xc.ep[e];
-            const uint16_t es = (uint16_t)(key[b] & 0xFFFFu);
-            q1[b] = rank_issue<LAYOUT>(ix, es, esp, lc);
-            const bool same = LAYOUT == kLayoutBytes ? (eep >> 7) == (esp >> 7) : false;
-            if (LAYOUT == kLayoutBytes) {
-              if (same) { q2[b] = q1[b]; q2[b].rem = (uint32_t)eep & 127u; }
-              else q2[b] = rank_issue<LAYOUT>(ix, es, eep, lc);
-              if (lc.t == 0) n_reqs += same ? 2u : 4u;
-            } else {
-              uint32_t b1, m1, b2, m2;
-              split448(esp, b1, m1);
-              split448(eep, b2, m2);
-              q2[b] = q1[b];
-              q2[b].rem = m2;
-              if (b2 != b1) q2[b].w = load_line16(block_addr(ix, es, b2, lc));
-              if (lc.t == 0) n_reqs += b2 != b1 ? 2u : 1u;
-            }
+            q[b] = byte_rank_issue(ix, (uint16_t)(key[b] & 0xFFFFu), esp, lc);
+            const bool two = (eep >> 7) != (esp >> 7);
+            m[b] = ((uint32_t)eep & 127u) | (two ? kTwo : 0u);
+            if (lc.t == 0) n_reqs += two ? 4u : 2u;
           }
         }
-  #pragma unroll
-        for (int b = 0; b < B; b++) {
+#pragma unroll
+        for (int b = 0; b < BB; b++) {
           if (key[b] != kNoQuery) {
             const uint32_t e = (uint32_t)(r0 + b) * EPS + grp;
-            const uint32_t ec = key[b] >> 16;
-            const uint64_t r1 = rank_complete<WIDE, LAYOUT>(q1[b], ec, lc);
-            const uint64_t r2 = rank_complete<WIDE, LAYOUT>(q2[b], ec, lc);
-            if (lc.t == 0) { xc.sp[e] = r1; xc.ep[e] = r2; }
+            const uint32_t ec = (key[b] >> 16) & 0xFFu;
+            const bool two = (m[b] & kTwo) != 0;
+            const uint64_t r1 = byte_rank_finish(q[b], ec, lc);
+            q[b].rem = m[b] & 127u;
+            const uint64_t r2 = byte_rank_finish(q[b], ec, lc);
+            if (lc.t == 0) {
+              xc.sp[e] = r1;
+              if (two) xc.key[e] |= kPending;      // ep's own block is still to be read
+              else xc.ep[e] = r2;
+            }
+            any_two |= two;
+          }
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(any_two)) {
+        pool_sync();
+#pragma unroll 1
+        for (int r = 0; r < G; r++) {
+          const uint32_t e = (uint32_t)r * EPS + grp;
+          const uint32_t key = xc.key[e];
+          if (key != kNoQuery && (key & kPending)) {
+            const ByteRankReq q2 = byte_rank_issue(ix, (uint16_t)(key & 0xFFFFu), xc.ep[e], lc);
+            const uint64_t r2 = byte_rank_finish(q2, (key >> 16) & 0xFFu, lc);
+            if (lc.t == 0) xc.ep[e] = r2;
           }
         }
       }

@@ -87,7 +87,7 @@ struct FrontierCtl {     // device-resident counters
   unsigned long long overflow;     // bit 0: queue, bit 1: results, bit 2: an appended entry never became readable
   unsigned long long truncated;    // some element was not expanded because its follows would have len >= max_len
   uint32_t max_len;
-  uint32_t pad_;
+  uint32_t fresh;                  // this chain of launches begins a call (k_frontier_reset -> k_frontier_init)
   unsigned long long left;         // entries queued when the launch began (k_frontier_reset / k_frontier_advance): 0 = nothing to do
 };
 struct FrontierSummary { // what the host reads after a chain of launches (k_frontier_advance)
@@ -813,6 +813,10 @@ struct ExportDst {
   fmx_result *out;
   unsigned long long cap;
   uint32_t *per;
+  // and what a call's first chain of launches starts from (k_frontier_reset reads it): the arguments of a captured
+  // graph are fixed, the call's own values travel through this page-locked struct
+  uint32_t max_len;
+  uint32_t fresh;        // 1: this chain begins a call (reset the queue, write the start elements); 0: it continues one
 };
 __global__ __launch_bounds__(256) void k_res_export(const fmx_result *__restrict__ res, const uint32_t *__restrict__ start, uint32_t k,
                                                      const uint32_t *__restrict__ rcnt, const BigGroups *__restrict__ big,
@@ -985,8 +989,11 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
 
 // A call starts from rewound buffers under fresh tags (one wave, lane = slice): buffer 0 of every slice receives
 // the slice's share of the start elements, buffer 1 is the first one written.
-__global__ __launch_bounds__(64) void k_frontier_reset(FrontierCtl *__restrict__ ctl, uint64_t count, uint32_t max_len) {
+__global__ __launch_bounds__(64) void k_frontier_reset(FrontierCtl *__restrict__ ctl, uint64_t count, const uint32_t *__restrict__ call /* {max_len, fresh}, pinned host */) {
   const uint32_t i = threadIdx.x;
+  const uint32_t max_len = call[0], fresh = call[1];
+  if (i == 0) ctl->fresh = fresh;
+  if (!fresh) return;                      // a chain that continues a call
   SliceCtl &q = ctl->q[i];
   q.tail[0] = count > i ? (count - i + kSub - 1) / kSub : 0;
   q.tail[1] = 0; q.head[0] = 0; q.head[1] = 0;
@@ -999,7 +1006,7 @@ __global__ __launch_bounds__(64) void k_frontier_reset(FrontierCtl *__restrict__
 __global__ void k_frontier_init(FlowQueue fq, NfaTables nfa, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n /* 0: the start elements carry the empty k-mer code */,
                                 uint64_t sub_cap, const FrontierCtl *__restrict__ ctl) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) {
+  if (i < count && ctl->fresh) {
     const uint32_t s = (uint32_t)(i % kSub);
     const uint64_t at = ((uint64_t)s * 2) * sub_cap + i / kSub;
     const uint32_t st = first_state[i];
@@ -1240,9 +1247,6 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   b->tag_bound++;
   mark("setup");
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
-  k_frontier_reset<<<1, 64, 0, st>>>(d_ctl, b->n_first, max_steps);
-  k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, st>>>(fq, b->nfa, b->d_first_state, b->n_first, kt.k ? 0 : h->n, sub_cap, d_ctl);
-  HIP_TRY(hipGetLastError(), "k_frontier_init");
   // Launches are chained on the stream without host round trips; the host looks at the summary after every
   // chain.  A launch that finds the queue empty returns at once.
   static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 2u;
@@ -1291,6 +1295,10 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   static const uint32_t kRoundsSmall = getenv("FMX_FRONTIER_ROUNDS_SMALL") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS_SMALL"))) : 32u;
   auto enqueue_chain = [&](hipStream_t s, int grid) -> hipError_t {
     const uint32_t len = grid == grid_small ? kChainSmall : kChain;
+    // a call's first chain begins with the reset and the start elements (h_dst->fresh; both return at once otherwise):
+    // one graph launch per call
+    k_frontier_reset<<<1, 64, 0, s>>>(d_ctl, b->n_first, &b->h_dst->max_len);
+    k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, s>>>(fq, b->nfa, b->d_first_state, b->n_first, kt.k ? 0 : h->n, sub_cap, d_ctl);
     for (uint32_t j = 0; j < len; j++) {
       launch_pass(s, grid, j, grid == grid_small ? kRoundsSmall : (plan.empty() ? kRounds : plan[std::min<size_t>(j, plan.size() - 1)]));
       k_frontier_advance<<<1, 64, 0, s>>>(d_ctl, sub_cap, b->d_sum);
@@ -1310,6 +1318,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   b->h_dst->out = export_out ? out : nullptr;
   b->h_dst->cap = cap;
   b->h_dst->per = export_per ? per_regex_count : nullptr;
+  b->h_dst->max_len = max_steps;
+  b->h_dst->fresh = 1;
   b->matches++;
   uint64_t total = b->n_first;               // elements in the input queue of the next pass
   const uint64_t kSmallTotal = (uint64_t)grid_small * per_wg;
@@ -1369,9 +1379,10 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     }
     HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
     const uint32_t done = small ? kChainSmall : kChain;
-    launches += 2 * done + 8;
+    launches += 2 * done + 10;
     b->tag_bound += done;
     HIP_TRY(hipStreamSynchronize(st), "sync(passes)");
+    b->h_dst->fresh = 0;               // further chains of this call continue the search
     sum = *b->h_sum;
     pass += done;
     if (sum.overflow & 4ull) { set_error("frontier work queue: an appended entry never became readable"); return FMX_ERR_HIP; }

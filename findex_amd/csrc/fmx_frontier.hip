@@ -7,22 +7,26 @@
 // not change the result multiset (whenever the reference's maxBranching / maxIterations do not bind),
 // and the device is free to choose the order that costs least memory traffic:
 //
-//   * A lane group (a quad in the one-hot layout, an octet in the bytes layout) HOLDS an element in
-//     registers and follows it: after a step that survives, the group keeps the first follow for
-//     itself (same sp/ep, len + 1) and goes on -- a literal stretch of a regex is walked like a
-//     literal pattern in k_search4, with no queue round trip per character.  The state record carries
-//     the bytes of its first follows, so the next step's rank blocks are requested together with the
-//     next state's record: one memory latency per step, not two.
-//   * The other follows go to the wave's own POOL in LDS (128 entries, newest first out: depth-first,
-//     so the live set stays small); lane groups whose element died take their next one from there.
-//   * Work enters and leaves a launch through two sliced HBM queues: a wave starts from its share of
-//     the input queue (batches of 16, requested one round ahead), spills the oldest pool entries to
-//     the output queue when the pool fills, and after `max_rounds` rounds hands everything it still
-//     holds to the output queue and ends.  The next launch deals that queue out evenly again: that is
-//     the whole load balancing -- no concurrent producer/consumer queue, no spin-waits, every wave
-//     reaches its exit after a bounded number of rounds.  Launches repeat until the output queue stays
-//     empty (round 1 ran one launch per match length: 64+ launches, most of them nearly empty, every
-//     element through HBM queues at every level; profiles/r02_c4_before_*).
+//   * A LANE holds an element in registers -- state, length, interval and the state's 32-byte record -- and
+//     follows it: after a step that survives, the lane keeps the first follow for itself (same sp/ep, len + 1) and
+//     goes on -- a literal stretch of a regex is walked like a literal pattern in k_search4, with no queue round
+//     trip per character.  The state record carries the bytes of its first follows, so the next step's rank blocks
+//     are requested together with the next state's record: one memory latency per step, not two.  All of an
+//     element's bookkeeping runs once, in its lane (64 elements per wave).
+//   * The rank queries themselves want a lane group (a quad in the one-hot layout, an octet in the bytes layout:
+//     16 bytes of the block per lane, DPP reductions).  Each round hands the 64 intervals through a wave-private
+//     exchange area in LDS to the lane groups in G sub-rounds of 64/G elements and takes the stepped intervals back
+//     the same way.  A narrowed interval lies inside one block: one line per element, the rare second block in a
+//     second trip.
+//   * The other follows go to the wave's own POOL in LDS (256 entries, newest first out: depth-first, so the live
+//     set stays small; a nearly empty pool is emptied oldest first); lanes whose element died take their next one
+//     from there.
+//   * What a wave cannot hold goes to a sliced work queue in HBM whose entries other waves may take DURING THE SAME
+//     LAUNCH (tagged 8-byte granules, agent-scope stores and loads; below), and what was queued before a launch is
+//     dealt out in fixed shares.  No wave ever waits for another: one that finds nothing ends, every wave ends
+//     after at most `max_rounds` rounds (handing over what it still holds), and launches repeat until the queue is
+//     empty.  A batch like C4 is one launch (round 1 ran one launch per match length: 64+ launches, every element
+//     through HBM queues at every level; profiles/r02_c4_analysis.md has the history).
 #include <fmx.h>
 
 #include <algorithm>

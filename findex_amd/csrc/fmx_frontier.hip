@@ -1280,7 +1280,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // One chain = kChain x (launch + k_frontier_advance) + the summary's copy to pinned host memory.  Its kernel
   // arguments do not change from chain to chain, so it is captured into a hipGraph once per batch and replayed:
   // one launch call per chain.  Two chains are kept: the full grid for a batch's wide phase, and a small grid
-  // (64 workgroups: enough lane groups for 4096 elements) for a single regex or the thin end of a batch, whose
+  // (64 workgroups: lanes for 16384 elements) for a single regex or the thin end of a batch, whose
   // launches cost a fraction of the full grid's when most of them find nothing to do.
   static const bool use_graph = !(getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) == 0);
   // experiments: rounds per launch of a chain as a comma list (the last entry repeats)
@@ -1325,7 +1325,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   b->h_dst->max_len = max_steps;
   b->h_dst->fresh = 1;
   b->matches++;
-  uint64_t total = b->n_first;               // elements in the input queue of the next pass
+  uint64_t total = b->n_first;               // elements queued for the next launch
   const uint64_t kSmallTotal = (uint64_t)grid_small * per_wg;
   if (b->chain_len != kChain || b->chain_rounds != kRounds) {
     for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec})

@@ -587,6 +587,8 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         }
       }
     }
+    // the table entry is not needed before this point: keeps its load in flight beside the rank lines'
+    asm volatile("" : "+v"(ent.x), "+v"(ent.y), "+v"(ent.z), "+v"(ent.w));
     pool_sync();
     if (have) {
       if (from_tab) {

@@ -1050,8 +1050,9 @@ def test_c4_full_size_regex_batch():
     """BASELINE config C4 at its own size: 100k seeded regexes (<= 32 Glushkov positions) over a 2^30-row
     sigma=28 index.  Properties of the answer that need no CPU index of that size: every result interval is
     non-empty and inside [0, n); for sampled results the rows really spell a string the regex matches (text
-    extracted with nextSubstr = Psi walks, checked with Python's `re`); the per-regex counts add up; and the
-    literal-only regexes of the batch give exactly what fmx_search_batch gives for the same strings."""
+    extracted with nextSubstr = Psi walks, checked with Python's `re`); the per-regex counts add up; the same
+    BWT opened in the bytes layout gives the identical result list; and the literal-only regexes of the batch give
+    exactly what fmx_search_batch gives for the same strings."""
     import re as pyre
     import sys
     torch = _torch()
@@ -1067,6 +1068,13 @@ def test_c4_full_size_regex_batch():
         bwt[a:b] = alpha[torch.randint(0, alpha.numel(), (b - a,), generator=g, device="cuda")]
     torch.cuda.synchronize()
     hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, n // 3, None)
+    findex_amd.set_layout("bytes")                 # the same BWT in the compact layout, for the cross-check below
+    findex_amd.set_checkpoints("superblock")
+    try:
+        hip_b = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, n // 3, None)
+    finally:
+        findex_amd.set_layout("auto")
+        findex_amd.set_checkpoints("auto")
     del bwt
     trees = []
 
@@ -1093,6 +1101,12 @@ def test_c4_full_size_regex_batch():
         sel = pick[out["len"][pick] == ln]
         for j, s in zip(sel, hip.nextSubstr_batch(out["sp"][sel], int(ln))):
             assert len(s) == ln and pyre.fullmatch(res[out[j]["regex"]].encode(), s, pyre.S), (res[out[j]["regex"]], s)
+    # the other layout (octets, two lines per rank query, 64-bit superblock counts) must give the same list, byte for byte
+    assert hip.stats()["layout"] == 0 and hip_b.stats()["layout"] == 1
+    out_b, per_b = findex_amd.ReTree.prepare_batch(hip_b, trees).match_raw(max_steps=64)
+    assert out_b.size == out.size and all(np.array_equal(out_b[f], out[f]) for f in ("regex", "len", "sp", "ep"))
+    assert np.array_equal(per_b, per)
+    del hip_b
     # regexes that are plain literals: the frontier's answer is the literal search's answer (the index is over
     # the reversed text and the regex engine walks forward with getPrevRange, so the literal is searched reversed)
     lit = [j for j, re in enumerate(res) if re.isalpha()][:2000]

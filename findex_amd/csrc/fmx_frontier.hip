@@ -196,6 +196,29 @@ struct Xchg {            // a round's intervals on their way to the lane groups 
   uint32_t key[64];      // slot | byte << 16, 0xFFFFFFFF: this element has no rank query this round
 };
 constexpr uint32_t kNoQuery = 0xFFFFFFFFu;
+// A workgroup's MAILBOX: a wave with a long backlog leaves some of its oldest pool entries here for the three other
+// waves of its workgroup, which look here first when they run dry -- the launch waits for its longest wave, and this
+// shares a long backlog at the price of LDS accesses (handing over through the HBM queue costs more than it
+// balances).  Guarded by a lock that one lane takes with an LDS compare-and-swap; the holder only copies entries.
+// Every wave empties the mailbox before it ends, so nothing is left behind.
+#ifndef FMX_MAIL
+#define FMX_MAIL 80
+#endif
+#ifndef FMX_MAIL_KEEP
+#define FMX_MAIL_KEEP 128
+#endif
+#ifndef FMX_MAIL_GIVE
+#define FMX_MAIL_GIVE 32
+#endif
+constexpr uint32_t kMail = FMX_MAIL, kMailKeep = FMX_MAIL_KEEP, kMailGive = FMX_MAIL_GIVE;
+struct Mailbox {
+  uint32_t lock;           // 0 free, 1 held
+  uint32_t n;              // entries held (a stack)
+  uint32_t state[kMail ? kMail : 1];
+  uint32_t meta[kMail ? kMail : 1];
+  uint64_t sp[kMail ? kMail : 1];
+  uint64_t ep[kMail ? kMail : 1];
+};
 
 template <bool WIDE, uint32_t LAYOUT>
 __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt, const NfaTables &nfa, const FlowQueue &fq, uint32_t j,
@@ -220,13 +243,14 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     s_wsel[threadIdx.x] = q.wsel;
     s_tags[threadIdx.x] = q.tag[0] | (q.tag[1] << 16);
   }
-  __shared__ uint64_t s_cf[256];
+  __shared__ Mailbox s_mail;
   __shared__ uint16_t s_slot[256];
   __shared__ Pool64 s_pool[kFThreads / 64];
   __shared__ ResStage64 s_res[kFThreads / 64];
   __shared__ Xchg s_xc[kFThreads / 64];
   __shared__ const uint4 *s_lvl[16];         // the k-mer table's levels (picked by an element's length at run time)
-  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) s_slot[c] = ix.slot[c];
+  if (threadIdx.x == 0) { s_mail.lock = 0; s_mail.n = 0; }
   if (threadIdx.x < 16) s_lvl[threadIdx.x] = kt.k ? kt.level_dev[threadIdx.x] : nullptr;
   __syncthreads();
   Pool64 &pl = s_pool[threadIdx.x >> 6];
@@ -385,6 +409,54 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     rs_n = 0;
   };
 
+  Mailbox &mb = s_mail;
+  auto mail_lock = [&]() {
+    if (lane == 0)
+      while (atomicCAS(&mb.lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto mail_unlock = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) atomicExch(&mb.lock, 0u);
+  };
+  // up to `room` mailbox entries enter the pool (wave-uniform; returns how many)
+  auto mail_take = [&](uint32_t room) -> uint32_t {
+    if (!kMail || !room) return 0;
+    pool_sync();
+    mail_lock();
+    const uint32_t have_n = uni(*(volatile uint32_t *)&mb.n);
+    const uint32_t cnt = have_n < room ? have_n : room;
+    if (lane < cnt) {
+      const uint32_t src = have_n - cnt + lane, idx = (pb + pn + lane) & kPool64Mask;
+      pl.state[idx] = mb.state[src]; pl.meta[idx] = mb.meta[src]; pl.sp[idx] = mb.sp[src]; pl.ep[idx] = mb.ep[src];
+    }
+    if (lane == 0 && cnt) *(volatile uint32_t *)&mb.n = have_n - cnt;
+    mail_unlock();
+    pn = uni(pn + cnt);
+    pool_sync();
+    return cnt;
+  };
+  // up to kMailGive of the pool's oldest entries go to the mailbox (wave-uniform)
+  auto mail_give = [&]() {
+    pool_sync();
+    mail_lock();
+    const uint32_t have_n = uni(*(volatile uint32_t *)&mb.n);
+    uint32_t cnt = kMail - have_n < kMailGive ? kMail - have_n : kMailGive;
+    if (cnt > pn) cnt = pn;
+    if (lane < cnt) {
+      const uint32_t dst = have_n + lane, idx = (pb + lane) & kPool64Mask;
+      mb.state[dst] = pl.state[idx]; mb.meta[dst] = pl.meta[idx]; mb.sp[dst] = pl.sp[idx]; mb.ep[dst] = pl.ep[idx];
+    }
+    if (lane == 0 && cnt) *(volatile uint32_t *)&mb.n = have_n + cnt;
+    mail_unlock();
+    pb = uni((pb + cnt) & kPool64Mask);
+    pn = uni(pn - cnt);
+    pool_sync();
+  };
+  auto mail_n = [&]() -> uint32_t { return kMail ? uni(*(volatile uint32_t *)&mb.n) : 0u; };
+
 #ifdef FMX_WAVELOG
   wl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -395,6 +467,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
       if (idle) {
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (pn < n_idle && mail_n()) mail_take(64u);                     // what a sibling wave left for this one
         if (pn < n_idle && !take_batch() && pn == 0 && n_idle == 64u) steal();
         if (pn) {
           const uint32_t take = n_idle < pn ? n_idle : pn;
@@ -424,7 +497,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     const uint32_t run = meta >> 24;          // > 0: inside a literal stretch whose bytes the held record carries
     const uint32_t c = (meta >> 16) & 0xFFu, len = meta & 0xFFFFu;
     const uint16_t slot = s_slot[c];
-    const uint64_t cfc = s_cf[c];
+    const uint64_t cfc = ix.cf[c];            // C[c]: needed only when the ranks are back, so its load rides along
     if (have && run == 0) {
       const uint4 *rp = reinterpret_cast<const uint4 *>(nfa.st + state);
       ra = rp[0];
@@ -597,7 +670,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       } else if (ranked) {
         if (len == 0) {       // every start element is (0, n): rank(c, 0) = 0, rank(c, n) = the symbol's count
           sp = cfc;
-          ep = (c == 255u) ? ix.n : s_cf[c + 1];
+          ep = (c == 255u) ? ix.n : ix.cf[c + 1];
           if (slot == kSlotNone) ep = sp;
           else if (slot == kSlotEof) ep = sp + 1;
         } else if (slot >= kSlotEof) {                  // absent symbol, or the EOF symbol 0
@@ -676,6 +749,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         // what the wave cannot work off soon goes to the queue, oldest (shallowest) first: waves that ran dry take it
         // what the wave cannot work off soon goes to the queue, oldest (shallowest) first: waves that ran dry take it
         if (pn > kPoolKeep) spill(pn - kPoolKeep / 2 < 64u ? pn - kPoolKeep / 2 : 64u);
+        // a backlog is shared with the workgroup's other waves while the mailbox is nearly empty (nobody takes: it
+        // fills once and stays)
+        if (kMail && pn > kMailKeep && mail_n() <= kMail - kMailGive) mail_give();
       }
       unsigned long long big = __builtin_amdgcn_ballot_w64(npush > kPoolSmall || demoted);
       while (big) {                                     // one long list at a time, written by the whole wave
@@ -724,6 +800,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       }
       while (pn) spill(pn < 64u ? pn : 64u);
       while (take_batch()) spill(pn);        // carried over, not consumed here
+      while (mail_n()) { mail_take(64u); spill(pn); }      // nothing stays in the mailbox when its waves are gone
       break;
     }
   }

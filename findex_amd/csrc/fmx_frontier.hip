@@ -51,7 +51,7 @@ namespace fmx {
 #define FMX_FTHREADS 256
 #endif
 constexpr int kFThreads = FMX_FTHREADS;      // threads of a frontier workgroup
-constexpr int kFScale = 256 / kFThreads;     // grids are stated in units of 256 threads
+constexpr int kFWaves = kFThreads / 64;       // waves of a workgroup (they share one mailbox)
 
 // The work queue in HBM.  An entry is three 8-byte GRANULES, each written by one aligned agent-scope (write-through)
 // store and carrying the tag of its buffer's current generation in its top 16 bits -- the data is its own "ready"
@@ -1341,7 +1341,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // long as the search does, so a second generation of workgroups would find nothing (measured 3 / 4 / 6: 0.567 /
   // 0.712 / 0.664 ms)
   static const int per_cu = getenv("FMX_FRONTIER_WGS") ? std::max(1, atoi(getenv("FMX_FRONTIER_WGS"))) : FMX_FWAVES;
-  const int grid_full = h->cu_count * per_cu * kFScale;
+  const int grid_full = std::max(1, h->cu_count * per_cu * 4 / kFWaves);      // per_cu counts 256-thread units
   const uint64_t per_wg = (uint64_t)kFThreads;                    // elements a workgroup holds at once
   FrontierSummary sum{};
   uint64_t n_res = 0;
@@ -1369,7 +1369,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       for (const char *p = e; *p;) { v.push_back((uint32_t)std::max(1l, strtol(p, const_cast<char **>(&p), 10))); if (*p == ',') p++; else break; }
     return v;
   }();
-  const int grid_small = 64 * kFScale;
+  const int grid_small = std::max(1, 256 / kFWaves);                           // 256 waves
   // the small grid's chain is short: a launch that finds nothing to do still costs ~3 us
   // The small grid serves a single regex or the thin end of a batch: there a search is a few elements that grow
   // into a tree, and what spreads it over the waves is the hand-over at the end of a launch -- short launches, more

@@ -1374,7 +1374,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // The small grid serves a single regex or the thin end of a batch: there a search is a few elements that grow
   // into a tree, and what spreads it over the waves is the hand-over at the end of a launch -- short launches, more
   // of them (a[ab]*c on 2 M rows: 302 us per call with 128-round launches, 250 with 32; a 24-character literal: 87 / 95 us)
-  static const uint32_t kChainSmall = getenv("FMX_FRONTIER_CHAIN_SMALL") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN_SMALL"))) : 4u;
+  static const uint32_t kChainSmall = getenv("FMX_FRONTIER_CHAIN_SMALL") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN_SMALL"))) : 2u;
   static const uint32_t kRoundsSmall = getenv("FMX_FRONTIER_ROUNDS_SMALL") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS_SMALL"))) : 32u;
   auto enqueue_chain = [&](hipStream_t s, int grid) -> hipError_t {
     const uint32_t len = grid == grid_small ? kChainSmall : kChain;

@@ -65,6 +65,54 @@ void run(const uint4 *tab, uint64_t bytes, uint32_t *out, int blocks_per_cu) {
          16 * LPG, CH, blocks_per_cu, (double)groups * CH, best, n / best / 1e6, n * 16 * LPG / best / 1e9, best * 1e6 / steps);
 }
 
+// One lane = one chain, each step reads a whole 64-byte line with four dwordx4 loads (no lane group): the shape a
+// frontier kernel with one element per lane would have if it did its rank queries in the element's own lane.
+template <int CH>
+__global__ __launch_bounds__(256) void k_chain_lane64(const uint4 *__restrict__ tab, uint64_t nline, uint32_t steps,
+                                                       uint32_t *__restrict__ out, uint64_t seed) {
+  const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint64_t g[CH];
+#pragma unroll
+  for (int u = 0; u < CH; u++) g[u] = mix(seed + id * CH + u) % nline;
+  uint32_t acc = 0;
+  for (uint32_t s = 0; s < steps; s++) {
+    uint4 w[CH][4];
+#pragma unroll
+    for (int u = 0; u < CH; u++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) w[u][j] = tab[g[u] * 4 + j];
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+      uint32_t p = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        p += __builtin_popcount(w[u][j].x) + __builtin_popcount(w[u][j].y) + __builtin_popcount(w[u][j].z) + __builtin_popcount(w[u][j].w);
+      acc += p;
+      g[u] = mix(g[u] + p) % nline;
+    }
+  }
+  if (acc == 0xFFFFFFFFu) out[0] = acc;
+}
+
+template <int CH>
+void run_lane64(const uint4 *tab, uint64_t bytes, uint32_t *out, int blocks_per_cu) {
+  const uint64_t nline = bytes / 64;
+  const int grid = 256 * blocks_per_cu;
+  const uint64_t chains = (uint64_t)grid * 256 * CH;
+  const uint32_t steps = (uint32_t)((1ull << 25) / chains) + 1;
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  float best = 1e9;
+  for (int r = 0; r < 4; r++) {
+    CK(hipEventRecord(a));
+    k_chain_lane64<CH><<<grid, 256>>>(tab, nline, steps, out, 99 + r);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); if (r && ms < best) best = ms;
+  }
+  double n = (double)steps * chains;
+  printf("lane-owned 64 B line  chains/lane %d  blocks/CU %d  in flight %7.0f : %7.3f ms  %6.2f G lines/s  %6.2f TB/s  step %5.0f ns\n",
+         CH, blocks_per_cu, (double)chains, best, n / best / 1e6, n * 64 / best / 1e9, best * 1e6 / steps);
+}
+
 int main(int argc, char **argv) {
   double gib = argc > 1 ? atof(argv[1]) : 64.0;
   uint64_t bytes = (uint64_t)(gib * (1ull << 30));
@@ -77,5 +125,6 @@ int main(int argc, char **argv) {
   run<4, 1>(tab, bytes, out, 4);  run<4, 1>(tab, bytes, out, 8);  run<4, 2>(tab, bytes, out, 8);  run<4, 4>(tab, bytes, out, 8);
   run<2, 1>(tab, bytes, out, 8);  run<2, 2>(tab, bytes, out, 8);
   run<1, 1>(tab, bytes, out, 8);  run<1, 2>(tab, bytes, out, 8);
+  run_lane64<1>(tab, bytes, out, 2);  run_lane64<1>(tab, bytes, out, 4);  run_lane64<1>(tab, bytes, out, 8);  run_lane64<2>(tab, bytes, out, 4);
   return 0;
 }

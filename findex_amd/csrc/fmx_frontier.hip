@@ -531,9 +531,18 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     const bool ranked = have && !cm;
     // a rank query is needed unless the symbol is absent / EOF or the element is a start element
     const bool query = ranked && len != 0 && slot < kSlotEof;
-    xc.sp[lane] = sp;
-    xc.ep[lane] = ep;
-    xc.key[lane] = query ? ((uint32_t)slot | (c << 16)) : kNoQuery;
+    // The elements that have a query take the exchange slots 0, 1, 2 .. in lane order, so the lane groups serve
+    // ceil(queries / (64/G)) sub-rounds, not all G: in a launch's thin end, and in rounds where most elements step
+    // through the k-mer table, most sub-rounds have nothing to do and are skipped.
+    const unsigned long long qmask = __builtin_amdgcn_ballot_w64(query);
+    const uint32_t n_query = (uint32_t)__builtin_popcountll(qmask);
+    const uint32_t xslot = (uint32_t)__builtin_popcountll(qmask & ((1ull << lane) - 1ull));      // this lane's slot, if it has a query
+    if (query) {
+      xc.sp[xslot] = sp;
+      xc.ep[xslot] = ep;
+      xc.key[xslot] = (uint32_t)slot | (c << 16);
+    }
+    if (lane >= n_query) xc.key[lane] = kNoQuery;      // the slots behind the last query
     pool_sync();
     if constexpr (LAYOUT == kLayoutBytes) {
       // Bytes layout: a rank query is the 128-position block (16 bytes per lane of the octet) plus its checkpoint.
@@ -679,8 +688,8 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
           sp = cfc + r1;
           ep = cfc + r2;
         } else {
-          sp = cfc + xc.sp[lane];
-          ep = cfc + xc.ep[lane];
+          sp = cfc + xc.sp[xslot];
+          ep = cfc + xc.ep[xslot];
         }
       }
       stepped++;

@@ -435,6 +435,42 @@ def test_concurrent_calls_on_one_handle():
     assert not errors, errors[:3]
 
 
+def test_concurrent_regex_batches_on_one_handle():
+    """Several resident regex batches matched at the same time from several threads on ONE index handle (each batch
+    has its own queue, counters and captured launch graph; the launches of different batches run side by side on
+    the device): every call must give the answer the batch gives alone."""
+    import threading
+    from findex_amd.regex import RegexBatch
+    bwt, eof, counts = synth_bwt(600_000, 97, 100, 5)            # 4 letters: a..d
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    sets = [["ab[a-c]*d", "a[ab]*c", "b(a|cd)[ad]*b"] + ["abcd"[(i + j) % 4] + "abcd"[(i // 4) % 4] + "c[ab]?d" for i in range(40)]
+            for j in range(4)]
+    batches = [RegexBatch(hip, [findex_amd.ReTree(findex_amd.REParser.re2post(r)) for r in rs]) for rs in sets]
+    want = []
+    for b in batches:
+        out, per = b.match_raw(max_steps=40, cap=1 << 20)
+        b.match_raw(max_steps=40, cap=1 << 20)               # the second match captures the batch's graph
+        want.append((out, per))
+    errors = []
+
+    def work(j):
+        try:
+            for _ in range(25):
+                out, per = batches[j].match_raw(max_steps=40, cap=1 << 20)
+                assert out.size == want[j][0].size and out.tobytes() == want[j][0].tobytes(), j
+                assert np.array_equal(per, want[j][1]), j
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(j,)) for j in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+    assert want[0][0].size > 1000
+
+
 def test_search_batch_multi_replicas():
     """fmx_search_batch_multi over three replica handles (all on device 0 here; one per GPU in production): the
     slices are searched from three host threads and land in their ranges of the output arrays."""

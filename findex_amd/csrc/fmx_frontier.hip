@@ -1764,6 +1764,12 @@ int fmx_regex_batch_match_multi(fmx_regex_batch_multi *mb, const fmx_limits *lim
   RegexBatchMulti *m = reinterpret_cast<RegexBatchMulti *>(mb);
   if (lim && lim->mode != FMX_MATCH_FRONTIER) { set_error("the multi-device form runs the frontier mode"); return FMX_ERR_UNSUPPORTED; }
   const size_t np = m->part.size();
+  {   // one slice holds the whole batch (one handle, or every regex in one slice): no thread, no merge
+    size_t only = np, busy = 0;
+    for (size_t r = 0; r < np; r++)
+      if (m->cut[r] != m->cut[r + 1]) { only = r; busy++; }
+    if (busy == 1 && m->cut[only] == 0) return regex_batch_match(m->idx[only], m->part[only], lim, out, cap, n_out, per_regex_count);
+  }
   m->buf.resize(np);
   m->buf_cap.resize(np, 0);
   for (size_t r = 0; r < np; r++)

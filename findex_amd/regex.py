@@ -305,12 +305,13 @@ class RegexBatchMulti:
     def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22, copy=True):
         """Same contract as RegexBatch.match_raw (copy=False: views of buffers the object keeps between calls)."""
         lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_FRONTIER, int(max_frontier), 1024, 1000)
-        if getattr(self, "_out", None) is None or self._out.size < cap:
-            self._out = np.empty(cap, dtype=RESULT_DTYPE)      # kept between calls: fresh pages fault on every call
-            self._per = np.zeros(max(self.k, 1), dtype=np.uint32)
+        from .searcher import PinnedArray
+        if getattr(self, "_out", None) is None or self._out.array.size < cap:
+            self._out = PinnedArray((cap,), RESULT_DTYPE)      # page-locked and kept between calls, as in RegexBatch
+            self._per = PinnedArray((max(self.k, 1),), np.uint32)
         n_out = ctypes.c_size_t()
-        rc = _lib.check(self._L.fmx_regex_batch_match_multi(self._h, ctypes.byref(lim), self._out.ctypes.data_as(ctypes.c_void_p),
-                                                            cap, ctypes.byref(n_out), self._per.ctypes.data_as(ctypes.c_void_p)))
+        rc = _lib.check(self._L.fmx_regex_batch_match_multi(self._h, ctypes.byref(lim), self._out.array.ctypes.data_as(ctypes.c_void_p),
+                                                            cap, ctypes.byref(n_out), self._per.array.ctypes.data_as(ctypes.c_void_p)))
         self.truncated = rc == _lib.FMX_TRUNCATED
-        out, per = self._out[: n_out.value], self._per[: self.k]
+        out, per = self._out.array[: n_out.value], self._per.array[: self.k]
         return (out.copy(), per.copy()) if copy else (out, per)

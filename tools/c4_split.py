@@ -18,10 +18,10 @@ ref = None
 for parts in (1, 2, 3, 4):
     mb = RegexBatchMulti([hip] * parts, trees)
     for _ in range(3):
-        out, per = mb.match_raw(max_steps=max_len, cap=1 << 22)
+        out, per = mb.match_raw(max_steps=max_len, cap=1 << 22, copy=False)
     ts = []
     for _ in range(15):
-        t0 = time.perf_counter(); out, per = mb.match_raw(max_steps=max_len, cap=1 << 22); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); out, per = mb.match_raw(max_steps=max_len, cap=1 << 22, copy=False); ts.append(time.perf_counter() - t0)
     if ref is None: ref = out.copy()
     assert out.size == ref.size and all(np.array_equal(out[f], ref[f]) for f in ("regex", "len", "sp", "ep"))
     print("%d slice(s): median %.3f ms per call, best %.3f" % (parts, sorted(ts)[len(ts)//2] * 1e3, min(ts) * 1e3))

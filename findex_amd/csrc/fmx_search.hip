@@ -20,6 +20,8 @@
 //     faster than lockstep batches on lengths uniform in 1..64, slower otherwise);
 //   * forming the batches from patterns sorted by length (idle lanes issue no requests, and requests
 //     are the limit: ragged batches already run at 91 % of the uniform rate; the sort added its 90 us).
+#include <algorithm>
+#include <cstdlib>
 #include "fmx_device.h"
 #include "fmx_host.h"
 
@@ -307,7 +309,8 @@ static int blocks_per_cu(K kernel) {
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
 static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
                              uint32_t k, hipStream_t st) {
-  static const int per_cu = blocks_per_cu(k_search4<WIDE, LAYOUT, KT>);
+  // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
+  static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT>);
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;

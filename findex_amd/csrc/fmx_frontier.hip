@@ -223,7 +223,7 @@ struct Mailbox {
 template <bool WIDE, uint32_t LAYOUT>
 __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt, const NfaTables &nfa, const FlowQueue &fq, uint32_t j,
                                               uint32_t max_rounds, uint64_t sub_cap, fmx_result *__restrict__ res,
-                                              uint64_t seg_cap, FrontierCtl *__restrict__ ctl,
+                                              uint64_t seg_cap, FrontierCtl *__restrict__ ctl, uint32_t *__restrict__ rcnt,
                                               unsigned long long *__restrict__ counters) {
   constexpr int G = Lay<LAYOUT>::G;
   constexpr uint32_t EPS = 64 / G;           // elements per sub-round
@@ -401,7 +401,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     rbase = __shfl(rbase, 0, 64);
     if (lane < rs_n) {
       const unsigned long long at = rbase + lane;
-      if (at < seg_cap) res[(uint64_t)so * seg_cap + at] = rs.r[lane];
+      if (at < seg_cap) { res[(uint64_t)so * seg_cap + at] = rs.r[lane]; atomicAdd(&rcnt[rs.r[lane].regex], 1u); }   // per-regex counts: the grouping starts from them
       else atomicOr(&ctl->overflow, 2ull);
     }
     pool_sync();
@@ -838,9 +838,9 @@ template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kFThreads, FMX_FWAVES) void k_frontier(DevIndex ix, KTab kt, NfaTables nfa, FlowQueue fq, uint32_t j,
                                                             uint32_t max_rounds, uint64_t sub_cap,
                                                             fmx_result *__restrict__ res, uint64_t seg_cap,
-                                                            FrontierCtl *__restrict__ ctl,
+                                                            FrontierCtl *__restrict__ ctl, uint32_t *__restrict__ rcnt,
                                                             unsigned long long *__restrict__ counters) {
-  frontier_pass<WIDE, LAYOUT>(ix, kt, nfa, fq, j, max_rounds, sub_cap, res, seg_cap, ctl, counters);
+  frontier_pass<WIDE, LAYOUT>(ix, kt, nfa, fq, j, max_rounds, sub_cap, res, seg_cap, ctl, rcnt, counters);
 }
 
 // Between launches (one wave, lane = slice): a buffer that has been emptied is rewound under its next tag; when that
@@ -947,7 +947,7 @@ struct RegexBatch {
   uint32_t *d_rcnt = nullptr, *d_rstart = nullptr, *d_rfill = nullptr;   // per-regex result counts / offsets
   uint32_t *d_rpart = nullptr;         // chunk totals of the offsets' scan
   BigGroups *d_big = nullptr;
-  FrontierSummary *d_sum = nullptr, *h_sum = nullptr;   // what a chain reports / its pinned host copy
+  FrontierSummary *h_sum = nullptr;    // pinned: what a chain reports (written by k_frontier_advance)
   ExportDst *h_dst = nullptr;          // pinned: where k_res_export writes (set per call)
   hipGraphExec_t chain_exec = nullptr; // one chain of launches + advance + counter copy, captured once (full grid)
   hipGraphExec_t chain_small_exec = nullptr;   // the same on the small grid
@@ -1096,9 +1096,11 @@ __global__ __launch_bounds__(64) void k_frontier_reset(FrontierCtl *__restrict__
 }
 // The start elements: states = firsts, len 0, (sp, ep) = (0, n), dealt round-robin over the slices.
 __global__ void k_frontier_init(FlowQueue fq, NfaTables nfa, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n /* 0: the start elements carry the empty k-mer code */,
-                                uint64_t sub_cap, const FrontierCtl *__restrict__ ctl) {
+                                uint64_t sub_cap, const FrontierCtl *__restrict__ ctl, uint32_t *__restrict__ rcnt, uint32_t k) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count && ctl->fresh) {
+  if (!ctl->fresh) return;
+  for (uint64_t r = i; r <= k; r += (uint64_t)gridDim.x * blockDim.x) rcnt[r] = 0;      // the frontier kernel counts results per regex
+  if (i < count) {
     const uint32_t s = (uint32_t)(i % kSub);
     const uint64_t at = ((uint64_t)s * 2) * sub_cap + i / kSub;
     const uint32_t st = first_state[i];
@@ -1109,16 +1111,8 @@ __global__ void k_frontier_init(FlowQueue fq, NfaTables nfa, const uint32_t *__r
   }
 }
 
-// Results leave the device grouped by regex: count per regex, scan, scatter (three small kernels; ordering
-// 50 k results on the host cost half as much as all the levels together).
-__global__ __launch_bounds__(256) void k_res_count(const fmx_result *__restrict__ seg, uint64_t seg_cap,
-                                                    const FrontierCtl *__restrict__ ctl, uint32_t *__restrict__ rcnt) {
-  const uint32_t sl = blockIdx.y;
-  const uint64_t mine = min((uint64_t)ctl->res_count[sl].v, seg_cap);
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mine; i += (uint64_t)gridDim.x * blockDim.x)
-    atomicAdd(&rcnt[seg[(uint64_t)sl * seg_cap + i].regex], 1u);
-}
-
+// Results leave the device grouped by regex: the frontier kernel counts them per regex where it flushes them; then scan,
+// scatter, sort.
 // Exclusive prefix sums of cnt[0..k] into start[0..k] in three small parallel launches: each workgroup scans
 // its chunk of 1024 counts (start = sums inside the chunk, part[chunk] = the chunk's total), one workgroup
 // scans the chunk totals, and every workgroup adds its chunk's offset.
@@ -1141,13 +1135,15 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s
 }
 
 __global__ __launch_bounds__(kScanChunk) void k_res_scan_chunks(const uint32_t *__restrict__ cnt, uint32_t n,
-                                                                uint32_t *__restrict__ start, uint32_t *__restrict__ part) {
+                                                                uint32_t *__restrict__ start, uint32_t *__restrict__ part,
+                                                                uint32_t *__restrict__ fill, BigGroups *__restrict__ big) {
   __shared__ uint32_t s_wave[16];
   const uint32_t i = blockIdx.x * kScanChunk + threadIdx.x;
   uint32_t total = 0;
   const uint32_t ex = block_excl_scan_1024(i < n ? cnt[i] : 0u, s_wave, total);
-  if (i < n) start[i] = ex;
+  if (i < n) { start[i] = ex; fill[i] = 0; }      // the scatter's cursors start from zero in every grouping
   if (threadIdx.x == 0) part[blockIdx.x] = total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { big->n = 0; big->n_host = 0; }
 }
 
 // Every workgroup adds up the totals of the chunks before its own (a hundred values for 100 k regexes) and adds
@@ -1295,7 +1291,6 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     for (unsigned long long **g : {&b->fq.g0, &b->fq.g1, &b->fq.g2}) {
       HIP_TRY(b->scratch->alloc(g, 2 * kSub * sub_cap), "hipMalloc(queue)");
     }
-    HIP_TRY(b->scratch->alloc(&b->d_sum, 1), "hipMalloc(summary)");
     HIP_TRY(b->scratch->alloc(&b->d_res, cap ? cap : 1), "hipMalloc(results)");
     HIP_TRY(b->scratch->alloc(&b->d_res_seg, kSub * seg_cap), "hipMalloc(result slices)");
     HIP_TRY(b->scratch->alloc(&b->d_ctl, 1), "hipMalloc(ctl)");
@@ -1359,11 +1354,11 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   bool alive = true, truncated = false;
   auto launch_pass = [&](hipStream_t s, int grid, uint32_t j, uint32_t rounds) {
     if (h->layout == kLayoutBytes)
-      k_frontier<true, kLayoutBytes><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier<true, kLayoutBytes><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, b->d_rcnt, h->d_counters);
     else if (h->n > (1ull << 32))
-      k_frontier<true, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier<true, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, b->d_rcnt, h->d_counters);
     else
-      k_frontier<false, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, h->d_counters);
+      k_frontier<false, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, b->d_rcnt, h->d_counters);
   };
   // One chain = kChain x (launch + k_frontier_advance) + the summary's copy to pinned host memory.  Its kernel
   // arguments do not change from chain to chain, so it is captured into a hipGraph once per batch and replayed:
@@ -1390,14 +1385,12 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     // a call's first chain begins with the reset and the start elements (h_dst->fresh; both return at once otherwise):
     // one graph launch per call
     k_frontier_reset<<<1, 64, 0, s>>>(d_ctl, b->n_first, &b->h_dst->max_len);
-    k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, s>>>(fq, b->nfa, b->d_first_state, b->n_first, kt.k ? 0 : h->n, sub_cap, d_ctl);
+    k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, s>>>(fq, b->nfa, b->d_first_state, b->n_first, kt.k ? 0 : h->n, sub_cap, d_ctl, b->d_rcnt, (uint32_t)b->k);
     for (uint32_t j = 0; j < len; j++) {
       launch_pass(s, grid, j, grid == grid_small ? kRoundsSmall : (plan.empty() ? kRounds : plan[std::min<size_t>(j, plan.size() - 1)]));
-      k_frontier_advance<<<1, 64, 0, s>>>(d_ctl, sub_cap, b->d_sum);
+      k_frontier_advance<<<1, 64, 0, s>>>(d_ctl, sub_cap, b->h_sum);      // the summary goes straight to pinned host memory
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return hipMemcpyAsync(b->h_sum, b->d_sum, sizeof(FrontierSummary), hipMemcpyDeviceToHost, s);
+    return hipGetLastError();
   };
   // page-locked caller buffers are written by the device itself (k_res_export, the last launch of the grouping)
   auto pinned = [](const void *p) {
@@ -1428,12 +1421,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // scratch, so this is a captured graph as well.
   const size_t rcap = b->rcap;
   auto enqueue_group = [&](hipStream_t s) -> hipError_t {
-    hipError_t e = hipMemsetAsync(b->d_rcnt, 0, 2 * (b->k + 1) * 4 + 8, s);      // counts, fill cursors, BigGroups{n, n_host}
-    if (e != hipSuccess) return e;
     const dim3 rg(8, kSub);
-    k_res_count<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rcnt);
     const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: start[k] = total
-    k_res_scan_chunks<<<nparts, kScanChunk, 0, s>>>(b->d_rcnt, n_scan, b->d_rstart, b->d_rpart);
+    k_res_scan_chunks<<<nparts, kScanChunk, 0, s>>>(b->d_rcnt, n_scan, b->d_rstart, b->d_rpart, b->d_rfill, b->d_big);
     k_res_scan_add<<<nparts, kScanChunk, 0, s>>>(b->d_rstart, n_scan, b->d_rpart);
     k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)rcap);
     k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);

@@ -918,9 +918,18 @@ __global__ __launch_bounds__(256) void k_res_export(const fmx_result *__restrict
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
   if (d.out) {
     const uint64_t n = start[k] < d.cap ? start[k] : d.cap;
-    const uint2 *src = reinterpret_cast<const uint2 *>(res);       // 24-byte results as three 8-byte words
-    uint2 *out = reinterpret_cast<uint2 *>(d.out);
-    for (uint64_t i = tid; i < 3 * n; i += nth) out[i] = src[i];
+    // 24-byte results as 16-byte words (both buffers are 16-byte aligned: hipMalloc / page-locked memory), the odd
+    // eight bytes at the end on their own
+    const uint64_t words = 3 * n;                                   // 8-byte words
+    const uint4 *src = reinterpret_cast<const uint4 *>(res);
+    uint4 *out = reinterpret_cast<uint4 *>(d.out);
+    const bool aligned = (reinterpret_cast<uintptr_t>(d.out) & 15u) == 0;
+    if (aligned) {
+      for (uint64_t i = tid; i < words / 2; i += nth) out[i] = src[i];
+      if ((words & 1u) && tid == 0) reinterpret_cast<uint2 *>(d.out)[words - 1] = reinterpret_cast<const uint2 *>(res)[words - 1];
+    } else {
+      for (uint64_t i = tid; i < words; i += nth) reinterpret_cast<uint2 *>(d.out)[i] = reinterpret_cast<const uint2 *>(res)[i];
+    }
   }
   if (d.per)
     for (uint64_t i = tid; i < k; i += nth) d.per[i] = rcnt[i];
@@ -1428,7 +1437,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)rcap);
     k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);
     k_res_sort_mid<<<256, 256, 0, s>>>(d_res, b->d_big);
-    k_res_export<<<128, 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst, b->h_tot);
+    k_res_export<<<256, 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst, b->h_tot);
     return hipGetLastError();
   };
   auto capture = [&](hipGraphExec_t *exec, int grid) {     // one graph: the chain of launches, then the grouping

@@ -144,6 +144,9 @@ constexpr uint32_t kPoolSmall = 6;      // follow lists with up to this many pus
 // constant 100 MHz clock, so that the occupancy of the wave slots over a launch can be drawn.
 constexpr uint32_t kLogPasses = 16, kLogWaves = 1u << 15;
 __device__ unsigned long long g_wavelog[kLogPasses][kLogWaves][4];
+// with -DFMX_PHASELOG=<round>: cycles (s_memtime) a wave spends in the four phases of its rounds from that round on
+// (take | stage + issue | wait + ranks | bookkeeping), rounds counted, in g_phaselog[wave][0..4] of launch 0
+__device__ unsigned long long g_phaselog[kLogWaves][8];
 #endif
 __device__ __forceinline__ void pool_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -460,7 +463,16 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
 #ifdef FMX_WAVELOG
   wl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef FMX_PHASELOG
+  unsigned long long ph_t = 0, ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0, ph_n = 0;
+#define PH_MARK(acc) do { if (rounds >= FMX_PHASELOG) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - ph_t; ph_t = now_; } } while (0)
+#else
+#define PH_MARK(acc) do {} while (0)
+#endif
   for (;;) {
+#ifdef FMX_PHASELOG
+    ph_t = __builtin_amdgcn_s_memtime();
+#endif
     // ---- lanes without an element take the newest pool entries; a pool that cannot feed them is refilled from the
     // wave's share, and a wave with nothing left at all looks for entries appended during this launch
     {
@@ -493,6 +505,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       continue;
     }
     idle_looks = 0;
+    PH_MARK(ph0);
     // ---- every element's state record and its step's lines are requested together
     const uint32_t run = meta >> 24;          // > 0: inside a literal stretch whose bytes the held record carries
     const uint32_t c = (meta >> 16) & 0xFFu, len = meta & 0xFFFFu;
@@ -544,6 +557,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     }
     if (lane >= n_query) xc.key[lane] = kNoQuery;      // the slots behind the last query
     pool_sync();
+    PH_MARK(ph1);
     if constexpr (LAYOUT == kLayoutBytes) {
       // Bytes layout: a rank query is the 128-position block (16 bytes per lane of the octet) plus its checkpoint.
       // As below, sp and ep of a narrowed interval lie in one block: one request pair per element, both ranks from
@@ -669,6 +683,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         }
       }
     }
+    PH_MARK(ph2);
     // the table entry is not needed before this point: keeps its load in flight beside the rank lines'
     asm volatile("" : "+v"(ent.x), "+v"(ent.y), "+v"(ent.z), "+v"(ent.w));
     pool_sync();
@@ -797,6 +812,10 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         have = false;
       }
     }
+    PH_MARK(ph3);
+#ifdef FMX_PHASELOG
+    if (rounds >= FMX_PHASELOG) ph_n++;
+#endif
     if (++rounds >= max_rounds) {
       // ---- out of rounds: everything this wave still holds goes to the output queue
       const unsigned long long held = __builtin_amdgcn_ballot_w64(have);
@@ -814,6 +833,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     }
   }
   flush_results();
+#ifdef FMX_PHASELOG
+  if (lane == 0 && j == 0 && w < kLogWaves) { unsigned long long *e = g_phaselog[w]; e[0] = ph0; e[1] = ph1; e[2] = ph2; e[3] = ph3; e[4] = ph_n; }
+#endif
 #ifdef FMX_WAVELOG
   {
     const unsigned long long st_all = wave_sum((unsigned long long)stepped);
@@ -1562,6 +1584,9 @@ using namespace fmx;
 
 extern "C" {
 #ifdef FMX_WAVELOG
+int fmx_debug_phaselog(void *out, size_t bytes) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phaselog), std::min(bytes, sizeof g_phaselog)) == hipSuccess ? FMX_OK : FMX_ERR_HIP;
+}
 int fmx_debug_wavelog(void *out, size_t bytes, int clear) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wavelog), std::min(bytes, sizeof g_wavelog)) != hipSuccess) return FMX_ERR_HIP;
   if (clear) {

@@ -60,3 +60,15 @@ for p in range(16):
           [(round((t0[i] - lo) * T, 1), round((t1[i] - lo) * T, 1), round((t2[i] - lo) * T, 1), int(rounds[i]), int(steps[i])) for i in late])
     hist = np.bincount(np.minimum(rounds, 20), minlength=21)
     print("         waves by rounds (0..20+):", hist.tolist())
+
+# ---- with a -DFMX_PHASELOG=<round> build: where the rounds from that round on spend their time
+if hasattr(L, "fmx_debug_phaselog"):
+    ph = np.zeros((1 << 15, 8), dtype=np.uint64)
+    L.fmx_debug_phaselog.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    if L.fmx_debug_phaselog(ph.ctypes.data_as(ctypes.c_void_p), ph.nbytes) == 0:
+        m = ph[:, 4] > 0
+        if m.any():
+            tot = ph[m, :4].sum(axis=0).astype(np.float64)
+            n = float(ph[m, 4].sum())
+            print("late rounds (%d waves, %d rounds): cycles per round  take %.0f | stage %.0f | wait + ranks %.0f | bookkeeping %.0f  (total %.0f)"
+                  % (m.sum(), n, tot[0] / n, tot[1] / n, tot[2] / n, tot[3] / n, tot.sum() / n))

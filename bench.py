@@ -537,20 +537,28 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     log(rank, "compiled %d regexes and made them resident in %.1fs (host)" % (k, time.time() - t0))
     cap = 1 << 22
 
-    from findex_amd.distributed import gather_results
+    from findex_amd.distributed import all_gather_varlen
+    from findex_amd.regex import RESULT_DTYPE
+
+    # A step = fmx_regex_batch_match_dev: the regex path's device-pointer form, results (grouped by regex, ordered) and
+    # per-regex counts left in HBM -- as the literal workloads' step leaves its intervals there.  The rate with the
+    # results delivered into page-locked host memory is reported beside it (`host_delivered`).
+    d_out = torch.empty(3 * cap, dtype=torch.int64, device=device)          # 24-byte records as three words
+    d_per = torch.empty(max(k, 1), dtype=torch.int32, device=device)
 
     def step():
-        r, per_regex = batch.match_raw(max_steps=max_len, cap=cap, copy=False)     # views of the batch's pinned buffers
-        if use_dist:        # the path's one exchange: every rank receives every rank's result list
-            gather_results(r, device)
-        return r, per_regex
+        n_res = batch.match_dev(d_out.data_ptr(), cap, d_per.data_ptr(), max_steps=max_len)
+        if use_dist:        # the path's one exchange: every rank receives every rank's result list (sizes, then payload)
+            all_gather_varlen(d_out[: 3 * n_res])
+        return n_res
 
     hip.stats_reset()
-    out_res, per = step()
+    n_results = int(step())
     s1 = hip.stats()
+    torch.cuda.synchronize()
+    out_res = d_out[: 3 * n_results].cpu().numpy().view(RESULT_DTYPE)
     steps_per_call = int(s1["frontier_elements"])
     ranks_per_step = 2 * steps_per_call
-    n_results = int(out_res.size)
     for _ in range(max(0, args.warmup - 1)):
         step()
     if use_dist:
@@ -566,6 +574,16 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         dist.barrier()
     dt = time.perf_counter() - t0
     kernel_ms = sum(kms) / len(kms)
+    host_delivered = None
+    if world == 1:          # the same call with the results written into page-locked host memory (PCIe-inclusive)
+        for _ in range(3):
+            batch.match_raw(max_steps=max_len, cap=cap, copy=False)
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            batch.match_raw(max_steps=max_len, cap=cap, copy=False)
+        th = (time.perf_counter() - th) / args.steps
+        host_delivered = {"ms_per_step": th * 1e3, "value": ranks_per_step / th / 1e6, "unit": "M rank-queries/s",
+                          "what": "fmx_regex_batch_match into page-locked host buffers (k_res_export over the link)"}
     tot = torch.tensor([dt, float(ranks_per_step), float(n_results), kernel_ms], dtype=torch.float64, device=device)
     if use_dist:
         mx = tot.clone()
@@ -624,9 +642,10 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         "dtype": "u64",
         "data": "synthetic",
         "regexes_per_sec": world * k * args.steps / dt,
+        "host_delivered": host_delivered,
         "config": {
             "workload": "%s: %d seeded regexes (<= 32 Glushkov positions) per GPU, 2^%d-byte sigma=%d synthetic BWT "
-                        "resident in HBM, SA-interval frontier expansion, results to the host"
+                        "resident in HBM, SA-interval frontier expansion, results (grouped by regex, ordered) left in HBM"
                         % (args.workload.upper(), k, log2n, len(C4_ALPHABET)),
             "n": n, "sigma": len(C4_ALPHABET), "regexes_per_gpu": k, "max_match_len": max_len,
             "results_per_call": results_all, "backward_steps_per_call": ranks_all / 2,

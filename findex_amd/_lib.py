@@ -101,6 +101,7 @@ SYMBOLS = {
     "fmx_regex_batch_create": (_i32, [_vp, _vp, _sz, _P(_vp)]),
     "fmx_regex_batch_free": (_i32, [_vp]),
     "fmx_regex_batch_match": (_i32, [_vp, _vp, _vp, _vp, _sz, _P(_sz), _vp]),
+    "fmx_regex_batch_match_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _P(_sz), _vp]),
     "fmx_regex_batch_create_multi": (_i32, [_vp, _sz, _vp, _sz, _P(_vp)]),
     "fmx_regex_batch_free_multi": (_i32, [_vp]),
     "fmx_regex_batch_match_multi": (_i32, [_vp, _vp, _vp, _sz, _P(_sz), _vp]),

@@ -1291,8 +1291,11 @@ __global__ __launch_bounds__(256) void k_res_sort_mid(fmx_result *__restrict__ o
   }
 }
 
+// `dev`: out / per_regex_count are DEVICE pointers -- the results stay in HBM (the export kernel's copy is then on
+// the device); the rare cases that need the host (groups of more than 1024 results, results the host adds for final
+// DFA start states) are staged through host memory and written back.
 int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_result *out, size_t cap,
-                      size_t *n_out, uint32_t *per_regex_count) {
+                      size_t *n_out, uint32_t *per_regex_count, bool dev = false) {
   static const bool trace = getenv("FMX_TRACE") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   auto mark = [&](const char *what) {
@@ -1302,9 +1305,15 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   const uint32_t max_steps = std::min<uint32_t>((lim && lim->max_steps) ? lim->max_steps : 4096u, kMaxLen);
   const uint64_t qcap = (lim && lim->max_frontier) ? lim->max_frontier : (1ull << 22);
   if (b->index_serial != h->serial) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
-  if (per_regex_count) std::fill(per_regex_count, per_regex_count + b->k, 0u);
+  if (per_regex_count && !dev) std::fill(per_regex_count, per_regex_count + b->k, 0u);
   *n_out = 0;
-  if (b->n_first == 0 && b->start_final.empty()) return FMX_OK;
+  if (b->n_first == 0 && b->start_final.empty()) {
+    if (per_regex_count && dev && b->k) {
+      HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+      HIP_TRY(hipMemset(per_regex_count, 0, b->k * 4), "hipMemset(result counts)");
+    }
+    return FMX_OK;
+  }
   if (b->n_first > qcap) { set_error("initial frontier exceeds max_frontier"); return FMX_ERR_OVERFLOW; }
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
   // slices: each holds its share of max_frontier plus a quarter of headroom (appends rotate over the slices,
@@ -1429,8 +1438,8 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
   };
-  const bool export_out = cap && pinned(out) && pinned(out + (cap - 1));
-  const bool export_per = per_regex_count && b->k && pinned(per_regex_count) && pinned(per_regex_count + (b->k - 1));
+  const bool export_out = cap && (dev || (pinned(out) && pinned(out + (cap - 1))));
+  const bool export_per = per_regex_count && b->k && (dev || (pinned(per_regex_count) && pinned(per_regex_count + (b->k - 1))));
   b->h_dst->out = export_out ? out : nullptr;
   b->h_dst->cap = cap;
   b->h_dst->per = export_per ? per_regex_count : nullptr;
@@ -1521,7 +1530,27 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   const size_t extra = b->start_final.size();
   *n_out = (size_t)tot.res_count + extra;
   if ((sum.overflow & 2ull) || tot.res_count + extra > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
-  if (tot.res_count && !export_out)
+  // device-resident results that the host has to touch after all
+  fmx_result *const dev_out = out;
+  uint32_t *const dev_per = per_regex_count;
+  std::vector<fmx_result> stage_out;
+  std::vector<uint32_t> stage_per;
+  bool staged = false;
+  if (dev) {
+    if (!extra && !nbig) {
+      mark("results on the device");
+      if (truncated) {
+        set_error("some matches run past max_steps: results hold every match of length <= max_steps");
+        return FMX_TRUNCATED;
+      }
+      return FMX_OK;
+    }
+    staged = true;
+    stage_out.resize((size_t)tot.res_count + extra);
+    out = stage_out.data();
+    if (per_regex_count) { stage_per.assign(b->k, 0u); per_regex_count = stage_per.data(); }
+  }
+  if (tot.res_count && (!export_out || staged))
     HIP_TRY(copy_sync(out, d_res, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost, st), "D2H(results)");
   mark("results copied");
   for (size_t j = 0; j < extra; j++) {           // dfa.scala:270-273 with the start StatePoint(0,0,0,n)
@@ -1553,7 +1582,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
         }
       }
       mark("large groups");
-      if (per_regex_count && ndev && !export_per)
+      if (per_regex_count && ndev && (!export_per || staged))
         HIP_TRY(copy_sync(per_regex_count, b->d_rcnt, b->k * 4, hipMemcpyDeviceToHost, st), "D2H(result counts)");
     } else {
       // host-made results to merge in (or too many large groups to list): bucket everything by regex id
@@ -1569,6 +1598,10 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
       if (per_regex_count)
         for (size_t r = 0; r < b->k; r++) per_regex_count[r] = cnt[r];
     }
+  }
+  if (staged) {
+    HIP_TRY(copy_sync(dev_out, out, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyHostToDevice, st), "H2D(results)");
+    if (dev_per) HIP_TRY(copy_sync(dev_per, per_regex_count, b->k * 4, hipMemcpyHostToDevice, st), "H2D(result counts)");
   }
   mark("results ordered");
   if (truncated) {
@@ -1716,6 +1749,14 @@ int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *b, const fmx_li
   }
   if (lim && lim->mode != FMX_MATCH_FRONTIER) { set_error("unknown fmx_limits.mode"); return FMX_ERR_ARG; }
   return regex_batch_match(h, rb, lim, out, cap, n_out, per_regex_count);
+}
+
+int fmx_regex_batch_match_dev(const fmx_index *idx, fmx_regex_batch *b, const fmx_limits *lim, void *d_out, size_t cap,
+                              size_t *n_out, void *d_per_regex_count) {
+  if (!idx || !b || !n_out || (cap && !d_out)) { set_error("null argument"); return FMX_ERR_ARG; }
+  if (lim && lim->mode != FMX_MATCH_FRONTIER) { set_error("the device-resident form runs the frontier mode"); return FMX_ERR_UNSUPPORTED; }
+  return regex_batch_match(reinterpret_cast<const Index *>(idx), reinterpret_cast<RegexBatch *>(b), lim,
+                           static_cast<fmx_result *>(d_out), cap, n_out, static_cast<uint32_t *>(d_per_regex_count), true);
 }
 
 // ---- one process, several GPUs: the batch is cut into contiguous slices of about equal ESTIMATED

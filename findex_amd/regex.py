@@ -280,6 +280,20 @@ class RegexBatch:
         return (out.copy(), per.copy()) if copy else (out, per)
 
 
+def _match_dev(self, d_out, cap, d_per=None, max_steps=0, max_frontier=0):
+    """fmx_regex_batch_match_dev: results stay in HBM.  d_out = device pointer (int) to room for `cap` 24-byte
+    records (RESULT_DTYPE), d_per = device pointer to k uint32 counts or None; returns the number of results."""
+    lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_FRONTIER, int(max_frontier), 1024, 1000)
+    n_out = ctypes.c_size_t()
+    rc = _lib.check(self._L.fmx_regex_batch_match_dev(self.sa.handle, self._h, ctypes.byref(lim), ctypes.c_void_p(int(d_out)),
+                                                      int(cap), ctypes.byref(n_out), ctypes.c_void_p(int(d_per)) if d_per else None))
+    self.truncated = rc == _lib.FMX_TRUNCATED
+    return int(n_out.value)
+
+
+RegexBatch.match_dev = _match_dev
+
+
 class RegexBatchMulti:
     """fmx_regex_batch_create_multi / _match_multi: one process, one replica handle per GPU, the regex batch cut by
     estimated frontier work; same results as RegexBatch on one handle."""

@@ -283,6 +283,13 @@ int fmx_regex_batch_create(const fmx_index *idx, fmx_regex *const *res, size_t k
 int fmx_regex_batch_free(fmx_regex_batch *batch);
 int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *batch, const fmx_limits *lim, fmx_result *out,
                           size_t cap, size_t *n_out, uint32_t *per_regex_count);
+/* The same with the results left in HBM (frontier mode): d_out = device memory for cap fmx_result records,
+ * d_per_regex_count = device memory for k counts or NULL; *n_out = the number of results.  The device-pointer
+ * form of the regex path, like fmx_search_batch_dev for literals: what a caller that post-processes on the device
+ * (or gathers over RCCL, findex_amd/distributed.py) uses -- nothing crosses the host link but the count.  The call
+ * is synchronous (the search needs the host between launch chains). */
+int fmx_regex_batch_match_dev(const fmx_index *idx, fmx_regex_batch *batch, const fmx_limits *lim, void *d_out,
+                              size_t cap, size_t *n_out, void *d_per_regex_count);
 
 /* One process, several GPUs (the single-process form of SURVEY.md 8e for regexes; one process per GPU uses
  * findex_amd/distributed.py and an RCCL gather instead): the batch is cut into contiguous slices of about equal

@@ -844,6 +844,44 @@ def test_regex_queue_tags_wrap_and_launches_hand_over():
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
 
 
+def test_regex_device_resident_results():
+    """fmx_regex_batch_match_dev leaves the grouped, ordered results and the per-regex counts in HBM: they must be the
+    bytes the host form returns -- for a plain batch, for one with a group of more than 1024 results (ordered on the
+    host: staged through host memory and written back) and for a DFA batch whose start state is final (a result the
+    host adds)."""
+    torch = _torch()
+    from findex_amd.regex import RegexBatch, RESULT_DTYPE
+    bwt, eof, counts = synth_bwt(600_000, 97, 100, 5)            # 4 letters: a..d
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    plain = ["ab[a-c]*d", "abca", "b(a|cd)[ad]*b"] + ["abcd"[i % 4] + "abcd"[(i // 4) % 4] + "c[ab]?d" for i in range(30)]
+    big = ["a[ab]*c", "[ab][a-d][a-d][a-d][a-d]"]                # the second: ~2 * 4^4 * ... distinct intervals, one group > 1024
+    sets = [[findex_amd.ReTree(findex_amd.REParser.re2post(r)) for r in plain],
+            [findex_amd.ReTree(findex_amd.REParser.re2post(r)) for r in plain + big]]
+    d1, d2 = findex_amd.DFA(2), findex_amd.DFA(4)
+    d1.addLink(0, 1, ord("a"))
+    d1.finishStates = {0, 1}                                     # final start state: the host adds (0, 0, n)
+    for f, t_, ch in [(0, 1, ord("a")), (1, 2, ord("b")), (2, 2, ord("b")), (2, 3, ord("c"))]:
+        d2.addLink(f, t_, ch)
+    d2.finishStates = {3}
+    d1.compileBuckets()
+    d2.compileBuckets()
+    sets.append([d1, d2])
+    seen_big = False
+    for trees in sets:
+        rb = RegexBatch(hip, trees)
+        out, per = rb.match_raw(max_steps=12, cap=1 << 20)
+        seen_big = seen_big or (per.size and int(per.max()) > 1024)
+        cap = 1 << 20
+        d_out = torch.zeros(cap * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        d_per = torch.full((len(trees),), 7, dtype=torch.int32, device="cuda")
+        n = rb.match_dev(d_out.data_ptr(), cap, d_per.data_ptr(), max_steps=12)
+        torch.cuda.synchronize()
+        got = np.frombuffer(d_out[: n * RESULT_DTYPE.itemsize].cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+        assert n == out.size and got.tobytes() == out.tobytes()
+        assert np.array_equal(d_per.cpu().numpy().astype(np.uint32), per)
+    assert seen_big
+
+
 # ---------------------------------------------------------------- the reference's other two engines
 class _OIdx:
     def __init__(self, sa):

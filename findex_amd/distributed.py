@@ -135,14 +135,28 @@ def match_batch_sharded(sa, trees, group=None, match_fn=None, weights=None, **kw
     result lists.  Returns the structured array of all results, regex ids global, on every rank.
     `match_fn(sa, trees_slice)` defaults to the GPU frontier search on a resident batch; it returns a structured
     array with slice-local regex ids (or, per regex, a list of (len, sp, ep) tuples / SAResult objects)."""
+    rank, world = _group_info(group)
+    k = len(trees)
+    cuts = work_bounds(weights if weights is not None else np.ones(k), world)
+    if match_fn is None and dist is not None and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        # RCCL: the results never leave HBM before the exchange (fmx_regex_batch_match_dev): the regex ids are
+        # made global on the device (word 0 of a record = regex | len << 32), the lists are all-gathered, and one
+        # copy brings the whole answer to the host
+        from .regex import ReTree
+        kw = dict(kw)
+        cap = int(kw.pop("cap", 1 << 22))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d_out = torch.empty(3 * cap, dtype=torch.int64, device=dev)
+        n_res = ReTree.prepare_batch(sa, trees[cuts[rank]:cuts[rank + 1]]).match_dev(d_out.data_ptr(), cap, None, **kw)
+        t = d_out[: 3 * n_res]
+        t[0::3] += int(cuts[rank])
+        parts = all_gather_varlen(t, group)
+        return np.concatenate([p.cpu().numpy().view(RESULT_DTYPE) for p in parts]) if parts else np.zeros(0, dtype=RESULT_DTYPE)
     if match_fn is None:
         from .regex import ReTree
 
         def match_fn(sa_, ts):
             return ReTree.prepare_batch(sa_, ts).match_raw(**kw)[0]
-    rank, world = _group_info(group)
-    k = len(trees)
-    cuts = work_bounds(weights if weights is not None else np.ones(k), world)
     mine = match_fn(sa, trees[cuts[rank]:cuts[rank + 1]])
     if not isinstance(mine, np.ndarray):      # per-regex lists (CPU stand-ins in the tests)
         rows = [(j, r.len, r.sp, r.ep) if hasattr(r, "len") else (j,) + tuple(r) for j, res in enumerate(mine) for r in res]

@@ -882,6 +882,30 @@ def test_regex_device_resident_results():
     assert seen_big
 
 
+def test_match_batch_sharded_device_exchange():
+    """distributed.match_batch_sharded with the nccl backend keeps the result lists in HBM until after the exchange
+    (fmx_regex_batch_match_dev + all_gather on device tensors): a one-rank RCCL group on this GPU must give what the
+    plain resident batch gives."""
+    torch = _torch()
+    import torch.distributed as dist
+    from findex_amd import distributed as D
+    from findex_amd.regex import RegexBatch
+    bwt, eof, counts = synth_bwt(300_000, 97, 100, 8)
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    res = ["ab[a-c]*d", "a[ab]*c", "abca"] + ["abcd"[i % 4] + "abcd"[(i // 4) % 4] + "c[ab]?d" for i in range(20)]
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(r)) for r in res]
+    want, _ = RegexBatch(hip, trees).match_raw(max_steps=20)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        got = D.match_batch_sharded(hip, trees, max_steps=20)
+    finally:
+        dist.destroy_process_group()
+    assert got.tobytes() == want.tobytes() and want.size > 100
+
+
 # ---------------------------------------------------------------- the reference's other two engines
 class _OIdx:
     def __init__(self, sa):

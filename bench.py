@@ -13,9 +13,15 @@ A "step" is one pass of the hot path over one batch that already sits in HBM:
   literal workloads (c3 default, c2, c5, tiny): fmx_search_batch_dev = ONE launch of k_search4 over 1M
     patterns per GPU; with N > 1 each rank searches its own shard and the step ends with the RCCL all-gather
     of the (sp, ep) intervals (overlapped with the next step's search);
-  regex workloads (c4, c4tiny): fmx_regex_batch_match on a resident batch of compiled regexes (the Glushkov
-    SA-interval frontier, ReTree._matchSA), results delivered to the host; with N > 1 every rank matches its own
+  regex workloads (c4, c4tiny): fmx_regex_batch_match_dev on a resident batch of compiled regexes (the Glushkov
+    SA-interval frontier, ReTree._matchSA with limits that do not bind), results and per-regex counts LEFT IN HBM
+    like the literal step's intervals; the rate with the results delivered into page-locked host memory is reported
+    beside it (`host_delivered`), and so is the one-shot rate of a batch that arrives as strings (`fresh_batch`:
+    fmx_regex_compile_batch + fmx_regex_batch_create + the first match).  With N > 1 every rank matches its own
     batch of the same size (weak scaling) and the per-rank result lists are all-gathered.
+  c4ref, c4reftiny: the same batch through FMX_MATCH_REFERENCE with the reference's default limits
+    (ReTree.matchSA: maxBranching 1024, maxIterations 1000, re2/retree.scala:570) -- its own pop order, its own
+    answer, results delivered to the host in its list order.
 
 torch is plumbing here (device buffers, the stream, torch.distributed); the product path is libfmx.so
 through its C ABI.  Only the cpu_baseline leg touches oracle/.
@@ -57,10 +63,13 @@ LITERAL = {
     "tiny": (22, 128, 100_000, 32, 9),
 }
 REGEX = {
-    # name: (log2 n, regexes per GPU, seed#, max match length explored)
-    "c4": (30, 100_000, 4, 64),
-    "c4tiny": (22, 5_000, 4, 64),
+    # name: (log2 n, regexes per GPU, seed#, max match length explored, reference-order mode)
+    "c4": (30, 100_000, 4, 64, False),
+    "c4tiny": (22, 5_000, 4, 64, False),
+    "c4ref": (30, 100_000, 4, 0, True),
+    "c4reftiny": (22, 5_000, 4, 0, True),
 }
+REF_LIMITS = (1024, 1000)      # ReTree.matchSA's defaults, re2/retree.scala:570
 C4_ALPHABET = "abcdefghijklmnopqrstuvwxyz \n"
 
 
@@ -184,21 +193,25 @@ def make_patterns(torch, hip, n, sigma, k, m, seed, device, stream):
 
 
 def make_regexes(k, seed):
-    """The seeded C4 grammar (tools/regex_workload.py); only shapes the reference's ReTree.apply accepts are kept.
-    Returns (regex strings, compiled ReTree handles)."""
+    """The seeded C4 grammar (tools/regex_workload.py); only shapes the reference's ReTree.apply accepts are kept:
+    the candidate stream is compiled in chunks with fmx_regex_compile_batch and the first k that compile are the
+    batch (the same list tools/regex_workload.generate draws one by one).
+    Returns (regex strings, CompiledRegexes holding their handles)."""
+    import random
     import findex_amd
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import regex_workload
-    trees = []
-
-    def compiles(re):
-        try:
-            trees.append(findex_amd.ReTree(findex_amd.REParser.re2post(re)))
-            return True
-        except (findex_amd.MatchError, findex_amd.Re2PostSyntax):
-            return False
-    res = regex_workload.generate(k, seed, compiles)
-    return res, trees
+    rng = random.Random(seed)
+    res, sets = [], []
+    while len(res) < k:
+        cand = [regex_workload.gen_one(rng) for _ in range(k - len(res) + 64)]
+        cs = findex_amd.ReTree.compile_batch(cand)
+        ok = np.nonzero(cs.ok())[0][: k - len(res)]
+        res += [cand[i] for i in ok]
+        sets.append(cs.select(ok))
+    if len(sets) == 1:
+        return res, sets[0]
+    return res, findex_amd.ReTree.compile_batch(res)
 
 
 def effective_cores():
@@ -321,25 +334,40 @@ def cpu_baseline_literal(torch, orc, t_build, n, pats, off, sp, ep, sample, m, c
                       "with OpenMP; the GPU's (sp, ep) for them are bit-equal" % (note, sample, m)}
 
 
-def cpu_baseline_regex(orc, t_build, n, trees, gpu_out, sample, max_len, cores, rank, note):
+def cpu_baseline_regex(orc, t_build, n, res, trees, gpu_out, sample, max_len, ref_mode, cores, rank, note):
     """ReTree._matchSA (re2/retree.scala:618-653) in C on this host's cores over the first `sample` regexes of
-    the timed batch, limits not binding, match length capped like the GPU run; result multisets compared."""
-    tables = [t.tables() for t in trees[:sample]]
+    the timed batch.  Frontier workloads: limits not binding, match length capped like the GPU run, result
+    multisets compared.  Reference-order workloads: the reference's default limits, result LISTS compared in the
+    reference's own order."""
+    import findex_amd
     t0 = time.time()
-    want, pops, trunc = orc.match_tables_batch(tables, max_len=max_len, threads=cores)
+    findex_amd.ReTree.compile_batch(res[:sample])           # the front-end's share of a one-shot batch (same host code)
+    t_compile = time.time() - t0
+    tables = [trees[i].tables() for i in range(sample)]
+    t0 = time.time()
+    if ref_mode:
+        want, pops, trunc = orc.match_tables_batch(tables, maxBranching=REF_LIMITS[0], maxIterations=REF_LIMITS[1],
+                                                   threads=cores, ordered=True)
+    else:
+        want, pops, trunc = orc.match_tables_batch(tables, max_len=max_len, threads=cores)
     dt = time.time() - t0
     got = gpu_out[gpu_out["regex"] < sample]
     ok = got.size == want.size and all(np.array_equal(got[f], want[f]) for f in ("regex", "len", "sp", "ep"))
     if not ok:
         raise SystemExit("bench: GPU regex results differ from the CPU oracle on the baseline sample "
                          "(%d vs %d results)" % (got.size, want.size))
-    log(rank, "cpu_baseline: %d cores, %.2fs for %d regexes (%d getPrevRange steps, %d results), index build %.1fs, parity ok"
-        % (cores, dt, sample, pops, want.size, t_build))
+    log(rank, "cpu_baseline: %d cores, %.2fs for %d regexes (%d getPrevRange steps, %d results), index build %.1fs, "
+        "front-end %.2fs, parity ok (%s)" % (cores, dt, sample, pops, want.size, t_build, t_compile,
+                                             "lists in the reference's order" if ref_mode else "multisets"))
+    how = ("the reference's default limits (maxBranching %d, maxIterations %d); result lists equal in the reference's "
+           "own order" % REF_LIMITS) if ref_mode else ("limits not binding, match length capped at %d like the GPU run; "
+                                                       "result multisets bit-equal" % max_len)
     return {"value": 2 * pops / dt / 1e6, "unit": "M rank-queries/s", "cores": cores, "kind": "port",
             "regexes_per_s": sample / dt, "index_build_s": t_build, "n": n,
+            "fresh_batch_regexes_per_s": sample / (dt + t_compile), "front_end_s": t_compile,
             "sample": "%s; first %d regexes of the timed batch; ReTree._matchSA with its priority queue in C, one "
-                      "regex per OpenMP task, limits not binding, match length capped at %d like the GPU run; "
-                      "result multisets bit-equal" % (note, sample, max_len)}
+                      "regex per OpenMP task, %s; fresh_batch adds the regex front-end (the library's "
+                      "fmx_regex_compile_batch on the same cores) for the sample" % (note, sample, how)}
 
 
 # ---------------------------------------------------------------- the two kinds of workload
@@ -518,7 +546,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
 
 
 def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream):
-    log2n, k, seed, max_len = REGEX[args.workload]
+    log2n, k, seed, max_len, ref_mode = REGEX[args.workload]
     n = 1 << log2n
     t0 = time.time()
     bwt, eof = make_bwt(torch, n, C4_ALPHABET, seed, device)
@@ -533,21 +561,48 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         torch.cuda.empty_cache()
     t0 = time.time()
     res, trees = make_regexes(k, seed * 1000 + rank)           # weak scaling: every rank its own k regexes
-    batch = findex_amd.ReTree.prepare_batch(hip, trees)
-    log(rank, "compiled %d regexes and made them resident in %.1fs (host)" % (k, time.time() - t0))
+    t_gen = time.time() - t0
     cap = 1 << 22
+    lim = dict(mode="reference", maxBranching=REF_LIMITS[0], maxIterations=REF_LIMITS[1]) if ref_mode else dict(max_steps=max_len)
+
+    # ---- a batch that arrives as strings and is matched once: front-end + resident + first match (fresh_batch)
+    hip.stats()                  # tables of the index built (k-mer table): not part of a batch's cost
+    findex_amd.ReTree.prepare_batch(hip, trees[:16]).match_raw(cap=cap, **lim)
+    t0 = time.perf_counter()
+    fresh_trees = findex_amd.ReTree.compile_batch(res)
+    t1 = time.perf_counter()
+    fresh = findex_amd.ReTree.prepare_batch(hip, fresh_trees)
+    t2 = time.perf_counter()
+    fresh.match_raw(cap=cap, copy=False, **lim)
+    t3 = time.perf_counter()
+    fresh_batch = {"regexes_per_s": k / (t3 - t0), "seconds_per_batch": t3 - t0, "compile_s": t1 - t0,
+                   "resident_s": t2 - t1, "first_match_s": t3 - t2, "host_threads": effective_cores(),
+                   "what": "fmx_regex_compile_batch (all host cores) + fmx_regex_batch_create + the first "
+                           "fmx_regex_batch_match of %d regexes given as strings, results in page-locked host memory" % k}
+    del fresh, fresh_trees
+    log(rank, "fresh batch of %d regexes: compile %.3fs + resident %.3fs + first match %.3fs (workload generation %.1fs)"
+        % (k, t1 - t0, t2 - t1, t3 - t2, t_gen))
+    batch = findex_amd.ReTree.prepare_batch(hip, trees)
 
     from findex_amd.distributed import all_gather_varlen
     from findex_amd.regex import RESULT_DTYPE
 
-    # A step = fmx_regex_batch_match_dev: the regex path's device-pointer form, results (grouped by regex, ordered) and
-    # per-regex counts left in HBM -- as the literal workloads' step leaves its intervals there.  The rate with the
-    # results delivered into page-locked host memory is reported beside it (`host_delivered`).
+    # A frontier step = fmx_regex_batch_match_dev: the regex path's device-pointer form, results (grouped by regex,
+    # ordered) and per-regex counts left in HBM -- as the literal workloads' step leaves its intervals there.  The rate
+    # with the results delivered into page-locked host memory is reported beside it (`host_delivered`).
+    # A reference-order step = fmx_regex_batch_match(FMX_MATCH_REFERENCE): the list order is the answer, it is
+    # delivered to the host.
     d_out = torch.empty(3 * cap, dtype=torch.int64, device=device)          # 24-byte records as three words
     d_per = torch.empty(max(k, 1), dtype=torch.int32, device=device)
 
     def step():
-        n_res = batch.match_dev(d_out.data_ptr(), cap, d_per.data_ptr(), max_steps=max_len)
+        if ref_mode:
+            out, _ = batch.match_raw(cap=cap, copy=False, **lim)
+            n_res = out.size
+            if use_dist:
+                d_out[: 3 * n_res].copy_(torch.from_numpy(out.view(np.int64).reshape(-1)))
+        else:
+            n_res = batch.match_dev(d_out.data_ptr(), cap, d_per.data_ptr(), max_steps=max_len)
         if use_dist:        # the path's one exchange: every rank receives every rank's result list (sizes, then payload)
             all_gather_varlen(d_out[: 3 * n_res])
         return n_res
@@ -556,8 +611,11 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     n_results = int(step())
     s1 = hip.stats()
     torch.cuda.synchronize()
-    out_res = d_out[: 3 * n_results].cpu().numpy().view(RESULT_DTYPE)
-    steps_per_call = int(s1["frontier_elements"])
+    if ref_mode:
+        out_res = batch.match_raw(cap=cap, **lim)[0]
+    else:
+        out_res = d_out[: 3 * n_results].cpu().numpy().view(RESULT_DTYPE)
+    steps_per_call = int(s1["backward_steps"])
     ranks_per_step = 2 * steps_per_call
     for _ in range(max(0, args.warmup - 1)):
         step()
@@ -575,7 +633,7 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     dt = time.perf_counter() - t0
     kernel_ms = sum(kms) / len(kms)
     host_delivered = None
-    if world == 1:          # the same call with the results written into page-locked host memory (PCIe-inclusive)
+    if not ref_mode:        # the same call with the results written into page-locked host memory (PCIe-inclusive)
         for _ in range(3):
             batch.match_raw(max_steps=max_len, cap=cap, copy=False)
         th = time.perf_counter()
@@ -583,7 +641,7 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
             batch.match_raw(max_steps=max_len, cap=cap, copy=False)
         th = (time.perf_counter() - th) / args.steps
         host_delivered = {"ms_per_step": th * 1e3, "value": ranks_per_step / th / 1e6, "unit": "M rank-queries/s",
-                          "what": "fmx_regex_batch_match into page-locked host buffers (k_res_export over the link)"}
+                          "what": "fmx_regex_batch_match into page-locked host buffers (k_res_export over the link); this rank"}
     tot = torch.tensor([dt, float(ranks_per_step), float(n_results), kernel_ms], dtype=torch.float64, device=device)
     if use_dist:
         mx = tot.clone()
@@ -596,38 +654,73 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         ranks_all, results_all, kernel_ms_max = float(ranks_per_step), float(n_results), kernel_ms
     if rank != 0:
         return None
-    # ---- roofline of the frontier kernels (k_frontier*): bytes this design moves per call, from the device's
-    # own counters: 64 B per rank-line request, 32 B per state record loaded, 24 B per work-queue entry read or
-    # appended, 24 B per result written.
-    line_bytes = 64.0 if st["layout"] == 0 else 66.0
-    alg_bytes = (s1["frontier_requests"] * line_bytes + 16.0 * s1["ktab_lookups"] + 32.0 * s1["frontier_records"] +
-                 24.0 * (s1["frontier_queue_reads"] + s1["frontier_queue_writes"]) + 24.0 * s1["frontier_results"])
     ksec = kernel_ms * 1e-3
-    achieved = alg_bytes / ksec / 1e9
-    traffic = pmc_traffic(args.workload, "k_frontier")
-    roof = {
-        "bound": "hbm", "kernel": "k_frontier* (all device work of one fmx_regex_batch_match: HIP events around reset, start "
-                                   "elements, the launch chain, result grouping and export)",
-        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic[0] if traffic else None,
-        "traffic_source": ("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
-                           % traffic[1]) if traffic else "no PMC profile of this workload committed",
-        "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d state records x 32 B + "
-                             "(%d + %d) queue entries x 24 B + %d results x 24 B"
-                             % (s1["frontier_requests"], line_bytes, s1["ktab_lookups"], s1["frontier_records"],
-                                                      s1["frontier_queue_reads"], s1["frontier_queue_writes"],
-                                                      s1["frontier_results"]),
-        "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
-        "requests_per_launch": int(s1["frontier_requests"] + s1["ktab_lookups"] + s1["frontier_records"]),
-        "rank_line_requests": int(s1["frontier_requests"]), "ktab_lookups": int(s1["ktab_lookups"]),
-        "state_records": int(s1["frontier_records"]), "ktab_k": int(s1["ktab_k"]),
-        "rank_queries_per_launch": ranks_per_step,
-        "requests_G_per_s": (s1["frontier_requests"] + s1["ktab_lookups"] + s1["frontier_records"]) / ksec / 1e9,
-        "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S,
-        "request_frac": (s1["frontier_requests"] + s1["ktab_lookups"] + s1["frontier_records"]) / ksec / 1e9 / REQUEST_CEILING_G_PER_S,
-        "device_rank_queries_G_per_s": ranks_per_step / ksec / 1e9,
-    }
+    line_bytes = 64.0 if st["layout"] == 0 else 66.0
+    if ref_mode:
+        # ---- k_match_ref_wave: one regex per wave, the heap in LDS; what it asks of memory (device counters):
+        # rank-dictionary lines of the steps made at push time, 16 B push record per pushed element, a 32-B slot
+        # written per element pushed with a non-empty interval and read when it is popped, 32 B per result.
+        alg_bytes = (s1["frontier_requests"] * line_bytes + 16.0 * s1["frontier_records"] +
+                     32.0 * (s1["frontier_queue_writes"] + s1["frontier_queue_reads"]) + 32.0 * s1["frontier_results"])
+        achieved = alg_bytes / ksec / 1e9
+        roof = {
+            "bound": "hbm", "kernel": "k_match_ref_wave (ReTree._matchSA replayed, one regex per wave, heap keys in LDS, steps "
+                                       "evaluated at push time)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "traffic_source": "see profiles/ (rocprofv3 --pmc of this workload)",
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes": "%d rank-line requests x %g B + %d push records x 16 B + (%d + %d) element slots x 32 B + "
+                                 "%d results x 32 B" % (s1["frontier_requests"], line_bytes, s1["frontier_records"],
+                                                        s1["frontier_queue_writes"], s1["frontier_queue_reads"],
+                                                        s1["frontier_results"]),
+            "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+            "pops_per_launch": steps_per_call, "elements_stepped_at_push": int(s1["frontier_elements"]),
+            "rank_queries_per_launch": ranks_per_step, "device_rank_queries_G_per_s": ranks_per_step / ksec / 1e9,
+            "note": "latency-bound by construction: a regex's pops are serial in the reference's own order (the answer "
+                    "depends on it); the launch lasts as long as the regexes that use all %d iterations "
+                    "(kernel_ms / %d = time per pop on the critical path)" % (REF_LIMITS[1] - 1, REF_LIMITS[1] - 1),
+            "us_per_pop_critical_path": kernel_ms * 1e3 / (REF_LIMITS[1] - 1),
+        }
+        traffic = pmc_traffic(args.workload.replace("tiny", ""), "k_match_ref_wave")
+    else:
+        # ---- roofline of the frontier kernels (k_frontier*), priced with what reaches HBM, from the device's own
+        # counters: 64 B per rank-line request, 16 B per k-mer table entry, 24 B per work-queue entry read or appended,
+        # 24 B per result written, and the state records ONCE each (32 B x the batch's states: the 6.9 M record loads
+        # of a call hit L2 -- round 2 priced every load and came out above the PMC figure).
+        n_states_batch = batch.info()["states"]
+        rec_bytes = 32.0 * min(s1["frontier_records"], n_states_batch)
+        alg_bytes = (s1["frontier_requests"] * line_bytes + 16.0 * s1["ktab_lookups"] + rec_bytes +
+                     24.0 * (s1["frontier_queue_reads"] + s1["frontier_queue_writes"]) + 24.0 * s1["frontier_results"])
+        achieved = alg_bytes / ksec / 1e9
+        traffic = pmc_traffic(args.workload.replace("tiny", ""), "k_frontier")
+        all_req = s1["frontier_requests"] + s1["ktab_lookups"] + s1["frontier_records"]
+        roof = {
+            "bound": "hbm", "kernel": "k_frontier* (all device work of one fmx_regex_batch_match: HIP events around reset, start "
+                                       "elements, the launch chain, result grouping and export)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d distinct state records x 32 B "
+                                 "(%d loads, L2-resident) + (%d + %d) queue entries x 24 B + %d results x 24 B"
+                                 % (s1["frontier_requests"], line_bytes, s1["ktab_lookups"], int(rec_bytes / 32),
+                                    s1["frontier_records"], s1["frontier_queue_reads"], s1["frontier_queue_writes"],
+                                    s1["frontier_results"]),
+            "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+            "requests_per_launch": int(all_req),
+            "rank_line_requests": int(s1["frontier_requests"]), "ktab_lookups": int(s1["ktab_lookups"]),
+            "state_records": int(s1["frontier_records"]), "ktab_k": int(s1["ktab_k"]),
+            "rank_queries_per_launch": ranks_per_step,
+            "requests_G_per_s": all_req / ksec / 1e9,
+            "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S,
+            "request_ceiling_source": "tools/ubench/chain.hip, profiles/r02_ubench_chain_sizes.txt",
+            "request_frac": all_req / ksec / 1e9 / REQUEST_CEILING_G_PER_S,
+            "device_rank_queries_G_per_s": ranks_per_step / ksec / 1e9,
+            "note": "the synthetic BWT is an i.i.d. string, not the BWT of a text: a handful of starred classes sit on LF "
+                    "cycles and never die, so the launch's critical path is %d dependent rounds cut by max_match_len "
+                    "(truncated_at_max_len); on a real text a frontier dies by itself" % max_len,
+        }
+    roof["traffic"] = traffic[0] if traffic else None
+    roof["traffic_source"] = (("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
+                               % traffic[1]) if traffic else "no PMC profile of this workload committed")
     out = {
         "metric": "rank_queries_per_sec",
         "value": ranks_all * args.steps / dt / 1e6,
@@ -642,27 +735,36 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         "dtype": "u64",
         "data": "synthetic",
         "regexes_per_sec": world * k * args.steps / dt,
+        "regexes_per_sec_is": "a RESIDENT batch (compiled and on the device) matched again and again; a batch given as "
+                              "strings and matched once runs at fresh_batch.regexes_per_s",
+        "fresh_batch": fresh_batch,
         "host_delivered": host_delivered,
         "config": {
-            "workload": "%s: %d seeded regexes (<= 32 Glushkov positions) per GPU, 2^%d-byte sigma=%d synthetic BWT "
-                        "resident in HBM, SA-interval frontier expansion, results (grouped by regex, ordered) left in HBM"
-                        % (args.workload.upper(), k, log2n, len(C4_ALPHABET)),
-            "n": n, "sigma": len(C4_ALPHABET), "regexes_per_gpu": k, "max_match_len": max_len,
+            "workload": ("%s: %d seeded regexes (<= 32 Glushkov positions) per GPU, 2^%d-byte sigma=%d synthetic BWT "
+                         "resident in HBM, " % (args.workload.upper(), k, log2n, len(C4_ALPHABET))) +
+                        ("ReTree.matchSA in the reference's own pop order under its default limits (maxBranching %d, "
+                         "maxIterations %d), result lists delivered to the host" % REF_LIMITS if ref_mode else
+                         "SA-interval frontier expansion, results (grouped by regex, ordered) left in HBM"),
+            "n": n, "sigma": len(C4_ALPHABET), "regexes_per_gpu": k,
             "results_per_call": results_all, "backward_steps_per_call": ranks_all / 2,
-            "truncated_at_max_len": bool(batch.truncated),
             "parallelism": "regexes sharded over %d GPU(s), index replicated" % world,
             "ranks_in_group": dist.get_world_size() if use_dist else 1,
             "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
         },
         "roofline": roof,
     }
+    if ref_mode:
+        out["config"]["max_branching"], out["config"]["max_iterations"] = REF_LIMITS
+    else:
+        out["config"]["max_match_len"] = max_len
+        out["config"]["truncated_at_max_len"] = bool(batch.truncated)
     if want_cpu:
         cores = effective_cores()
         sample = min(k, 20_000)
         orc, t_build = oracle_index(torch, bwt, eof, cores, rank)
         if orc is not None:
-            out["cpu_baseline"] = cpu_baseline_regex(orc, t_build, n, trees, out_res, sample, max_len, cores, rank,
-                                                     "the timed run's own index (n=2^%d)" % log2n)
+            out["cpu_baseline"] = cpu_baseline_regex(orc, t_build, n, res, trees, out_res, sample, max_len, ref_mode, cores,
+                                                     rank, "the timed run's own index (n=2^%d)" % log2n)
             orc.close()
     return out
 

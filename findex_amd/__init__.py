@@ -15,7 +15,7 @@ library and a HIP device and fails loudly otherwise.
 """
 from ._lib import FmxError, MatchError, Re2PostSyntax, LIB_PATH, load  # noqa: F401
 from .searcher import HipFMSearcher  # noqa: F401
-from .regex import DFA, NFA, REParser, ReTree, SAResult  # noqa: F401
+from .regex import DFA, NFA, REParser, ReTree, SAResult, CompiledRegexes  # noqa: F401
 
 
 
@@ -37,4 +37,4 @@ def set_ktab(name):
     _lib.check(_lib.load().fmx_config_set(b"ktab", name.encode()))
 
 
-__all__ = ["set_layout", "set_checkpoints", "set_ktab", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "FmxError", "MatchError", "Re2PostSyntax"]
+__all__ = ["set_layout", "set_checkpoints", "set_ktab", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "CompiledRegexes", "FmxError", "MatchError", "Re2PostSyntax"]

@@ -92,6 +92,8 @@ SYMBOLS = {
     "fmx_extract": (_i32, [_vp, _u64, _u32, _i32, _vp, _P(_u32)]),
     "fmx_write_fm": (_i32, [_vp, _cp]),
     "fmx_regex_compile": (_i32, [_cp, _i32, _P(_vp)]),
+    "fmx_regex_compile_batch": (_i32, [_vp, _sz, _i32, _vp, _vp]),
+    "fmx_regex_free_batch": (_i32, [_vp, _sz]),
     "fmx_nfa_compile": (_i32, [_cp, _i32, _i32, _P(_vp)]),
     "fmx_dfa_compile": (_i32, [_vp, _u32, _u32, _vp, _P(_vp)]),
     "fmx_regex_free": (_i32, [_vp]),
@@ -100,6 +102,7 @@ SYMBOLS = {
     "fmx_regex_match_batch": (_i32, [_vp, _vp, _sz, _vp, _vp, _sz, _P(_sz), _vp]),
     "fmx_regex_batch_create": (_i32, [_vp, _vp, _sz, _P(_vp)]),
     "fmx_regex_batch_free": (_i32, [_vp]),
+    "fmx_regex_batch_info": (_i32, [_vp, _P(_u64), _P(_u64), _P(_u64), _P(_u64)]),
     "fmx_regex_batch_match": (_i32, [_vp, _vp, _vp, _vp, _sz, _P(_sz), _vp]),
     "fmx_regex_batch_match_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _P(_sz), _vp]),
     "fmx_regex_batch_create_multi": (_i32, [_vp, _sz, _vp, _sz, _P(_vp)]),

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -13,6 +14,7 @@
 #include <vector>
 
 #include "fmx_host.h"
+#include "fmx_hostpar.h"
 #include "fmx_regex.h"
 
 namespace fmx {
@@ -446,6 +448,13 @@ int fmx_config_set(const char *key, const char *value) {
     if (std::strcmp(value, "auto") == 0) g_force_superblocks.store(0);
     else if (std::strcmp(value, "superblock") == 0) g_force_superblocks.store(1);
     else return arg_fail("checkpoints must be auto or superblock");
+    return FMX_OK;
+  }
+  if (std::strcmp(key, "threads") == 0) {
+    char *end = nullptr;
+    const long v = std::strtol(value, &end, 10);
+    if (end == value || *end || v < 0) return arg_fail("threads must be a non-negative integer");
+    set_host_threads((unsigned)v);
     return FMX_OK;
   }
   return arg_fail("unknown configuration key");

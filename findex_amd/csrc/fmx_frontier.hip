@@ -30,6 +30,7 @@
 #include <fmx.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,7 @@
 
 #include "fmx_device.h"
 #include "fmx_host.h"
+#include "fmx_hostpar.h"
 #include "fmx_nfa.h"
 #include "fmx_regex.h"
 
@@ -965,7 +967,7 @@ struct RegexBatch {
   uint64_t n_index = 0;
   uint64_t index_serial = 0;           // the fmx_index this batch was made for (Index::serial): its pointers are inside the
                                        // captured level chain, so no other handle may match against the batch
-  size_t n_first = 0;
+  size_t n_first = 0, n_states = 0, n_fol = 0;
   std::vector<uint32_t> start_final;   // DFA engines whose start state is final: result (len 0, 0, n)
   DevMem mem;
   // scratch reused across matches of this batch (one match at a time per batch object)
@@ -999,7 +1001,8 @@ struct RegexBatch {
   uint32_t *d_first_state = nullptr;
   // reference-order mode (ReTree batches only): heap keys, per-regex firsts, the largest fan-out
   uint32_t *d_st_num = nullptr, *d_first_off = nullptr;
-  uint32_t max_fanout = 1;
+  FolRec *d_fol_rec = nullptr, *d_first_rec = nullptr;
+  uint32_t max_fanout = 1, max_num = 0;
   bool all_retree = true;
 };
 
@@ -1011,69 +1014,89 @@ static hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyK
 }
 
 int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexBatch **out) {
-  // sizes first, then one pass that fills pre-sized arrays (100 k regexes: 1.3 M states, 2 M follows)
-  size_t n_states = 0, n_fol = 0, n_first = 0;
-  bool all_retree = true;
-  for (size_t r = 0; r < k; r++) {
-    const Regex &re = *res[r];
-    n_states += re.st_c.size();
-    n_first += re.firsts.size();
-    all_retree = all_retree && re.engine == 0;
-    for (size_t s = 0; s < re.st_c.size(); s++)
-      if (!(re.last_stops && re.st_last[s])) n_fol += (size_t)(re.fol_off[s + 1] - re.fol_off[s]);
-  }
+  // Sizes first (per regex, then one prefix sum), then every regex fills its own stretch of the pre-sized arrays:
+  // both passes run on all host cores (100 k regexes: 1.3 M states, 2 M follows).
+  std::vector<size_t> st_base(k + 1, 0), fol_base(k + 1, 0), first_base(k + 1, 0);
+  std::atomic<int> not_retree{0}, too_many{0};
+  parallel_for(k, 1024, [&](size_t a, size_t b) {
+    for (size_t r = a; r < b; r++) {
+      const Regex &re = *res[r];
+      size_t nf = 0;
+      for (size_t s = 0; s < re.st_c.size(); s++)
+        if (!(re.last_stops && re.st_last[s])) {
+          const size_t cnt = (size_t)(re.fol_off[s + 1] - re.fol_off[s]);
+          if (cnt > kMaxFollows) too_many.store(1);
+          nf += cnt;
+        }
+      st_base[r + 1] = re.st_c.size();
+      fol_base[r + 1] = nf;
+      first_base[r + 1] = re.firsts.size();
+      if (re.engine != 0) not_retree.store(1);
+    }
+  });
+  if (too_many.load()) { set_error("a state has more than 65535 follows"); return FMX_ERR_UNSUPPORTED; }
+  for (size_t r = 0; r < k; r++) { st_base[r + 1] += st_base[r]; fol_base[r + 1] += fol_base[r]; first_base[r + 1] += first_base[r]; }
+  const size_t n_states = st_base[k], n_fol = fol_base[k], n_first = first_base[k];
+  if (n_states >= (1ull << 32) || n_fol >= (1ull << 32)) { set_error("regex batch too large (2^32 states or follows)"); return FMX_ERR_UNSUPPORTED; }
+  const bool all_retree = not_retree.load() == 0;
   std::vector<StateRec> recs(n_states);
   std::vector<uint32_t> fol(n_fol), q_state(n_first), st_num(n_states), first_off(k + 1, 0), start_final;
   std::vector<uint8_t> fol_c(n_fol);
-  uint32_t max_fanout = 1;
-  size_t base = 0, fo = 0, qo = 0;
-  for (size_t r = 0; r < k; r++) {
-    const Regex &re = *res[r];
-    for (size_t s = 0; s < re.st_c.size(); s++) {
-      StateRec &rec = recs[base + s];
-      rec.fol_off = (uint32_t)fo;
-      // ReTree: `if (q.state.isLast) ret ::= ... else pqFront ++= follows` -- last states do not expand
-      if (!(re.last_stops && re.st_last[s]))
-        for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) {
-          fol_c[fo] = re.st_c[(size_t)re.fol[j]];
-          fol[fo++] = (uint32_t)base + (uint32_t)re.fol[j];
-        }
-      const uint32_t cnt = (uint32_t)fo - rec.fol_off;
-      if (cnt > kMaxFollows) { set_error("a state has more than 65535 follows"); return FMX_ERR_UNSUPPORTED; }
-      rec.cnt_c_emit = cnt | ((uint32_t)re.st_c[s] << 16) | ((uint32_t)(re.st_last[s] ? 1 : 0) << 24);
-      rec.regex = (uint32_t)r;
-      rec.fc = 0;
-      for (uint32_t j = 0; j < kInlineFollows; j++) {
-        rec.f[j] = j < cnt ? fol[rec.fol_off + j] : 0u;
-        if (j < cnt) rec.fc |= (uint32_t)fol_c[rec.fol_off + j] << (8 * j);
-      }
-      st_num[base + s] = (uint32_t)re.st_num[s];
-      max_fanout = std::max(max_fanout, cnt);
-    }
-    // literal stretches (fmx_nfa.h): chain lengths from the regex's last state backwards, then the bytes
-    {
-      const size_t ns = re.st_c.size();
-      auto single = [&](size_t s) {
-        const StateRec &rec = recs[base + s];
-        return rec_cnt(rec) == 1 && !rec_emit(rec) && s + 1 < ns && rec.f[0] == (uint32_t)(base + s + 1);
-      };
-      uint32_t next_chain = 0;
-      for (size_t s = ns; s-- > 0;) {
-        const uint32_t chain = single(s) ? std::min<uint32_t>(kMaxChain, 1 + next_chain) : 0;
-        next_chain = chain;
-        if (!chain) continue;
+  std::vector<uint32_t> fanout(k, 1);
+  parallel_for(k, 1024, [&](size_t ra, size_t rb) {
+    for (size_t r = ra; r < rb; r++) {
+      const Regex &re = *res[r];
+      const size_t base = st_base[r];
+      size_t fo = fol_base[r], qo = first_base[r];
+      uint32_t max_fanout = 1;
+      for (size_t s = 0; s < re.st_c.size(); s++) {
         StateRec &rec = recs[base + s];
-        rec.cnt_c_emit |= chain << 25;
-        uint8_t rr[kMaxChain] = {0};
-        for (uint32_t j = 0; j < chain; j++) rr[chain - 1 - j] = re.st_c[s + 1 + j];
-        std::memcpy(&rec.f[1], rr, kMaxChain);
+        rec.fol_off = (uint32_t)fo;
+        // ReTree: `if (q.state.isLast) ret ::= ... else pqFront ++= follows` -- last states do not expand
+        if (!(re.last_stops && re.st_last[s]))
+          for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) {
+            fol_c[fo] = re.st_c[(size_t)re.fol[j]];
+            fol[fo++] = (uint32_t)base + (uint32_t)re.fol[j];
+          }
+        const uint32_t cnt = (uint32_t)fo - rec.fol_off;
+        rec.cnt_c_emit = cnt | ((uint32_t)re.st_c[s] << 16) | ((uint32_t)(re.st_last[s] ? 1 : 0) << 24);
+        rec.regex = (uint32_t)r;
+        rec.fc = 0;
+        for (uint32_t j = 0; j < kInlineFollows; j++) {
+          rec.f[j] = j < cnt ? fol[rec.fol_off + j] : 0u;
+          if (j < cnt) rec.fc |= (uint32_t)fol_c[rec.fol_off + j] << (8 * j);
+        }
+        st_num[base + s] = (uint32_t)re.st_num[s];
+        max_fanout = std::max(max_fanout, cnt);
       }
+      // literal stretches (fmx_nfa.h): chain lengths from the regex's last state backwards, then the bytes
+      {
+        const size_t ns = re.st_c.size();
+        auto single = [&](size_t s) {
+          const StateRec &rec = recs[base + s];
+          return rec_cnt(rec) == 1 && !rec_emit(rec) && s + 1 < ns && rec.f[0] == (uint32_t)(base + s + 1);
+        };
+        uint32_t next_chain = 0;
+        for (size_t s = ns; s-- > 0;) {
+          const uint32_t chain = single(s) ? std::min<uint32_t>(kMaxChain, 1 + next_chain) : 0;
+          next_chain = chain;
+          if (!chain) continue;
+          StateRec &rec = recs[base + s];
+          rec.cnt_c_emit |= chain << 25;
+          uint8_t rr[kMaxChain] = {0};
+          for (uint32_t j = 0; j < chain; j++) rr[chain - 1 - j] = re.st_c[s + 1 + j];
+          std::memcpy(&rec.f[1], rr, kMaxChain);
+        }
+      }
+      for (int32_t f : re.firsts) q_state[qo++] = (uint32_t)base + (uint32_t)f;
+      first_off[r + 1] = (uint32_t)qo;
+      fanout[r] = std::max<uint32_t>(max_fanout, (uint32_t)re.firsts.size());
     }
-    for (int32_t f : re.firsts) q_state[qo++] = (uint32_t)base + (uint32_t)f;
-    first_off[r + 1] = (uint32_t)qo;
-    max_fanout = std::max<uint32_t>(max_fanout, (uint32_t)re.firsts.size());
-    if (re.start_is_final) start_final.push_back((uint32_t)r);
-    base += re.st_c.size();
+  });
+  uint32_t max_fanout = 1;
+  for (size_t r = 0; r < k; r++) {
+    max_fanout = std::max(max_fanout, fanout[r]);
+    if (res[r]->start_is_final) start_final.push_back((uint32_t)r);
   }
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
   CtxLease lease(h);
@@ -1085,6 +1108,8 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   b->n_index = h->n;
   b->index_serial = h->serial;
   b->n_first = q_state.size();
+  b->n_states = n_states;
+  b->n_fol = n_fol;
   b->start_final = start_final;
   b->max_fanout = max_fanout;
   b->all_retree = all_retree;
@@ -1104,6 +1129,18 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
     HIP_TRY(b->mem.alloc(&b->d_first_off, first_off.size()), "hipMalloc");
     if (!st_num.empty()) HIP_TRY(copy_sync(b->d_st_num, st_num.data(), st_num.size() * 4, hipMemcpyHostToDevice, st), "H2D");
     HIP_TRY(copy_sync(b->d_first_off, first_off.data(), first_off.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+    // the reference-order kernel's push records (fmx_nfa.h)
+    std::vector<FolRec> fr(fol.size()), qr(q_state.size());
+    auto rec_of = [&](uint32_t sid) { return FolRec{sid, recs[sid].fol_off, recs[sid].cnt_c_emit & 0x01FFFFFFu, st_num[sid]}; };
+    parallel_for(fol.size(), 1 << 16, [&](size_t a, size_t e) { for (size_t i = a; i < e; i++) fr[i] = rec_of(fol[i]); });
+    for (size_t i = 0; i < q_state.size(); i++) qr[i] = rec_of(q_state[i]);
+    uint32_t mx = 0;
+    for (uint32_t v : st_num) mx = std::max(mx, v);
+    b->max_num = mx;
+    HIP_TRY(b->mem.alloc(&b->d_fol_rec, fr.size()), "hipMalloc");
+    HIP_TRY(b->mem.alloc(&b->d_first_rec, qr.size()), "hipMalloc");
+    if (!fr.empty()) HIP_TRY(copy_sync(b->d_fol_rec, fr.data(), fr.size() * sizeof(FolRec), hipMemcpyHostToDevice, st), "H2D");
+    if (!qr.empty()) HIP_TRY(copy_sync(b->d_first_rec, qr.data(), qr.size() * sizeof(FolRec), hipMemcpyHostToDevice, st), "H2D");
   }
   b->nfa = NfaTables{d_st, d_fol, d_fol_c};
   *out = b.release();
@@ -1646,6 +1683,55 @@ int fmx_regex_compile(const char *re, int line_only, fmx_regex **out) {
   }
 }
 
+// The batched front-end: REParser.re2post + ReTree.apply are independent per regex, so a batch is compiled on all the
+// host cores the process may use (fmx_hostpar.h).  status[i] = FMX_OK / FMX_ERR_SYNTAX / FMX_ERR_MATCH as
+// fmx_regex_compile would return for res[i]; out[i] = its handle or NULL.
+int fmx_regex_compile_batch(const char *const *res, size_t k, int line_only, fmx_regex **out, int *status) {
+  if ((k && (!res || !out))) { set_error("null argument"); return FMX_ERR_ARG; }
+  for (size_t i = 0; i < k; i++) {
+    out[i] = nullptr;
+    if (!res[i]) { set_error("null regex string"); return FMX_ERR_ARG; }
+  }
+  std::atomic<size_t> first_bad{k};
+  std::atomic<int> nomem{0};
+  parallel_for(k, 256, [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; i++) {
+      int rc = FMX_OK;
+      try {
+        out[i] = reinterpret_cast<fmx_regex *>(new Regex(compile_regex(res[i], line_only != 0)));
+      } catch (const RegexError &e) {
+        rc = e.code;
+      } catch (const std::bad_alloc &) {
+        rc = FMX_ERR_NOMEM;
+        nomem.store(1);
+      }
+      if (status) status[i] = rc;
+      if (rc != FMX_OK) {
+        size_t cur = first_bad.load();
+        while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+      }
+    }
+  });
+  if (nomem.load()) {
+    for (size_t i = 0; i < k; i++) { delete reinterpret_cast<Regex *>(out[i]); out[i] = nullptr; }
+    set_error("out of host memory");
+    return FMX_ERR_NOMEM;
+  }
+  const size_t bad = first_bad.load();
+  if (bad < k) {        // the first failure's message, as the one-regex entry point would have left it
+    try { (void)compile_regex(res[bad], line_only != 0); } catch (const RegexError &e) { set_error(e.msg + " (regex " + std::to_string(bad) + " of the batch)"); } catch (...) {}
+  }
+  return FMX_OK;
+}
+
+int fmx_regex_free_batch(fmx_regex *const *res, size_t k) {
+  if (k && !res) { set_error("null argument"); return FMX_ERR_ARG; }
+  parallel_for(k, 4096, [&](size_t a, size_t b) {
+    for (size_t i = a; i < b; i++) delete reinterpret_cast<Regex *>(res[i]);
+  });
+  return FMX_OK;
+}
+
 // REParser.createNFA (re2/re2.scala:264-334): `src` is a regex (parsed by re2post) or, with
 // src_is_postfix, a postfix string for post2re (:188-205, '.' = concat) as the reference's tests use.
 int fmx_nfa_compile(const char *src, int line_only, int src_is_postfix, fmx_regex **out) {
@@ -1725,6 +1811,17 @@ int fmx_regex_batch_create(const fmx_index *idx, fmx_regex *const *res, size_t k
   return rc;
 }
 
+int fmx_regex_batch_info(const fmx_regex_batch *b, uint64_t *n_regexes, uint64_t *n_states, uint64_t *n_follows,
+                         uint64_t *n_firsts) {
+  if (!b) { set_error("null argument"); return FMX_ERR_ARG; }
+  const RegexBatch *rb = reinterpret_cast<const RegexBatch *>(b);
+  if (n_regexes) *n_regexes = rb->k;
+  if (n_states) *n_states = rb->n_states;
+  if (n_follows) *n_follows = rb->n_fol;
+  if (n_firsts) *n_firsts = rb->n_first;
+  return FMX_OK;
+}
+
 int fmx_regex_batch_free(fmx_regex_batch *b) {
   RegexBatch *rb = reinterpret_cast<RegexBatch *>(b);
   if (rb) { (void)hipSetDevice(rb->device); delete rb; }
@@ -1743,7 +1840,7 @@ int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *b, const fmx_li
       return FMX_ERR_UNSUPPORTED;
     }
     if (rb->index_serial != h->serial) { set_error("regex batch was prepared for another index"); return FMX_ERR_ARG; }
-    const RefTables rt{rb->nfa.st, rb->nfa.fol, rb->d_st_num, rb->d_first_off, rb->d_first_state};
+    const RefTables rt{rb->nfa.st, rb->nfa.fol, rb->d_st_num, rb->d_first_off, rb->d_first_state, rb->d_fol_rec, rb->d_first_rec, rb->max_num};
     return regex_match_reference(h, rt, rb->k, rb->max_fanout, lim->max_branching, lim->max_iterations, out, cap, n_out,
                                  per_regex_count, nullptr);
   }

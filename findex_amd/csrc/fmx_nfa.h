@@ -34,12 +34,24 @@ struct NfaTables {
 };
 
 // What ReTree._matchSA's replay needs on top: CharNode.num (the heap key) and each regex's firsts.
+// FolRec: everything a push needs about the state it pushes, one 16-byte load per follow entry (parallel to `fol`;
+// `first_rec` the same for the firsts) -- the state's own follow list and byte ride along, so the element is stepped
+// and later expanded without a load of its StateRec.
+struct FolRec {
+  uint32_t state;        // global CharNode id
+  uint32_t fol_off;      // that state's follows (StateRec::fol_off)
+  uint32_t cnt_c_emit;   // that state's StateRec::cnt_c_emit (count, byte, isLast)
+  uint32_t num;          // CharNode.num
+};
 struct RefTables {
   const StateRec *st;
   const uint32_t *fol;
   const uint32_t *st_num;
   const uint32_t *first_off;   // k + 1: firsts of regex r are first[first_off[r] .. first_off[r+1])
   const uint32_t *first;
+  const FolRec *fol_rec;       // parallel to fol
+  const FolRec *first_rec;     // parallel to first
+  uint32_t max_num;            // largest CharNode.num of the batch
 };
 
 }  // namespace fmx

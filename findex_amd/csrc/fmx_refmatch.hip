@@ -17,6 +17,7 @@
 #include <fmx.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -164,12 +165,267 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
   counters_add(counters, t == 0 ? 2ull * stepped : 0ull, t == 0 ? stepped : 0u, 0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same replay, one regex per WAVE, for limits that fit LDS (the reference's defaults do).  Two things make a pop
+// cheap here that the kernel above pays ~10 us for:
+//  * The heap is an array of 4-byte entries {num:16 | slot:16} in LDS.  Only `num` orders the queue (:564), so the
+//    sifts move 4-byte keys; what an element carries (state, len, interval) sits in a slab in device memory under
+//    its slot number.  Free slots need no list: the entries of the array behind the heap are always a permutation of
+//    the unused slot numbers (a pop swaps the popped entry to a[size - 1], just outside the heap; a push takes the
+//    slot number it finds at a[size]).  A push is one LDS round trip (every ancestor read at once, one ballot, the
+//    shifted entries written back at once); a pop walks down one level per round trip (both children in one read).
+//  * An element's step does not depend on WHEN it is popped, only the heap's shape does.  So getPrevRange is
+//    evaluated when the element is PUSHED: a pop's follows are stepped together, one lane group each, all their rank
+//    blocks in flight at once (the reference pays one dependent rank query per pop), and whether the step came back
+//    empty is kept in LDS beside the heap.  Popping an element whose interval is empty -- most pops, once the
+//    intervals are narrow: a row has one preceding character, the others die -- then touches no memory at all:
+//    it only counts as an iteration and leaves the heap, exactly as in the reference's loop.
+// Elements still queued when a limit ends the loop were stepped for nothing; nothing of them is observable
+// (the statistics count pops, like the reference's own getPrevRange calls).
+struct RefSlot {           // 32 bytes, written when the element is pushed (only for non-empty intervals)
+  uint64_t sp, ep;         // the interval AFTER the element's own step
+  uint32_t state, len;     // len = the StatePoint's len (the step makes it len + 1)
+  uint32_t fol_off, cnt_c_emit;
+};
+struct RefCtl2 {
+  unsigned long long res_count;
+  unsigned long long overflow;
+  unsigned int next;       // next regex to hand out
+  unsigned int pad;
+};
+constexpr uint32_t kWaveCf = 256 * 8 + 256 * 2;      // bytes of the C[] / slot tables in front of the waves' heaps
+
+__device__ __forceinline__ uint32_t runi(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// a[size0] = key, sifted up as `+=` does (fixUp: while k > 1 && a[k/2] < a[k] swap): one LDS round trip
+__device__ __forceinline__ void wave_heap_push(uint32_t *a, uint32_t &size0, uint32_t key, uint32_t lane) {
+  const uint32_t k = size0;
+  const uint32_t pos = lane < 32u ? k >> lane : 0u;              // lane l: the l-th ancestor of position k
+  const bool is_anc = lane >= 1u && pos >= 1u;
+  const uint32_t anc = is_anc ? a[pos] : 0u;
+  const bool up = is_anc && (anc >> 16) > (key >> 16);            // heap_lt(ancestor, e): the new element moves above it
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(up);
+  const uint32_t m = (uint32_t)__builtin_ctzll(~(bal >> 1));     // ancestors passed, from the nearest on
+  if (lane >= 1u && lane <= m) a[k >> (lane - 1u)] = anc;
+  if (lane == 0u) a[k >> m] = key;
+  size0 = k + 1u;
+  lds_sync();
+}
+
+// dequeue (:  swap(1, size - 1), fixDown inside a[1 .. size - 2]); returns the popped entry, which now sits at a[size0]
+__device__ __forceinline__ uint32_t wave_heap_pop(uint32_t *a, uint32_t &size0, uint32_t lane) {
+  size0 -= 1u;
+  const uint32_t top = runi(a[1]);
+  const uint32_t x = runi(a[size0]);
+  const uint32_t n = size0 - 1u;
+  uint32_t k = 1u;
+  if (lane == 0u) a[size0] = top;
+  while (n >= 2u * k) {
+    uint32_t j = 2u * k;
+    const uint2 cc = *reinterpret_cast<const uint2 *>(a + j);     // both children (j is even)
+    uint32_t c = runi(cc.x);
+    const uint32_t c2 = runi(cc.y);
+    if (j < n && (c >> 16) > (c2 >> 16)) { j += 1u; c = c2; }     // right child only when left < right
+    if (!((x >> 16) > (c >> 16))) break;                          // a[k] >= a[j]
+    if (lane == 0u) a[k] = c;
+    k = j;
+  }
+  if (n >= 1u && lane == 0u) a[k] = x;
+  lds_sync();
+  return top;
+}
+
+template <bool WIDE, uint32_t LAYOUT>
+__global__ __launch_bounds__(kRThreads) void k_match_ref_wave(DevIndex ix, RefTables rt, uint32_t k_regex,
+                                                               RefSlot *__restrict__ slabs, uint32_t heap_cap,
+                                                               uint32_t max_branching, uint32_t max_iterations,
+                                                               RefResult *__restrict__ res, uint64_t res_cap,
+                                                               uint32_t *__restrict__ front_left, RefCtl2 *__restrict__ ctl,
+                                                               unsigned long long *__restrict__ counters) {
+  extern __shared__ __align__(16) unsigned char s_raw[];
+  uint64_t *s_cf = reinterpret_cast<uint64_t *>(s_raw);
+  uint16_t *s_slot = reinterpret_cast<uint16_t *>(s_raw + 256 * 8);
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  constexpr int G = Lay<LAYOUT>::G;
+  constexpr uint32_t NG = 64 / G;                 // lane groups of a wave = follows stepped at once
+  const LaneConst lc = lane_const<G>();
+  const uint32_t lane = __lane_id();
+  const uint32_t wv = runi(threadIdx.x >> 6);
+  const uint32_t q = lane / G;                    // this lane's group
+  const uint32_t wave_bytes = (heap_cap * 5u + 15u) & ~15u;
+  uint32_t *a = reinterpret_cast<uint32_t *>(s_raw + kWaveCf + (size_t)wv * wave_bytes);   // the heap, 1-based
+  uint8_t *alive = reinterpret_cast<uint8_t *>(a + heap_cap);                               // by slot number
+  RefSlot *slab = slabs + (size_t)(blockIdx.x * (blockDim.x >> 6) + wv) * heap_cap;
+  for (uint32_t i = lane; i < heap_cap; i += 64u) a[i] = i;       // every slot number once
+  __syncthreads();
+  uint32_t stepped = 0;
+  uint32_t n_reqs = 0, n_push = 0, n_live_push = 0, n_live_pop = 0, n_res = 0;      // per lane / wave-uniform tallies for fmx_stats
+  for (;;) {
+    uint32_t r = 0;
+    if (lane == 0u) r = atomicAdd(&ctl->next, 1u);
+    r = runi(r);
+    if (r >= k_regex) break;
+    uint32_t size0 = 1u, nres = 0u, it = 1u;
+    bool bad = false;
+    // pqFront ++= / += of `cnt` elements whose records are recs[0 .. cnt): each is stepped from the parent's interval
+    // right away (lane group g steps element j0 + g), then pushed in order
+    auto push_all = [&](const FolRec *recs, uint32_t cnt, uint64_t psp, uint64_t pep, uint32_t clen) {
+      for (uint32_t j0 = 0; j0 < cnt && !bad; j0 += NG) {
+        const uint32_t nb = cnt - j0 < NG ? cnt - j0 : NG;
+        if (size0 + nb > heap_cap) { bad = true; if (lane == 0u) atomicOr(&ctl->overflow, 1ull); break; }
+        const bool act = q < nb;
+        uint4 fr = make_uint4(0, 0, 0, 0);
+        if (act) fr = *reinterpret_cast<const uint4 *>(recs + j0 + q);
+        const uint32_t slotno = act ? (a[size0 + q] & 0xFFFFu) : 0u;      // the free slot this push will take
+        uint64_t sp = psp, ep = pep;
+        if (act) {
+          const uint32_t c = (fr.z >> 16) & 0xFFu;
+          const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, c, s_slot[c], s_cf[c], lc, sp, ep);
+          if (lc.t == 0u) n_reqs += rq;
+        }
+        const bool live = act && sp < ep;
+        n_push += nb;
+        if (act && lc.t == 0u) {
+          n_live_push += live ? 1u : 0u;
+          alive[slotno] = live ? 1 : 0;
+          if (live) {
+            uint4 *d = reinterpret_cast<uint4 *>(slab + slotno);
+            d[0] = make_uint4((uint32_t)sp, (uint32_t)(sp >> 32), (uint32_t)ep, (uint32_t)(ep >> 32));
+            d[1] = make_uint4(fr.x, clen, fr.y, fr.z);
+          }
+        }
+        lds_sync();
+        for (uint32_t g = 0; g < nb; g++) {
+          const uint32_t num = (uint32_t)__builtin_amdgcn_readlane((int)fr.w, (int)(g * G));
+          const uint32_t sn = (uint32_t)__builtin_amdgcn_readlane((int)slotno, (int)(g * G));
+          wave_heap_push(a, size0, (num << 16) | sn, lane);
+        }
+      }
+    };
+    {
+      const uint32_t f0 = rt.first_off[r], f1 = rt.first_off[r + 1];
+      push_all(rt.first_rec + f0, f1 - f0, 0ull, ix.n, 0u);                 // pqFront ++= inputStates, :624
+    }
+    // loop condition, :628
+    while (!bad && size0 >= 2u && (size0 - 1u) < max_branching && (max_iterations == 0u || it < max_iterations)) {
+      const uint32_t e = wave_heap_pop(a, size0, lane);
+      const uint32_t sn = e & 0xFFFFu;
+      stepped++;
+      it++;
+      if (!runi((uint32_t)alive[sn])) continue;                             // None, :634: nothing to do
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      n_live_pop++;
+      const uint4 *sp4 = reinterpret_cast<const uint4 *>(slab + sn);
+      const uint4 p0 = sp4[0], p1 = sp4[1];
+      const uint64_t psp = ((uint64_t)runi(p0.y) << 32) | runi(p0.x), pep = ((uint64_t)runi(p0.w) << 32) | runi(p0.z);
+      const uint32_t len = runi(p1.y), fol_off = runi(p1.z), cce = runi(p1.w);
+      if ((cce >> 24) & 1u) {                                                // isLast, :636-638
+        if (lane == 0u) {
+          const unsigned long long at = atomicAdd(&ctl->res_count, 1ull);
+          if (at < res_cap) {
+            RefResult o;
+            o.regex = r; o.len = len + 1u; o.seq = nres; o.pad = 0; o.sp = psp; o.ep = pep;
+            res[at] = o;
+          } else {
+            atomicOr(&ctl->overflow, 2ull);
+          }
+        }
+        nres++;
+        n_res++;
+      } else {                                                               // :641
+        push_all(rt.fol_rec + fol_off, cce & 0xFFFFu, psp, pep, len + 1u);
+      }
+    }
+    if (lane == 0u && front_left) front_left[r] = size0 - 1u;
+  }
+  counters_add(counters, lane == 0u ? 2ull * stepped : 0ull, lane == 0u ? stepped : 0u, 0);
+  // the frontier counters of fmx_stats, read for this kernel as: rank-line requests | slots written (elements pushed
+  // with a non-empty interval) | results | elements stepped at push time | slots read (non-empty elements popped) |
+  // push records loaded
+  counters_add_frontier(counters, n_reqs, n_live_push, lane == 0u ? n_res : 0u, lane == 0u ? n_push : 0u,
+                        lane == 0u ? n_live_pop : 0u, lane == 0u ? n_push : 0u);
+}
+
 #define HIP_TRY(call, what)                            \
   do {                                                 \
     hipError_t e__ = (call);                           \
     if (e__ != hipSuccess) return hip_fail(e__, what); \
   } while (0)
 
+
+// results per regex, newest first: the order of the reference's prepended list (:638)
+static void deliver_results(std::vector<RefResult> &tmp, fmx_result *out, uint32_t *per_regex_count) {
+  std::sort(tmp.begin(), tmp.end(), [](const RefResult &a, const RefResult &b) {
+    if (a.regex != b.regex) return a.regex < b.regex;
+    return a.seq > b.seq;
+  });
+  for (size_t j = 0; j < tmp.size(); j++) {
+    out[j].regex = tmp[j].regex; out[j].len = tmp[j].len; out[j].sp = tmp[j].sp; out[j].ep = tmp[j].ep;
+    if (per_regex_count) per_regex_count[tmp[j].regex]++;
+  }
+}
+
+static int match_reference_wave(const Index *h, const RefTables &rt, size_t k, uint32_t heap_cap, uint32_t max_branching,
+                                uint32_t max_iterations, fmx_result *out, size_t cap, size_t *n_out,
+                                uint32_t *per_regex_count, uint32_t *front_left) {
+  const size_t wave_bytes = ((size_t)heap_cap * 5 + 15) & ~(size_t)15;
+  // waves per workgroup: as many of 4 as fit 64 KB of LDS; workgroups per CU: what LDS (160 KB) and the wave slots allow
+  uint32_t wpw = 4;
+  while (wpw > 1 && kWaveCf + wpw * wave_bytes > (64u << 10)) wpw >>= 1;
+  const size_t lds = kWaveCf + wpw * wave_bytes;
+  const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160u << 10) / lds, 32 / 4));
+  uint64_t grid = std::min<uint64_t>((k + wpw - 1) / wpw, (uint64_t)h->cu_count * wg_per_cu);
+  // bound the slab arena (32 B x heap_cap per wave) to ~2 GiB
+  grid = std::max<uint64_t>(1, std::min<uint64_t>(grid, (2ull << 30) / ((uint64_t)heap_cap * sizeof(RefSlot) * wpw)));
+  CtxLease lease(h);
+  if (!lease.c) return FMX_ERR_HIP;
+  hipStream_t st = lease.c->stream;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t waves = (size_t)grid * wpw;
+  const size_t o_ctl = 0, o_slab = up(sizeof(RefCtl2)), o_res = o_slab + up(waves * heap_cap * sizeof(RefSlot)),
+               o_left = o_res + up((cap ? cap : 1) * sizeof(RefResult)), total = o_left + up(k * 4);
+  void *arena_v = nullptr;
+  HIP_TRY(ctx_scratch(lease.c, 0, total, &arena_v), "hipMalloc(reference-order arena)");
+  uint8_t *arena = static_cast<uint8_t *>(arena_v);
+  HIP_TRY(hipMemsetAsync(arena + o_ctl, 0, sizeof(RefCtl2), st), "memset(ctl)");
+  RefSlot *d_slab = reinterpret_cast<RefSlot *>(arena + o_slab);
+  RefResult *d_res = reinterpret_cast<RefResult *>(arena + o_res);
+  RefCtl2 *d_ctl = reinterpret_cast<RefCtl2 *>(arena + o_ctl);
+  uint32_t *d_left = front_left ? reinterpret_cast<uint32_t *>(arena + o_left) : nullptr;
+  // the caller's view of the call: pinned staging for {ctl} so that one synchronisation ends it
+  hipEvent_t e0 = lease.c->ev_a, e1 = lease.c->ev_b;
+  HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
+#define CALL(W, L)                                                                                                    \
+  k_match_ref_wave<W, L><<<(int)grid, (int)(wpw * 64), lds, st>>>(h->dev, rt, (uint32_t)k, d_slab, heap_cap, max_branching, \
+                                                            max_iterations, d_res, (uint64_t)cap, d_left, d_ctl, h->d_counters)
+  FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError(), "k_match_ref_wave");
+  HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
+  RefCtl2 ctl{};
+  HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
+  HIP_TRY(hipStreamSynchronize(st), "sync(k_match_ref_wave)");
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->last_kernel_ms = ms;
+    h->launches += 1;
+  }
+  if (ctl.overflow & 1ull) { set_error("reference-order heap overflow (internal bound)"); return FMX_ERR_OVERFLOW; }
+  *n_out = (size_t)ctl.res_count;
+  if (ctl.res_count > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
+  if (front_left) HIP_TRY(hipMemcpyAsync(front_left, d_left, k * 4, hipMemcpyDeviceToHost, st), "D2H(front_left)");
+  std::vector<RefResult> tmp((size_t)ctl.res_count);
+  if (ctl.res_count) HIP_TRY(hipMemcpyAsync(tmp.data(), d_res, tmp.size() * sizeof(RefResult), hipMemcpyDeviceToHost, st), "D2H(results)");
+  if (front_left || ctl.res_count) HIP_TRY(hipStreamSynchronize(st), "sync(results)");
+  deliver_results(tmp, out, per_regex_count);
+  return FMX_OK;
+}
 
 int regex_match_reference(const Index *h, const RefTables &rt, size_t k, uint32_t max_fanout, uint32_t max_branching,
                           uint32_t max_iterations, fmx_result *out, size_t cap, size_t *n_out,
@@ -182,6 +438,12 @@ int regex_match_reference(const Index *h, const RefTables &rt, size_t k, uint32_
   if (heap_cap64 > (1u << 22)) { set_error("max_branching too large for the reference-order mode"); return FMX_ERR_ARG; }
   const uint32_t heap_cap = (uint32_t)heap_cap64;
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
+  // The wave-per-regex kernel when a regex's heap fits LDS (FMX_REFMATCH=group keeps the kernel above)
+  const char *which = getenv("FMX_REFMATCH");
+  const bool force_group = which && std::strcmp(which, "group") == 0;
+  const size_t wave_bytes = ((size_t)heap_cap * 5 + 15) & ~(size_t)15;
+  if (!force_group && heap_cap <= 0xFFFFu && rt.max_num <= 0xFFFFu && rt.fol_rec && kWaveCf + wave_bytes <= (64u << 10))
+    return match_reference_wave(h, rt, k, heap_cap, max_branching, max_iterations, out, cap, n_out, per_regex_count, front_left);
   const uint64_t per_wg = kRThreads / (h->layout == kLayoutBytes ? Lay<kLayoutBytes>::G : Lay<kLayoutOneHot>::G);   // regexes per workgroup
   uint64_t want = (k + per_wg - 1) / per_wg;
   uint64_t gcap = (uint64_t)h->cu_count * 8;
@@ -237,15 +499,7 @@ int regex_match_reference(const Index *h, const RefTables &rt, size_t k, uint32_
     std::vector<RefResult> tmp((size_t)ctl.res_count);
     HIP_TRY(hipMemcpyAsync(tmp.data(), d_res, tmp.size() * sizeof(RefResult), hipMemcpyDeviceToHost, st), "D2H(results)");
     HIP_TRY(hipStreamSynchronize(st), "sync(results)");
-    // per regex, newest first: the order of the reference's prepended list (:638)
-    std::sort(tmp.begin(), tmp.end(), [](const RefResult &a, const RefResult &b) {
-      if (a.regex != b.regex) return a.regex < b.regex;
-      return a.seq > b.seq;
-    });
-    for (size_t j = 0; j < tmp.size(); j++) {
-      out[j].regex = tmp[j].regex; out[j].len = tmp[j].len; out[j].sp = tmp[j].sp; out[j].ep = tmp[j].ep;
-      if (per_regex_count) per_regex_count[tmp[j].regex]++;
-    }
+    deliver_results(tmp, out, per_regex_count);
   }
   return FMX_OK;
 }

@@ -8,6 +8,9 @@
 #include <fmx.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
 
 namespace fmx {
 namespace {
@@ -26,6 +29,7 @@ std::vector<PostPoint> re2post(const std::string &s, bool line_only) {
   const int l = (int)s.size();
   int natom = 0, nalt = 0;
   std::vector<PostPoint> dst;          // appended in emission order (the Scala code prepends, then reverses)
+  dst.reserve(2 * (size_t)l + 2);
   std::vector<Paren> stack;
   auto emit = [&](PostPoint::Kind k) { PostPoint p; p.kind = k; dst.push_back(p); };
   auto concat_if = [&]() {
@@ -173,12 +177,72 @@ namespace {
 enum NodeKind { N_CHAR, N_STAR, N_QUESTION, N_PLUS, N_OR, N_FOLLOW };
 constexpr int ROOT = -1;
 
+// The lists of the tree code -- childs, firsts, follows -- hold a handful of node ids and are built by prepending;
+// a regex compile made ~300 of them, each a heap allocation (12 us per regex, most of it malloc/free).  IVec keeps up
+// to 12 ids in place and only longer lists (a '.' has 253 children) on the heap.
+class IVec {
+ public:
+  IVec() = default;
+  IVec(const int *b, const int *e) { assign(b, e); }
+  IVec(const IVec &o) { assign(o.begin(), o.end()); }
+  IVec(IVec &&o) noexcept { steal(o); }
+  IVec &operator=(const IVec &o) { if (this != &o) assign(o.begin(), o.end()); return *this; }
+  IVec &operator=(IVec &&o) noexcept { if (this != &o) { release(); steal(o); } return *this; }
+  ~IVec() { release(); }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  int *begin() { return p_; }
+  int *end() { return p_ + n_; }
+  const int *begin() const { return p_; }
+  const int *end() const { return p_ + n_; }
+  int front() const { return p_[0]; }
+  int operator[](size_t i) const { return p_[i]; }
+  void push_back(int v) { grow(n_ + 1); p_[n_++] = v; }
+  void push_front(int v) { grow(n_ + 1); std::memmove(p_ + 1, p_, n_ * sizeof(int)); p_[0] = v; n_++; }
+  void append(const IVec &o) { const size_t m = o.n_; grow(n_ + m); std::memmove(p_ + n_, o.p_, m * sizeof(int)); n_ += m; }   // o may be *this
+  void prepend(const IVec &o) {             // o ++ this
+    const size_t m = o.n_;
+    if (&o == this) { append(o); return; }
+    grow(n_ + m);
+    std::memmove(p_ + m, p_, n_ * sizeof(int));
+    std::memcpy(p_, o.p_, m * sizeof(int));
+    n_ += m;
+  }
+  void drop_front(size_t k) { std::memmove(p_, p_ + k, (n_ - k) * sizeof(int)); n_ -= k; }
+  void swap(IVec &o) { IVec t(std::move(o)); o = std::move(*this); *this = std::move(t); }
+
+ private:
+  static constexpr size_t kInline = 12;
+  void assign(const int *b, const int *e) { n_ = 0; grow((size_t)(e - b)); std::memmove(p_, b, (size_t)(e - b) * sizeof(int)); n_ = (size_t)(e - b); }
+  void grow(size_t want) {
+    if (want <= cap_) return;
+    size_t c = cap_ * 2;
+    if (c < want) c = want;
+    int *q = static_cast<int *>(std::malloc(c * sizeof(int)));
+    if (!q) throw std::bad_alloc();
+    std::memcpy(q, p_, n_ * sizeof(int));
+    if (p_ != in_) std::free(p_);
+    p_ = q;
+    cap_ = c;
+  }
+  void release() { if (p_ != in_) std::free(p_); p_ = in_; cap_ = kInline; n_ = 0; }
+  void steal(IVec &o) {
+    n_ = o.n_;
+    if (o.p_ == o.in_) { p_ = in_; cap_ = kInline; std::memcpy(in_, o.in_, o.n_ * sizeof(int)); }
+    else { p_ = o.p_; cap_ = o.cap_; o.p_ = o.in_; o.cap_ = kInline; }
+    o.n_ = 0;
+  }
+  int in_[kInline];
+  int *p_ = in_;
+  size_t n_ = 0, cap_ = kInline;
+};
+
 struct Node {
   NodeKind kind;
   int c = 0;
   int num = 0;
   int parent = ROOT;
-  std::vector<int> childs;    // head first
+  IVec childs;    // head first
 };
 
 struct Tree {
@@ -198,12 +262,10 @@ struct Tree {
     Node &s = a[self];
     if (s.kind == N_OR && a[n].kind == N_OR) {
       for (int ch : a[n].childs) a[ch].parent = self;
-      std::vector<int> merged = a[n].childs;
-      merged.insert(merged.end(), s.childs.begin(), s.childs.end());
-      s.childs.swap(merged);
+      s.childs.prepend(a[n].childs);
     } else {
       a[n].parent = self;
-      s.childs.insert(s.childs.begin(), n);
+      s.childs.push_front(n);
     }
   }
 
@@ -222,51 +284,40 @@ struct Tree {
     return false;
   }
 
-  std::vector<int> firsts(int x) const {
+  IVec firsts(int x) const {
     const Node &n = a[x];
-    std::vector<int> ret;
+    IVec ret;
     if (n.kind == N_CHAR) { ret.push_back(x); return ret; }
     if (n.kind == N_FOLLOW) {                              // :117-127
       size_t p = 0;
-      auto prepend = [&](int ch) {
-        std::vector<int> f = firsts(ch);
-        f.insert(f.end(), ret.begin(), ret.end());
-        ret.swap(f);
-      };
+      auto prepend = [&](int ch) { ret.prepend(firsts(ch)); };
       while (p < n.childs.size() && is_null(n.childs[p])) { prepend(n.childs[p]); p++; }
       if (p < n.childs.size()) prepend(n.childs[p]);
       return ret;
     }
-    for (int ch : n.childs) {                              // flatMap, :78,97
-      std::vector<int> f = firsts(ch);
-      ret.insert(ret.end(), f.begin(), f.end());
-    }
+    for (int ch : n.childs) ret.append(firsts(ch));        // flatMap, :78,97
     return ret;
   }
 
-  std::vector<int> siblings_after(int parent, int me) const {   // childs.dropWhile(_ != this).tail
-    const std::vector<int> &ch = a[parent].childs;
+  IVec siblings_after(int parent, int me) const {   // childs.dropWhile(_ != this).tail
+    const IVec &ch = a[parent].childs;
     size_t k = 0;
     while (k < ch.size() && ch[k] != me) k++;
     if (k >= ch.size()) return {};
-    return std::vector<int>(ch.begin() + k + 1, ch.end());
+    return IVec(ch.begin() + k + 1, ch.end());
   }
 
-  std::vector<int> follows(int x) const {                  // :14-38
+  IVec follows(int x) const {                  // :14-38
     const int p = a[x].parent;
     if (p == ROOT) return {};
     const Node &pn = a[p];
     switch (pn.kind) {
       case N_OR: return follows(p);
       case N_FOLLOW: {
-        std::vector<int> last = siblings_after(p, x);
+        const IVec last = siblings_after(p, x);
         if (last.empty()) return follows(p);
-        std::vector<int> ret = firsts(last[0]);
-        auto prepend = [&](int ch) {
-          std::vector<int> f = firsts(ch);
-          f.insert(f.end(), ret.begin(), ret.end());
-          ret.swap(f);
-        };
+        IVec ret = firsts(last[0]);
+        auto prepend = [&](int ch) { ret.prepend(firsts(ch)); };
         if (is_null(last[0])) {
           size_t k = 1;
           while (k < last.size() && is_null(last[k])) { prepend(last[k]); k++; }
@@ -275,9 +326,8 @@ struct Tree {
         return ret;
       }
       case N_STAR: {
-        std::vector<int> ret = firsts(x);
-        std::vector<int> pf = follows(p);
-        ret.insert(ret.end(), pf.begin(), pf.end());
+        IVec ret = firsts(x);
+        ret.append(follows(p));
         return ret;
       }
       case N_QUESTION: return follows(p);
@@ -291,7 +341,7 @@ struct Tree {
     const Node &pn = a[p];
     if (pn.kind == N_OR || unar(pn.kind)) return is_last(p);
     if (pn.kind == N_FOLLOW) {
-      std::vector<int> last = siblings_after(p, x);
+      const IVec last = siblings_after(p, x);
       bool all_null = true;
       for (int s : last) if (!is_null(s)) { all_null = false; break; }
       return (last.empty() || all_null) ? is_last(p) : false;
@@ -352,19 +402,19 @@ int post_process(Tree &t, int r) {
   if (k == N_CHAR) return t.make(N_CHAR, t.a[r].c);
   if (k == N_PLUS) match_error("postProcess: PlusNode has no case");
   const int nc = t.make(k);
-  const std::vector<int> old = t.a[r].childs;
+  const IVec old = t.a[r].childs;
   for (int ch : old) {
     if (t.a[ch].kind == N_PLUS) {
       const int inner = t.a[ch].childs.front();
       const int a1 = post_process(t, inner);
       const int a2 = t.make(N_STAR);
       t.append(a2, post_process(t, inner));
-      std::vector<int> &c = t.a[nc].childs;              // a1 :: a2 :: newL
-      c.insert(c.begin(), a2);
-      c.insert(c.begin(), a1);
+      IVec &c = t.a[nc].childs;                          // a1 :: a2 :: newL
+      c.push_front(a2);
+      c.push_front(a1);
     } else {
       const int pc = post_process(t, ch);
-      t.a[nc].childs.insert(t.a[nc].childs.begin(), pc);
+      t.a[nc].childs.push_front(pc);
     }
   }
   return nc;
@@ -372,14 +422,14 @@ int post_process(Tree &t, int r) {
 
 int remove_border_nulls(Tree &t, int a1) {                 // :371-385
   const int n = t.make(N_FOLLOW);
-  std::vector<int> p = t.a[a1].childs;
+  IVec p = t.a[a1].childs;
   size_t b = 0;
   while (b < p.size() && t.is_null(p[b])) b++;
-  p.erase(p.begin(), p.begin() + b);
+  p.drop_front(b);
   std::reverse(p.begin(), p.end());
   b = 0;
   while (b < p.size() && t.is_null(p[b])) b++;
-  p.erase(p.begin(), p.begin() + b);
+  p.drop_front(b);
   for (int x : p) t.append(n, x);
   return n;
 }
@@ -427,8 +477,11 @@ void collect_chars(const Tree &t, int r, std::vector<int> &out) {
 // ReTree.apply, retree.scala:156-370, then the flattening the kernels use.
 Regex compile_regex(const std::string &re, bool line_only) {
   const std::vector<PostPoint> post = re2post(re, line_only);
-  Tree t;
-  std::vector<int> args;                                   // mutable.Stack, top = back
+  // the node arena and the operand stack keep their capacity from one compile of this thread to the next
+  static thread_local Tree t;
+  static thread_local std::vector<int> args;               // mutable.Stack, top = back
+  t.a.clear();
+  args.clear();
   for (const PostPoint &c : post) {
     switch (c.kind) {
       case PostPoint::Interval: {                          // :165-173, end exclusive
@@ -498,12 +551,18 @@ Regex compile_regex(const std::string &re, bool line_only) {
   set_parents(t, a3, ROOT);
   set_nums_scope(t, a3, 1);
 
-  std::vector<int> chars;
+  static thread_local std::vector<int> chars, index_of;
+  chars.clear();
   collect_chars(t, a3, chars);
-  std::vector<int> index_of(t.a.size(), -1);
+  index_of.assign(t.a.size(), -1);
   for (size_t k = 0; k < chars.size(); k++) index_of[chars[k]] = (int)k;
   Regex out;
   out.source = re;
+  out.st_c.reserve(chars.size());
+  out.st_num.reserve(chars.size());
+  out.st_last.reserve(chars.size());
+  out.fol_off.reserve(chars.size() + 1);
+  out.fol.reserve(2 * chars.size());
   out.fol_off.push_back(0);
   for (int x : chars) {
     if (t.a[x].c < 0 || t.a[x].c > 255) throw RegexError{FMX_ERR_SYNTAX, "character outside 0..255"};

@@ -204,6 +204,12 @@ class ReTree:
         return ReTree.matchSA_batch(sa, [self], max_steps=max_steps, max_frontier=max_frontier, cap=cap)[0]
 
     @staticmethod
+    def compile_batch(res, lineOnly=False):
+        """ReTree(REParser.re2post(re, lineOnly)) for every string of `res` in one library call on all host
+        cores (fmx_regex_compile_batch) -> CompiledRegexes."""
+        return CompiledRegexes(res, lineOnly)
+
+    @staticmethod
     def prepare_batch(sa, trees):
         """Make a batch of compiled regexes resident on sa's device (fmx_regex_batch_create)."""
         return RegexBatch(sa, trees)
@@ -215,8 +221,7 @@ class ReTree:
         every match; mode="reference": ReTree._matchSA's queue replayed per regex with
         maxBranching / maxIterations."""
         L = _lib.load()
-        k = len(trees)
-        arr = (ctypes.c_void_p * max(k, 1))(*[t._h for t in trees])
+        arr, k, _keep = _handle_array(trees)
         lim = _lib.fmx_limits(int(max_steps), _lib.FMX_MATCH_REFERENCE if mode == "reference" else _lib.FMX_MATCH_FRONTIER,
                               int(max_frontier), int(maxBranching), int(maxIterations))
         out = (_lib.fmx_result * cap)()
@@ -235,6 +240,98 @@ class ReTree:
 RESULT_DTYPE = np.dtype([("regex", np.uint32), ("len", np.uint32), ("sp", np.uint64), ("ep", np.uint64)])
 
 
+class _TreeView:
+    """One regex of a CompiledRegexes set, with ReTree's read-only surface (tables())."""
+
+    def __init__(self, owner, h):
+        self._owner, self._h, self._L = owner, h, owner._L      # the owner keeps the handle alive
+
+    tables = ReTree.tables
+
+
+class CompiledRegexes:
+    """fmx_regex_compile_batch: REParser.re2post + ReTree(...) for a list of regex strings in ONE library call,
+    compiled on all the host cores the process may use -- no Python object and no ctypes call per regex.
+    `status[i]` is 0 or the code ReTree(REParser.re2post(res[i])) would raise with (7 = Re2PostSyntax,
+    8 = MatchError); regexes that failed have no handle.  `select(idx)` gives a view of some of them (what a
+    workload generator keeps); RegexBatch / RegexBatchMulti / matchSA_batch take either form."""
+
+    def __init__(self, res, lineOnly=False, _view=None):
+        self._L = _lib.load()
+        if _view is not None:
+            self._owner, self.handles, self.status, self.k = _view
+            return
+        self._owner = None
+        self.k = len(res)
+        # the k C strings as ONE buffer and an array of pointers into it, made with array operations (a ctypes
+        # c_char_p per regex costs more than compiling it)
+        if all(isinstance(r, str) for r in res):
+            blob = ("\0".join(res) + "\0").encode("latin-1")
+            lens = np.fromiter(map(len, res), dtype=np.int64, count=self.k)
+        else:
+            raw = [r.encode("latin-1") if isinstance(r, str) else bytes(r) for r in res]
+            blob = b"\0".join(raw) + b"\0"
+            lens = np.fromiter(map(len, raw), dtype=np.int64, count=self.k)
+        if blob.count(b"\0") != self.k + (0 if self.k else 1):
+            raise ValueError("a regex holds a NUL character")
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        ptrs = np.zeros(max(self.k, 1), dtype=np.uint64)
+        if self.k:
+            ptrs[0] = 0
+            np.cumsum(lens[:-1] + 1, out=ptrs[1:self.k].view(np.int64))
+            ptrs[: self.k] += np.uint64(ctypes.addressof(buf))
+        self.handles = (ctypes.c_void_p * max(self.k, 1))()
+        self.status = np.zeros(max(self.k, 1), dtype=np.int32)
+        _lib.check(self._L.fmx_regex_compile_batch(ptrs.ctypes.data_as(ctypes.c_void_p), self.k, 1 if lineOnly else 0,
+                                                   self.handles, self.status.ctypes.data_as(ctypes.c_void_p)))
+        self.status = self.status[: self.k]
+
+    def __len__(self):
+        return self.k
+
+    def ok(self):
+        """Boolean mask of the regexes that compiled."""
+        return self.status == 0
+
+    def select(self, idx):
+        """A view holding the handles res[idx] (all must have compiled); the parent owns them."""
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size and (self.status[idx] != 0).any():
+            raise ValueError("select: some of the chosen regexes did not compile")
+        h = (ctypes.c_void_p * max(idx.size, 1))(*[self.handles[int(i)] for i in idx])
+        return CompiledRegexes(None, _view=(self._owner or self, h, np.zeros(idx.size, dtype=np.int32), int(idx.size)))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.select(np.arange(self.k)[i])
+        if self.status[i] != 0:
+            raise (Re2PostSyntaxOrMatch(int(self.status[i])))
+        return _TreeView(self._owner or self, ctypes.c_void_p(self.handles[i]))
+
+    def __del__(self):
+        try:
+            if self._owner is None and self.k:
+                self._L.fmx_regex_free_batch(self.handles, self.k)
+                self.k = 0
+        except Exception:
+            pass
+
+
+def Re2PostSyntaxOrMatch(code):
+    return (_lib.Re2PostSyntax if code == 7 else _lib.MatchError if code == 8 else _lib.FmxError)(code, "regex did not compile")
+
+
+def _handle_array(trees):
+    """(ctypes array of fmx_regex handles, k, object to keep alive) for a list of ReTree / NFA / DFA objects or a
+    CompiledRegexes set."""
+    if isinstance(trees, CompiledRegexes):
+        if (trees.status != 0).any():
+            raise ValueError("the set holds regexes that did not compile: select() the good ones")
+        return trees.handles, trees.k, trees
+    k = len(trees)
+    return (ctypes.c_void_p * max(k, 1))(*[t._h for t in trees]), k, list(trees)
+
+
 class RegexBatch:
     """A regex batch resident on the device: build once, match many times (serving shape of
     ReTree.matchSA over many regexes)."""
@@ -242,9 +339,7 @@ class RegexBatch:
     def __init__(self, sa, trees):
         self._L = _lib.load()
         self.sa = sa
-        self.k = len(trees)
-        self._trees = list(trees)            # keep the handles alive
-        arr = (ctypes.c_void_p * max(self.k, 1))(*[t._h for t in trees])
+        arr, self.k, self._trees = _handle_array(trees)      # keeps the handles alive
         self._h = ctypes.c_void_p()
         _lib.check(self._L.fmx_regex_batch_create(sa.handle, arr, self.k, ctypes.byref(self._h)))
 
@@ -255,6 +350,12 @@ class RegexBatch:
                 self._h = None
         except Exception:
             pass
+
+    def info(self):
+        """fmx_regex_batch_info: {"regexes", "states", "follows", "firsts"} of the resident batch."""
+        v = [ctypes.c_uint64() for _ in range(4)]
+        _lib.check(self._L.fmx_regex_batch_info(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("regexes", "states", "follows", "firsts"), (int(x.value) for x in v)))
 
     def match_raw(self, max_steps=0, max_frontier=0, cap=1 << 22, mode="frontier", maxBranching=1024, maxIterations=1000,
                   copy=True):
@@ -301,10 +402,8 @@ class RegexBatchMulti:
     def __init__(self, searchers, trees):
         self._L = _lib.load()
         self.searchers = list(searchers)
-        self.k = len(trees)
-        self._trees = list(trees)
+        arr, self.k, self._trees = _handle_array(trees)
         idxs = (ctypes.c_void_p * len(self.searchers))(*[s.handle for s in self.searchers])
-        arr = (ctypes.c_void_p * max(self.k, 1))(*[t._h for t in trees])
         self._h = ctypes.c_void_p()
         _lib.check(self._L.fmx_regex_batch_create_multi(idxs, len(self.searchers), arr, self.k, ctypes.byref(self._h)))
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 2
+#define FMX_ABI_VERSION 3
 
 enum {
   FMX_OK = 0,
@@ -68,7 +68,9 @@ int fmx_abi_version(void);
  * point then checks on the device that d_off is non-decreasing and fails with FMX_ERR_ARG otherwise (one more small
  * kernel and a synchronisation per call: a debugging aid; the host-pointer form always checks).  key "checkpoints": "auto" (default: the bytes layout keeps absolute
  * 32-bit checkpoints whenever every symbol occurs fewer than 2^32 times) or "superblock" (always the relative
- * checkpoints + 64-bit superblock counts that larger counts need; for tests).  Affects indexes opened afterwards. */
+ * checkpoints + 64-bit superblock counts that larger counts need; for tests).  Affects indexes opened afterwards.
+ * key "threads": host threads the library's own parallel parts use (fmx_regex_compile_batch, making a regex batch
+ * resident); "0" = detect (default). */
 int fmx_config_set(const char *key, const char *value);
 /* Page-locked host memory for batch buffers (hipHostMalloc): the host-pointer entry points move such buffers
  * by DMA at link speed; pageable memory works everywhere too, through the runtime's staging copies.  A JNI adapter
@@ -196,6 +198,15 @@ int fmx_write_fm(const fmx_index *idx, const char *path);
  * "re2post syntax" exception and scala.MatchError. */
 int fmx_regex_compile(const char *re, int line_only, fmx_regex **out);
 int fmx_regex_free(fmx_regex *re);
+/* The same for k regexes at once, compiled on all the host cores the process may use (its affinity mask capped by the
+ * cgroup CPU quota; fmx_config_set("threads", "N") overrides): out[i] = the handle of res[i] or NULL, status[i]
+ * (optional) = FMX_OK / FMX_ERR_SYNTAX / FMX_ERR_MATCH exactly as fmx_regex_compile(res[i]) returns.  The call itself
+ * returns FMX_OK when it ran (whatever the regexes' own statuses; fmx_last_error() then describes the first one that
+ * failed), FMX_ERR_ARG / FMX_ERR_NOMEM otherwise.  The reference compiles one regex per REParser.re2post + ReTree
+ * call (re2/re2.scala:50-185, re2/retree.scala:156-423); a batch of 100 k is what config C4 hands over at once.
+ * fmx_regex_free_batch frees k handles (NULL entries allowed). */
+int fmx_regex_compile_batch(const char *const *res, size_t k, int line_only, fmx_regex **out, int *status);
+int fmx_regex_free_batch(fmx_regex *const *res, size_t k);
 /* Flat Glushkov tables (what ReTree._matchSA touches): per CharNode its byte, `num`
  * (retree.scala:393-423), isLast (:40-50), and `follows` (:14-38) as a CSR list that keeps the
  * reference's order and multiplicity; `firsts` = root.firsts.  Any output pointer may be NULL;
@@ -281,6 +292,9 @@ int fmx_regex_match_batch(const fmx_index *idx, fmx_regex *const *res, size_t k,
  * (FMX_MATCH_REFERENCE needs a batch of fmx_regex_compile handles only).  One match at a time per batch. */
 int fmx_regex_batch_create(const fmx_index *idx, fmx_regex *const *res, size_t k, fmx_regex_batch **out);
 int fmx_regex_batch_free(fmx_regex_batch *batch);
+/* Sizes of a resident batch: regexes, CharNode states, follow entries, start elements (any pointer may be NULL). */
+int fmx_regex_batch_info(const fmx_regex_batch *batch, uint64_t *n_regexes, uint64_t *n_states, uint64_t *n_follows,
+                         uint64_t *n_firsts);
 int fmx_regex_batch_match(const fmx_index *idx, fmx_regex_batch *batch, const fmx_limits *lim, fmx_result *out,
                           size_t cap, size_t *n_out, uint32_t *per_regex_count);
 /* The same with the results left in HBM (frontier mode): d_out = device memory for cap fmx_result records,

@@ -94,6 +94,8 @@ def lib():
     L.orc_match_sa_batch.restype = i64
     L.orc_match_sa_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32,
                                      vp, vp, vp, vp, i64, P(i64), P(i64)]
+    L.orc_match_sa_batch_ordered.restype = i64
+    L.orc_match_sa_batch_ordered.argtypes = L.orc_match_sa_batch.argtypes
     _lib = L
     return L
 
@@ -335,10 +337,12 @@ class NaiveFMSearcher:
         return [(int(rl[j]), int(rs[j]), int(re_[j])) for j in range(k)], left.value, pops.value
 
 
-    def match_tables_batch(self, tables, maxBranching=1 << 40, maxIterations=0, max_len=0, threads=1):
+    def match_tables_batch(self, tables, maxBranching=1 << 40, maxIterations=0, max_len=0, threads=1, ordered=False):
         """C _matchSA over a list of ReTree.tables() dicts on `threads` cores; max_len > 0 caps the match
         length like the product's max_steps.  Returns (structured array of (regex, len, sp, ep) grouped by regex
-        and sorted by (len, sp, ep) inside a group, getPrevRange calls made, regexes cut at max_len)."""
+        and sorted by (len, sp, ep) inside a group -- ordered=True: in the reference's own list order, newest
+        first, what ReTree.matchSA returns when its limits bind --, getPrevRange calls made, regexes cut at
+        max_len)."""
         k = len(tables)
         st_off = np.zeros(k + 1, dtype=np.int64)
         fol_base = np.zeros(k + 1, dtype=np.int64)
@@ -371,7 +375,8 @@ class NaiveFMSearcher:
             out_sp = np.zeros(cap, dtype=np.uint64)
             out_ep = np.zeros(cap, dtype=np.uint64)
             pops, trunc = ctypes.c_int64(), ctypes.c_int64()
-            got = self._L.orc_match_sa_batch(self._h, k, _ptr(st_off), _ptr(st_c), _ptr(st_num), _ptr(st_last),
+            fn = self._L.orc_match_sa_batch_ordered if ordered else self._L.orc_match_sa_batch
+            got = fn(self._h, k, _ptr(st_off), _ptr(st_c), _ptr(st_num), _ptr(st_last),
                                              _ptr(fol_off), _ptr(fol_base), _ptr(fol), _ptr(first_off), _ptr(firsts),
                                              int(maxBranching), int(maxIterations), int(max_len), int(threads),
                                              _ptr(res_start), _ptr(out_len), _ptr(out_sp), _ptr(out_ep), cap,

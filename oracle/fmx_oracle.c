@@ -575,12 +575,12 @@ static int res_cmp(const void *a, const void *b) {
   if (x->ep != y->ep) return x->ep < y->ep ? -1 : 1;
   return 0;
 }
-int64_t orc_match_sa_batch(const orc_index *ix, int64_t k, const int64_t *st_off, const uint8_t *st_c,
+static int64_t match_sa_batch_impl(const orc_index *ix, int64_t k, const int64_t *st_off, const uint8_t *st_c,
                            const int32_t *st_num, const uint8_t *st_last, const int32_t *fol_off,
                            const int64_t *fol_base, const int32_t *fol, const int64_t *first_off,
                            const int32_t *firsts, int64_t max_branching, int64_t max_iterations, int64_t max_len,
                            int threads, int64_t *res_start, int64_t *out_len, uint64_t *out_sp, uint64_t *out_ep,
-                           int64_t cap, int64_t *pops_total, int64_t *n_truncated) {
+                           int64_t cap, int64_t *pops_total, int64_t *n_truncated, int sorted) {
   orc_res **per = (orc_res **)calloc((size_t)(k ? k : 1), sizeof(orc_res *));
   int64_t *cnt = (int64_t *)calloc((size_t)(k ? k : 1), sizeof(int64_t));
   if (!per || !cnt) { free(per); free(cnt); return ORC_ERR_NOMEM; }
@@ -616,7 +616,7 @@ int64_t orc_match_sa_batch(const orc_index *ix, int64_t k, const int64_t *st_off
       if (!per[r]) { bad++; cnt[r] = 0; }
       else {
         for (int64_t j = 0; j < got; j++) { per[r][j].len = rl[j]; per[r][j].sp = rs[j]; per[r][j].ep = re[j]; }
-        qsort(per[r], (size_t)got, sizeof(orc_res), res_cmp);
+        if (sorted) qsort(per[r], (size_t)got, sizeof(orc_res), res_cmp);
       }
     }
     free(rl); free(rs); free(re);
@@ -636,4 +636,29 @@ int64_t orc_match_sa_batch(const orc_index *ix, int64_t k, const int64_t *st_off
   if (pops_total) *pops_total = pops_sum;
   if (n_truncated) *n_truncated = trunc_sum;
   return bad ? ORC_ERR_NOMEM : total;
+}
+
+/* per regex sorted by (len, sp, ep): the form results are compared in while the limits do not bind */
+int64_t orc_match_sa_batch(const orc_index *ix, int64_t k, const int64_t *st_off, const uint8_t *st_c,
+                           const int32_t *st_num, const uint8_t *st_last, const int32_t *fol_off,
+                           const int64_t *fol_base, const int32_t *fol, const int64_t *first_off,
+                           const int32_t *firsts, int64_t max_branching, int64_t max_iterations, int64_t max_len,
+                           int threads, int64_t *res_start, int64_t *out_len, uint64_t *out_sp, uint64_t *out_ep,
+                           int64_t cap, int64_t *pops_total, int64_t *n_truncated) {
+  return match_sa_batch_impl(ix, k, st_off, st_c, st_num, st_last, fol_off, fol_base, fol, first_off, firsts, max_branching,
+                             max_iterations, max_len, threads, res_start, out_len, out_sp, out_ep, cap, pops_total,
+                             n_truncated, 1);
+}
+
+/* per regex in the reference's own list order (`ret ::= ...`, newest first, retree.scala:638): what
+ * ReTree.matchSA returns under binding limits */
+int64_t orc_match_sa_batch_ordered(const orc_index *ix, int64_t k, const int64_t *st_off, const uint8_t *st_c,
+                           const int32_t *st_num, const uint8_t *st_last, const int32_t *fol_off,
+                           const int64_t *fol_base, const int32_t *fol, const int64_t *first_off,
+                           const int32_t *firsts, int64_t max_branching, int64_t max_iterations, int64_t max_len,
+                           int threads, int64_t *res_start, int64_t *out_len, uint64_t *out_sp, uint64_t *out_ep,
+                           int64_t cap, int64_t *pops_total, int64_t *n_truncated) {
+  return match_sa_batch_impl(ix, k, st_off, st_c, st_num, st_last, fol_off, fol_base, fol, first_off, firsts, max_branching,
+                             max_iterations, max_len, threads, res_start, out_len, out_sp, out_ep, cap, pops_total,
+                             n_truncated, 0);
 }

@@ -654,18 +654,27 @@ REF_REGEXES = ["th(e|a)", "q[a-z]*k", "co(m|n)+e", "a.*(b|c)d.*f", "s[aeiou]+t",
                "a.*(b|c)da.*f"]        # the regex the reference's WordsDB suite runs on words (T/REParser.scala:630)
 
 
+@pytest.mark.parametrize("kernel", ["wave", "group"])
 @pytest.mark.parametrize("name,be", [("test.cmp", False), ("words", True)])
-def test_regex_reference_order_and_limits(testdata, name, be):
+def test_regex_reference_order_and_limits(testdata, name, be, kernel, monkeypatch):
     """ReTree.matchSA as the reference runs it: default limits 1024 / 1000 (which bind for '.*'
     regexes) and tighter ones; results must equal the oracle's replay of _matchSA -- same
-    elements, same (newest-first) order."""
+    elements, same (newest-first) order, same number of getPrevRange calls.  Both kernels: one regex per wave
+    with the heap in LDS and the steps made at push time (limits that fit LDS: all here but 2^14), and one
+    regex per lane group with the heap in device memory (FMX_REFMATCH=group forces it)."""
+    monkeypatch.setenv("FMX_REFMATCH", kernel)
     hip, orc = pair_from_files(testdata, name, be)
     trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re, lineOnly=True)) for re in REF_REGEXES]
-    for mb, mi in ((1024, 1000), (16, 50), (4, 0), (1 << 14, 3000), (1024, 2)):
+    for mb, mi in ((1024, 1000), (16, 50), (4, 0), (1 << 14, 3000), (1024, 2), (1, 0), (300, 1 << 20)):
+        hip.stats_reset()
         got = findex_amd.ReTree.matchSA_batch(hip, trees, mode="reference", maxBranching=mb, maxIterations=mi)
+        total_pops = 0
         for re, g in zip(REF_REGEXES, got):
             want, left, pops = orc.match_tables(R.ReTree(R.re2post(re, True)).tables(), mb, mi)
+            total_pops += pops
             assert [r.key() for r in g] == want, (re, mb, mi)
+        st = hip.stats()
+        assert st["backward_steps"] == total_pops and st["rank_queries"] == 2 * total_pops, (mb, mi)
     # the same through a resident batch (fmx_regex_batch_match in reference mode): one flat, per-regex-ordered list
     batch = findex_amd.ReTree.prepare_batch(hip, trees)
     flat, per = batch.match_raw(mode="reference", maxBranching=1024, maxIterations=1000)
@@ -677,6 +686,47 @@ def test_regex_reference_order_and_limits(testdata, name, be):
     one = trees[3].matchSA(hip)
     want, _, _ = orc.match_tables(R.ReTree(R.re2post(REF_REGEXES[3], True)).tables(), 1024, 1000)
     assert [r.key() for r in one] == want
+
+
+@pytest.mark.parametrize("layout", ["onehot", "bytes"])
+def test_regex_reference_mode_c4_shape(layout):
+    """BASELINE C4's regex grammar under the reference's default limits (1024 / 1000) on a C4-like synthetic index
+    (sigma = 28, i.i.d.): 3000 regexes, every regex's result LIST equal to the oracle's replay of _matchSA
+    (re2/retree.scala:618-653) in the reference's own order, pops counted; a handful of them use all 999
+    iterations.  What `bench.py --workload c4ref` checks on its sample, here in both layouts."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import regex_workload
+    n = (1 << 22) + 77
+    rng = np.random.default_rng(44)
+    alpha = np.frombuffer(regex_workload.ALPHABET.encode(), dtype=np.uint8)
+    bwt = alpha[rng.integers(0, alpha.size, n)]
+    eof = n // 3
+    counts = oracle.histogram(bwt, eof, threads=4)
+    findex_amd.set_layout(layout)
+    try:
+        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    finally:
+        findex_amd.set_layout("auto")
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts, threads=4)
+    import random
+    prng = random.Random(4004)
+    cand = [regex_workload.gen_one(prng) for _ in range(3300)]
+    cs = findex_amd.ReTree.compile_batch(cand)
+    trees = cs.select(np.nonzero(cs.ok())[0][:3000])
+    batch = findex_amd.ReTree.prepare_batch(hip, trees)
+    hip.stats_reset()
+    got, per = batch.match_raw(mode="reference", maxBranching=1024, maxIterations=1000)
+    tables = [trees[i].tables() for i in range(len(trees))]
+    want, pops, _ = orc.match_tables_batch(tables, maxBranching=1024, maxIterations=1000, threads=4, ordered=True)
+    assert got.size == want.size and all(np.array_equal(got[f], want[f]) for f in ("regex", "len", "sp", "ep"))
+    assert np.array_equal(per, np.bincount(want["regex"], minlength=len(trees)).astype(np.uint32))
+    assert hip.stats()["backward_steps"] == pops
+    # tighter limits bind for many more of them
+    got2, _ = batch.match_raw(mode="reference", maxBranching=12, maxIterations=60)
+    want2, _, _ = orc.match_tables_batch(tables, maxBranching=12, maxIterations=60, threads=4, ordered=True)
+    assert got2.size == want2.size and all(np.array_equal(got2[f], want2[f]) for f in ("regex", "len", "sp", "ep"))
+    assert got2.size != got.size or not np.array_equal(got2["sp"], got["sp"])
 
 
 def test_random_regexes_all_engines_vs_oracle(testdata):

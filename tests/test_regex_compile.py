@@ -116,3 +116,45 @@ def test_random_regexes_agree_with_oracle():
         assert ReTree(REParser.re2post(re)).tables() == want, re
         ok += 1
     assert ok > 100 and bad > 50
+
+
+def test_compile_batch_matches_one_by_one_and_the_oracle():
+    """fmx_regex_compile_batch (all host cores inside the library): per regex the same tables and the same
+    FMX_ERR_SYNTAX / FMX_ERR_MATCH status as fmx_regex_compile, which the tests above pin to the oracle's
+    restatement of re2post / ReTree.apply (re2/re2.scala:50-185, re2/retree.scala:156-423)."""
+    import numpy as np
+    rng = random.Random(99)
+    res = [random_regex(rng) for _ in range(3000)] + ["|a", "a)", "*a", "(a", "[a", "[a-]", "a||b", "(a|b)c", "a", "ab?j", "\xe9[\xe8-\xea]+z"]
+    for threads in (b"1", b"3", b"0"):
+        assert findex_amd.load().fmx_config_set(b"threads", threads) == 0
+        cs = ReTree.compile_batch(res)
+        assert len(cs) == len(res)
+        n_ok = n_syntax = n_match = 0
+        for i, re in enumerate(res):
+            try:
+                want = R.ReTree(R.re2post(re)).tables()
+                code = 0
+            except R.Re2PostSyntax:
+                code = 7
+            except R.MatchError:
+                code = 8
+            assert cs.status[i] == code, (re, cs.status[i], code)
+            if code == 0:
+                if i % 7 == 0 or i >= 3000:
+                    assert cs[i].tables() == want, re
+                n_ok += 1
+            else:
+                with pytest.raises(findex_amd.Re2PostSyntax if code == 7 else findex_amd.MatchError):
+                    cs[i]
+                n_syntax += code == 7
+                n_match += code == 8
+        assert n_ok > 500 and n_syntax >= 7 and n_match > 100
+        good = cs.select(np.nonzero(cs.ok())[0])
+        assert len(good) == n_ok and good[0].tables() == cs[int(np.nonzero(cs.ok())[0][0])].tables()
+        # the first failure's message, as the one-regex entry point leaves it
+        assert b"regex" in findex_amd.load().fmx_last_error()
+    assert len(ReTree.compile_batch([])) == 0
+    with pytest.raises(ValueError):
+        ReTree.compile_batch(["a\0b"])
+    with pytest.raises(findex_amd.FmxError):
+        findex_amd._lib.check(findex_amd.load().fmx_config_set(b"threads", b"many"))

@@ -99,7 +99,7 @@ CallCtx *ctx_acquire(const Index *h) {
 // Contexts holding more than kKeepBytes of scratch, and contexts beyond kKeep idle ones, are released.
 void ctx_release(const Index *h, CallCtx *c) {
   constexpr size_t kKeep = 4;
-  constexpr size_t kKeepBytes = 512u << 20;
+  constexpr size_t kKeepBytes = 2048ull << 20;    // the reference-order match of a 100 k batch holds ~0.5 GiB (element slabs + raw results)
   bool keep = c->total() <= kKeepBytes;
   if (keep) {
     std::lock_guard<std::mutex> lk(h->mu);

@@ -1131,7 +1131,7 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
     HIP_TRY(copy_sync(b->d_first_off, first_off.data(), first_off.size() * 4, hipMemcpyHostToDevice, st), "H2D");
     // the reference-order kernel's push records (fmx_nfa.h)
     std::vector<FolRec> fr(fol.size()), qr(q_state.size());
-    auto rec_of = [&](uint32_t sid) { return FolRec{sid, recs[sid].fol_off, recs[sid].cnt_c_emit & 0x01FFFFFFu, st_num[sid]}; };
+    auto rec_of = [&](uint32_t sid) { return FolRec{recs[sid].fc, recs[sid].fol_off, recs[sid].cnt_c_emit & 0x01FFFFFFu, st_num[sid]}; };
     parallel_for(fol.size(), 1 << 16, [&](size_t a, size_t e) { for (size_t i = a; i < e; i++) fr[i] = rec_of(fol[i]); });
     for (size_t i = 0; i < q_state.size(); i++) qr[i] = rec_of(q_state[i]);
     uint32_t mx = 0;

@@ -38,7 +38,8 @@ struct NfaTables {
 // `first_rec` the same for the firsts) -- the state's own follow list and byte ride along, so the element is stepped
 // and later expanded without a load of its StateRec.
 struct FolRec {
-  uint32_t state;        // global CharNode id
+  uint32_t fc;           // the bytes of that state's first four follows (StateRec::fc): when the element is popped, its
+                         // follows' rank blocks can be requested before their own records have arrived
   uint32_t fol_off;      // that state's follows (StateRec::fol_off)
   uint32_t cnt_c_emit;   // that state's StateRec::cnt_c_emit (count, byte, isLast)
   uint32_t num;          // CharNode.num

@@ -166,38 +166,52 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref(DevIndex ix, RefTables 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The same replay, one regex per WAVE, for limits that fit LDS (the reference's defaults do).  Two things make a pop
-// cheap here that the kernel above pays ~10 us for:
+// The same replay, one regex per WAVE, for limits that fit LDS (the reference's defaults do).  A regex's pops are
+// serial by definition (which results come out depends on their order), so what a launch lasts is (pops of the
+// longest regex) x (time per pop), and a pop is a chain of dependent accesses.  What keeps that chain short here:
 //  * The heap is an array of 4-byte entries {num:16 | slot:16} in LDS.  Only `num` orders the queue (:564), so the
-//    sifts move 4-byte keys; what an element carries (state, len, interval) sits in a slab in device memory under
-//    its slot number.  Free slots need no list: the entries of the array behind the heap are always a permutation of
-//    the unused slot numbers (a pop swaps the popped entry to a[size - 1], just outside the heap; a push takes the
-//    slot number it finds at a[size]).  A push is one LDS round trip (every ancestor read at once, one ballot, the
-//    shifted entries written back at once); a pop walks down one level per round trip (both children in one read).
+//    sifts move 4-byte keys; what an element carries (len, interval, its state's follow list) sits in a slab in
+//    device memory under its slot number.  Free slots need no list: the entries of the array behind the heap are
+//    always a permutation of the unused slot numbers (a pop swaps the popped entry to a[size - 1], just outside the
+//    heap; a push takes the slot number it finds at a[size]).  A push is one LDS round trip (every ancestor read at
+//    once, one ballot, the shifted entries written back at once); a pop walks down one level per round trip (both
+//    children in one read).
 //  * An element's step does not depend on WHEN it is popped, only the heap's shape does.  So getPrevRange is
 //    evaluated when the element is PUSHED: a pop's follows are stepped together, one lane group each, all their rank
 //    blocks in flight at once (the reference pays one dependent rank query per pop), and whether the step came back
-//    empty is kept in LDS beside the heap.  Popping an element whose interval is empty -- most pops, once the
-//    intervals are narrow: a row has one preceding character, the others die -- then touches no memory at all:
+//    empty is kept in LDS beside the heap.  Popping an element whose interval is empty -- most pops once the
+//    intervals are narrow: a row has one preceding character, the others die -- touches no memory at all:
 //    it only counts as an iteration and leaves the heap, exactly as in the reference's loop.
+//  * The elements of the last push stay in the registers of the lane groups that stepped them; a pop that takes one
+//    of them (the usual case: the search runs depth-first through a regex's positions) reads no slab entry.
+//  * An element carries the bytes of its state's first four follows (FolRec::fc), so when it is popped its follows'
+//    rank blocks are requested at once, beside the loads of the follows' own records.
+//  * Results are written to chunks of 64 slots a wave reserves with one atomic; a second small launch puts them in
+//    the reference's order: one wave owns a regex, so result `seq` of a regex with `cnt` results belongs at
+//    start[regex] + cnt - 1 - seq (newest first, the order of `ret ::= ...`, :638) -- no sort.
 // Elements still queued when a limit ends the loop were stepped for nothing; nothing of them is observable
 // (the statistics count pops, like the reference's own getPrevRange calls).
 struct RefSlot {           // 32 bytes, written when the element is pushed (only for non-empty intervals)
   uint64_t sp, ep;         // the interval AFTER the element's own step
-  uint32_t state, len;     // len = the StatePoint's len (the step makes it len + 1)
+  uint32_t fc, len;        // FolRec::fc; len = the StatePoint's len (the step makes it len + 1)
   uint32_t fol_off, cnt_c_emit;
 };
 struct RefCtl2 {
-  unsigned long long res_count;
+  unsigned long long res_count;      // result slots reserved (chunks of kResChunk)
   unsigned long long overflow;
-  unsigned int next;       // next regex to hand out
+  unsigned long long valid;          // results written
+  unsigned int next;                 // next regex to hand out
   unsigned int pad;
 };
 constexpr uint32_t kWaveCf = 256 * 8 + 256 * 2;      // bytes of the C[] / slot tables in front of the waves' heaps
+constexpr uint32_t kResChunk = 64;
+constexpr uint32_t kNoRegex = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t runi(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// LDS traffic of one wave is processed in program order; what must not happen is the compiler moving accesses across
+// the points where lanes read what other lanes wrote
 __device__ __forceinline__ void lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -216,25 +230,29 @@ __device__ __forceinline__ void wave_heap_push(uint32_t *a, uint32_t &size0, uin
   lds_sync();
 }
 
-// dequeue (:  swap(1, size - 1), fixDown inside a[1 .. size - 2]); returns the popped entry, which now sits at a[size0]
-__device__ __forceinline__ uint32_t wave_heap_pop(uint32_t *a, uint32_t &size0, uint32_t lane) {
+// dequeue (swap(1, size - 1), fixDown inside a[1 .. size - 2]); returns the popped entry, which now sits at a[size0].
+// Everything here is wave-uniform and kept in scalar registers; every lane writes the same value to the same LDS
+// address (no exec-mask juggling around a one-lane store: the launch is bound by instruction issue, not by latency).
+__device__ __forceinline__ uint32_t wave_heap_pop(uint32_t *a, uint32_t &size0) {
   size0 -= 1u;
   const uint32_t top = runi(a[1]);
   const uint32_t x = runi(a[size0]);
-  const uint32_t n = size0 - 1u;
+  const uint32_t n = size0 - 1u, xnum = x >> 16;
   uint32_t k = 1u;
-  if (lane == 0u) a[size0] = top;
+  a[size0] = top;
   while (n >= 2u * k) {
     uint32_t j = 2u * k;
     const uint2 cc = *reinterpret_cast<const uint2 *>(a + j);     // both children (j is even)
     uint32_t c = runi(cc.x);
     const uint32_t c2 = runi(cc.y);
-    if (j < n && (c >> 16) > (c2 >> 16)) { j += 1u; c = c2; }     // right child only when left < right
-    if (!((x >> 16) > (c >> 16))) break;                          // a[k] >= a[j]
-    if (lane == 0u) a[k] = c;
+    const bool right = j < n && (c >> 16) > (c2 >> 16);           // right child only when left < right
+    j += right ? 1u : 0u;
+    c = right ? c2 : c;
+    if (!(xnum > (c >> 16))) break;                               // a[k] >= a[j]
+    a[k] = c;
     k = j;
   }
-  if (n >= 1u && lane == 0u) a[k] = x;
+  if (n >= 1u) a[k] = x;
   lds_sync();
   return top;
 }
@@ -244,7 +262,8 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref_wave(DevIndex ix, RefTa
                                                                RefSlot *__restrict__ slabs, uint32_t heap_cap,
                                                                uint32_t max_branching, uint32_t max_iterations,
                                                                RefResult *__restrict__ res, uint64_t res_cap,
-                                                               uint32_t *__restrict__ front_left, RefCtl2 *__restrict__ ctl,
+                                                               uint32_t *__restrict__ rcnt, uint32_t *__restrict__ front_left,
+                                                               RefCtl2 *__restrict__ ctl,
                                                                unsigned long long *__restrict__ counters) {
   extern __shared__ __align__(16) unsigned char s_raw[];
   uint64_t *s_cf = reinterpret_cast<uint64_t *>(s_raw);
@@ -264,6 +283,12 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref_wave(DevIndex ix, RefTa
   __syncthreads();
   uint32_t stepped = 0;
   uint32_t n_reqs = 0, n_push = 0, n_live_push = 0, n_live_pop = 0, n_res = 0;      // per lane / wave-uniform tallies for fmx_stats
+  unsigned long long res_at = 0, res_end = 0;     // the wave's current chunk of result slots (wave-uniform)
+  // the elements of the last push, one per lane group: interval after their step, push record, slot (h_ok: non-empty)
+  uint64_t h_sp = 0, h_ep = 0;
+  uint4 h_fr = make_uint4(0, 0, 0, 0);
+  uint32_t h_slot = 0, h_len = 0;
+  bool h_ok = false;
   for (;;) {
     uint32_t r = 0;
     if (lane == 0u) r = atomicAdd(&ctl->next, 1u);
@@ -272,8 +297,9 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref_wave(DevIndex ix, RefTa
     uint32_t size0 = 1u, nres = 0u, it = 1u;
     bool bad = false;
     // pqFront ++= / += of `cnt` elements whose records are recs[0 .. cnt): each is stepped from the parent's interval
-    // right away (lane group g steps element j0 + g), then pushed in order
-    auto push_all = [&](const FolRec *recs, uint32_t cnt, uint64_t psp, uint64_t pep, uint32_t clen) {
+    // right away (lane group g steps element j0 + g), then pushed in order.  pfc = the bytes of the first four
+    // (FolRec::fc of the parent) when known: their rank blocks are then requested beside their records.
+    auto push_all = [&](const FolRec *recs, uint32_t cnt, uint64_t psp, uint64_t pep, uint32_t clen, uint32_t pfc, bool have_fc) {
       for (uint32_t j0 = 0; j0 < cnt && !bad; j0 += NG) {
         const uint32_t nb = cnt - j0 < NG ? cnt - j0 : NG;
         if (size0 + nb > heap_cap) { bad = true; if (lane == 0u) atomicOr(&ctl->overflow, 1ull); break; }
@@ -282,7 +308,13 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref_wave(DevIndex ix, RefTa
         if (act) fr = *reinterpret_cast<const uint4 *>(recs + j0 + q);
         const uint32_t slotno = act ? (a[size0 + q] & 0xFFFFu) : 0u;      // the free slot this push will take
         uint64_t sp = psp, ep = pep;
-        if (act) {
+        if (have_fc && j0 == 0u && nb <= 4u) {          // wave-uniform: the bytes come from the parent, the records ride along
+          if (act) {
+            const uint32_t c = (pfc >> (8u * q)) & 0xFFu;
+            const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, c, s_slot[c], s_cf[c], lc, sp, ep);
+            if (lc.t == 0u) n_reqs += rq;
+          }
+        } else if (act) {
           const uint32_t c = (fr.z >> 16) & 0xFFu;
           const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, c, s_slot[c], s_cf[c], lc, sp, ep);
           if (lc.t == 0u) n_reqs += rq;
@@ -298,6 +330,7 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref_wave(DevIndex ix, RefTa
             d[1] = make_uint4(fr.x, clen, fr.y, fr.z);
           }
         }
+        h_sp = sp; h_ep = ep; h_fr = fr; h_slot = slotno; h_ok = live; h_len = clen;
         lds_sync();
         for (uint32_t g = 0; g < nb; g++) {
           const uint32_t num = (uint32_t)__builtin_amdgcn_readlane((int)fr.w, (int)(g * G));
@@ -308,46 +341,116 @@ __global__ __launch_bounds__(kRThreads) void k_match_ref_wave(DevIndex ix, RefTa
     };
     {
       const uint32_t f0 = rt.first_off[r], f1 = rt.first_off[r + 1];
-      push_all(rt.first_rec + f0, f1 - f0, 0ull, ix.n, 0u);                 // pqFront ++= inputStates, :624
+      push_all(rt.first_rec + f0, f1 - f0, 0ull, ix.n, 0u, 0u, false);      // pqFront ++= inputStates, :624
     }
     // loop condition, :628
     while (!bad && size0 >= 2u && (size0 - 1u) < max_branching && (max_iterations == 0u || it < max_iterations)) {
-      const uint32_t e = wave_heap_pop(a, size0, lane);
+      const uint32_t e = wave_heap_pop(a, size0);
       const uint32_t sn = e & 0xFFFFu;
       stepped++;
       it++;
+#ifdef FMX_REF_PRIO
+      if (it == FMX_REF_PRIO) __builtin_amdgcn_s_setprio(3);               // a long regex is the launch's critical path
+#endif
       if (!runi((uint32_t)alive[sn])) continue;                             // None, :634: nothing to do
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       n_live_pop++;
-      const uint4 *sp4 = reinterpret_cast<const uint4 *>(slab + sn);
-      const uint4 p0 = sp4[0], p1 = sp4[1];
-      const uint64_t psp = ((uint64_t)runi(p0.y) << 32) | runi(p0.x), pep = ((uint64_t)runi(p0.w) << 32) | runi(p0.z);
-      const uint32_t len = runi(p1.y), fol_off = runi(p1.z), cce = runi(p1.w);
+      uint64_t psp, pep;
+      uint32_t len, fol_off, cce, fc;
+      const unsigned long long held = __builtin_amdgcn_ballot_w64(h_ok && h_slot == sn);
+      if (held) {                                                            // still in the registers of the group that stepped it
+        const int src = (int)__builtin_ctzll(held);
+        psp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(h_sp >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)h_sp, src);
+        pep = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(h_ep >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)h_ep, src);
+        fc = (uint32_t)__builtin_amdgcn_readlane((int)h_fr.x, src);
+        fol_off = (uint32_t)__builtin_amdgcn_readlane((int)h_fr.y, src);
+        cce = (uint32_t)__builtin_amdgcn_readlane((int)h_fr.z, src);
+        len = h_len;
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the wave's own slab stores have landed
+        const uint4 *sp4 = reinterpret_cast<const uint4 *>(slab + sn);
+        const uint4 p0 = sp4[0], p1 = sp4[1];
+        psp = ((uint64_t)runi(p0.y) << 32) | runi(p0.x);
+        pep = ((uint64_t)runi(p0.w) << 32) | runi(p0.z);
+        fc = runi(p1.x); len = runi(p1.y); fol_off = runi(p1.z); cce = runi(p1.w);
+      }
       if ((cce >> 24) & 1u) {                                                // isLast, :636-638
+        if (res_at == res_end) {
+          unsigned long long base = 0;
+          if (lane == 0u) base = atomicAdd(&ctl->res_count, (unsigned long long)kResChunk);
+          res_at = ((unsigned long long)runi((uint32_t)(base >> 32)) << 32) | runi((uint32_t)base);
+          res_end = res_at + kResChunk;
+        }
         if (lane == 0u) {
-          const unsigned long long at = atomicAdd(&ctl->res_count, 1ull);
-          if (at < res_cap) {
+          if (res_at < res_cap) {
             RefResult o;
             o.regex = r; o.len = len + 1u; o.seq = nres; o.pad = 0; o.sp = psp; o.ep = pep;
-            res[at] = o;
+            res[res_at] = o;
           } else {
             atomicOr(&ctl->overflow, 2ull);
           }
         }
+        res_at++;
         nres++;
         n_res++;
       } else {                                                               // :641
-        push_all(rt.fol_rec + fol_off, cce & 0xFFFFu, psp, pep, len + 1u);
+        push_all(rt.fol_rec + fol_off, cce & 0xFFFFu, psp, pep, len + 1u, fc, true);
       }
     }
-    if (lane == 0u && front_left) front_left[r] = size0 - 1u;
+    if (lane == 0u) {
+      rcnt[r] = nres;
+      if (front_left) front_left[r] = size0 - 1u;
+    }
+    h_ok = false;
+#ifdef FMX_REF_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
+  // the rest of the wave's last chunk holds no results
+  for (unsigned long long i = res_at + lane; i < res_end; i += 64u)
+    if (i < res_cap) res[i].regex = kNoRegex;
+  if (lane == 0u && n_res) atomicAdd(&ctl->valid, (unsigned long long)n_res);
   counters_add(counters, lane == 0u ? 2ull * stepped : 0ull, lane == 0u ? stepped : 0u, 0);
   // the frontier counters of fmx_stats, read for this kernel as: rank-line requests | slots written (elements pushed
   // with a non-empty interval) | results | elements stepped at push time | slots read (non-empty elements popped) |
   // push records loaded
   counters_add_frontier(counters, n_reqs, n_live_push, lane == 0u ? n_res : 0u, lane == 0u ? n_push : 0u,
                         lane == 0u ? n_live_pop : 0u, lane == 0u ? n_push : 0u);
+}
+
+// Exclusive prefix sums of the per-regex result counts, one workgroup (k is a batch's regex count: 100 k = 98 trips).
+__global__ __launch_bounds__(1024) void k_ref_scan(const uint32_t *__restrict__ cnt, uint32_t k, uint32_t *__restrict__ start) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (uint32_t base = 0; base <= k; base += 1024u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < k ? cnt[i] : 0u;
+    uint32_t x = v;                                   // inclusive scan inside the wave
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if ((int)lane >= d) x += y; }
+    if (lane == 63u) s_wave[wv] = x;
+    __syncthreads();
+    uint32_t before = s_carry;
+    for (uint32_t j = 0; j < wv; j++) before += s_wave[j];
+    if (i <= k) start[i] = before + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023u) s_carry = before + x;
+    __syncthreads();
+  }
+}
+
+// raw result i of regex r with sequence number seq goes to start[r] + cnt[r] - 1 - seq
+__global__ __launch_bounds__(256) void k_ref_place(const RefResult *__restrict__ raw, const RefCtl2 *__restrict__ ctl, uint64_t res_cap,
+                                                    const uint32_t *__restrict__ start, const uint32_t *__restrict__ cnt,
+                                                    fmx_result *__restrict__ out, uint64_t out_cap) {
+  const uint64_t total = ctl->res_count < res_cap ? ctl->res_count : res_cap;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const RefResult r = raw[i];
+    if (r.regex == kNoRegex) continue;
+    const uint64_t at = (uint64_t)start[r.regex] + (cnt[r.regex] - 1u - r.seq);
+    if (at < out_cap) { fmx_result o; o.regex = r.regex; o.len = r.len; o.sp = r.sp; o.ep = r.ep; out[at] = o; }
+  }
 }
 
 #define HIP_TRY(call, what)                            \
@@ -377,7 +480,8 @@ static int match_reference_wave(const Index *h, const RefTables &rt, size_t k, u
   uint32_t wpw = 4;
   while (wpw > 1 && kWaveCf + wpw * wave_bytes > (64u << 10)) wpw >>= 1;
   const size_t lds = kWaveCf + wpw * wave_bytes;
-  const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160u << 10) / lds, 32 / 4));
+  uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160u << 10) / lds, 32 / wpw));
+  if (const char *e = getenv("FMX_REF_WGS")) wg_per_cu = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)wg_per_cu));      // A/B runs
   uint64_t grid = std::min<uint64_t>((k + wpw - 1) / wpw, (uint64_t)h->cu_count * wg_per_cu);
   // bound the slab arena (32 B x heap_cap per wave) to ~2 GiB
   grid = std::max<uint64_t>(1, std::min<uint64_t>(grid, (2ull << 30) / ((uint64_t)heap_cap * sizeof(RefSlot) * wpw)));
@@ -386,44 +490,61 @@ static int match_reference_wave(const Index *h, const RefTables &rt, size_t k, u
   hipStream_t st = lease.c->stream;
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t waves = (size_t)grid * wpw;
-  const size_t o_ctl = 0, o_slab = up(sizeof(RefCtl2)), o_res = o_slab + up(waves * heap_cap * sizeof(RefSlot)),
-               o_left = o_res + up((cap ? cap : 1) * sizeof(RefResult)), total = o_left + up(k * 4);
+  // raw results: the caller's capacity plus one chunk of slack per wave (a wave reserves result slots 64 at a time)
+  const size_t raw_cap = (cap ? cap : 1) + waves * kResChunk;
+  const size_t o_ctl = 0, o_slab = up(sizeof(RefCtl2)), o_raw = o_slab + up(waves * heap_cap * sizeof(RefSlot)),
+               o_out = o_raw + up(raw_cap * sizeof(RefResult)), o_cnt = o_out + up((cap ? cap : 1) * sizeof(fmx_result)),
+               o_start = o_cnt + up((k + 1) * 4), o_left = o_start + up((k + 1) * 4), total = o_left + up(k * 4);
   void *arena_v = nullptr;
   HIP_TRY(ctx_scratch(lease.c, 0, total, &arena_v), "hipMalloc(reference-order arena)");
   uint8_t *arena = static_cast<uint8_t *>(arena_v);
   HIP_TRY(hipMemsetAsync(arena + o_ctl, 0, sizeof(RefCtl2), st), "memset(ctl)");
   RefSlot *d_slab = reinterpret_cast<RefSlot *>(arena + o_slab);
-  RefResult *d_res = reinterpret_cast<RefResult *>(arena + o_res);
+  RefResult *d_raw = reinterpret_cast<RefResult *>(arena + o_raw);
+  fmx_result *d_out = reinterpret_cast<fmx_result *>(arena + o_out);
+  uint32_t *d_cnt = reinterpret_cast<uint32_t *>(arena + o_cnt), *d_start = reinterpret_cast<uint32_t *>(arena + o_start);
   RefCtl2 *d_ctl = reinterpret_cast<RefCtl2 *>(arena + o_ctl);
   uint32_t *d_left = front_left ? reinterpret_cast<uint32_t *>(arena + o_left) : nullptr;
-  // the caller's view of the call: pinned staging for {ctl} so that one synchronisation ends it
+  struct HostCtl { RefCtl2 ctl; };
+  void *pin_v = nullptr;
+  if (lease.c->pin_cap < sizeof(RefCtl2)) {
+    if (lease.c->pin) { (void)hipHostFree(lease.c->pin); lease.c->pin = nullptr; lease.c->pin_cap = 0; }
+    HIP_TRY(hipHostMalloc(&lease.c->pin, 4096, hipHostMallocDefault), "hipHostMalloc");
+    lease.c->pin_cap = 4096;
+  }
+  pin_v = lease.c->pin;
+  RefCtl2 *h_ctl = static_cast<RefCtl2 *>(pin_v);
   hipEvent_t e0 = lease.c->ev_a, e1 = lease.c->ev_b;
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
-#define CALL(W, L)                                                                                                    \
+#define CALL(W, L)                                                                                                          \
   k_match_ref_wave<W, L><<<(int)grid, (int)(wpw * 64), lds, st>>>(h->dev, rt, (uint32_t)k, d_slab, heap_cap, max_branching, \
-                                                            max_iterations, d_res, (uint64_t)cap, d_left, d_ctl, h->d_counters)
+                                                                  max_iterations, d_raw, (uint64_t)raw_cap, d_cnt, d_left, d_ctl, h->d_counters)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
   HIP_TRY(hipGetLastError(), "k_match_ref_wave");
+  k_ref_scan<<<1, 1024, 0, st>>>(d_cnt, (uint32_t)k, d_start);
+  k_ref_place<<<256, 256, 0, st>>>(d_raw, d_ctl, (uint64_t)raw_cap, d_start, d_cnt, d_out, (uint64_t)cap);
+  HIP_TRY(hipGetLastError(), "k_ref_scan / k_ref_place");
   HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
-  RefCtl2 ctl{};
-  HIP_TRY(hipMemcpyAsync(&ctl, d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st), "D2H(ctl)");
+  HIP_TRY(hipMemcpyAsync(h_ctl, d_ctl, sizeof(RefCtl2), hipMemcpyDeviceToHost, st), "D2H(ctl)");
+  if (per_regex_count) HIP_TRY(hipMemcpyAsync(per_regex_count, d_cnt, k * 4, hipMemcpyDeviceToHost, st), "D2H(result counts)");
+  if (front_left) HIP_TRY(hipMemcpyAsync(front_left, d_left, k * 4, hipMemcpyDeviceToHost, st), "D2H(front_left)");
   HIP_TRY(hipStreamSynchronize(st), "sync(k_match_ref_wave)");
+  const RefCtl2 ctl = *h_ctl;
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
   {
     std::lock_guard<std::mutex> lk(h->mu);
     h->last_kernel_ms = ms;
-    h->launches += 1;
+    h->launches += 3;
   }
   if (ctl.overflow & 1ull) { set_error("reference-order heap overflow (internal bound)"); return FMX_ERR_OVERFLOW; }
-  *n_out = (size_t)ctl.res_count;
-  if (ctl.res_count > cap) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
-  if (front_left) HIP_TRY(hipMemcpyAsync(front_left, d_left, k * 4, hipMemcpyDeviceToHost, st), "D2H(front_left)");
-  std::vector<RefResult> tmp((size_t)ctl.res_count);
-  if (ctl.res_count) HIP_TRY(hipMemcpyAsync(tmp.data(), d_res, tmp.size() * sizeof(RefResult), hipMemcpyDeviceToHost, st), "D2H(results)");
-  if (front_left || ctl.res_count) HIP_TRY(hipStreamSynchronize(st), "sync(results)");
-  deliver_results(tmp, out, per_regex_count);
+  *n_out = (size_t)ctl.valid;
+  if (ctl.valid > cap || (ctl.overflow & 2ull)) { set_error("result buffer too small"); return FMX_ERR_OVERFLOW; }
+  if (ctl.valid) {
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)ctl.valid * sizeof(fmx_result), hipMemcpyDeviceToHost, st), "D2H(results)");
+    HIP_TRY(hipStreamSynchronize(st), "sync(results)");
+  }
   return FMX_OK;
 }
 

@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +94,7 @@ struct FrontierCtl {     // device-resident counters
   unsigned long long overflow;     // bit 0: queue, bit 1: results, bit 2: an appended entry never became readable
   unsigned long long truncated;    // some element was not expanded because its follows would have len >= max_len
   uint32_t max_len;
+  uint32_t deep_len;               // elements of looping states at least this long jump the wave's queue (express pool)
   uint32_t fresh;                  // this chain of launches begins a call (k_frontier_reset -> k_frontier_init)
   unsigned long long left;         // entries queued when the launch began (k_frontier_reset / k_frontier_advance): 0 = nothing to do
 };
@@ -146,6 +148,8 @@ constexpr uint32_t kPoolSmall = 6;      // follow lists with up to this many pus
 // constant 100 MHz clock, so that the occupancy of the wave slots over a launch can be drawn.
 constexpr uint32_t kLogPasses = 16, kLogWaves = 1u << 15;
 __device__ unsigned long long g_wavelog[kLogPasses][kLogWaves][4];
+// launch 0, per wave and round (first 128): elements held | pool entries << 8 | deepest held length << 20 | narrow << 28 | express << 29
+__device__ unsigned int g_wavetrace[kLogWaves][128];
 // with -DFMX_PHASELOG=<round>: cycles (s_memtime) a wave spends in the four phases of its rounds from that round on
 // (take | stage + issue | wait + ranks | bookkeeping), rounds counted, in g_phaselog[wave][0..4] of launch 0
 __device__ unsigned long long g_phaselog[kLogWaves][8];
@@ -181,6 +185,15 @@ constexpr uint32_t kGrab = FMX_GRAB;            // entries taken from the queue 
 #ifndef FMX_IDLE_LOOKS
 #define FMX_IDLE_LOOKS 3
 #endif
+#ifndef FMX_NARROW
+#define FMX_NARROW 1
+#endif
+#ifndef FMX_DEEP_PRIO
+#define FMX_DEEP_PRIO 1
+#endif
+#ifndef FMX_DEEP_SLACK
+#define FMX_DEEP_SLACK 4u
+#endif
 constexpr uint32_t kIdleLooks = FMX_IDLE_LOOKS; // looks that find nothing before a wave without work ends
 constexpr uint32_t kTagLimit = 60000;          // host-side bound on a buffer's generation tag before everything is zeroed
 constexpr uint32_t kTagSpins = 1u << 16;        // re-reads of a reserved entry before the wave gives up (an error)
@@ -194,6 +207,24 @@ struct Pool64 {          // 24 bytes per entry, 6 KiB per wave
 constexpr uint32_t kRes64 = 64;
 struct ResStage64 {
   fmx_result r[kRes64];
+};
+// The EXPRESS pool of a wave: follows pushed deep into a match (FrontierCtl::deep_len: past the length at which an
+// interval has narrowed to a row).  Few elements get there, and those that keep branching there (a starred class that
+// keeps matching) are links of a chain of dependent steps that may run to the longest match explored -- the launch's
+// critical path -- while the newest-first pool serves whatever was pushed last: under the push traffic of a wave's
+// busy phase a chain's entries sank at length 9 and were only stepped again when the pool had drained (the last waves
+// of a launch did 30 rounds of bulk work at lengths <= 8, then one level of one chain per round up to length 64:
+// profiles/r03_c4_wave_trace_before.txt).  Idle lanes take express entries before anything else.
+#ifndef FMX_EXPRESS
+#define FMX_EXPRESS 0      // measured on C4 (profiles/r03_c4_k5_experiments.md): no gain -- a chain starts late because its ANCESTOR at
+                           // length <= 8 is one of a wave's few thousand bulk elements, not because its deep entries wait
+#endif
+constexpr uint32_t kXp = FMX_EXPRESS;
+struct Express {
+  uint32_t state[kXp ? kXp : 1];
+  uint32_t meta[kXp ? kXp : 1];
+  uint64_t sp[kXp ? kXp : 1];
+  uint64_t ep[kXp ? kXp : 1];
 };
 struct Xchg {            // a round's intervals on their way to the lane groups and back, by element (= lane) number
   uint64_t sp[64];
@@ -253,6 +284,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
   __shared__ Pool64 s_pool[kFThreads / 64];
   __shared__ ResStage64 s_res[kFThreads / 64];
   __shared__ Xchg s_xc[kFThreads / 64];
+  __shared__ Express s_xp[kFThreads / 64];
   __shared__ const uint4 *s_lvl[16];         // the k-mer table's levels (picked by an element's length at run time)
   for (int c = threadIdx.x; c < 256; c += blockDim.x) s_slot[c] = ix.slot[c];
   if (threadIdx.x == 0) { s_mail.lock = 0; s_mail.n = 0; }
@@ -261,6 +293,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
   Pool64 &pl = s_pool[threadIdx.x >> 6];
   ResStage64 &rs = s_res[threadIdx.x >> 6];
   Xchg &xc = s_xc[threadIdx.x >> 6];
+  Express &xp = s_xp[threadIdx.x >> 6];
+  uint32_t xn = 0;                           // entries in the express pool (wave-uniform)
+  const uint32_t deep_len = ctl->deep_len;
   uint32_t rs_n = 0;                         // wave-uniform
   const LaneConst lc = lane_const<G>();
   const uint32_t grp = lane / G;             // this lane's group: it serves element r * EPS + grp in sub-round r
@@ -284,6 +319,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     a_next = uni64(a_next);
     a_end = uni64(a_end);
   }
+  bool prio_up = false;                      // wave-uniform: running at raised issue priority (FMX_DEEP_PRIO)
   bool have = false;                         // the element this lane holds
   uint32_t state = 0, meta = 0;
   uint64_t sp = 0, ep = 0;
@@ -475,13 +511,69 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
 #ifdef FMX_PHASELOG
     ph_t = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- lanes without an element take the newest pool entries; a pool that cannot feed them is refilled from the
-    // wave's share, and a wave with nothing left at all looks for entries appended during this launch
-    {
+    // ---- NARROW rounds.  A wave that holds no more elements than it has lane groups (the thin end of a launch: a
+    // few chains of dependent steps, which are the launch's critical path) keeps them in the groups' first lanes and
+    // steps each in its own group, like k_search4 does: the interval goes to the group's lanes by DPP, the ranks come
+    // back the same way -- no exchange area, no LDS round trips around the memory latency.
+    if (kXp && xn) {                         // express entries first, newest first
       const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
       if (idle) {
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (pn < n_idle && mail_n()) mail_take(64u);                     // what a sibling wave left for this one
+        const uint32_t take = n_idle < xn ? n_idle : xn;
+        const uint32_t rank = (uint32_t)__builtin_popcountll(idle & ((1ull << lane) - 1ull));
+        if (!have && rank < take) {
+          const uint32_t idx = xn - 1u - rank;
+          state = xp.state[idx]; meta = xp.meta[idx]; sp = xp.sp[idx]; ep = xp.ep[idx];
+          have = true;
+        }
+        xn = uni(xn - take);
+        pool_sync();
+      }
+    }
+    bool narrow = false;
+#if FMX_NARROW
+    {
+      const unsigned long long havem = __builtin_amdgcn_ballot_w64(have);
+      const uint32_t n_have = (uint32_t)__builtin_popcountll(havem);
+      narrow = n_have + pn + xn <= (uint32_t)(64 / G) && n_have + pn != 0u && xn == 0u && a_next >= a_end;
+      if (narrow) {
+        constexpr unsigned long long kLeaders = G == 4 ? 0x1111111111111111ull : 0x0101010101010101ull;
+        const unsigned long long stray = havem & ~kLeaders;       // elements held by other lanes go through the pool
+        if (stray) {
+          if (have && lc.t != 0u) {
+            const uint32_t idx = (pb + pn + (uint32_t)__builtin_popcountll(stray & ((1ull << lane) - 1ull))) & kPool64Mask;
+            pl.state[idx] = state; pl.meta[idx] = meta & 0x00FFFFFFu; pl.sp[idx] = sp; pl.ep[idx] = ep;   // the stretch context stays behind
+            have = false;
+          }
+          pn = uni(pn + (uint32_t)__builtin_popcountll(stray));
+          pool_sync();
+        }
+        const unsigned long long idle_l = ~__builtin_amdgcn_ballot_w64(have) & kLeaders;
+        if (idle_l && pn) {
+          const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_l);
+          const uint32_t take = n_idle < pn ? n_idle : pn;
+          const uint32_t rank = (uint32_t)__builtin_popcountll(idle_l & ((1ull << lane) - 1ull));
+          if (!have && lc.t == 0u && rank < take) {
+            const uint32_t idx = (pb + rank) & kPool64Mask;       // a small pool: oldest first
+            state = pl.state[idx]; meta = pl.meta[idx]; sp = pl.sp[idx]; ep = pl.ep[idx];
+            have = true;
+          }
+          pb = uni((pb + take) & kPool64Mask);
+          pn = uni(pn - take);
+          pool_sync();
+        }
+      }
+    }
+#endif
+    // ---- lanes without an element take the newest pool entries; a pool that cannot feed them is refilled from the
+    // wave's share, and a wave with nothing left at all looks for entries appended during this launch
+    if (!narrow) {
+      const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
+      if (idle) {
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        // what a sibling wave left for this one -- looked for only by a wave that cannot fill half its lanes (every look
+        // is an LDS round trip on the round's critical path)
+        if (pn < n_idle && n_idle > 32u && mail_n()) mail_take(64u);
         if (pn < n_idle && !take_batch() && pn == 0 && n_idle == 64u) steal();
         if (pn) {
           const uint32_t take = n_idle < pn ? n_idle : pn;
@@ -507,6 +599,27 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       continue;
     }
     idle_looks = 0;
+#ifdef FMX_WAVELOG
+    if (j == 0 && w < kLogWaves && rounds < 128u) {
+      const uint32_t nh = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
+      uint32_t ml = have ? (meta & 0xFFFFu) : 0u;
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)ml, d, 64); ml = o > ml ? o : ml; }
+      if (lane == 0) g_wavetrace[w][rounds] = nh | (pn << 8) | ((ml > 255u ? 255u : ml) << 20) | ((narrow ? 1u : 0u) << 28) | ((xn > 7u ? 7u : xn) << 29);
+    }
+#endif
+#if FMX_DEEP_PRIO
+    // A wave that holds an element which has advanced in (nearly) every round since the launch began is on the
+    // launch's critical path -- a chain of dependent steps as long as the deepest match explored: it gets the SIMD's
+    // issue slots ahead of its neighbours, whose backlog is throughput work.
+    {
+      const uint32_t floor_len = (rounds > 16u ? rounds : 16u);
+      const bool deep_now = __builtin_amdgcn_ballot_w64(have && (meta & 0xFFFFu) + FMX_DEEP_SLACK >= floor_len) != 0ull;
+      if (deep_now != prio_up) {
+        if (deep_now) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        prio_up = deep_now;
+      }
+    }
+#endif
     PH_MARK(ph0);
     // ---- every element's state record and its step's lines are requested together
     const uint32_t run = meta >> 24;          // > 0: inside a literal stretch whose bytes the held record carries
@@ -552,6 +665,19 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     const unsigned long long qmask = __builtin_amdgcn_ballot_w64(query);
     const uint32_t n_query = (uint32_t)__builtin_popcountll(qmask);
     const uint32_t xslot = (uint32_t)__builtin_popcountll(qmask & ((1ull << lane) - 1ull));      // this lane's slot, if it has a query
+    uint64_t nsp = 0, nep = 0;                         // narrow rounds: the group's ranks
+    if (narrow) {
+      PH_MARK(ph1);
+      // the first lane's interval and symbol to its whole group, then the step where the data is
+      const uint32_t qk = group_bcast<G, 0>(query ? ((uint32_t)slot | (c << 16)) : kNoQuery);
+      uint64_t gsp = group_bcast64<G, 0>(sp), gep = group_bcast64<G, 0>(ep);
+      if (qk != kNoQuery) {
+        const uint32_t rq = backward_step<WIDE, LAYOUT>(ix, qk >> 16, (uint16_t)(qk & 0xFFFFu), 0ull, lc, gsp, gep);
+        if (lc.t == 0) n_reqs += rq;
+        nsp = gsp;
+        nep = gep;
+      }
+    } else {
     if (query) {
       xc.sp[xslot] = sp;
       xc.ep[xslot] = ep;
@@ -685,10 +811,11 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         }
       }
     }
+    pool_sync();
+    }      // !narrow
     PH_MARK(ph2);
     // the table entry is not needed before this point: keeps its load in flight beside the rank lines'
     asm volatile("" : "+v"(ent.x), "+v"(ent.y), "+v"(ent.z), "+v"(ent.w));
-    pool_sync();
     if (have) {
       if (from_tab) {
         sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
@@ -704,6 +831,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
           const uint64_t r2 = (slot == kSlotEof && ep > ix.eof) ? 1 : 0;
           sp = cfc + r1;
           ep = cfc + r2;
+        } else if (narrow) {
+          sp = cfc + nsp;
+          ep = cfc + nep;
         } else {
           sp = cfc + xc.sp[xslot];
           ep = cfc + xc.ep[xslot];
@@ -746,6 +876,30 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     {
       uint32_t nsmall = npush <= kPoolSmall ? npush : 0u;
       bool demoted = false;
+      if (kXp) {
+        // follows pushed deep into a match go to the express pool while it has room
+        const uint32_t nx = (nsmall != 0u && len1 >= deep_len) ? nsmall : 0u;
+        if (__builtin_amdgcn_ballot_w64(nx != 0u)) {
+          uint32_t x_total = 0;
+          const uint32_t x_off = wave_excl_scan(nx, x_total);
+          if (xn + x_total <= kXp) {
+            for (uint32_t q = 0; q < nx; q++) {
+              const uint32_t fj = q + 1;
+              const uint32_t fst = fj < kInlineFollows ? (fj == 1 ? ra.w : (fj == 2 ? rb.x : rb.y)) : nfa.fol[ra.x + fj];
+              const uint32_t fch = fj < kInlineFollows ? ((rb.z >> (8u * fj)) & 0xFFu) : (uint32_t)nfa.fol_c[ra.x + fj];
+              const uint32_t idx = xn + x_off + q;
+              xp.state[idx] = fst;
+              xp.meta[idx] = len1 | (fch << 16);
+              xp.sp[idx] = ssp;
+              xp.ep[idx] = sep;
+            }
+            xn = uni(xn + x_total);
+            if (nx) nsmall = 0u;
+            pool_sync();
+          }
+        }
+      }
+      const bool via_express = kXp && npush != 0u && nsmall == 0u && npush <= kPoolSmall;
       if (__builtin_amdgcn_ballot_w64(nsmall != 0)) {
         uint32_t small_total = 0;
         uint32_t my_off = wave_excl_scan(nsmall, small_total);
@@ -779,7 +933,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
         // fills once and stays)
         if (kMail && pn > kMailKeep && mail_n() <= kMail - kMailGive) mail_give();
       }
-      unsigned long long big = __builtin_amdgcn_ballot_w64(npush > kPoolSmall || demoted);
+      unsigned long long big = __builtin_amdgcn_ballot_w64((npush > kPoolSmall || demoted) && !via_express);
       while (big) {                                     // one long list at a time, written by the whole wave
         const int src = __builtin_ctzll(big);
         big &= big - 1;
@@ -827,6 +981,16 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
           pl.state[idx] = state; pl.meta[idx] = meta & 0x00FFFFFFu; pl.sp[idx] = sp; pl.ep[idx] = ep;   // the stretch context stays behind
         }
         pn = uni(pn + (uint32_t)__builtin_popcountll(held));
+      }
+      if (kXp && xn) {                       // express entries leave through the pool
+        if (pn + xn + 64u > kPool64) spill(pn < 64u ? pn : 64u);
+        if (lane < xn) {
+          const uint32_t idx = (pb + pn + lane) & kPool64Mask;
+          pl.state[idx] = xp.state[lane]; pl.meta[idx] = xp.meta[lane]; pl.sp[idx] = xp.sp[lane]; pl.ep[idx] = xp.ep[lane];
+        }
+        pn = uni(pn + xn);
+        xn = 0;
+        pool_sync();
       }
       while (pn) spill(pn < 64u ? pn : 64u);
       while (take_batch()) spill(pn);        // carried over, not consumed here
@@ -933,14 +1097,24 @@ struct ExportDst {
   // graph are fixed, the call's own values travel through this page-locked struct
   uint32_t max_len;
   uint32_t fresh;        // 1: this chain begins a call (reset the queue, write the start elements); 0: it continues one
+  uint32_t direct;       // 1: `out` is device memory (fmx_regex_batch_match_dev): the grouping kernels scatter and order the
+                         // results right there, no export copy of them
+  uint32_t deep_len;     // FrontierCtl::deep_len of this call
 };
+// where the grouping works: the batch's own result buffer, or straight in the caller's device memory
+__device__ __forceinline__ fmx_result *group_out(const ExportDst *dst, fmx_result *own, uint64_t own_cap, uint64_t &cap) {
+  const ExportDst d = *dst;
+  if (d.direct) { cap = d.cap < own_cap ? d.cap : own_cap; return d.out; }
+  cap = own_cap;
+  return own;
+}
 __global__ __launch_bounds__(256) void k_res_export(const fmx_result *__restrict__ res, const uint32_t *__restrict__ start, uint32_t k,
                                                      const uint32_t *__restrict__ rcnt, const BigGroups *__restrict__ big,
                                                      const ExportDst *__restrict__ dst, GroupTotals *__restrict__ tot /* pinned host */) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { tot->n_results = start[k]; tot->n_big = big->n_host ? big->n : 0u; }
   const ExportDst d = *dst;
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
-  if (d.out) {
+  if (d.out && !d.direct) {
     const uint64_t n = start[k] < d.cap ? start[k] : d.cap;
     // 24-byte results as 16-byte words (both buffers are 16-byte aligned: hipMalloc / page-locked memory), the odd
     // eight bytes at the end on their own
@@ -998,7 +1172,8 @@ struct RegexBatch {
   uint64_t qcap = 0;
   size_t rcap = 0;
   NfaTables nfa{};
-  uint32_t *d_first_state = nullptr;
+  uint32_t *d_first_state = nullptr;   // root.firsts of every regex, regex by regex
+  uint32_t *d_start_state = nullptr;   // the same states in the order the frontier kernel's start elements are queued
   // reference-order mode (ReTree batches only): heap keys, per-regex firsts, the largest fan-out
   uint32_t *d_st_num = nullptr, *d_first_off = nullptr;
   FolRec *d_fol_rec = nullptr, *d_first_rec = nullptr;
@@ -1011,6 +1186,71 @@ struct RegexBatch {
 static hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
   hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
   return e == hipSuccess ? hipStreamSynchronize(st) : e;
+}
+
+// Expected number of frontier elements a regex makes on an index of n rows over sigma symbols whose BWT looks random:
+// an element at depth d (characters matched so far) holds an interval of about n / sigma^d rows; its step survives
+// with probability min(1, rows / sigma), and a surviving element pushes its follows.  Summed over depths until the
+// expectation has died away.  Used to deal the start elements to the waves so that every wave gets about the same
+// amount of work (a starred class next to the regex's end is a few hundred elements, one next to its beginning a
+// handful), and to cut a batch into slices for several GPUs.
+static double frontier_work_estimate(const Regex &re, double n, double sigma, std::vector<double> &cur, std::vector<double> &nxt) {
+  const size_t ns = re.st_c.size();
+  if (!ns || re.firsts.empty()) return 1.0;
+  cur.assign(ns, 0.0);
+  for (int32_t f : re.firsts) cur[(size_t)f] += 1.0;
+  double work = 0.0, rows = n;
+  if (sigma < 2.0) sigma = 2.0;
+  for (int depth = 0; depth < 48; depth++) {
+    const double p = std::min(1.0, rows / sigma);      // the step at this depth survives
+    rows = std::max(1.0, rows / sigma);
+    nxt.assign(ns, 0.0);
+    double level = 0.0, alive = 0.0;
+    for (size_t s = 0; s < ns; s++) {
+      const double c = cur[s];
+      if (c == 0.0) continue;
+      level += c;
+      if (re.last_stops && re.st_last[s]) continue;
+      const double live = c * p;
+      for (int32_t j = re.fol_off[s]; j < re.fol_off[s + 1]; j++) { nxt[(size_t)re.fol[j]] += live; alive += live; }
+    }
+    work += level;
+    if (alive < 1e-3) break;
+    if (work > 1e9) break;
+    cur.swap(nxt);
+  }
+  return work;
+}
+
+// The order in which a batch's start elements are written to the work queue.  k_frontier_init deals element i to
+// slice i % kSub, and a launch hands slice s's entries to the waves s, s + kSub, s + 2 kSub .. in contiguous chunks
+// (frontier_pass): which wave gets element i is a function of i, the element count and the number of waves.  The
+// elements are sorted by expected work and dealt to the waves in serpentine passes (heaviest first), so the waves'
+// totals come out even; the element order itself carries no meaning (results are grouped by regex afterwards).
+static void balanced_start_order(const std::vector<double> &work, size_t waves, std::vector<uint32_t> &perm /* position -> element */) {
+  const size_t count = work.size();
+  perm.resize(count);
+  std::vector<uint32_t> by_work(count);
+  for (size_t i = 0; i < count; i++) by_work[i] = (uint32_t)i;
+  std::stable_sort(by_work.begin(), by_work.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
+  if (waves < kSub) waves = kSub;
+  std::vector<std::vector<uint32_t>> pos(waves);
+  for (size_t i = 0; i < count; i++) {
+    const size_t s = i % kSub, j = i / kSub;
+    const size_t cnt_s = count > s ? (count - s + kSub - 1) / kSub : 0;
+    const size_t class_waves = (waves - s + kSub - 1) / kSub;
+    const size_t chunk = (cnt_s + class_waves - 1) / class_waves;
+    size_t w = s + kSub * (chunk ? j / chunk : 0);
+    if (w >= waves) w = s;
+    pos[w].push_back((uint32_t)i);
+  }
+  size_t next = 0;
+  for (size_t pass = 0; next < count; pass++) {
+    for (size_t q = 0; q < waves; q++) {
+      const size_t w = (pass & 1u) ? waves - 1 - q : q;
+      if (pass < pos[w].size()) perm[pos[w][pass]] = by_work[next++];
+    }
+  }
 }
 
 int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexBatch **out) {
@@ -1043,10 +1283,17 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   std::vector<uint32_t> fol(n_fol), q_state(n_first), st_num(n_states), first_off(k + 1, 0), start_final;
   std::vector<uint8_t> fol_c(n_fol);
   std::vector<uint32_t> fanout(k, 1);
+  std::vector<double> elem_work(n_first, 1.0);
+  const double est_n = (double)h->n, est_sigma = (double)std::max<uint32_t>(h->nslots, 2u);
   parallel_for(k, 1024, [&](size_t ra, size_t rb) {
+    std::vector<double> dp_a, dp_b;
     for (size_t r = ra; r < rb; r++) {
       const Regex &re = *res[r];
       const size_t base = st_base[r];
+      if (!re.firsts.empty()) {
+        const double w = frontier_work_estimate(re, est_n, est_sigma, dp_a, dp_b) / (double)re.firsts.size();
+        for (size_t f = 0; f < re.firsts.size(); f++) elem_work[first_base[r] + f] = w;
+      }
       size_t fo = fol_base[r], qo = first_base[r];
       uint32_t max_fanout = 1;
       for (size_t s = 0; s < re.st_c.size(); s++) {
@@ -1124,6 +1371,18 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   if (!recs.empty()) HIP_TRY(copy_sync(d_st, recs.data(), recs.size() * sizeof(StateRec), hipMemcpyHostToDevice, st), "H2D");
   if (!fol.empty()) HIP_TRY(copy_sync(d_fol, fol.data(), fol.size() * 4, hipMemcpyHostToDevice, st), "H2D");
   if (!q_state.empty()) HIP_TRY(copy_sync(b->d_first_state, q_state.data(), q_state.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+  {   // the frontier kernel's start elements, in the order that balances the waves (the full grid's wave count)
+    static const bool balance = !(getenv("FMX_FRONTIER_BALANCE") && atoi(getenv("FMX_FRONTIER_BALANCE")) == 0);      // A/B runs
+    std::vector<uint32_t> perm, q_perm(q_state.size());
+    if (balance && !q_state.empty()) {
+      balanced_start_order(elem_work, (size_t)std::max(1, h->cu_count * FMX_FWAVES * 4 / kFWaves) * kFWaves, perm);
+      for (size_t i = 0; i < q_state.size(); i++) q_perm[i] = q_state[perm[i]];
+    } else {
+      q_perm = q_state;
+    }
+    HIP_TRY(b->mem.alloc(&b->d_start_state, q_perm.size()), "hipMalloc");
+    if (!q_perm.empty()) HIP_TRY(copy_sync(b->d_start_state, q_perm.data(), q_perm.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+  }
   if (all_retree) {
     HIP_TRY(b->mem.alloc(&b->d_st_num, st_num.size()), "hipMalloc");
     HIP_TRY(b->mem.alloc(&b->d_first_off, first_off.size()), "hipMalloc");
@@ -1151,8 +1410,8 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
 // the slice's share of the start elements, buffer 1 is the first one written.
 __global__ __launch_bounds__(64) void k_frontier_reset(FrontierCtl *__restrict__ ctl, uint64_t count, const uint32_t *__restrict__ call /* {max_len, fresh}, pinned host */) {
   const uint32_t i = threadIdx.x;
-  const uint32_t max_len = call[0], fresh = call[1];
-  if (i == 0) ctl->fresh = fresh;
+  const uint32_t max_len = call[0], fresh = call[1], deep_len = call[3];
+  if (i == 0) { ctl->fresh = fresh; ctl->deep_len = deep_len; }
   if (!fresh) return;                      // a chain that continues a call
   SliceCtl &q = ctl->q[i];
   q.tail[0] = count > i ? (count - i + kSub - 1) / kSub : 0;
@@ -1233,7 +1492,9 @@ __global__ __launch_bounds__(kScanChunk) void k_res_scan_add(uint32_t *__restric
 __global__ __launch_bounds__(256) void k_res_scatter(const fmx_result *__restrict__ seg, uint64_t seg_cap,
                                                       const FrontierCtl *__restrict__ ctl,
                                                       const uint32_t *__restrict__ start, uint32_t *__restrict__ fill,
-                                                      fmx_result *__restrict__ out, uint64_t out_cap) {
+                                                      fmx_result *__restrict__ own, uint64_t own_cap, const ExportDst *__restrict__ dst) {
+  uint64_t out_cap;
+  fmx_result *out = group_out(dst, own, own_cap, out_cap);
   const uint32_t sl = blockIdx.y;
   const uint64_t mine = min((uint64_t)ctl->res_count[sl].v, seg_cap);
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mine; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -1248,12 +1509,15 @@ __global__ __launch_bounds__(256) void k_res_scatter(const fmx_result *__restric
 // contiguous stretch of `out`: when it fits (it nearly always does) it is sorted in LDS -- an insertion sort is a
 // chain of dependent accesses, 0.1 us each in LDS against 0.5 in L2.
 constexpr uint32_t kSortStage = 768;      // results (18 KB)
-__global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ out, const uint32_t *__restrict__ start, uint32_t k,
-                                                   BigGroups *__restrict__ big) {
+__global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ own, uint64_t own_cap, const uint32_t *__restrict__ start, uint32_t k,
+                                                   BigGroups *__restrict__ big, const ExportDst *__restrict__ dst) {
   __shared__ fmx_result s_r[kSortStage];
+  uint64_t out_cap;
+  fmx_result *out = group_out(dst, own, own_cap, out_cap);
   const uint32_t r0 = blockIdx.x * blockDim.x, r = r0 + threadIdx.x;
   const uint32_t r_end = r0 + blockDim.x < k ? r0 + blockDim.x : k;
   const uint32_t base = start[r0], span = start[r_end] - base;      // uniform over the workgroup
+  if ((uint64_t)start[r_end] > out_cap) return;                      // more results than the buffer holds: the call fails with FMX_ERR_OVERFLOW, nothing to order
   const bool staged = span <= kSortStage;
   if (staged) {
     for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) s_r[i] = out[base + i];
@@ -1287,8 +1551,10 @@ __global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ out, 
 
 // The groups k_res_sort listed: one workgroup per group, bitonic sort by (len, sp, ep) in LDS (100 k regexes give a
 // few hundred such groups -- a starred class matches at every length; ordering them on the host cost 0.13 ms).
-__global__ __launch_bounds__(256) void k_res_sort_mid(fmx_result *__restrict__ out, BigGroups *__restrict__ big) {
+__global__ __launch_bounds__(256) void k_res_sort_mid(fmx_result *__restrict__ own, uint64_t own_cap, BigGroups *__restrict__ big, const ExportDst *__restrict__ dst) {
   __shared__ fmx_result s_r[kMidGroup];
+  uint64_t out_cap;
+  fmx_result *out = group_out(dst, own, own_cap, out_cap);
   const uint32_t nb = big->n < kBigMax ? big->n : kBigMax;
   if (blockIdx.x == 0 && threadIdx.x == 0 && big->n > kBigMax) atomicAdd(&big->n_host, big->n - kBigMax);
   auto less = [](const fmx_result &a, const fmx_result &b) {
@@ -1298,6 +1564,7 @@ __global__ __launch_bounds__(256) void k_res_sort_mid(fmx_result *__restrict__ o
   };
   for (uint32_t g = blockIdx.x; g < nb; g += gridDim.x) {
     const uint32_t lo = big->ent[2 * g], m = big->ent[2 * g + 1];
+    if ((uint64_t)lo + m > out_cap) continue;
     if (m > kMidGroup) {
       if (threadIdx.x == 0) atomicAdd(&big->n_host, 1u);
       continue;
@@ -1413,7 +1680,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   HIP_TRY(hipEventRecord(e0, st), "hipEventRecord");
   // Launches are chained on the stream without host round trips; the host looks at the summary after every
   // chain.  A launch that finds the queue empty returns at once.
-  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 2u;
+  // one launch per chain on the full grid: a batch like C4 is done by one, and a second launch that finds nothing costs
+  // ~8 us with its advance kernel (0.4170 -> 0.4109 ms per call); a search that needs more pays a host look per launch
+  static const uint32_t kChain = getenv("FMX_FRONTIER_CHAIN") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_CHAIN"))) : 1u;
   // rounds a wave works at most in one launch (what it still holds then goes to the queue): the bound that makes
   // every wave end.  C4 is done in one launch of ~50 rounds per wave (the longest wave: 113); measured 64 / 96 / 128 /
   // 256: 0.565 / 0.548 / 0.527 / 0.534 ms
@@ -1462,7 +1731,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     // a call's first chain begins with the reset and the start elements (h_dst->fresh; both return at once otherwise):
     // one graph launch per call
     k_frontier_reset<<<1, 64, 0, s>>>(d_ctl, b->n_first, &b->h_dst->max_len);
-    k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, s>>>(fq, b->nfa, b->d_first_state, b->n_first, kt.k ? 0 : h->n, sub_cap, d_ctl, b->d_rcnt, (uint32_t)b->k);
+    k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, s>>>(fq, b->nfa, b->d_start_state, b->n_first, kt.k ? 0 : h->n, sub_cap, d_ctl, b->d_rcnt, (uint32_t)b->k);
     for (uint32_t j = 0; j < len; j++) {
       launch_pass(s, grid, j, grid == grid_small ? kRoundsSmall : (plan.empty() ? kRounds : plan[std::min<size_t>(j, plan.size() - 1)]));
       k_frontier_advance<<<1, 64, 0, s>>>(d_ctl, sub_cap, b->h_sum);      // the summary goes straight to pinned host memory
@@ -1482,6 +1751,15 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   b->h_dst->per = export_per ? per_regex_count : nullptr;
   b->h_dst->max_len = max_steps;
   b->h_dst->fresh = 1;
+  {   // ceil(log_sigma n) steps narrow an interval to a single row; what still branches two steps later is rare on any
+      // index (a row has one preceding character) and is what the longest chains of dependent steps are made of
+    const double sig = (double)std::max<uint32_t>(h->nslots, 2u);
+    static const int deep_extra = getenv("FMX_FRONTIER_DEEP") ? atoi(getenv("FMX_FRONTIER_DEEP")) : 2;      // A/B runs
+    b->h_dst->deep_len = (uint32_t)std::max(1.0, std::ceil(std::log((double)h->n + 1.0) / std::log(sig)) + deep_extra);
+  }
+  static const bool no_direct = getenv("FMX_EXPORT_DIRECT") && atoi(getenv("FMX_EXPORT_DIRECT")) == 0;      // A/B runs
+  b->h_dst->direct = (dev && export_out && !no_direct) ? 1u : 0u;
+  const bool direct = b->h_dst->direct != 0;
   b->matches++;
   uint64_t total = b->n_first;               // elements queued for the next launch
   const uint64_t kSmallTotal = (uint64_t)grid_small * per_wg;
@@ -1502,9 +1780,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: start[k] = total
     k_res_scan_chunks<<<nparts, kScanChunk, 0, s>>>(b->d_rcnt, n_scan, b->d_rstart, b->d_rpart, b->d_rfill, b->d_big);
     k_res_scan_add<<<nparts, kScanChunk, 0, s>>>(b->d_rstart, n_scan, b->d_rpart);
-    k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)rcap);
-    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_big);
-    k_res_sort_mid<<<256, 256, 0, s>>>(d_res, b->d_big);
+    k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)rcap, b->h_dst);
+    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, (uint64_t)rcap, b->d_rstart, (uint32_t)b->k, b->d_big, b->h_dst);
+    k_res_sort_mid<<<256, 256, 0, s>>>(d_res, (uint64_t)rcap, b->d_big, b->h_dst);
     k_res_export<<<256, 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst, b->h_tot);
     return hipGetLastError();
   };
@@ -1588,7 +1866,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (per_regex_count) { stage_per.assign(b->k, 0u); per_regex_count = stage_per.data(); }
   }
   if (tot.res_count && (!export_out || staged))
-    HIP_TRY(copy_sync(out, d_res, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost, st), "D2H(results)");
+    HIP_TRY(copy_sync(out, direct ? dev_out : d_res, (size_t)tot.res_count * sizeof(fmx_result), hipMemcpyDeviceToHost, st), "D2H(results)");
   mark("results copied");
   for (size_t j = 0; j < extra; j++) {           // dfa.scala:270-273 with the start StatePoint(0,0,0,n)
     fmx_result &o = out[tot.res_count + j];
@@ -1656,6 +1934,9 @@ extern "C" {
 #ifdef FMX_WAVELOG
 int fmx_debug_phaselog(void *out, size_t bytes) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phaselog), std::min(bytes, sizeof g_phaselog)) == hipSuccess ? FMX_OK : FMX_ERR_HIP;
+}
+int fmx_debug_wavetrace(void *out, size_t bytes) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wavetrace), std::min(bytes, sizeof g_wavetrace)) == hipSuccess ? FMX_OK : FMX_ERR_HIP;
 }
 int fmx_debug_wavelog(void *out, size_t bytes, int clear) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wavelog), std::min(bytes, sizeof g_wavelog)) != hipSuccess) return FMX_ERR_HIP;
@@ -1877,8 +2158,9 @@ struct RegexBatchMulti {
 
 // What a regex is expected to cost: its start elements, its states (each is stepped at least once per path through
 // it) and its follow entries (every one is a push); a starred class shows up as many follows.
-static double regex_work_estimate(const Regex &re) {
-  return 4.0 * (double)re.firsts.size() + (double)re.st_c.size() + (double)re.fol.size();
+static double regex_work_estimate(const Regex &re, double n, double sigma) {
+  std::vector<double> a, b;
+  return frontier_work_estimate(re, n, sigma, a, b) + 4.0 * (double)re.firsts.size();
 }
 
 int fmx_regex_batch_create_multi(fmx_index *const *idxs, size_t n_idx, fmx_regex *const *res, size_t k,
@@ -1895,7 +2177,15 @@ int fmx_regex_batch_create_multi(fmx_index *const *idxs, size_t n_idx, fmx_regex
   std::unique_ptr<RegexBatchMulti> m(new RegexBatchMulti());
   m->k = k;
   std::vector<double> cum(k + 1, 0.0);
-  for (size_t r = 0; r < k; r++) cum[r + 1] = cum[r] + regex_work_estimate(*reinterpret_cast<const Regex *>(res[r]));
+  {
+    const Index *h0 = reinterpret_cast<const Index *>(idxs[0]);
+    std::vector<double> w(k, 0.0);
+    parallel_for(k, 1024, [&](size_t a, size_t b) {
+      for (size_t r = a; r < b; r++)
+        w[r] = regex_work_estimate(*reinterpret_cast<const Regex *>(res[r]), (double)h0->n, (double)std::max<uint32_t>(h0->nslots, 2u));
+    });
+    for (size_t r = 0; r < k; r++) cum[r + 1] = cum[r] + w[r];
+  }
   m->cut.assign(n_idx + 1, k);
   m->cut[0] = 0;
   for (size_t r = 1; r < n_idx; r++) {

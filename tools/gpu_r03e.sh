@@ -1,0 +1,15 @@
+#!/bin/bash
+# K5 A/B on one box: critical-path priority, direct export, wave timeline
+set -o pipefail
+O=gpurun_out/${1:-r03e}; mkdir -p $O
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo build failed; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "regex" > $O/pytest_regex.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $O/pytest_regex.log
+[ $rc -eq 0 ] || exit $rc
+export FMX_FRONTIER_CHAIN=1
+run() { timeout -k 10 200 python tools/c4_quick.py 40 2>&1 | grep -v amdgpu.ids | tee -a $O/ab.txt; }
+unset FMX_LIB; run
+FMX_EXPORT_DIRECT=0 run
+for v in noprio prio8; do export FMX_LIB=$PWD/findex_amd/lib/variants/libfmx_$v.so; run; done
+unset FMX_LIB; run
+export FMX_LIB=$PWD/findex_amd/lib/variants/libfmx_wl.so
+timeout -k 10 200 python tools/wave_timeline.py c4 2>&1 | grep -v amdgpu.ids | cut -c1-900 > $O/timeline.txt; tail -12 $O/timeline.txt

@@ -1,0 +1,14 @@
+#!/bin/bash
+set -o pipefail
+O=gpurun_out/${1:-r03i}; mkdir -p $O
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo build failed; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "regex or thompson or dfa" > $O/pytest_regex.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 $O/pytest_regex.log
+[ $rc -eq 0 ] || exit $rc
+export FMX_FRONTIER_CHAIN=1
+run() { timeout -k 10 200 python tools/c4_quick.py 40 2>&1 | grep -v amdgpu.ids | tee -a $O/ab.txt; }
+unset FMX_LIB; run
+export FMX_LIB=$PWD/findex_amd/lib/variants/libfmx_noxp.so; run
+unset FMX_LIB
+for d in 1 3 4; do echo "deep_extra=$d" | tee -a $O/ab.txt; FMX_FRONTIER_DEEP=$d run; done
+export FMX_LIB=$PWD/findex_amd/lib/variants/libfmx_wl.so
+timeout -k 10 200 python tools/wave_timeline.py c4 2>&1 | grep -v amdgpu.ids | cut -c1-2500 > $O/timeline.txt; sed -n 3,6p $O/timeline.txt | cut -c1-400; tail -2 $O/timeline.txt | cut -c1-700

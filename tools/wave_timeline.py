@@ -10,7 +10,7 @@ import numpy as np, torch
 import bench, findex_amd
 from findex_amd import _lib
 wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
-log2n, k, seed, max_len = bench.REGEX[wl]
+log2n, k, seed, max_len = bench.REGEX[wl][:4]
 n = 1 << log2n
 dev = torch.device("cuda", 0)
 bwt, eof = bench.make_bwt(torch, n, bench.C4_ALPHABET, seed, dev); torch.cuda.synchronize()
@@ -72,3 +72,16 @@ if hasattr(L, "fmx_debug_phaselog"):
             n = float(ph[m, 4].sum())
             print("late rounds (%d waves, %d rounds): cycles per round  take %.0f | stage %.0f | wait + ranks %.0f | bookkeeping %.0f  (total %.0f)"
                   % (m.sum(), n, tot[0] / n, tot[1] / n, tot[2] / n, tot[3] / n, tot.sum() / n))
+
+# ---- per-round trace of the waves that ended last (launch 0): held elements / pool / deepest length / narrow / express
+if hasattr(L, "fmx_debug_wavetrace"):
+    tr = np.zeros((1 << 15, 128), dtype=np.uint32)
+    L.fmx_debug_wavetrace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    if L.fmx_debug_wavetrace(tr.ctypes.data_as(ctypes.c_void_p), tr.nbytes) == 0:
+        e = log[0]
+        order = np.argsort(e[:, 2])[::-1][:4]
+        for wv in order:
+            row = tr[wv]
+            txt = " ".join("%d/%d/L%d%s%s" % (v & 0xFF, (v >> 8) & 0xFFF, (v >> 20) & 0xFF, "n" if (v >> 28) & 1 else "", ("x%d" % (v >> 29)) if v >> 29 else "")
+                           for v in row.tolist() if v)
+            print("wave %d (held/pool/deepest by round): %s" % (wv, txt))

@@ -1085,12 +1085,22 @@ def test_bytes_layout_synthetic(n, lo, hi, bytes_layout):
         check_search(hip, orc, lf_walk_patterns(orc, rng, 300, m, 0.1, alphabet=syms) + [b"", b"\x00"])
 
 
-def test_bytes_layout_c5_shape(bytes_layout):
-    """BASELINE config C5's index shape at a quarter of its size (n = 2^32 + 999, sigma = 128: the
-    one-hot vectors would still fit, the compact layout is forced): positions beyond 32 bits, the
-    same size-independent properties as test_full_size_properties."""
-    torch = _torch()
-    n = (1 << 32) + 999
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("checkpoints", ["auto", "superblock"])
+def test_bytes_layout_c5_shape(checkpoints):
+    """BASELINE config C5's index at its own size: n = 2^34 rows (a 16 GiB BWT), sigma = 128, the bytes + checkpoints
+    layout the library picks by itself (the one-hot vectors would need 314 GB), 80 GiB resident, and C5's per-GPU
+    batch of 1M x 24-character patterns.  Run in both checkpoint forms (absolute 32-bit counts; relative counts +
+    64-bit superblocks).  The reference cannot represent such an index (Int positions) and the oracle's 32-bit lists
+    stop at 2^32, so the checks are size-independent properties:
+      * occ(c, i) equals a brute-force count of the device BWT prefix (torch), also past row 2^32 and 2^33,
+      * the symbol totals add up to n - 1 and the column sums to i + 1,
+      * 1M LF-walk patterns hit and each hit interval contains the row its walk ended on; misses made by replacing
+        one byte report sp == ep; ragged prefixes of the patterns hit intervals that contain the full patterns',
+      * getPrevRange over the alphabet partitions an interval (getIntervalPrevRange)."""
+    import torch
+    assert torch.cuda.is_available()
+    n = 1 << 34
     g = torch.Generator(device="cuda")
     g.manual_seed(55)
     bwt = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -1099,11 +1109,15 @@ def test_bytes_layout_c5_shape(bytes_layout):
         bwt[a:b] = torch.randint(1, 129, (b - a,), generator=g, device="cuda", dtype=torch.uint8)
     eof = n // 3
     torch.cuda.synchronize()
-    hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None)
+    findex_amd.set_checkpoints(checkpoints)        # the layout itself is left to the library ("auto")
+    try:
+        hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None)
+    finally:
+        findex_amd.set_checkpoints("auto")
     st = hip.stats()
-    assert st["layout"] == 1 and st["block_bytes"] == 132
+    assert st["layout"] == 1 and st["block_bytes"] == 132 and st["index_bytes"] > 75 << 30
     rng = np.random.default_rng(2)
-    qs_i = np.concatenate([rng.integers(0, n, 5), [0, eof, n - 1]]).astype(np.int64)
+    qs_i = np.concatenate([rng.integers(0, n, 4), [0, eof, (1 << 32) - 1, 1 << 32, (1 << 33) + 12345, n - 1]]).astype(np.int64)
     qs_c = rng.integers(1, 129, qs_i.size).astype(np.uint8)
     got = hip.occ_batch(qs_c, qs_i)
     for c, i, gv in zip(qs_c, qs_i, got):
@@ -1116,12 +1130,36 @@ def test_bytes_layout_c5_shape(bytes_layout):
         assert int(gv) == want, (c, i)
     col = hip.occ_batch(np.arange(0, 129, dtype=np.uint8), np.full(129, n - 1, dtype=np.int64))
     assert int(col.sum()) == n
-    k, m = 20000, 24
+    for i in (0, eof, (1 << 33) + 7):
+        assert int(hip.occ_batch(np.arange(0, 129, dtype=np.uint8), np.full(129, i, dtype=np.int64)).sum()) == i + 1
+    del bwt
+    k, m = 1_000_000, 24
     rows = rng.integers(0, n, k).astype(np.uint64)
     b, end = hip.lf_walk_batch(rows, m)
     pats = np.ascontiguousarray(b[:, ::-1])
-    sp, ep = hip.search_batch(pats.reshape(-1), np.arange(k + 1, dtype=np.uint64) * m)
+    off = np.arange(k + 1, dtype=np.uint64) * m
+    hip.stats_reset()
+    sp, ep = hip.search_batch(pats.reshape(-1), off)
     assert (sp < ep).all() and (sp <= end).all() and (end < ep).all()
+    assert hip.stats()["backward_steps"] == k * m                 # every step of a hit pattern is executed
+    # misses: one byte replaced by a symbol outside the alphabet -> the loop's final values are an empty interval
+    bad = pats[:50_000].copy()
+    bad[np.arange(50_000), rng.integers(0, m, 50_000)] = 200
+    bsp, bep = hip.search_batch(bad.reshape(-1), off[:50_001])
+    assert (bsp == bep).all()
+    # the same patterns cut into ragged pieces: a prefix of a hit pattern hits an interval that contains the full hit
+    cut = rng.integers(1, m + 1, 100_000)
+    pieces = [pats[j, :cut[j]].tobytes() for j in range(100_000)]
+    pbuf, poff = pack_patterns(pieces)
+    psp, pep = hip.search_batch(pbuf, poff)
+    assert (psp <= sp[:100_000]).all() and (ep[:100_000] <= pep).all() and (psp < pep).all()
+    full = cut == m
+    assert np.array_equal(psp[full], sp[:100_000][full]) and np.array_equal(pep[full], ep[:100_000][full])
+    for a, bnd in ((0, n), (int(sp[0]), int(ep[0])), ((1 << 33) - 5, (1 << 33) + 100000)):
+        parts = hip.getIntervalPrevRange(a, bnd, 0, 255)
+        assert sum(e - s for s, e in parts) == bnd - a
+        srt = sorted(parts)
+        assert all(srt[j][1] <= srt[j + 1][0] for j in range(len(srt) - 1))
 
 
 # ---------------------------------------------------------------- full-size properties (on device)
@@ -1129,6 +1167,20 @@ def _torch():
     import torch
     assert torch.cuda.is_available()
     return torch
+
+
+def oracle_at_size(torch, bwt_dev, eof, what):
+    """The CPU oracle over the SAME device BWT a full-size test uses (bytes copied to the host, inverted position
+    lists sorted on all the box's cores: 6 n bytes of host memory, 32-bit entries so n <= 2^32) -- or None, with the
+    reason printed, when the host cannot hold it: the size-independent properties are then all that is checked."""
+    import bench
+    cores = bench.effective_cores()
+    orc, t_build = bench.oracle_index(torch, bwt_dev, eof, cores, 0)
+    if orc is None:
+        print("[%s] FALLBACK: properties only (the host cannot hold the oracle's index at n=%d)" % (what, bwt_dev.numel()))
+        return None, cores
+    print("[%s] oracle built on the run's own index (n=%d) in %.1fs on %d cores: comparing bit for bit" % (what, bwt_dev.numel(), t_build, cores))
+    return orc, cores
 
 
 @pytest.mark.timeout(900)
@@ -1185,6 +1237,31 @@ def test_full_size_properties(log2n, extra, sigma):
     off = (np.arange(k + 1, dtype=np.uint64) * m)
     sp, ep = hip.search_batch(pats.reshape(-1), off)
     assert (sp < ep).all() and (sp <= end).all() and (end < ep).all()
+    # the oracle at the config's own size: the reference algorithm (inverted lists + binary-search occ,
+    # bwtmerger.scala:354-375, findex.scala:15-31) over this very BWT, 100k+ patterns (hits, and misses made by
+    # replacing one byte) and random occ / getPrevRange operands, bit for bit, executed steps included
+    orc, cores = oracle_at_size(torch, bwt, eof, "full_size[%d-%d-%d]" % (log2n, extra, sigma)) if n <= (1 << 32) else (None, 0)
+    if orc is not None:
+        ks = min(k, 120_000)
+        sample = pats[:ks].copy()
+        mut = rng.random(ks) < 0.2
+        sample[mut, rng.integers(0, m, int(mut.sum()))] = rng.integers(1, sigma + 1, int(mut.sum())).astype(np.uint8)
+        s_off = np.arange(ks + 1, dtype=np.uint64) * m
+        hip.stats_reset()
+        gsp, gep = hip.search_batch(sample.reshape(-1), s_off)
+        wsp, wep, wsteps = orc.search_batch(sample.reshape(-1), s_off, threads=cores)
+        assert np.array_equal(gsp, wsp) and np.array_equal(gep, wep)
+        assert hip.stats()["backward_steps"] == int(wsteps.sum())
+        assert 0 < int((wsp >= wep).sum()) < ks          # both hits and misses were compared
+        qc = rng.integers(0, sigma + 2, 50_000).astype(np.uint8)
+        qi = rng.integers(-1, n, 50_000).astype(np.int64)
+        assert np.array_equal(hip.occ_batch(qc, qi).astype(np.int64), orc.occ_batch(qc, qi))
+        a_sp = rng.integers(0, n, 50_000).astype(np.uint64)
+        a_ep = np.minimum(a_sp + rng.integers(0, 1 << 20, 50_000).astype(np.uint64), np.uint64(n))
+        g1, g2 = hip.prev_range_batch(a_sp, a_ep, qc)
+        w1, w2 = orc.prev_range_batch(a_sp, a_ep, qc)
+        assert np.array_equal(g1, w1) and np.array_equal(g2, w2)
+        orc.close()
     # partition property of one step
     for a, bnd in ((0, n), (int(sp[0]), int(ep[0])), (n // 2, n // 2 + 100000)):
         parts = hip.getIntervalPrevRange(a, bnd, 0, 255)
@@ -1223,17 +1300,16 @@ def test_c4_full_size_regex_batch():
     finally:
         findex_amd.set_layout("auto")
         findex_amd.set_checkpoints("auto")
-    del bwt
-    trees = []
-
-    def compiles(re):
-        try:
-            trees.append(findex_amd.ReTree(findex_amd.REParser.re2post(re)))
-            return True
-        except (findex_amd.MatchError, findex_amd.Re2PostSyntax):
-            return False
-    res = regex_workload.generate(k, 4, compiles)
-    assert max(len(t.tables()["c"]) for t in trees[:500]) <= 32
+    # the bench's regex list (tools/regex_workload.py, seed 4): candidates compiled in one fmx_regex_compile_batch call
+    import random
+    prng = random.Random(4)
+    cand = [regex_workload.gen_one(prng) for _ in range(k + 64)]
+    cs = findex_amd.ReTree.compile_batch(cand)
+    keep = np.nonzero(cs.ok())[0][:k]
+    assert keep.size == k
+    res = [cand[i] for i in keep]
+    trees = cs.select(keep)
+    assert max(len(trees[i].tables()["c"]) for i in range(500)) <= 32
     batch = findex_amd.ReTree.prepare_batch(hip, trees)
     hip.stats_reset()
     out, per = batch.match_raw(max_steps=64)
@@ -1249,6 +1325,29 @@ def test_c4_full_size_regex_batch():
         sel = pick[out["len"][pick] == ln]
         for j, s in zip(sel, hip.nextSubstr_batch(out["sp"][sel], int(ln))):
             assert len(s) == ln and pyre.fullmatch(res[out[j]["regex"]].encode(), s, pyre.S), (res[out[j]["regex"]], s)
+    # the oracle at C4's own size: ReTree._matchSA (re2/retree.scala:618-653) in C over this very BWT for the first
+    # 12k regexes -- every match up to length 64 as a multiset, and the reference's own answer under its default limits
+    # (1024 / 1000) as lists in its own order -- against the two GPU modes, bit for bit
+    orc, cores = oracle_at_size(torch, bwt, n // 3, "c4_full_size")
+    del bwt
+    if orc is not None:
+        ks = 12_000
+        tables = [trees[i].tables() for i in range(ks)]
+        want, pops, _ = orc.match_tables_batch(tables, max_len=64, threads=cores)
+        got = out[out["regex"] < ks]
+        assert got.size == want.size and all(np.array_equal(got[f], want[f]) for f in ("regex", "len", "sp", "ep"))
+        sub = findex_amd.ReTree.prepare_batch(hip, trees.select(np.arange(ks)))
+        hip.stats_reset()
+        sub_out, _ = sub.match_raw(max_steps=64)
+        assert hip.stats()["backward_steps"] == pops and np.array_equal(sub_out, got)
+        hip.stats_reset()
+        ref_out, ref_per = sub.match_raw(mode="reference", maxBranching=1024, maxIterations=1000)
+        wref, rpops, _ = orc.match_tables_batch(tables, maxBranching=1024, maxIterations=1000, threads=cores, ordered=True)
+        assert ref_out.size == wref.size and all(np.array_equal(ref_out[f], wref[f]) for f in ("regex", "len", "sp", "ep"))
+        assert hip.stats()["backward_steps"] == rpops
+        assert np.array_equal(ref_per, np.bincount(wref["regex"], minlength=ks).astype(np.uint32))
+        orc.close()
+        del sub
     # the other layout (octets, two lines per rank query, 64-bit superblock counts) must give the same list, byte for byte
     assert hip.stats()["layout"] == 0 and hip_b.stats()["layout"] == 1
     out_b, per_b = findex_amd.ReTree.prepare_batch(hip_b, trees).match_raw(max_steps=64)

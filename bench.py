@@ -263,18 +263,33 @@ def host_mem_available():
         return 0
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the library's sources: what a committed PMC profile is stamped with, so that
+    a profile of another build is not quoted as this one's traffic (there is no .git on the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "findex_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "fmx.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of the dominant kernel from the newest COMMITTED PMC profile of this workload
     (profiles/r*_<workload>_counters.csv, written by tools/summarize_prof.py from separate rocprofv3 --pmc
     passes): FETCH_SIZE KiB x the bytes one KiB stands for in this access pattern (calibrated in the same
     profile on a k_occ launch of known byte count, MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB x 1024.
-    Not measured in this run: returns (bytes, file name) or None when no such profile is in the tree."""
+    Not measured in this run: returns (bytes, file name) or None when no such profile is in the tree -- or (None,
+    reason) when the newest one was taken from other sources than the ones running now (its SRC_SHA16 stamp)."""
     import csv
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_counters.csv" % workload))):
-        vals, per_kib, calls, disp = {}, None, None, None
+        vals, per_kib, calls, disp, stamp = {}, None, None, None, None
         for r in csv.DictReader(open(f)):
+            if r["Counter"] == "SRC_SHA16":
+                stamp = r["Mean"]
             if kernel in r["Kernel"]:
                 vals[r["Counter"]] = float(r["Mean"])
                 disp = float(r["Dispatches"])
@@ -285,6 +300,8 @@ def pmc_traffic(workload, kernel):
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals and per_kib:
             per_launch = calls is None and 1.0 or disp / calls      # a regex call = several dispatches of the kernel
             best = (int((vals["FETCH_SIZE"] * per_kib + vals["WRITE_SIZE"] * 1024) * per_launch), os.path.basename(f))
+            if stamp != source_hash():
+                best = (None, "%s is stale: taken at source hash %s, this build is %s" % (os.path.basename(f), stamp, source_hash()))
     return best
 
 
@@ -466,8 +483,9 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "bound": "hbm", "kernel": "k_search4",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic[0] if traffic else None,
-        "traffic_source": ("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
-                           % traffic[1]) if traffic else "no PMC profile of this workload committed",
+        "traffic_source": (traffic[1] if traffic and traffic[0] is None else
+                           ("committed profile profiles/%s (separate rocprofv3 --pmc passes of this very source; not "
+                            "measured in this run)" % traffic[1]) if traffic else "no PMC profile of this workload committed"),
         "algorithmic_bytes_per_launch": alg_bytes,
         "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d operand bytes (patterns, "
                              "offsets, intervals)" % (requests_per_step, line_bytes, lookups_per_step, operand_bytes),
@@ -484,6 +502,8 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         # the limit that binds this access pattern: distinct dependent memory requests per second
         roof["requests_G_per_s"] = all_requests / ksec / 1e9
         roof["request_ceiling_G_per_s"] = REQUEST_CEILING_G_PER_S
+        roof["request_ceiling_source"] = ("tools/ubench/chain.hip (dependent 64-byte requests, 16 chains per wave, full occupancy): "
+                                          "profiles/r02_ubench_chain_sizes.txt -- 54 G/s over 8 GiB, 51 G/s over a 77 GiB table")
         roof["request_frac"] = roof["requests_G_per_s"] / REQUEST_CEILING_G_PER_S
     else:
         roof["note"] = ("the rank dictionary (%.0f MB) stays in the 256 MiB Infinity Cache: bytes are served on die, the "
@@ -514,7 +534,10 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
             "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
                            % (world, ", all_gather of (sp,ep) per step overlapped with the next step's search" if use_dist else ""),
             "ranks_in_group": dist.get_world_size() if use_dist else 1,
-            "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
+            "index_gib": s1["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
+            "tables_build_ms": s1["tables_build_ms"],
+            "tables_build_ms_is": "the k-mer jump table (K = %d), built at the handle's first search (or by fmx_prepare): "
+                                  "paid once per open on top of index_build_ms" % int(s1["ktab_k"]),
             "index_layout": "one-hot bit-vectors, 64-B blocks" if onehot else "BWT bytes + checkpoints",
         },
         "roofline": roof,
@@ -719,8 +742,9 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
                     "(truncated_at_max_len); on a real text a frontier dies by itself" % max_len,
         }
     roof["traffic"] = traffic[0] if traffic else None
-    roof["traffic_source"] = (("committed profile profiles/%s (separate rocprofv3 --pmc passes; not measured in this run)"
-                               % traffic[1]) if traffic else "no PMC profile of this workload committed")
+    roof["traffic_source"] = (traffic[1] if traffic and traffic[0] is None else
+                              ("committed profile profiles/%s (separate rocprofv3 --pmc passes of this very source; not "
+                               "measured in this run)" % traffic[1]) if traffic else "no PMC profile of this workload committed")
     out = {
         "metric": "rank_queries_per_sec",
         "value": ranks_all * args.steps / dt / 1e6,
@@ -749,7 +773,7 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
             "results_per_call": results_all, "backward_steps_per_call": ranks_all / 2,
             "parallelism": "regexes sharded over %d GPU(s), index replicated" % world,
             "ranks_in_group": dist.get_world_size() if use_dist else 1,
-            "index_gib": st["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
+            "index_gib": s1["index_bytes"] / 2**30, "index_build_ms": st["build_ms"], "tables_build_ms": s1["tables_build_ms"],
         },
         "roofline": roof,
     }

@@ -12,9 +12,12 @@
  *      bindings/fmx_jni.c -Lfindex_amd/lib -lfmx -o libfmx_jni.so
  *
  * Conventions: handles travel as jlong; a non-zero fmx status becomes java.lang.Exception(fmx_last_error()) --
- * the reference throws plain Exceptions for bad files too (bwtmerger.scala:153,261-262,430); primitive arrays
- * are pinned with Get/ReleasePrimitiveArrayCritical around the one library call, so nothing is copied or
- * allocated on the native side; direct ByteBuffers over fmx_host_alloc memory give the pipelined DMA path.
+ * the reference throws plain Exceptions for bad files too (bwtmerger.scala:153,261-262,430).  Primitive arrays
+ * are COPIED in and out with Get/Set<Type>ArrayRegion around the library call: every batch entry point of libfmx
+ * blocks on the GPU (stream synchronisation, device allocation, graph capture), and JNI forbids blocking inside a
+ * Get/ReleasePrimitiveArrayCritical region (it stalls the collector for every thread and can deadlock when several
+ * threads call in) -- critical regions are used only around plain copy loops.  Callers with large batches use the
+ * Direct variants: direct ByteBuffers over fmx_host_alloc memory, no copy at all and the pipelined DMA path.
  */
 #include <jni.h>
 #include <stdint.h>
@@ -25,6 +28,18 @@
 
 #define H(h) ((fmx_index *)(intptr_t)(h))
 #define FN(name) Java_org_fmindex_HipFM_00024_##name
+
+/* copies of primitive arrays (see the header comment); NULL when the JVM is out of memory */
+static jbyte *in_bytes(JNIEnv *e, jbyteArray a, jsize n) {
+  jbyte *p = malloc((size_t)(n > 0 ? n : 1));
+  if (p && n > 0) (*e)->GetByteArrayRegion(e, a, 0, n, p);
+  return p;
+}
+static jlong *in_longs(JNIEnv *e, jlongArray a, jsize n) {
+  jlong *p = malloc(sizeof(jlong) * (size_t)(n > 0 ? n : 1));
+  if (p && n > 0) (*e)->GetLongArrayRegion(e, a, 0, n, p);
+  return p;
+}
 
 static int rethrow(JNIEnv *e, int rc) { /* returns 1 when an exception is now pending */
   if (rc == FMX_OK || rc == FMX_TRUNCATED) return 0;
@@ -50,13 +65,13 @@ JNIEXPORT jlong JNICALL FN(openBlock0)(JNIEnv *e, jobject self, jbyteArray bwt, 
                                        jint device) {
   if ((*e)->GetArrayLength(e, bucketStarts) != 256) { rethrow(e, FMX_ERR_ARG); return 0; }
   jsize n = (*e)->GetArrayLength(e, bwt);
-  jbyte *b = (*e)->GetPrimitiveArrayCritical(e, bwt, 0);
-  jlong *bs = (*e)->GetPrimitiveArrayCritical(e, bucketStarts, 0);
+  jbyte *b = in_bytes(e, bwt, n);
+  jlong *bs = in_longs(e, bucketStarts, 256);
   fmx_index *h = 0;
   int rc = (b && bs) ? fmx_open_block((const uint8_t *)b, (uint64_t)n, (const int64_t *)bs, (uint64_t)rk0, device, &h)
                      : FMX_ERR_NOMEM;
-  if (bs) (*e)->ReleasePrimitiveArrayCritical(e, bucketStarts, bs, JNI_ABORT);
-  if (b) (*e)->ReleasePrimitiveArrayCritical(e, bwt, b, JNI_ABORT);
+  free(bs);
+  free(b);
   rethrow(e, rc);
   return (jlong)(intptr_t)h;
 }
@@ -84,14 +99,15 @@ JNIEXPORT jlong JNICALL FN(cf0)(JNIEnv *e, jobject self, jlong h, jint c) {
 JNIEXPORT void JNICALL FN(occBatch0)(JNIEnv *e, jobject self, jlong h, jbyteArray c, jlongArray i, jlongArray out) {
   jsize k = (*e)->GetArrayLength(e, c);
   if ((*e)->GetArrayLength(e, i) != k || (*e)->GetArrayLength(e, out) < k) { rethrow(e, FMX_ERR_ARG); return; }
-  jbyte *pc = (*e)->GetPrimitiveArrayCritical(e, c, 0);
-  jlong *pi = (*e)->GetPrimitiveArrayCritical(e, i, 0);
-  jlong *po = (*e)->GetPrimitiveArrayCritical(e, out, 0);
+  jbyte *pc = in_bytes(e, c, k);
+  jlong *pi = in_longs(e, i, k);
+  jlong *po = malloc(sizeof(jlong) * (size_t)(k > 0 ? k : 1));
   int rc = (pc && pi && po) ? fmx_occ_batch(H(h), (const uint8_t *)pc, (const int64_t *)pi, (uint64_t *)po, (size_t)k)
                             : FMX_ERR_NOMEM;
-  if (po) (*e)->ReleasePrimitiveArrayCritical(e, out, po, 0);
-  if (pi) (*e)->ReleasePrimitiveArrayCritical(e, i, pi, JNI_ABORT);
-  if (pc) (*e)->ReleasePrimitiveArrayCritical(e, c, pc, JNI_ABORT);
+  if (rc == FMX_OK && k > 0) (*e)->SetLongArrayRegion(e, out, 0, k, po);
+  free(po);
+  free(pi);
+  free(pc);
   rethrow(e, rc);
 }
 
@@ -99,15 +115,16 @@ JNIEXPORT void JNICALL FN(occBatch0)(JNIEnv *e, jobject self, jlong h, jbyteArra
 JNIEXPORT void JNICALL FN(searchBatch0)(JNIEnv *e, jobject self, jlong h, jbyteArray pat, jlongArray off, jlongArray out) {
   jsize k = (*e)->GetArrayLength(e, off) - 1;
   if (k < 0 || (*e)->GetArrayLength(e, out) < 2 * k) { rethrow(e, FMX_ERR_ARG); return; }
-  jbyte *p = (*e)->GetPrimitiveArrayCritical(e, pat, 0);
-  jlong *o = (*e)->GetPrimitiveArrayCritical(e, off, 0);
-  jlong *r = (*e)->GetPrimitiveArrayCritical(e, out, 0);
+  jbyte *p = in_bytes(e, pat, (*e)->GetArrayLength(e, pat));
+  jlong *o = in_longs(e, off, k + 1);
+  jlong *r = malloc(sizeof(jlong) * (size_t)(k > 0 ? 2 * k : 1));
   int rc = (p && o && r) ? fmx_search_batch(H(h), (const uint8_t *)p, (const uint64_t *)o, (uint64_t *)r,
                                             (uint64_t *)r + k, (size_t)k)
                          : FMX_ERR_NOMEM;
-  if (r) (*e)->ReleasePrimitiveArrayCritical(e, out, r, 0);
-  if (o) (*e)->ReleasePrimitiveArrayCritical(e, off, o, JNI_ABORT);
-  if (p) (*e)->ReleasePrimitiveArrayCritical(e, pat, p, JNI_ABORT);
+  if (rc == FMX_OK && k > 0) (*e)->SetLongArrayRegion(e, out, 0, 2 * k, r);
+  free(r);
+  free(o);
+  free(p);
   rethrow(e, rc);
 }
 
@@ -134,18 +151,19 @@ JNIEXPORT void JNICALL FN(prevRangeBatch0)(JNIEnv *e, jobject self, jlong h, jlo
     rethrow(e, FMX_ERR_ARG);
     return;
   }
-  jlong *ps = (*e)->GetPrimitiveArrayCritical(e, sp, 0);
-  jlong *pe = (*e)->GetPrimitiveArrayCritical(e, ep, 0);
-  jbyte *pc = (*e)->GetPrimitiveArrayCritical(e, c, 0);
-  jlong *po = (*e)->GetPrimitiveArrayCritical(e, out, 0);
+  jlong *ps = in_longs(e, sp, k);
+  jlong *pe = in_longs(e, ep, k);
+  jbyte *pc = in_bytes(e, c, k);
+  jlong *po = malloc(sizeof(jlong) * (size_t)(k > 0 ? 2 * k : 1));
   int rc = (ps && pe && pc && po)
                ? fmx_prev_range_batch(H(h), (const uint64_t *)ps, (const uint64_t *)pe, (const uint8_t *)pc,
                                       (uint64_t *)po, (uint64_t *)po + k, (size_t)k)
                : FMX_ERR_NOMEM;
-  if (po) (*e)->ReleasePrimitiveArrayCritical(e, out, po, 0);
-  if (pc) (*e)->ReleasePrimitiveArrayCritical(e, c, pc, JNI_ABORT);
-  if (pe) (*e)->ReleasePrimitiveArrayCritical(e, ep, pe, JNI_ABORT);
-  if (ps) (*e)->ReleasePrimitiveArrayCritical(e, sp, ps, JNI_ABORT);
+  if (rc == FMX_OK && k > 0) (*e)->SetLongArrayRegion(e, out, 0, 2 * k, po);
+  free(po);
+  free(pc);
+  free(pe);
+  free(ps);
   rethrow(e, rc);
 }
 
@@ -203,15 +221,20 @@ JNIEXPORT void JNICALL FN(nextSubstrBatch0)(JNIEnv *e, jobject self, jlong h, jl
     rethrow(e, FMX_ERR_ARG);
     return;
   }
-  jlong *pr = (*e)->GetPrimitiveArrayCritical(e, rows, 0);
-  jbyte *po = (*e)->GetPrimitiveArrayCritical(e, out, 0);
-  jint *pl = (*e)->GetPrimitiveArrayCritical(e, outLen, 0);
+  jlong *pr = in_longs(e, rows, k);
+  const size_t nbytes = (size_t)k * (size_t)len;
+  jbyte *po = malloc(nbytes ? nbytes : 1);
+  jint *pl = malloc(sizeof(jint) * (size_t)(k > 0 ? k : 1));
   int rc = (pr && po && pl) ? fmx_next_substr_batch(H(h), (const uint64_t *)pr, (size_t)k, (uint32_t)len, (uint8_t *)po,
                                                     (uint32_t *)pl)
                             : FMX_ERR_NOMEM;
-  if (pl) (*e)->ReleasePrimitiveArrayCritical(e, outLen, pl, 0);
-  if (po) (*e)->ReleasePrimitiveArrayCritical(e, out, po, 0);
-  if (pr) (*e)->ReleasePrimitiveArrayCritical(e, rows, pr, JNI_ABORT);
+  if (rc == FMX_OK && k > 0) {
+    if (nbytes) (*e)->SetByteArrayRegion(e, out, 0, (jsize)nbytes, po);
+    (*e)->SetIntArrayRegion(e, outLen, 0, k, pl);
+  }
+  free(pl);
+  free(po);
+  free(pr);
   rethrow(e, rc);
 }
 
@@ -244,6 +267,9 @@ JNIEXPORT jlong JNICALL FN(regexBatchMatchDirect0)(JNIEnv *e, jobject self, jlon
     return 0;
   }
   size_t cap = (size_t)((*e)->GetDirectBufferCapacity(e, out) / (jlong)sizeof(fmx_result)), got = 0;
+  uint64_t k_batch = 0;
+  if (rethrow(e, fmx_regex_batch_info((const fmx_regex_batch *)(intptr_t)batch, &k_batch, 0, 0, 0))) return 0;
+  if (per && (uint64_t)(*e)->GetDirectBufferCapacity(e, perRegex) < 4 * k_batch) { rethrow(e, FMX_ERR_ARG); return 0; }
   int rc = fmx_regex_batch_match(H(h), (fmx_regex_batch *)(intptr_t)batch, &lim, res, cap, &got, per);
   if ((rc == FMX_OK || rc == FMX_TRUNCATED) && status) {
     jint st = rc == FMX_TRUNCATED ? 1 : 0;
@@ -282,20 +308,59 @@ JNIEXPORT jlong JNICALL FN(regexCompile0)(JNIEnv *e, jobject self, jbyteArray la
 }
 JNIEXPORT void JNICALL FN(regexFree0)(JNIEnv *e, jobject self, jlong r) { fmx_regex_free((fmx_regex *)(intptr_t)r); }
 
+/* k regexes in one call, compiled on all host cores inside the library (fmx_regex_compile_batch): `packed` = the k
+ * Latin-1 strings, each followed by a 0 byte; handles[i] = regex i's handle or 0, status[i] = 0 / FMX_ERR_SYNTAX (7) /
+ * FMX_ERR_MATCH (8) as regexCompile0 would throw for it.  No exception for a regex that does not compile. */
+JNIEXPORT void JNICALL FN(regexCompileBatch0)(JNIEnv *e, jobject self, jbyteArray packed, jint k, jboolean lineOnly,
+                                              jlongArray handles, jintArray status) {
+  jsize n = (*e)->GetArrayLength(e, packed);
+  if (k < 0 || (*e)->GetArrayLength(e, handles) < k || (*e)->GetArrayLength(e, status) < k) { rethrow(e, FMX_ERR_ARG); return; }
+  jbyte *buf = in_bytes(e, packed, n);
+  const char **ptr = malloc(sizeof(char *) * (size_t)(k ? k : 1));
+  fmx_regex **out = malloc(sizeof(fmx_regex *) * (size_t)(k ? k : 1));
+  jint *st = malloc(sizeof(jint) * (size_t)(k ? k : 1));
+  jlong *hl = malloc(sizeof(jlong) * (size_t)(k ? k : 1));
+  int rc = FMX_ERR_NOMEM;
+  if (buf && ptr && out && st && hl) {
+    jsize at = 0, found = 0;
+    for (; found < k && at < n; found++) {           /* the start of each 0-terminated string */
+      ptr[found] = (const char *)buf + at;
+      while (at < n && buf[at] != 0) at++;
+      if (at >= n) break;                              /* unterminated */
+      at++;
+    }
+    rc = found == k ? fmx_regex_compile_batch(ptr, (size_t)k, lineOnly ? 1 : 0, out, (int *)st) : FMX_ERR_ARG;
+    if (rc == FMX_OK) {
+      for (jint j = 0; j < k; j++) hl[j] = (jlong)(intptr_t)out[j];
+      (*e)->SetLongArrayRegion(e, handles, 0, k, hl);
+      (*e)->SetIntArrayRegion(e, status, 0, k, st);
+    }
+  }
+  free(hl); free(st); free(out); free(ptr); free(buf);
+  rethrow(e, rc);
+}
+JNIEXPORT void JNICALL FN(regexFreeBatch0)(JNIEnv *e, jobject self, jlongArray handles) {
+  jsize k = (*e)->GetArrayLength(e, handles);
+  jlong *hl = in_longs(e, handles, k);
+  if (hl) for (jsize j = 0; j < k; j++) fmx_regex_free((fmx_regex *)(intptr_t)hl[j]);
+  free(hl);
+}
+
+/* fmx_prepare: build the k-mer jump table (what & 1) / the select directory (what & 2) now, not at first use */
+JNIEXPORT void JNICALL FN(prepare0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_prepare(H(h), (unsigned)what)); }
+
 JNIEXPORT jlong JNICALL FN(regexBatchCreate0)(JNIEnv *e, jobject self, jlong h, jlongArray regexes) {
   jsize k = (*e)->GetArrayLength(e, regexes);
   fmx_regex **arr = malloc(sizeof(fmx_regex *) * (size_t)(k ? k : 1));
   fmx_regex_batch *b = 0;
   int rc = FMX_ERR_NOMEM;
-  if (arr) {
-    jlong *pr = (*e)->GetPrimitiveArrayCritical(e, regexes, 0);
-    if (pr) {
-      for (jsize j = 0; j < k; j++) arr[j] = (fmx_regex *)(intptr_t)pr[j];
-      (*e)->ReleasePrimitiveArrayCritical(e, regexes, pr, JNI_ABORT);
-      rc = fmx_regex_batch_create(H(h), arr, (size_t)k, &b);
-    }
-    free(arr);
+  jlong *pr = in_longs(e, regexes, k);
+  if (arr && pr) {
+    for (jsize j = 0; j < k; j++) arr[j] = (fmx_regex *)(intptr_t)pr[j];
+    rc = fmx_regex_batch_create(H(h), arr, (size_t)k, &b);
   }
+  free(pr);
+  free(arr);
   rethrow(e, rc);
   return (jlong)(intptr_t)b;
 }
@@ -317,9 +382,17 @@ JNIEXPORT jlong JNICALL FN(regexBatchMatch0)(JNIEnv *e, jobject self, jlong h, j
   lim.max_branching = (uint32_t)lim4[2];
   lim.max_iterations = (uint32_t)lim4[3];
   size_t cap = (size_t)(*e)->GetArrayLength(e, out) / 3, got = 0;
+  uint64_t k_batch = 0;
+  if (rethrow(e, fmx_regex_batch_info((const fmx_regex_batch *)(intptr_t)batch, &k_batch, 0, 0, 0))) return 0;
+  jsize kper = perRegex ? (*e)->GetArrayLength(e, perRegex) : 0;
+  if (perRegex && (uint64_t)kper < k_batch) {      /* the library writes one count per regex of the batch */
+    jclass ex = (*e)->FindClass(e, "java/lang/IllegalArgumentException");
+    if (ex) (*e)->ThrowNew(e, ex, "perRegex is shorter than the batch");
+    return 0;
+  }
+  kper = perRegex ? (jsize)k_batch : 0;
   fmx_result *res = malloc(sizeof(fmx_result) * (cap ? cap : 1));
   uint32_t *per = 0;
-  jsize kper = perRegex ? (*e)->GetArrayLength(e, perRegex) : 0;
   if (kper) per = malloc(sizeof(uint32_t) * (size_t)kper);
   int rc = (res && (!kper || per))
                ? fmx_regex_batch_match(H(h), (fmx_regex_batch *)(intptr_t)batch, &lim, res, cap, &got, per)

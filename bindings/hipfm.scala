@@ -42,6 +42,9 @@ object HipFM {
   @native def hostFree0(buf: ByteBuffer): Unit
   @native def regexCompile0(latin1: Array[Byte], lineOnly: Boolean): Long
   @native def regexFree0(r: Long): Unit
+  @native def regexCompileBatch0(packed: Array[Byte], k: Int, lineOnly: Boolean, handles: Array[Long], status: Array[Int]): Unit
+  @native def regexFreeBatch0(handles: Array[Long]): Unit
+  @native def prepare0(h: Long, what: Int): Unit
   @native def regexBatchCreate0(h: Long, regexes: Array[Long]): Long
   @native def regexBatchFree0(b: Long): Unit
   @native def regexBatchMatch0(h: Long, batch: Long, limits: Array[Int], maxFrontier: Long, out: Array[Long],
@@ -180,7 +183,17 @@ object HipRegex {
 
   def matchBatch(sa: HipFMSearcher, res: Array[String], lineOnly: Boolean, mode: Int, maxSteps: Int, maxBranching: Int,
                  maxIterations: Int, cap: Int = 1 << 20, maxFrontier: Long = 0): Array[List[SAResult]] = {
-    val handles = res.map(r => regexCompile0(latin1(r), lineOnly))
+    // one native call compiles the whole batch on all host cores (fmx_regex_compile_batch); a regex the reference
+    // would refuse raises what it raises there: "re2post syntax" (status 7) or a MatchError (status 8)
+    val packed = res.flatMap(r => latin1(r) :+ 0.toByte)
+    val handles = new Array[Long](res.length)
+    val st = new Array[Int](res.length)
+    regexCompileBatch0(packed, res.length, lineOnly, handles, st)
+    val bad = st.indexWhere(_ != 0)
+    if (bad >= 0) {
+      regexFreeBatch0(handles)
+      if (st(bad) == 7) throw new Exception("re2post syntax") else throw new MatchError(res(bad))
+    }
     val batch = regexBatchCreate0(sa.handle, handles)
     try {
       val out = new Array[Long](3 * cap)

@@ -49,7 +49,8 @@ class fmx_stats_t(ctypes.Structure):
                 ("frontier_requests", ctypes.c_uint64), ("frontier_elements", ctypes.c_uint64),
                 ("frontier_queue_reads", ctypes.c_uint64), ("frontier_queue_writes", ctypes.c_uint64),
                 ("frontier_results", ctypes.c_uint64), ("frontier_records", ctypes.c_uint64),
-                ("ktab_lookups", ctypes.c_uint64), ("ktab_k", ctypes.c_uint32), ("reserved3", ctypes.c_uint32)]
+                ("ktab_lookups", ctypes.c_uint64), ("ktab_k", ctypes.c_uint32), ("reserved3", ctypes.c_uint32),
+                ("tables_build_ms", ctypes.c_double)]
 
 
 # name -> (restype, argtypes); every symbol include/fmx.h declares
@@ -68,6 +69,7 @@ SYMBOLS = {
     "fmx_open_dev": (_i32, [_vp, _u64, _u64, _vp, _i32, _vp, _P(_vp)]),
     "fmx_open_block": (_i32, [_vp, _u64, _vp, _u64, _i32, _P(_vp)]),
     "fmx_close": (_i32, [_vp]),
+    "fmx_prepare": (_i32, [_vp, _u32]),
     "fmx_n": (_i32, [_vp, _P(_u64)]),
     "fmx_eof": (_i32, [_vp, _P(_u64)]),
     "fmx_cf": (_i32, [_vp, _i32, _P(_u64)]),
@@ -109,6 +111,12 @@ SYMBOLS = {
     "fmx_regex_batch_free_multi": (_i32, [_vp]),
     "fmx_regex_batch_match_multi": (_i32, [_vp, _vp, _vp, _sz, _P(_sz), _vp]),
     "fmx_gather": (_i32, [_vp, _sz, _vp, _vp, _sz, _vp]),
+    "fmx_comm_unique_id": (_i32, [_vp]),
+    "fmx_comm_create_rank": (_i32, [_vp, _i32, _i32, _vp, _P(_vp)]),
+    "fmx_comm_create_all": (_i32, [_vp, _sz, _P(_vp)]),
+    "fmx_comm_info": (_i32, [_vp, _P(_i32), _P(_i32)]),
+    "fmx_comm_free": (_i32, [_vp]),
+    "fmx_allgather_dev": (_i32, [_vp, _vp, _vp, _sz]),
     "fmx_stats": (_i32, [_vp, _P(fmx_stats_t)]),
     "fmx_stats_reset": (_i32, [_vp]),
     "fmx_last_kernel_ms": (_i32, [_vp, _P(ctypes.c_double)]),

@@ -256,8 +256,15 @@ static int load_aux(const char *path, bool be, int64_t counts[256]) {
   return FMX_OK;
 }
 
+Worker *worker_of(const Index *h) {
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->worker) h->worker.reset(new Worker());
+  return h->worker.get();
+}
+
 static void destroy(Index *h) {
   if (!h) return;
+  h->worker.reset();                  // finishes what was submitted, joins
   (void)hipSetDevice(h->device);
   if (h->d_bv) (void)hipFree(h->d_bv);
   if (h->d_chk) (void)hipFree(h->d_chk);
@@ -516,6 +523,22 @@ int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[2
   return open_common(bwt, false, nullptr, n, rk0, nullptr, device, nullptr, out, &spec);
 }
 
+int fmx_prepare(const fmx_index *idx, unsigned what) {
+  if (!idx) return arg_fail("null argument");
+  if (what & ~(unsigned)(FMX_PREPARE_KTAB | FMX_PREPARE_SELECT)) return arg_fail("unknown fmx_prepare flag");
+  const Index *h = H(idx);
+  int rc = use_device(h);
+  if (rc) return rc;
+  CtxLease lease(h);
+  if (!lease.c) return FMX_ERR_HIP;
+  if (what & FMX_PREPARE_KTAB) {
+    KTab kt;
+    HIP_TRY(ktab_get(h, lease.c->stream, &kt), "k-mer table");
+  }
+  if (what & FMX_PREPARE_SELECT) HIP_TRY(select_prepare(h, lease.c->stream), "select directory");
+  return FMX_OK;
+}
+
 int fmx_close(fmx_index *idx) {
   destroy(H(idx));
   return FMX_OK;
@@ -665,12 +688,16 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
   HIP_TRY(c0.alloc(d_off, (k + 1) * 8), "hipMalloc");
   HIP_TRY(c0.alloc(d_sp, k * 8), "hipMalloc");
   HIP_TRY(c0.alloc(d_ep, k * 8), "hipMalloc");
-  auto pinned = [](const void *p) {
+  auto pinned1 = [](const void *p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
   };
-  if (!(pinned(sp) && pinned(ep) && pinned(offp) && (!total || pinned(pat + lo)))) {
+  // both ends of a buffer: a partly registered one must not take the asynchronous path
+  auto pinned = [&](const void *p, size_t bytes) {
+    return pinned1(p) && (bytes == 0 || pinned1(static_cast<const uint8_t *>(p) + bytes - 1));
+  };
+  if (!(pinned(sp, k * 8) && pinned(ep, k * 8) && pinned(offp, (k + 1) * 8) && (!total || pinned(pat + lo, (size_t)total)))) {
     // Pageable caller memory: "asynchronous" copies of it are staged piecewise by the runtime and block the calling
     // thread (measured: 8 chunks, 0.37 ms each, nothing overlapped), while one synchronous copy per array runs at
     // link speed.  So: whole arrays up, one kernel, whole arrays down.
@@ -701,6 +728,13 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
   // searches it and sends its intervals back: uploads of later chunks run beside the kernels and downloads of
   // earlier ones
   hipStream_t up = c1.stream(), run = c0.stream();
+  // Whatever ends this call early -- a failed enqueue, a bad offset -- both streams are drained first: copies still in
+  // flight read and write the CALLER's buffers, and the device buffers go back to the handle's pool on return.
+  struct Drain {
+    hipStream_t a, b;
+    bool armed = true;
+    ~Drain() { if (armed) { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); } }
+  } drain{up, run};
   for (size_t j = 0; j <= nchunk; j++)            // the chunks' byte ranges come from these: checked before any copy
     if (offp[k * j / nchunk] > total || (j && offp[k * j / nchunk] < offp[k * (j - 1) / nchunk]))
       return arg_fail("pattern offsets must be non-decreasing");
@@ -722,11 +756,7 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
     const size_t a = k * j / nchunk, b = k * (j + 1) / nchunk;
     HIP_TRY(hipStreamWaitEvent(run, cev[j], 0), "hipStreamWaitEvent");
     if (a == b) continue;
-    if (!monotonic(a, b)) {                        // while the uploads are under way
-      (void)hipStreamSynchronize(up);
-      (void)hipStreamSynchronize(run);
-      return arg_fail("pattern offsets must be non-decreasing");
-    }
+    if (!monotonic(a, b)) return arg_fail("pattern offsets must be non-decreasing");      // while the uploads are under way
     HIP_TRY(launch_search(h, d_pat.p, (const uint64_t *)d_off.p + a, (uint64_t *)d_sp.p + a, (uint64_t *)d_ep.p + a, b - a, run),
             "k_search");
     HIP_TRY(hipMemcpyAsync(sp + a, (uint64_t *)d_sp.p + a, (b - a) * 8, hipMemcpyDeviceToHost, run), "D2H(sp)");
@@ -734,8 +764,8 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
     mark("chunk enqueued", j);
   }
   HIP_TRY(hipEventRecord(c0.ev_b(), run), "hipEventRecord");
-  hipStream_t sts[1] = {run};
-  HIP_TRY(hipStreamSynchronize(sts[0]), "hipStreamSynchronize");
+  HIP_TRY(hipStreamSynchronize(run), "hipStreamSynchronize");      // `run` waited for every upload: both streams are idle
+  drain.armed = false;
   mark("synchronized", 0);
   float ms = 0;
   if (hipEventElapsedTime(&ms, c0.ev_a(), c0.ev_b()) == hipSuccess) {
@@ -767,18 +797,21 @@ int fmx_search_batch_multi(fmx_index *const *idxs, size_t n_idx, const uint8_t *
     if (cut[r] < cut[r - 1]) cut[r] = cut[r - 1];
     if (cut[r] > k) cut[r] = k;
   }
+  // slice r runs on handle r's own host thread (kept with the handle: a call wakes it, it does not create it)
   std::vector<int> rc(n_idx, FMX_OK);
   std::vector<std::string> msg(n_idx);
-  std::vector<std::thread> th;
+  std::vector<Worker *> busy;
   for (size_t r = 0; r < n_idx; r++) {
     const size_t a = cut[r], b = cut[r + 1];
     if (a == b) continue;
-    th.emplace_back([&, r, a, b]() {
+    Worker *w = worker_of(H(idxs[r]));
+    w->submit([&, r, a, b]() {
       rc[r] = fmx_search_batch(idxs[r], pat, off + a, sp + a, ep + a, b - a);
       if (rc[r] != FMX_OK) msg[r] = fmx_last_error();        // the message is thread-local: carry it over
     });
+    busy.push_back(w);
   }
-  for (std::thread &t : th) t.join();
+  for (Worker *w : busy) w->wait();
   for (size_t r = 0; r < n_idx; r++)
     if (rc[r] != FMX_OK) { g_err = msg[r]; return rc[r]; }
   return FMX_OK;
@@ -1003,6 +1036,7 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->ktab_lookups = cnt[9];
   out->ktab_k = h->kt.k;
   out->build_ms = h->build_ms;
+  out->tables_build_ms = h->tables_ms;
   return FMX_OK;
 }
 

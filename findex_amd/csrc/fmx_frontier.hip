@@ -2239,17 +2239,19 @@ int fmx_regex_batch_match_multi(fmx_regex_batch_multi *mb, const fmx_limits *lim
   std::vector<size_t> cnt(np, 0);
   std::vector<int> rc(np, FMX_OK);
   std::vector<std::string> msg(np);
-  std::vector<std::thread> th;
+  std::vector<Worker *> busy;          // slice r runs on handle r's own host thread (kept with the handle)
   for (size_t r = 0; r < np; r++) {
     if (m->cut[r] == m->cut[r + 1]) continue;
-    th.emplace_back([&, r]() {
+    Worker *w = worker_of(m->idx[r]);
+    w->submit([&, r]() {
       // every slice may fill the caller's whole capacity
       uint32_t *per = per_regex_count ? per_regex_count + m->cut[r] : nullptr;
       rc[r] = regex_batch_match(m->idx[r], m->part[r], lim, m->buf[r].get(), cap, &cnt[r], per);
       if (rc[r] != FMX_OK) msg[r] = fmx_last_error();
     });
+    busy.push_back(w);
   }
-  for (std::thread &t : th) t.join();
+  for (Worker *w : busy) w->wait();
   size_t total = 0;
   bool truncated = false;
   for (size_t r = 0; r < np; r++) {

@@ -3,11 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "fmx_device.h"
+#include "fmx_hostpar.h"
 
 namespace fmx {
 
@@ -72,6 +74,7 @@ struct Index {
   mutable KTab kt;
   mutable void *d_ktab = nullptr, *d_kt_dense = nullptr, *d_kt_levels = nullptr;
   mutable uint64_t kt_bytes = 0;
+  mutable double tables_ms = 0.0;             // host time spent building the k-mer table and the select directory (under their mutexes)
   // select directory for Psi (fmx_select.hip), built on first use
   mutable std::mutex sel_mu;
   mutable bool sel_ready = false;
@@ -79,7 +82,11 @@ struct Index {
   mutable uint64_t sel_bytes = 0;
   mutable uint64_t launches = 0;
   mutable double last_kernel_ms = 0.0;
+  // the handle's host thread for the one-process-several-GPUs entry points (made at the first such call; fmx_hostpar.h)
+  mutable std::unique_ptr<Worker> worker;
 };
+
+Worker *worker_of(const Index *h);     // fmx_api.cpp
 
 void set_error(const std::string &msg);
 // Borrow / return one of the handle's call contexts (stream + events created on first use).  ctx_acquire
@@ -97,6 +104,7 @@ struct CtxLease {            // scope guard around ctx_acquire / ctx_release
 };
 bool ktab_enabled();                            // fmx_config_set("ktab", "auto" | "off")
 hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out);     // fmx_ktab.hip
+hipError_t select_prepare(const Index *h, hipStream_t st);          // fmx_select.hip: builds the select directory now
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP

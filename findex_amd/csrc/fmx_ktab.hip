@@ -18,6 +18,7 @@
 #include "fmx_host.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 namespace fmx {
@@ -136,8 +137,16 @@ static hipError_t build_ktab(const Index *h, hipStream_t st) {
 hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out) {
   std::lock_guard<std::mutex> lk(h->kt_mu);
   if (!h->kt_ready) {
+    const auto t0 = std::chrono::steady_clock::now();
     const hipError_t e = build_ktab(h, st);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {
+      // No table (out of memory for it, usually): searches walk every step on the rank dictionary, which is always
+      // correct.  The failure must not stick to the handle -- or to the HIP runtime's last-error slot.
+      (void)hipGetLastError();
+      h->kt = KTab{};
+      h->kt.sigma = h->nslots;
+    }
+    h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     h->kt_ready = true;
   }
   *out = h->kt;

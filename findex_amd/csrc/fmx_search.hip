@@ -241,10 +241,15 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         const uint64_t vb = ((uint64_t)e.w << 32) | e.z;
         if (vb > 1) {
           if (LAYOUT == kLayoutBytes) {
+            // narrow intervals: sp and ep share a 128-position block -- one block line and one checkpoint, both ranks
             const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), sp, lc);
-            const ByteRankReq q2 = byte_rank_issue(ix, (uint16_t)(vb - 2), ep, lc);
+            ByteRankReq q2 = q1;
+            const bool two = (ep >> 7) != (sp >> 7);
+            if (two) q2 = byte_rank_issue(ix, (uint16_t)(vb - 2), ep, lc);
+            else q2.rem = (uint32_t)ep & 127u;
             sp = cfc + byte_rank_finish(q1, c, lc);
             ep = cfc + byte_rank_finish(q2, c, lc);
+            reqs += two ? 2 * R : R;
           } else {
             uint32_t b1, b2, m1, m2;
             split448(sp, b1, m1);
@@ -257,7 +262,6 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
             ep = cfc + rank_finish<WIDE>(w2, m2, lc);
             reqs += 1;
           }
-          if (LAYOUT == kLayoutBytes) reqs += 2 * R;
         } else {
           const uint64_t r1 = special(cfc, vb, sp);
           ep = special(cfc, vb, ep);

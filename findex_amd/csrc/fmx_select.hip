@@ -17,6 +17,8 @@
 #include "fmx_device.h"
 #include "fmx_host.h"
 
+#include <chrono>
+
 namespace fmx {
 
 constexpr int kSelThreads = 256;
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(kSelThreads) void k_next_substr(DevIndex ix, SelDir
 static hipError_t ensure_select(const Index *h, hipStream_t st, SelDir *out) {
   std::lock_guard<std::mutex> lk(h->sel_mu);
   if (!h->sel_ready) {
+    const auto t_build = std::chrono::steady_clock::now();
     std::vector<uint64_t> off(h->nslots + 1, 0), totals(h->nslots ? h->nslots : 1, 0);
     std::vector<uint8_t> shift(h->nslots ? h->nslots : 1, 0);
     const double rows_per_block = h->layout == kLayoutBytes ? (double)kByteBlock : (double)kBlockBits;
@@ -261,11 +264,17 @@ static hipError_t ensure_select(const Index *h, hipStream_t st, SelDir *out) {
     if (e != hipSuccess) return e;
     h->sel_bytes = entries * 4;
     h->sel_ready = true;
+    h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
   }
   out->dir = (const uint32_t *)h->d_sel_dir;
   out->off = (const uint64_t *)h->d_sel_off;
   out->shift = (const uint8_t *)h->d_sel_shift;
   return hipSuccess;
+}
+
+hipError_t select_prepare(const Index *h, hipStream_t st) {
+  SelDir d;
+  return ensure_select(h, st, &d);
 }
 
 static inline int sel_grid(const Index *h, uint64_t k, int per_block) {

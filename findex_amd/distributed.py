@@ -129,29 +129,50 @@ def group_results(res, k):
     return [list(map(tuple, cols[bounds[r]:bounds[r + 1]].tolist())) for r in range(k)]
 
 
+MATCH_KW = ("max_steps", "max_frontier", "cap")      # what the sharded regex match passes on to a rank's search
+
+
+def exchange_result_words(t, first_regex, group=None):
+    """The regex path's exchange on tensors, device or host alike (what the RCCL branch of match_batch_sharded runs
+    on HBM-resident results): `t` = this rank's result list as int64 words, three per result (word 0 = regex |
+    len << 32, then sp, ep -- RESULT_DTYPE's bits), regex ids local to the rank's slice.  Makes the ids global
+    (+ first_regex), all-gathers the lists (sizes, then the payload padded to the longest: all_gather_varlen) and
+    returns the concatenation in rank order as a structured host array."""
+    if t.numel() % 3:
+        raise ValueError("result words come three per result")
+    t = t.clone()
+    t[0::3] += int(first_regex)
+    parts = all_gather_varlen(t, group)
+    if not parts:
+        return np.zeros(0, dtype=RESULT_DTYPE)
+    return np.concatenate([np.ascontiguousarray(p.cpu().numpy()).view(RESULT_DTYPE) for p in parts])
+
+
 def match_batch_sharded(sa, trees, group=None, match_fn=None, weights=None, **kw):
     """ReTree.matchSA over a regex batch sharded across the ranks: contiguous slices balanced by `weights`
     (estimated frontier work per regex; by count when None), each rank matches its slice, one gather of the
     result lists.  Returns the structured array of all results, regex ids global, on every rank.
     `match_fn(sa, trees_slice)` defaults to the GPU frontier search on a resident batch; it returns a structured
-    array with slice-local regex ids (or, per regex, a list of (len, sp, ep) tuples / SAResult objects)."""
+    array with slice-local regex ids (or, per regex, a list of (len, sp, ep) tuples / SAResult objects).
+    Keyword arguments for the search: max_steps, max_frontier, cap (every match, frontier mode) -- the same on every
+    backend; anything else is refused."""
+    unknown = sorted(set(kw) - set(MATCH_KW))
+    if unknown:
+        raise TypeError("match_batch_sharded: unsupported keyword(s) %s (the sharded match runs the frontier mode: %s)"
+                        % (", ".join(unknown), ", ".join(MATCH_KW)))
     rank, world = _group_info(group)
     k = len(trees)
     cuts = work_bounds(weights if weights is not None else np.ones(k), world)
     if match_fn is None and dist is not None and dist.is_initialized() and dist.get_backend(group) == "nccl":
         # RCCL: the results never leave HBM before the exchange (fmx_regex_batch_match_dev): the regex ids are
-        # made global on the device (word 0 of a record = regex | len << 32), the lists are all-gathered, and one
-        # copy brings the whole answer to the host
+        # made global on the device, the lists are all-gathered, and one copy brings the whole answer to the host
         from .regex import ReTree
         kw = dict(kw)
         cap = int(kw.pop("cap", 1 << 22))
         dev = torch.device("cuda", torch.cuda.current_device())
         d_out = torch.empty(3 * cap, dtype=torch.int64, device=dev)
         n_res = ReTree.prepare_batch(sa, trees[cuts[rank]:cuts[rank + 1]]).match_dev(d_out.data_ptr(), cap, None, **kw)
-        t = d_out[: 3 * n_res]
-        t[0::3] += int(cuts[rank])
-        parts = all_gather_varlen(t, group)
-        return np.concatenate([p.cpu().numpy().view(RESULT_DTYPE) for p in parts]) if parts else np.zeros(0, dtype=RESULT_DTYPE)
+        return exchange_result_words(d_out[: 3 * n_res], cuts[rank], group)
     if match_fn is None:
         from .regex import ReTree
 
@@ -161,9 +182,9 @@ def match_batch_sharded(sa, trees, group=None, match_fn=None, weights=None, **kw
     if not isinstance(mine, np.ndarray):      # per-regex lists (CPU stand-ins in the tests)
         rows = [(j, r.len, r.sp, r.ep) if hasattr(r, "len") else (j,) + tuple(r) for j, res in enumerate(mine) for r in res]
         mine = np.array(rows, dtype=RESULT_DTYPE) if rows else np.zeros(0, dtype=RESULT_DTYPE)
-    mine = mine.copy()
-    mine["regex"] += np.uint32(cuts[rank])
-    return gather_results(mine, group=group)
+    mine = np.ascontiguousarray(mine, dtype=RESULT_DTYPE)
+    words = torch.from_numpy(mine.view(np.int64).reshape(-1).copy())
+    return exchange_result_words(words, cuts[rank], group)
 
 
 def gather_intervals_dev(sp, ep, group=None):

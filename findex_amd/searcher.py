@@ -290,6 +290,10 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_next_substr_batch_dev(self._h, _dp(d_rows), int(k), int(length), _dp(d_out),
                                                      _dp(d_out_len), _dp(stream)))
 
+    def prepare(self, ktab=True, select=False):
+        """fmx_prepare: build the k-mer jump table / the select directory now instead of at first use."""
+        _lib.check(self._L.fmx_prepare(self._h, (1 if ktab else 0) | (2 if select else 0)))
+
     # ---- statistics
     def stats(self):
         s = _lib.fmx_stats_t()

@@ -108,6 +108,14 @@ int fmx_open_dev(const void *d_bwt, uint64_t n, uint64_t eof, const int64_t *cou
 int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[256], uint64_t rk0, int device,
                    fmx_index **out);
 int fmx_close(fmx_index *idx);
+/* Builds now what a handle otherwise builds at first use -- FMX_PREPARE_KTAB: the k-mer jump table (first search or
+ * regex match; up to min(16 GiB, a quarter of the free HBM)), FMX_PREPARE_SELECT: the select directory (first Psi /
+ * nextSubstr; at most ~n bytes) -- so that no later call allocates device memory or synchronises a stream: for a
+ * caller that captures its stream, or that times its first search.  A table that cannot be built (no memory) is
+ * left out: searches then walk every step on the rank dictionary, with the same results.  The time spent is reported as
+ * fmx_stats_t.tables_build_ms. */
+enum { FMX_PREPARE_KTAB = 1, FMX_PREPARE_SELECT = 2 };
+int fmx_prepare(const fmx_index *idx, unsigned what);
 
 /* ---- scalars: SuffixAlgo.n / cf, findex.scala:10-12; NaiveFMSearcher.cf bwtmerger.scala:346-352 */
 int fmx_n(const fmx_index *idx, uint64_t *n);
@@ -326,6 +334,26 @@ int fmx_regex_batch_match_multi(fmx_regex_batch_multi *mb, const fmx_limits *lim
 int fmx_gather(fmx_index *const *idxs, size_t n_idx, const void *const *d_src, const size_t *cnt, size_t elem,
                void *dst);
 
+/* ---- the exchange itself: an RCCL all-gather of the ranks' device-resident result slices over xGMI (SURVEY.md 8e:
+ * "ncclAllGather of uint64 sp[], ep[] slices after the kernels finish"), for callers below the Python mirror -- a JVM.
+ * RCCL is loaded at first use (dlopen); FMX_ERR_UNSUPPORTED when the process has none.
+ *   one process per GPU : rank 0 calls fmx_comm_unique_id, ships the 128 bytes to the other ranks by its own
+ *                         means, every rank calls fmx_comm_create_rank(its handle, n_ranks, rank, id).
+ *   one process, N GPUs : fmx_comm_create_all(one handle per device) -- ncclCommInitAll.
+ * fmx_allgather_dev(comm, d_send, d_recv, bytes): every rank contributes `bytes` bytes at d_send[i] and receives all
+ * ranks' contributions, in rank order, at d_recv[i] (n_ranks * bytes); the arrays have one entry per LOCAL rank of
+ * the communicator (1, or N for fmx_comm_create_all, in the order of `idxs`).  The call returns when the gather has
+ * completed on every local rank.  Slices of different lengths (regex result lists): gather the counts first, then the
+ * payload padded to the longest, as findex_amd/distributed.py all_gather_varlen does. */
+#define FMX_COMM_ID_BYTES 128
+typedef struct fmx_comm fmx_comm;
+int fmx_comm_unique_id(void *id /* FMX_COMM_ID_BYTES */);
+int fmx_comm_create_rank(const fmx_index *idx, int n_ranks, int rank, const void *id, fmx_comm **out);
+int fmx_comm_create_all(fmx_index *const *idxs, size_t n_idx, fmx_comm **out);
+int fmx_comm_info(const fmx_comm *comm, int *n_ranks, int *n_local);
+int fmx_comm_free(fmx_comm *comm);
+int fmx_allgather_dev(fmx_comm *comm, const void *const *d_send, void *const *d_recv, size_t bytes);
+
 /* ---- statistics (since open or the last reset; device counters are read with a sync).
  * rank_queries counts occ(c,i) evaluations in the REFERENCE's terms: two per backward step (findex.scala:26-27,
  * 32-36), one per occ_batch operand or LF step -- the number the Scala path would execute on the same inputs
@@ -356,6 +384,8 @@ typedef struct fmx_stats_t {
   uint64_t ktab_lookups;        /* 16-byte k-mer table entries fetched (each stands for up to ktab_k backward steps) */
   uint32_t ktab_k;              /* K of the k-mer jump table (0: none, or not built yet) */
   uint32_t reserved3;           /* 0 */
+  double tables_build_ms;       /* host time spent building the k-mer table and the select directory (at first use or in
+                                 * fmx_prepare): what a handle's first search / first Psi pays on top of build_ms */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 /* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */

@@ -73,6 +73,17 @@ def _rank_main(rank, world, port, q):
         sp, ep = D.search_batch_sharded(s, buf, off)
         res = D.group_results(D.match_batch_sharded(s, REGEXES, match_fn=oracle_match, weights=[1, 3, 9, 2, 8]), len(REGEXES))
         cuts = D.shard_bounds(off, world)
+        # the exchange the RCCL branch runs on device tensors, here on host tensors: a non-zero first regex id on
+        # rank 1, lists of different lengths, and an empty list on rank 0 in the second round
+        mine = np.array([(j, 5 + j + rank, 1000 * rank + j, 1000 * rank + j + 3) for j in range(2 + 3 * rank)], dtype=D.RESULT_DTYPE)
+        ex1 = D.exchange_result_words(torch.from_numpy(mine.view(np.int64).reshape(-1).copy()), 7 * rank)
+        none = mine[:0] if rank == 0 else mine
+        ex2 = D.exchange_result_words(torch.from_numpy(none.view(np.int64).reshape(-1).copy()), 7 * rank)
+        try:
+            D.match_batch_sharded(s, REGEXES, match_fn=oracle_match, mode="reference")
+            kw_refused = False
+        except TypeError:
+            kw_refused = True
         t = torch.arange(3 + 2 * rank, dtype=torch.int64) + 100 * rank
         parts = D.all_gather_varlen(t)
         # the pipelined gather bench.py uses: 5 batches through 2 slots, gather i overlapping batch i+1
@@ -89,7 +100,7 @@ def _rank_main(rank, world, port, q):
                 seen.append(outs[i - 1].clone().tolist())
         g.finish()
         seen.append(outs[4].clone().tolist())
-        q.put((rank, sp, ep, res, cuts, [p.tolist() for p in parts], seen))
+        q.put((rank, sp, ep, res, cuts, [p.tolist() for p in parts], seen, ex1.tolist(), ex2.tolist(), kw_refused))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -117,7 +128,11 @@ def test_two_rank_gloo_matches_single_process():
     s = OracleSearcher(*idx)
     wsp, wep = s.search_batch(buf, off)
     wres = oracle_match(s, REGEXES)
-    for rank, sp, ep, res, cuts, parts, seen in got:
+    want1 = [(j + 7 * r, 5 + j + r, 1000 * r + j, 1000 * r + j + 3) for r in range(world) for j in range(2 + 3 * r)]
+    want2 = [w for w in want1 if w[2] >= 1000]                 # rank 0 contributed nothing in the second round
+    for rank, sp, ep, res, cuts, parts, seen, ex1, ex2, kw_refused in got:
+        assert [tuple(x) for x in ex1] == want1 and [tuple(x) for x in ex2] == want2
+        assert kw_refused
         for i, batch in enumerate(seen):    # (world, 2, k): every rank sees every rank's rows of batch i
             for r in range(world):
                 assert batch[r][0] == [j + 10 * i + 1000 * r for j in range(4)]

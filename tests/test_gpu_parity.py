@@ -956,6 +956,126 @@ def test_match_batch_sharded_device_exchange():
     assert got.tobytes() == want.tobytes() and want.size > 100
 
 
+def test_allgather_dev_rccl_in_the_library():
+    """fmx_comm_* / fmx_allgather_dev: the exchange as an RCCL call inside libfmx.so (what a JVM caller uses).  One
+    GPU here, so the communicators have one rank -- created both ways (ncclCommInitAll over the handles of one
+    process; unique id + ncclCommInitRank as one process per GPU does) -- and the gather of the intervals of a real
+    search must reproduce them; with two or more GPUs a second handle joins and every rank receives both slices."""
+    import ctypes
+    torch = _torch()
+    from findex_amd import _lib
+    L = _lib.load()
+    ndev = min(torch.cuda.device_count(), 2)
+    bwt, eof, counts = synth_bwt(200_000, 97, 100, 5)
+    hips = [findex_amd.HipFMSearcher.from_mem(bwt, eof, counts, device=d) for d in range(ndev)]
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(6)
+    buf, off = pack_patterns(lf_walk_patterns(orc, rng, 1000 * ndev, 6, 0.2, alphabet=[97, 98, 99, 100]))
+    wsp, wep, _ = orc.search_batch(buf, off)
+    k = 1000
+    sends, recvs = [], []
+    for d, hip in enumerate(hips):                      # rank d searches patterns [d*k, (d+1)*k) on its own GPU
+        dev = torch.device("cuda", d)
+        with torch.cuda.device(dev):
+            lo = int(off[d * k])
+            d_pat = torch.from_numpy(buf[lo:int(off[(d + 1) * k])].copy()).to(dev)
+            d_off = torch.from_numpy((off[d * k:(d + 1) * k + 1] - np.uint64(lo)).astype(np.int64)).to(dev)
+            both = torch.empty(2 * k, dtype=torch.int64, device=dev)
+            hip.search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), both.data_ptr(), both.data_ptr() + 8 * k, k, 0)
+            torch.cuda.synchronize(dev)
+            sends.append(both)
+            recvs.append(torch.zeros(2 * k * ndev, dtype=torch.int64, device=dev))
+    comm = ctypes.c_void_p()
+    idxs = (ctypes.c_void_p * ndev)(*[h.handle for h in hips])
+    _lib.check(L.fmx_comm_create_all(idxs, ndev, ctypes.byref(comm)))
+    nr, nl = ctypes.c_int(), ctypes.c_int()
+    _lib.check(L.fmx_comm_info(comm, ctypes.byref(nr), ctypes.byref(nl)))
+    assert nr.value == ndev and nl.value == ndev
+    sp_ = (ctypes.c_void_p * ndev)(*[t.data_ptr() for t in sends])
+    rp_ = (ctypes.c_void_p * ndev)(*[t.data_ptr() for t in recvs])
+    _lib.check(L.fmx_allgather_dev(comm, sp_, rp_, 16 * k))
+    for d in range(ndev):
+        got = recvs[d].cpu().numpy().astype(np.uint64).reshape(ndev, 2, k)
+        for r in range(ndev):
+            assert np.array_equal(got[r, 0], wsp[r * k:(r + 1) * k]) and np.array_equal(got[r, 1], wep[r * k:(r + 1) * k])
+    _lib.check(L.fmx_comm_free(comm))
+    # the one-process-per-GPU bootstrap with a single rank: unique id -> ncclCommInitRank
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(L.fmx_comm_unique_id(uid))
+    _lib.check(L.fmx_comm_create_rank(hips[0].handle, 1, 0, uid, ctypes.byref(comm)))
+    recvs[0].zero_()
+    one_s = (ctypes.c_void_p * 1)(sends[0].data_ptr())
+    one_r = (ctypes.c_void_p * 1)(recvs[0].data_ptr())
+    _lib.check(L.fmx_allgather_dev(comm, one_s, one_r, 16 * k))
+    assert torch.equal(recvs[0][: 2 * k], sends[0])
+    _lib.check(L.fmx_comm_free(comm))
+    # refused: two handles on one device (RCCL has one rank per GPU)
+    twice = (ctypes.c_void_p * 2)(hips[0].handle, hips[0].handle)
+    assert L.fmx_comm_create_all(twice, 2, ctypes.byref(comm)) == 3
+
+
+def _nccl_rank(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from findex_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        bwt, eof, counts = synth_bwt(300_000, 97, 100, 8)
+        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts, device=rank)
+        res = ["ab[a-c]*d", "a[ab]*c", "abca"] + ["abcd"[i % 4] + "abcd"[(i // 4) % 4] + "c[ab]?d" for i in range(20)]
+        trees = [findex_amd.ReTree(findex_amd.REParser.re2post(r)) for r in res]
+        got = D.match_batch_sharded(hip, trees, weights=[len(r) for r in res], max_steps=20)
+        rng = np.random.default_rng(3)
+        orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+        buf, off = pack_patterns(lf_walk_patterns(orc, rng, 500, 7, 0.2, alphabet=[97, 98, 99, 100]))
+        sp, ep = D.search_batch_sharded(hip, buf, off)
+        q.put((rank, got.tobytes(), sp.tobytes(), ep.tobytes()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_and_match_two_ranks_rccl():
+    """The N > 1 path on real RCCL: two processes, one GPU each, a replica of the index per rank, the regex batch
+    cut by weight (rank 1's regex ids start past 0), result lists of different lengths exchanged from HBM
+    (exchange_result_words), pattern intervals all-gathered.  Every rank must hold what one process computes.
+    Skipped on a box with one GPU (the same code path runs on CPU tensors over gloo in tests/test_distributed_cpu.py)."""
+    torch = _torch()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    from findex_amd.regex import RegexBatch
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_rank, args=(r, 2, port, q), daemon=True) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        got = [q.get(timeout=240) for _ in range(2)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    bwt, eof, counts = synth_bwt(300_000, 97, 100, 8)
+    hip, orc = pair_from_mem(bwt, eof, counts)
+    res = ["ab[a-c]*d", "a[ab]*c", "abca"] + ["abcd"[i % 4] + "abcd"[(i // 4) % 4] + "c[ab]?d" for i in range(20)]
+    want, _ = RegexBatch(hip, [findex_amd.ReTree(findex_amd.REParser.re2post(r)) for r in res]).match_raw(max_steps=20)
+    rng = np.random.default_rng(3)
+    buf, off = pack_patterns(lf_walk_patterns(orc, rng, 500, 7, 0.2, alphabet=[97, 98, 99, 100]))
+    wsp, wep, _ = orc.search_batch(buf, off)
+    for rank, res_b, sp_b, ep_b in got:
+        assert res_b == want.tobytes() and sp_b == wsp.tobytes() and ep_b == wep.tobytes()
+
+
 # ---------------------------------------------------------------- the reference's other two engines
 class _OIdx:
     def __init__(self, sa):

@@ -31,8 +31,10 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 stream = torch.cuda.current_stream().cuda_stream
 regex = a.workload in bench.REGEX
+print("SRC_SHA16=%s" % bench.source_hash())
+ref_mode = False
 if regex:
-    log2n, k, seed, max_len = bench.REGEX[a.workload]
+    log2n, k, seed, max_len, ref_mode = bench.REGEX[a.workload]
     n, sigma = 1 << log2n, None
     bwt, eof = bench.make_bwt(torch, n, bench.C4_ALPHABET, seed, dev)
 else:
@@ -46,8 +48,17 @@ torch.cuda.empty_cache()
 if regex:
     res, trees = bench.make_regexes(k, seed * 1000)
     batch = findex_amd.ReTree.prepare_batch(hip, trees)
-    batch.match_raw(max_steps=max_len, cap=1 << 22)          # first call: allocations (the level chain is captured from the 2nd)
-    batch.match_raw(max_steps=max_len, cap=1 << 22)
+    cap = 1 << 22
+    d_out = torch.empty(3 * cap, dtype=torch.int64, device=dev)
+    d_per = torch.empty(k, dtype=torch.int32, device=dev)
+
+    def regex_step():       # the bench's step
+        if ref_mode:
+            batch.match_raw(mode="reference", maxBranching=bench.REF_LIMITS[0], maxIterations=bench.REF_LIMITS[1], cap=cap, copy=False)
+        else:
+            batch.match_dev(d_out.data_ptr(), cap, d_per.data_ptr(), max_steps=max_len)
+    regex_step()          # first call: allocations (the level chain is captured from the 2nd)
+    regex_step()
 else:
     pats, off = bench.make_patterns(torch, hip, n, sigma, k, m, seed * 1000, dev, stream)
     sp = torch.empty(k, dtype=torch.int64, device=dev)
@@ -66,7 +77,7 @@ torch.cuda.synchronize()
 hip.stats_reset()
 for _ in range(a.steps):
     if regex:
-        batch.match_raw(max_steps=max_len, cap=1 << 22)
+        regex_step()
     else:
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
 torch.cuda.synchronize()

@@ -68,8 +68,15 @@ for f in glob.glob(os.path.join(src, "*.log")):
     m = re.search(r"frontier: (\d+) calls;", open(f, errors="replace").read())
     if m:
         calls = int(m.group(1)) + 2          # prof_workload.py makes two untimed calls first
+src_sha = None        # the source hash the profiled build was made from (prof_workload.py prints bench.source_hash())
+for f in glob.glob(os.path.join(src, "*.log")):
+    m = re.search(r"SRC_SHA16=([0-9a-f]{16})", open(f, errors="replace").read())
+    if m:
+        src_sha = m.group(1)
 with open(dst + "_counters.csv", "a", newline="") as fo:
     csv.writer(fo).writerow(["(calibration)", "FETCH_BYTES_PER_KIB", 1, "%.6g" % bytes_per_kib])
+    if src_sha:
+        csv.writer(fo).writerow(["(source)", "SRC_SHA16", 1, src_sha])
     if calls:
         csv.writer(fo).writerow(["(workload)", "CALLS", 1, calls])
 

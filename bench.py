@@ -128,17 +128,42 @@ def check_launch(args, rank, world):
         dist.init_process_group("gloo")
     if os.environ.get("FMX_BENCH_FAIL_RANK") == str(rank):
         raise SystemExit("bench: rank %d told to fail (FMX_BENCH_FAIL_RANK)" % rank)
-    k = (LITERAL.get(args.workload) or (0, 0, 1000))[2]
-    gather = IntervalGather(k, torch.device("cpu"))
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        sp, ep = gather.slot(i)
-        sp.copy_(torch.arange(k, dtype=torch.int64) * (rank + 1) + i)
-        ep.copy_(sp + rank + 1)
-        out = gather.launch(i)
-        gather.finish()
-        for r in range(world):
-            assert int(out[r, 0, 7]) == 7 * (r + 1) + i and int(out[r, 1, 7]) == 7 * (r + 1) + i + r + 1, "gather content"
+    if args.workload in REGEX:
+        # the regex workloads' exchange: result lists of different lengths per rank -- rank 1 has none at all in odd
+        # steps -- as int64 words (three per result), ids made global, sizes gathered, then the padded payload
+        from findex_amd.distributed import exchange_result_words, RESULT_DTYPE
+        k = REGEX[args.workload][1]
+
+        def fake(r, i):       # the list rank r would send in step i: len depends on the rank, values predictable
+            cnt = 0 if (r == 1 and i % 2) else 1000 + 37 * r + i
+            a = np.zeros(cnt, dtype=RESULT_DTYPE)
+            a["regex"] = np.arange(cnt) % k
+            a["len"] = 4 + (np.arange(cnt) + r) % 60
+            a["sp"] = np.arange(cnt, dtype=np.uint64) * np.uint64(r + 1) + np.uint64(i)
+            a["ep"] = a["sp"] + np.uint64(r + 1)
+            return a
+        for i in range(args.steps):
+            mine = fake(rank, i)
+            got = exchange_result_words(torch.from_numpy(mine.view(np.int64).reshape(-1).copy()), rank * k)
+            want = []
+            for r in range(world):
+                w = fake(r, i)
+                w["regex"] += np.uint32(r * k)
+                want.append(w)
+            want = np.concatenate(want)
+            assert got.size == want.size and got.tobytes() == want.tobytes(), "regex exchange content"
+    else:
+        k = (LITERAL.get(args.workload) or (0, 0, 1000))[2]
+        gather = IntervalGather(k, torch.device("cpu"))
+        for i in range(args.steps):
+            sp, ep = gather.slot(i)
+            sp.copy_(torch.arange(k, dtype=torch.int64) * (rank + 1) + i)
+            ep.copy_(sp + rank + 1)
+            out = gather.launch(i)
+            gather.finish()
+            for r in range(world):
+                assert int(out[r, 0, 7]) == 7 * (r + 1) + i and int(out[r, 1, 7]) == 7 * (r + 1) + i + r + 1, "gather content"
     dt = time.perf_counter() - t0
     if use_dist:
         dist.barrier()

@@ -346,6 +346,32 @@ JNIEXPORT void JNICALL FN(regexFreeBatch0)(JNIEnv *e, jobject self, jlongArray h
   free(hl);
 }
 
+/* ---- BWTMerger2.calcGaps' rank loop (bwtmerger.scala:981-1023) on the host-side dictionary */
+JNIEXPORT jlong JNICALL FN(occHost0)(JNIEnv *e, jobject self, jlong h, jint c, jlong i) {
+  uint64_t v = 0;
+  rethrow(e, fmx_occ_host(H(h), c, (int64_t)i, &v));
+  return (jlong)v;
+}
+JNIEXPORT jint JNICALL FN(calcGapsChain0)(JNIEnv *e, jobject self, jlong h, jbyteArray text, jint from, jlong rank0,
+                                          jint lastChar, jlong rklst, jlongArray ranks) {
+  jsize n = (*e)->GetArrayLength(e, text);
+  if (from < 0 || from > n || (*e)->GetArrayLength(e, ranks) < n - from) { rethrow(e, FMX_ERR_ARG); return 0; }
+  jsize k = n - from;
+  jbyte *t = malloc((size_t)(k > 0 ? k : 1));
+  jlong *r = malloc(sizeof(jlong) * (size_t)(k > 0 ? k : 1));
+  size_t done = 0;
+  int rc = FMX_ERR_NOMEM;
+  if (t && r) {
+    if (k > 0) (*e)->GetByteArrayRegion(e, text, from, k, t);
+    rc = fmx_calc_gaps_chain(H(h), (const uint8_t *)t, (size_t)k, (uint64_t)rank0, lastChar, (uint64_t)rklst, (uint64_t *)r, &done);
+    if (rc == FMX_OK && k > 0) (*e)->SetLongArrayRegion(e, ranks, 0, (jsize)(done < (size_t)k ? done + 1 : done), r);
+  }
+  free(r);
+  free(t);
+  rethrow(e, rc);
+  return (jint)done;
+}
+
 /* fmx_prepare: build the k-mer jump table (what & 1) / the select directory (what & 2) now, not at first use */
 JNIEXPORT void JNICALL FN(prepare0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_prepare(H(h), (unsigned)what)); }
 

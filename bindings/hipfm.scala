@@ -45,6 +45,8 @@ object HipFM {
   @native def regexCompileBatch0(packed: Array[Byte], k: Int, lineOnly: Boolean, handles: Array[Long], status: Array[Int]): Unit
   @native def regexFreeBatch0(handles: Array[Long]): Unit
   @native def prepare0(h: Long, what: Int): Unit
+  @native def occHost0(h: Long, c: Int, i: Long): Long
+  @native def calcGapsChain0(h: Long, text: Array[Byte], from: Int, rank0: Long, lastChar: Int, rklst: Long, ranks: Array[Long]): Int
   @native def regexBatchCreate0(h: Long, regexes: Array[Long]): Long
   @native def regexBatchFree0(b: Long): Unit
   @native def regexBatchMatch0(h: Long, batch: Long, limits: Array[Int], maxFrontier: Long, out: Array[Long],
@@ -161,7 +163,15 @@ object HipFMSearcher {
 class HipBWTSearcher(bwt: Array[Byte], bucketStarts: Array[Long], rk0: Int, device: Int = 0) extends HipSuffixAlgo {
   protected val h: Long = HipFM.openBlock0(bwt, bucketStarts, rk0, device)
   val K = bucketStarts.length
-  override def occ(c: Int, key: Int): Int = super.occ(c & 0xff, key)        // `val ci = c & 0xff`, :480
+  // calcGaps (bwtmerger.scala:981-1023) asks ONE occ at a time, each depending on the last: answered on the host from
+  // the library's copy of the dictionary (fmx_occ_host: a count + a scan of < 256 bytes), not by a kernel launch
+  override def occ(c: Int, key: Int): Int = HipFM.occHost0(h, c & 0xff, key).toInt        // `val ci = c & 0xff`, :480
+
+  /** The rank chain of calcGaps over text(from until text.length) from curRank = rank0 in one native call
+    * (fmx_calc_gaps_chain): ranks(j) = curRank after byte from + j; returns how many bytes were processed -- fewer than
+    * the rest when a rank equal to rklst needs kmpOut / longSuffixCmp (:1004-1010): fix that rank and call again. */
+  def calcGapsChain(text: Array[Byte], from: Int, rank0: Long, lastChar: Int, rklst: Long, ranks: Array[Long]): Int =
+    HipFM.calcGapsChain0(h, text, from, rank0, lastChar, rklst, ranks)
 }
 
 /** ReTree.matchSA on the device.  A regex string is parsed by the library with the reference's own grammar and tree

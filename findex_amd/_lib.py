@@ -93,6 +93,8 @@ SYMBOLS = {
     "fmx_search_batch_multi": (_i32, [_vp, _sz, _vp, _vp, _vp, _vp, _sz]),
     "fmx_extract": (_i32, [_vp, _u64, _u32, _i32, _vp, _P(_u32)]),
     "fmx_write_fm": (_i32, [_vp, _cp]),
+    "fmx_occ_host": (_i32, [_vp, _i32, ctypes.c_int64, _P(_u64)]),
+    "fmx_calc_gaps_chain": (_i32, [_vp, _vp, _sz, _u64, _i32, _u64, _vp, _P(_sz)]),
     "fmx_regex_compile": (_i32, [_cp, _i32, _P(_vp)]),
     "fmx_regex_compile_batch": (_i32, [_vp, _sz, _i32, _vp, _vp]),
     "fmx_regex_free_batch": (_i32, [_vp, _sz]),

@@ -38,6 +38,14 @@ struct KTab {
   uint32_t k = 0, sigma = 0;
 };
 
+// Host-resident rank dictionary of a (block-sized) index, for ONE dependent chain of rank queries (fmx_hostrank.cpp):
+// per 256 positions one record = the running count of every symbol that occurs (nslots x u32), then the 256 BWT' bytes --
+// a query touches its symbol's count and the bytes behind it, neighbours in memory.
+struct HostRank {
+  std::vector<uint8_t> blob;        // (n / 256 + 1) records of `stride` bytes
+  size_t stride = 0;                // nslots * 4 + 256
+};
+
 struct Index {
   uint64_t serial = 0;          // unique per open in this process: what a resident regex batch remembers of its index
   int device = 0;
@@ -84,6 +92,9 @@ struct Index {
   mutable double last_kernel_ms = 0.0;
   // the handle's host thread for the one-process-several-GPUs entry points (made at the first such call; fmx_hostpar.h)
   mutable std::unique_ptr<Worker> worker;
+  // host-side rank dictionary (fmx_occ_host / fmx_calc_gaps_chain), built at first use
+  mutable std::mutex hr_mu;
+  mutable std::unique_ptr<HostRank> hr;
 };
 
 Worker *worker_of(const Index *h);     // fmx_api.cpp

@@ -290,6 +290,25 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_next_substr_batch_dev(self._h, _dp(d_rows), int(k), int(length), _dp(d_out),
                                                      _dp(d_out_len), _dp(stream)))
 
+    # ---- BWTMerger2.calcGaps' rank loop (bwtmerger.scala:981-1023): one dependent chain, answered on the host
+    def occ_host(self, c, i):
+        """fmx_occ_host: occ(c, i) from the host-side copy of the dictionary (same answer as occ)."""
+        if not 0 <= int(c) < 256:
+            raise IndexError("symbol %r (reference: ArrayIndexOutOfBoundsException)" % (c,))
+        v = ctypes.c_uint64()
+        _lib.check(self._L.fmx_occ_host(self._h, int(c), int(i), ctypes.byref(v)))
+        return int(v.value)
+
+    def calc_gaps_chain(self, text, rank0=0, last_char=-1, rklst=0):
+        """fmx_calc_gaps_chain: (ranks, done) -- ranks[j] = calcGaps' curRank after byte j; done < len(text) when the
+        chain stopped at a rank equal to rklst for the caller to decide (bwtmerger.scala:1004-1010)."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        ranks = np.zeros(max(text.size, 1), dtype=np.uint64)
+        done = ctypes.c_size_t()
+        _lib.check(self._L.fmx_calc_gaps_chain(self._h, _ptr(text), text.size, int(rank0), int(last_char), int(rklst),
+                                               _ptr(ranks), ctypes.byref(done)))
+        return ranks[: text.size], int(done.value)
+
     def prepare(self, ktab=True, select=False):
         """fmx_prepare: build the k-mer jump table / the select directory now instead of at first use."""
         _lib.check(self._L.fmx_prepare(self._h, (1 if ktab else 0) | (2 if select else 0)))

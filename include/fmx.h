@@ -195,6 +195,25 @@ int fmx_prev_substr(const fmx_index *idx, uint64_t sp, uint32_t len, uint8_t *ou
  * (len bytes, *out_len = len).  out needs len bytes. */
 int fmx_extract(const fmx_index *idx, uint64_t row, uint32_t len, int direction, uint8_t *out, uint32_t *out_len);
 
+/* ---- BWTMerger2.calcGaps' rank loop, bwtmerger.scala:981-1023.  calcGaps keeps ONE running rank over
+ * the bytes of the older text -- curRank = bucketStarts(c) + searcher.occ(c, curRank - 1): each rank query needs the
+ * one before, so the loop cannot be batched, and one such chain runs slower on the GPU than on a host core
+ * (profiles/r02_calcgaps_chain.txt).  These two entry points therefore answer on the HOST, from a host copy of the
+ * handle's BWT' with symbol counts every 256 positions (built at first use; n <= 2^31: a merge block) -- one
+ * count + a scan of < 256 bytes per query where NaiveBWTSearcher.occ (findex.scala:479-505) binary-searches an
+ * inverted list.  Same answers as fmx_occ_batch on the handle (fmx_open_block quirks included).  Not a fallback:
+ * every batch entry point stays on the device.
+ * fmx_occ_host        : one occ(c, i) -- what a `searcher: SuffixAlgo` adapter hands calcGaps unchanged.
+ * fmx_calc_gaps_chain : the loop's rank chain itself over k bytes from curRank = rank0: ranks[j] = the rank after byte
+ *                       j, with the loop's own correction for c == last_char (last_char < 0: none): a rank above
+ *                       rklst is bumped by one (:1011-1012); a rank EQUAL to rklst needs the caller's KMP buffer /
+ *                       longSuffixCmp (:1004-1010), so the chain stops there: *done = j < k, ranks[j] = the
+ *                       uncorrected rank; the caller fixes ranks[j] and calls again from byte j + 1 with rank0 =
+ *                       the fixed value.  *done == k: all bytes processed. */
+int fmx_occ_host(const fmx_index *idx, int c, int64_t i, uint64_t *out);
+int fmx_calc_gaps_chain(const fmx_index *idx, const uint8_t *c, size_t k, uint64_t rank0, int last_char, uint64_t rklst,
+                        uint64_t *ranks, size_t *done);
+
 /* ---- FMCreator.create, bwtmerger.scala:424-533: writes the reference's .fm file (inverted position
  * lists, 4-byte big-endian entries) from the device structure, so that findex's own NaiveFMSearcher
  * and tests can consume an index this engine prepared.  n must be < 0xffffffff (the reference has

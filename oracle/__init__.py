@@ -94,6 +94,7 @@ def lib():
     L.orc_match_sa_batch.restype = i64
     L.orc_match_sa_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i32,
                                      vp, vp, vp, vp, i64, P(i64), P(i64)]
+    L.orc_occ_chain.argtypes = [vp, vp, u64, i64, vp]
     L.orc_match_sa_batch_ordered.restype = i64
     L.orc_match_sa_batch_ordered.argtypes = L.orc_match_sa_batch.argtypes
     _lib = L
@@ -274,6 +275,13 @@ class NaiveFMSearcher:
     def lf_chain(self, row, steps):
         """`steps` dependent LF steps from `row` -> the row reached (one core, in C)."""
         return int(self._L.orc_lf_chain(self._h, int(row), int(steps)))
+
+    def occ_chain(self, text, rank0):
+        """calcGaps' rank chain (bwtmerger.scala:999-1001) over `text` from curRank = rank0, in C on one core."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        ranks = np.zeros(max(text.size, 1), dtype=np.int64)
+        self._L.orc_occ_chain(self._h, _ptr(text), text.size, int(rank0), _ptr(ranks))
+        return ranks[: text.size].astype(np.uint64)
 
     def fm(self):
         """The inverted list (= .fm payload) as a uint32 view copy."""

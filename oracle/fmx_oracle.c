@@ -413,6 +413,17 @@ int64_t orc_lf_chain(const orc_index *ix, int64_t row, int64_t steps) {
   return row;
 }
 
+/* calcGaps' own chain over a given text (F/bwtmerger.scala:999-1001, without the lastChar correction):
+ * curRank = cFirst if curRank == 0 else cFirst + occ(c, curRank - 1); ranks[j] = curRank after byte j. */
+int orc_occ_chain(const orc_index *ix, const uint8_t *c, uint64_t k, int64_t rank0, int64_t *ranks) {
+  int64_t cur = rank0;
+  for (uint64_t j = 0; j < k; j++) {
+    cur = (int64_t)ix->bs[c[j]] + (cur == 0 ? 0 : orc_occ(ix, c[j], cur - 1));
+    ranks[j] = cur;
+  }
+  return ORC_OK;
+}
+
 int orc_occ_batch(const orc_index *ix, const uint8_t *c, const int64_t *i, int64_t *out, uint64_t k) {
   for (uint64_t q = 0; q < k; q++) out[q] = orc_occ(ix, c[q], i[q]);
   return ORC_OK;

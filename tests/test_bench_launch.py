@@ -11,12 +11,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(extra, env_extra=None):
+def run_bench(extra, env_extra=None, workload="tiny"):
     env = dict(os.environ)
     for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--check-launch", "--workload", "tiny",
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--check-launch", "--workload", workload,
                            "--steps", "3", "--warmup", "1"] + extra, capture_output=True, text=True, env=env, timeout=280)
 
 
@@ -47,3 +47,15 @@ def test_single_rank_needs_no_launcher():
 def test_rank_count_must_match_gpus_flag():
     p = run_bench(["--gpus", "1"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "started 2 ranks" in p.stderr
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("workload,ranks", [("c5", 2), ("c4", 3), ("c4ref", 2)])
+def test_driver_shapes_dry_run(workload, ranks):
+    """What the driver's scaling run launches, without GPUs: C5's per-rank batch (1M x 24: 16 MB of intervals per
+    rank through the pipelined all-gather) and the regex workloads' exchange -- result lists of unequal lengths with an
+    empty rank, ids made global, sizes then padded payload -- over gloo, three ranks for C4."""
+    p = run_bench(["--gpus", str(ranks)], workload=workload)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == ranks and out["config"]["ranks_in_group"] == ranks and workload in out["config"]["workload"]

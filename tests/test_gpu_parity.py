@@ -171,6 +171,77 @@ def test_naive_bwt_searcher_through_the_product(golden):
             assert hip.occ_batch(np.full(n, c, dtype=np.uint8), ks).tolist() == [ref.occ(c, int(key)) for key in ks], (trial, c)
 
 
+def test_calc_gaps_rank_chain_on_the_host(golden, testdata):
+    """SURVEY 8f-4, BWTMerger2.calcGaps' rank loop (bwtmerger.scala:981-1023) over the product's dictionary on the
+    host: fmx_occ_host gives NaiveBWTSearcher.occ's answers (the 22 known ones, random blocks with the last-slot
+    rule, a file-backed index), and fmx_calc_gaps_chain reproduces the loop -- curRank = bucketStarts(c) +
+    occ(c, curRank - 1), the bump past rklst for c == lastChar, a stop where the reference consults its KMP buffer --
+    against a plain restatement of the loop over the oracle's NaiveBWTSearcher."""
+    import json
+    from oracle.naive_bwt import NaiveBWTSearcher
+    kat = json.load(open(os.path.join(golden, "naive_bwt_searcher_kat.json")))
+    for name in ("case1", "case2"):
+        k = kat[name]
+        bwt = np.array(k["bwt"], dtype=np.int64).astype(np.uint8)
+        hip = findex_amd.HipFMSearcher.from_block(bwt, k["bs"], k["rk0"])
+        for c, key, want in k["occ"]:
+            assert hip.occ_host(c & 0xFF, key) == want, (name, c, key)
+    rng = np.random.default_rng(15)
+    for trial in range(8):
+        n = int(rng.integers(2, 5000))
+        sigma_hi = 7 if trial % 2 else 256
+        bwt = rng.integers(1, sigma_hi, n).astype(np.uint8)
+        rk0 = int(rng.integers(0, n))
+        if trial == 3:
+            bwt[0] = 250
+            bwt[1:][bwt[1:] == 250] = 1
+            rk0 = n - 1
+        cnt = np.bincount(bwt, minlength=256)
+        bs = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+        hip = findex_amd.HipFMSearcher.from_block(bwt, bs, rk0)
+        ref = NaiveBWTSearcher(bwt, bs, rk0)
+        for c in {int(bwt[0]), int(bwt[rk0]), 1, 2, 255}:
+            ks = np.concatenate([[-1], rng.integers(0, n, 300), [n - 1, n + 3]])
+            assert [hip.occ_host(c, int(key)) for key in ks] == [ref.occ(c, int(min(key, n - 1))) if key >= 0 else 0 for key in ks], (trial, c)
+        # the loop itself over an "older text" of 3000 bytes
+        text = rng.integers(1, sigma_hi, 3000).astype(np.uint8)
+        last_char, rklst = int(text[7]), int(rng.integers(0, n))
+        c0 = int(text[0])
+        cur = int(bs[c0])                                # :985-987
+        want, stops = [cur], []
+        for j in range(1, text.size):
+            ch = int(text[j])
+            cur = int(bs[ch]) if cur == 0 else int(bs[ch]) + ref.occ(ch, cur - 1)      # :999-1001
+            if ch == last_char:                              # :1003-1013
+                if cur == rklst:
+                    stops.append(j)
+                    cur += j & 1                             # the "KMP buffer's" verdict, made up: the caller's business
+                elif cur > rklst:
+                    cur += 1
+            want.append(cur)
+        # drive the chain the way a caller does: byte 0 by hand, then stretches between the stops
+        got = [int(bs[c0])]
+        at, cur = 1, got[0]
+        while at < text.size:
+            ranks, done = hip.calc_gaps_chain(text[at:], rank0=cur, last_char=last_char, rklst=rklst)
+            got += [int(x) for x in ranks[:done]]
+            at += done
+            if done:
+                cur = got[-1]
+            if at < text.size:                               # stopped at a rank == rklst: decide, go on
+                assert int(ranks[done]) == rklst and at in stops
+                cur = rklst + (at & 1)
+                got.append(cur)
+                at += 1
+        assert got == want, trial
+    # any handle serves it: a file-backed index gives the same occ on the host as on the device
+    hip, orc = pair_from_files(testdata, "test1024.cmp", False)
+    cs = rng.integers(0, 256, 2000).astype(np.uint8)
+    ks = rng.integers(-1, hip.n + 2, 2000).astype(np.int64)
+    dev = hip.occ_batch(cs, ks)
+    assert [hip.occ_host(int(c), int(k)) for c, k in zip(cs, ks)] == dev.tolist()
+
+
 def test_extract_is_next_and_prev_substr(testdata):
     hip, orc = pair_from_files(testdata, "test1024.cmp", False)
     for row in (0, 1, 48, 462, 517, hip.n - 1):

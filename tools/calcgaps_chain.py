@@ -45,3 +45,32 @@ print("  GPU (one lane group, k_lf_walk):        %.3f us/step  (call %.1f ms, ke
 print("  CPU (oracle, inverted lists, one core): %.3f us/step" % (t_cpu * 1e6 / steps))
 print("  -> the chain is %.1fx %s on the GPU; calcGaps stays on the host"
       % ((hip.stats()["last_kernel_ms"] * 1e3 / steps) / (t_cpu * 1e6 / steps), "slower"))
+
+# ---- the same kind of chain on the host over the product's own dictionary (fmx_calc_gaps_chain: BWT' + symbol counts
+# every 256 positions in front of those bytes, one count + a scan per step) against the reference's structure (inverted lists,
+# binary-searched) on one core: curRank = cf(c) + occ(c, curRank - 1) over a random "older text"
+rng = np.random.default_rng(3)
+text = rng.integers(1, sigma + 1, steps).astype(np.uint8)
+hip.occ_host(1, 0)                      # builds the host-side dictionary (not timed)
+t0 = time.perf_counter()
+ranks, done = hip.calc_gaps_chain(text, rank0=row)
+t_host = time.perf_counter() - t0
+assert done == steps
+cur = row
+t0 = time.perf_counter()
+want = orc.occ_chain(text, row) if hasattr(orc, "occ_chain") else None
+t_ref = time.perf_counter() - t0
+if want is None:                        # the oracle has no C loop for this chain: time its occ on a sample, in Python
+    t0 = time.perf_counter()
+    cur = row
+    for j in range(20000):
+        cur = orc.cf(int(text[j])) + (0 if cur == 0 else orc.occ(int(text[j]), cur - 1))
+        assert cur == int(ranks[j])
+    t_ref = (time.perf_counter() - t0) * steps / 20000
+    note = "oracle occ through ctypes, 20k steps scaled (includes ~1 us of Python per step)"
+else:
+    assert np.array_equal(want, ranks)
+    note = "oracle C loop"
+print("calcGaps rank chain on the host, same index, %d steps, same ranks:" % steps)
+print("  product dictionary (fmx_calc_gaps_chain, one core): %.3f us/step" % (t_host * 1e6 / steps))
+print("  reference structure (%s): %.3f us/step" % (note, t_ref * 1e6 / steps))

@@ -451,6 +451,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     ranks_per_step = int(s1["rank_queries"])
     requests_per_step = int(s1["search_requests"])
     lookups_per_step = int(s1["ktab_lookups"])
+    jumps_per_step = int(s1["jump_lookups"])
     hits = int((sp < ep).sum().item())
     sp0, ep0 = sp.clone(), ep.clone()
     for _ in range(max(0, args.warmup - 1)):
@@ -498,8 +499,8 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     onehot = st["layout"] == 0
     line_bytes = 64.0 if onehot else 66.0        # bytes layout: a 128-B block and its 4-B checkpoint, one request each
     operand_bytes = k * m + 8 * (k + 1) + 16 * k
-    alg_bytes = requests_per_step * line_bytes + 16.0 * lookups_per_step + operand_bytes
-    all_requests = requests_per_step + lookups_per_step      # every one a dependent random request
+    alg_bytes = requests_per_step * line_bytes + 16.0 * (lookups_per_step + jumps_per_step) + operand_bytes
+    all_requests = requests_per_step + lookups_per_step + jumps_per_step      # every one a dependent random request
     ksec = kernel_ms * 1e-3
     achieved = alg_bytes / ksec / 1e9
     resident = "hbm" if st["index_bytes"] > INFINITY_CACHE_BYTES else "infinity-cache"
@@ -512,10 +513,12 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
                            ("committed profile profiles/%s (separate rocprofv3 --pmc passes of this very source; not "
                             "measured in this run)" % traffic[1]) if traffic else "no PMC profile of this workload committed"),
         "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d operand bytes (patterns, "
-                             "offsets, intervals)" % (requests_per_step, line_bytes, lookups_per_step, operand_bytes),
+        "algorithmic_bytes": "%d rank-line requests x %g B + (%d k-mer table + %d row jump table) entries x 16 B + %d operand "
+                             "bytes (patterns, offsets, intervals)" % (requests_per_step, line_bytes, lookups_per_step,
+                                                                        jumps_per_step, operand_bytes),
         "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
         "requests_per_launch": all_requests, "rank_line_requests": requests_per_step, "ktab_lookups": lookups_per_step,
+        "jump_lookups": jumps_per_step, "jump_table_gib": s1["jump_bytes"] / 2**30,
         "ktab_k": int(s1["ktab_k"]), "rank_queries_per_launch": ranks_per_step,
         "rank_queries_per_request": ranks_per_step / max(all_requests, 1),
         # SURVEY 8d's own pricing (its structure fetches 128/132 B per rank query; this layout does not): reported
@@ -555,14 +558,17 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
             "hit_patterns_fraction": hits_all / (world * k),
             "rank_queries_per_step": ranks_all,
             "rank_queries_are": "occ evaluations of the reference's loop on these inputs (2 per backward step, early "
-                                "exits counted); the kernel serves them with rank_queries_per_request per memory request",
+                                "exits counted) -- a reference-equivalent count, not executed popcounts: the kernel serves them "
+                                "with rank_queries_per_request per memory request (k-mer table for the first K steps, one "
+                                "row-jump-table entry per 8 steps once the interval is a row, shared blocks)",
             "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
                            % (world, ", all_gather of (sp,ep) per step overlapped with the next step's search" if use_dist else ""),
             "ranks_in_group": dist.get_world_size() if use_dist else 1,
             "index_gib": s1["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
             "tables_build_ms": s1["tables_build_ms"],
-            "tables_build_ms_is": "the k-mer jump table (K = %d), built at the handle's first search (or by fmx_prepare): "
-                                  "paid once per open on top of index_build_ms" % int(s1["ktab_k"]),
+            "tables_build_ms_is": "the k-mer jump table (K = %d) and the row jump table (%.1f GiB), built at the handle's first "
+                                  "search (or by fmx_prepare): paid once per open on top of index_build_ms"
+                                  % (int(s1["ktab_k"]), s1["jump_bytes"] / 2**30),
             "index_layout": "one-hot bit-vectors, 64-B blocks" if onehot else "BWT bytes + checkpoints",
         },
         "roofline": roof,

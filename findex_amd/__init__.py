@@ -37,4 +37,10 @@ def set_ktab(name):
     _lib.check(_lib.load().fmx_config_set(b"ktab", name.encode()))
 
 
-__all__ = ["set_layout", "set_checkpoints", "set_ktab", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "CompiledRegexes", "FmxError", "MatchError", "Re2PostSyntax"]
+def set_jump(name):
+    """fmx_config_set("jump", ...): "auto" | "off" -- the row jump table (handles that have not searched yet)."""
+    from . import _lib
+    _lib.check(_lib.load().fmx_config_set(b"jump", name.encode()))
+
+
+__all__ = ["set_layout", "set_checkpoints", "set_ktab", "set_jump", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "CompiledRegexes", "FmxError", "MatchError", "Re2PostSyntax"]

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libfmx.so")
-SOURCES = ["fmx_api.cpp", "fmx_hostpar.cpp", "fmx_comm.cpp", "fmx_hostrank.cpp", "fmx_regex.cpp", "fmx_build.hip", "fmx_kernels.hip", "fmx_search.hip", "fmx_ktab.hip", "fmx_select.hip", "fmx_frontier.hip", "fmx_refmatch.hip"]
+SOURCES = ["fmx_api.cpp", "fmx_hostpar.cpp", "fmx_comm.cpp", "fmx_hostrank.cpp", "fmx_regex.cpp", "fmx_build.hip", "fmx_kernels.hip", "fmx_search.hip", "fmx_ktab.hip", "fmx_jump.hip", "fmx_select.hip", "fmx_frontier.hip", "fmx_refmatch.hip"]
 HEADERS = ["fmx_device.h", "fmx_host.h", "fmx_hostpar.h", "fmx_nfa.h", "fmx_regex.h"]
 ARCH = "gfx950"
 

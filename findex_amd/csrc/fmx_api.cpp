@@ -276,6 +276,7 @@ static void destroy(Index *h) {
   if (h->d_ktab) (void)hipFree(h->d_ktab);
   if (h->d_kt_dense) (void)hipFree(h->d_kt_dense);
   if (h->d_kt_levels) (void)hipFree(h->d_kt_levels);
+  if (h->d_jump) (void)hipFree(h->d_jump);
   if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
   if (h->d_sel_off) (void)hipFree(h->d_sel_off);
   if (h->d_sel_shift) (void)hipFree(h->d_sel_shift);
@@ -457,6 +458,12 @@ int fmx_config_set(const char *key, const char *value) {
     else return arg_fail("checkpoints must be auto or superblock");
     return FMX_OK;
   }
+  if (std::strcmp(key, "jump") == 0) {
+    if (std::strcmp(value, "auto") == 0) jump_set_enabled(true);
+    else if (std::strcmp(value, "off") == 0) jump_set_enabled(false);
+    else return arg_fail("jump must be auto or off");
+    return FMX_OK;
+  }
   if (std::strcmp(key, "threads") == 0) {
     char *end = nullptr;
     const long v = std::strtol(value, &end, 10);
@@ -525,7 +532,7 @@ int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[2
 
 int fmx_prepare(const fmx_index *idx, unsigned what) {
   if (!idx) return arg_fail("null argument");
-  if (what & ~(unsigned)(FMX_PREPARE_KTAB | FMX_PREPARE_SELECT)) return arg_fail("unknown fmx_prepare flag");
+  if (what & ~(unsigned)(FMX_PREPARE_KTAB | FMX_PREPARE_SELECT | FMX_PREPARE_JUMP)) return arg_fail("unknown fmx_prepare flag");
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
@@ -536,6 +543,10 @@ int fmx_prepare(const fmx_index *idx, unsigned what) {
     HIP_TRY(ktab_get(h, lease.c->stream, &kt), "k-mer table");
   }
   if (what & FMX_PREPARE_SELECT) HIP_TRY(select_prepare(h, lease.c->stream), "select directory");
+  if (what & FMX_PREPARE_JUMP) {
+    const uint4 *jt = nullptr;
+    HIP_TRY(jump_get(h, lease.c->stream, &jt), "jump table");
+  }
   return FMX_OK;
 }
 
@@ -1007,21 +1018,23 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
-  unsigned long long cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   std::memset(out, 0, sizeof *out);
   HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
   {   // the counters live in per-workgroup slots (fmx_device.h): sum them
     std::vector<unsigned long long> slots((size_t)kCounterSlots * kCounterStride);
     HIP_TRY(hipMemcpy(slots.data(), h->d_counters, kCounterBytes, hipMemcpyDeviceToHost), "D2H(counters)");
     for (uint32_t sl = 0; sl < kCounterSlots; sl++)
-      for (int j = 0; j < 10; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
+      for (int j = 0; j < 11; j++) cnt[j] += slots[(size_t)sl * kCounterStride + j];
   }
   std::lock_guard<std::mutex> lk(h->mu);
   out->rank_queries = cnt[0];
   out->backward_steps = cnt[1];
   out->launches = h->launches;
   out->last_kernel_ms = h->last_kernel_ms;
-  out->index_bytes = h->index_bytes + h->sel_bytes + h->kt_bytes;
+  out->index_bytes = h->index_bytes + h->sel_bytes + h->kt_bytes + h->jump_bytes;
+  out->jump_lookups = cnt[10];
+  out->jump_bytes = h->jump_bytes;
   out->n_blocks = h->nblocks;
   out->n_symbols = h->nslots;
   out->block_bytes = h->layout == kLayoutBytes ? kByteBlock + 4 : kBlockBytes;

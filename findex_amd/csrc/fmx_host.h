@@ -82,6 +82,11 @@ struct Index {
   mutable KTab kt;
   mutable void *d_ktab = nullptr, *d_kt_dense = nullptr, *d_kt_levels = nullptr;
   mutable uint64_t kt_bytes = 0;
+  // row jump table (fmx_jump.hip), built at the first literal search
+  mutable std::mutex jt_mu;
+  mutable bool jt_ready = false;
+  mutable void *d_jump = nullptr;
+  mutable uint64_t jump_bytes = 0;
   mutable double tables_ms = 0.0;             // host time spent building the k-mer table and the select directory (under their mutexes)
   // select directory for Psi (fmx_select.hip), built on first use
   mutable std::mutex sel_mu;
@@ -116,6 +121,8 @@ struct CtxLease {            // scope guard around ctx_acquire / ctx_release
 bool ktab_enabled();                            // fmx_config_set("ktab", "auto" | "off")
 hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out);     // fmx_ktab.hip
 hipError_t select_prepare(const Index *h, hipStream_t st);          // fmx_select.hip: builds the select directory now
+hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out);   // fmx_jump.hip (nullptr: the handle has none)
+void jump_set_enabled(bool on);                                     // fmx_config_set("jump", "auto" | "off")
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP

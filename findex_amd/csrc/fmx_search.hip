@@ -77,9 +77,12 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // 4, 8 or 12 -- a compile-time constant, so that the step loop below starts at a constant step number and is
 // compiled exactly as without the table, and the pattern pipeline prefetches exactly the KT tail bytes the table
 // is indexed with (4 at sigma = 128: nothing more than before).
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
+// JT: the handle has a row jump table (fmx_jump.hip): once every stepping group of the wave holds one row, eight steps
+// at a time are ONE 16-byte lookup for every group whose next eight pattern characters are the ones its row's entry
+// names; the others walk those eight steps as before while the ones that jumped wait.
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT>
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
-                                                        uint32_t ksigma, const uint8_t *__restrict__ pat,
+                                                        uint32_t ksigma, const uint4 *__restrict__ jtab, const uint8_t *__restrict__ pat,
                                                         const uint64_t *__restrict__ off,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
                                                         uint32_t k, unsigned long long *__restrict__ counters) {
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   uint32_t len0, len1, len2;
   Tail tail0;
   uint32_t ktl = 0;                 // k-mer table lookups (counters[9])
+  uint32_t jtl = 0;                 // row jump table lookups (counters[10])
   load_off(wave, end0, len0);
   tail0 = load_tail(end0, len0);
   load_off((uint64_t)wave + nwaves, end1, len1);
@@ -202,9 +206,36 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
       }
       ch = pat_chunk(pat, own, end, len, KT / 4);              // the chunk step KT starts
     }
+    uint32_t skip = 0;                                         // steps this group has jumped over and still sits out
     for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
-      const bool stepping = it < len && sp < ep;
-      if (!__builtin_amdgcn_ballot_w64(stepping)) break;
+      const bool alive = it < len && sp < ep;
+      if (!__builtin_amdgcn_ballot_w64(alive)) break;
+      if (JT && (it & 3u) == 0u && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) != 1))) {
+        // ---- every live group holds one row and starts a chunk of the pattern: the next eight characters are
+        // `ch` and `nx`.  A group with eight or more left looks its row up; if the characters agree the eight steps
+        // are done -- [r, r + 1) -> [LF^8 r, LF^8 r + 1).  The chunks behind them are requested beside the lookup.
+        const bool can = alive && len - it >= 8u;
+        if (__builtin_amdgcn_ballot_w64(can)) {
+          const uint32_t ch2 = pat_chunk(pat, own, end, len, (it >> 2) + 2);
+          const uint32_t nx2 = pat_chunk(pat, own, end, len, (it >> 2) + 3);
+          bool jumped = false;
+          if (can) {
+            const uint4 je = jtab[sp];
+            jumped = je.x == ch && je.y == nx;
+            if (jumped) { sp = ((uint64_t)je.w << 32) | je.z; ep = sp + 1; steps += 8; }
+            if (t == 0) jtl++;
+          }
+          if (!__builtin_amdgcn_ballot_w64(alive && !jumped)) {     // everybody jumped: go on eight steps further
+            it += 7;
+            ch = ch2;
+            nx = nx2;
+            continue;
+          }
+          skip = jumped ? 8u : 0u;                                   // the others walk; this group waits for them
+        }
+      }
+      const bool stepping = alive && skip == 0u;
+      skip -= skip ? 1u : 0u;
       const bool wide_iv = stepping && (ep - sp) != 1;
       if (!__builtin_amdgcn_ballot_w64(wide_iv)) {
         // ---- every stepping group holds one row: one rank query + one bit (byte) test
@@ -286,6 +317,11 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
     if ((threadIdx.x & 63u) == 0 && lookups)
       atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 9, lookups);
   }
+  if (JT) {
+    const unsigned long long lookups = wave_sum((unsigned long long)jtl);
+    if ((threadIdx.x & 63u) == 0 && lookups)
+      atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 10, lookups);
+  }
 }
 
 // generic kernel (fmx_kernels.hip)
@@ -310,18 +346,27 @@ static int blocks_per_cu(K kernel) {
   return nb > 8 ? 8 : nb;
 }
 
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
-static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
-                             uint32_t k, hipStream_t st) {
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT>
+static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const uint8_t *pat, const uint64_t *off, uint64_t *sp,
+                              uint64_t *ep, uint32_t k, hipStream_t st) {
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
-  static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT>);
+  static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT>);
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search4<WIDE, LAYOUT, KT><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, pat, off, sp, ep, k,
-                                                          h->d_counters);
+  k_search4<WIDE, LAYOUT, KT, JT><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, pat, off, sp,
+                                                              ep, k, h->d_counters);
   return hipGetLastError();
+}
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
+static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
+                             uint32_t k, hipStream_t st) {
+  const uint4 *jt = nullptr;
+  const hipError_t e = jump_get(h, st, &jt);
+  if (e != hipSuccess) return e;
+  return jt ? launch_v4kj<WIDE, LAYOUT, KT, true>(h, kt, jt, pat, off, sp, ep, k, st)
+            : launch_v4kj<WIDE, LAYOUT, KT, false>(h, kt, nullptr, pat, off, sp, ep, k, st);
 }
 
 template <bool WIDE, uint32_t LAYOUT>

@@ -69,6 +69,10 @@ int fmx_abi_version(void);
  * kernel and a synchronisation per call: a debugging aid; the host-pointer form always checks).  key "checkpoints": "auto" (default: the bytes layout keeps absolute
  * 32-bit checkpoints whenever every symbol occurs fewer than 2^32 times) or "superblock" (always the relative
  * checkpoints + 64-bit superblock counts that larger counts need; for tests).  Affects indexes opened afterwards.
+ * key "jump": "auto" (default) / "off": the row jump table -- for every row the eight BWT characters an LF walk from
+ * it reads and the row it ends on, 16 n bytes: a search whose interval has narrowed to one row takes eight backward
+ * steps with one 16-byte lookup when its next eight characters match (built on a handle's first literal search when
+ * 32 n bytes + 8 GiB of HBM are free; fmx_stats_t.jump_bytes).
  * key "threads": host threads the library's own parallel parts use (fmx_regex_compile_batch, making a regex batch
  * resident); "0" = detect (default). */
 int fmx_config_set(const char *key, const char *value);
@@ -110,11 +114,12 @@ int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[2
 int fmx_close(fmx_index *idx);
 /* Builds now what a handle otherwise builds at first use -- FMX_PREPARE_KTAB: the k-mer jump table (first search or
  * regex match; up to min(16 GiB, a quarter of the free HBM)), FMX_PREPARE_SELECT: the select directory (first Psi /
- * nextSubstr; at most ~n bytes) -- so that no later call allocates device memory or synchronises a stream: for a
+ * nextSubstr; at most ~n bytes), FMX_PREPARE_JUMP: the row jump table (first literal search; 16 n bytes, twice that
+ * while it is built, skipped when that much HBM is not free) -- so that no later call allocates device memory or synchronises a stream: for a
  * caller that captures its stream, or that times its first search.  A table that cannot be built (no memory) is
  * left out: searches then walk every step on the rank dictionary, with the same results.  The time spent is reported as
  * fmx_stats_t.tables_build_ms. */
-enum { FMX_PREPARE_KTAB = 1, FMX_PREPARE_SELECT = 2 };
+enum { FMX_PREPARE_KTAB = 1, FMX_PREPARE_SELECT = 2, FMX_PREPARE_JUMP = 4 };
 int fmx_prepare(const fmx_index *idx, unsigned what);
 
 /* ---- scalars: SuffixAlgo.n / cf, findex.scala:10-12; NaiveFMSearcher.cf bwtmerger.scala:346-352 */
@@ -403,8 +408,12 @@ typedef struct fmx_stats_t {
   uint64_t ktab_lookups;        /* 16-byte k-mer table entries fetched (each stands for up to ktab_k backward steps) */
   uint32_t ktab_k;              /* K of the k-mer jump table (0: none, or not built yet) */
   uint32_t reserved3;           /* 0 */
-  double tables_build_ms;       /* host time spent building the k-mer table and the select directory (at first use or in
-                                 * fmx_prepare): what a handle's first search / first Psi pays on top of build_ms */
+  double tables_build_ms;       /* host time spent building the k-mer table, the row jump table and the select directory
+                                 * (at first use or in fmx_prepare): what a handle's first search / first Psi pays on top
+                                 * of build_ms */
+  uint64_t jump_lookups;        /* 16-byte row-jump-table entries fetched by fmx_search_batch[_dev]'s kernel (each stands
+                                 * for 8 backward steps when the pattern's next 8 characters match it) */
+  uint64_t jump_bytes;          /* device bytes of the row jump table (0: the handle has none); part of index_bytes */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 /* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */

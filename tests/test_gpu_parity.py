@@ -425,6 +425,65 @@ def test_kmer_table_on_and_off_agree():
     assert ks[0] == 0 and ks[1] >= 5                                 # 5^6 = 15625 <= n/8
 
 
+@pytest.mark.parametrize("layout", ["onehot", "bytes"])
+def test_row_jump_table_on_and_off_agree(layout):
+    """The row jump table (fmx_jump.hip) takes eight backward steps with one lookup once a search holds one row; with
+    it and without it every (sp, ep) -- misses with the reference loop's values at the failing step -- and the
+    executed-step counter must equal the oracle's.  Patterns of every length around the eight-step groups, misses at
+    every depth, foreign bytes and byte 0 inside a group, patterns whose walk crosses the EOF row, ragged batches in
+    which only some groups of a wave can jump; the k-mer table on and off beside it (the jump starts where it ends)."""
+    text = bytes(np.random.default_rng(77).integers(97, 101, 40_000).astype(np.uint8))      # real text: LF walks cross the EOF row
+    cases = [synth_bwt(300_000, 1, 5, 19), bwt_of_text(text[:3000])]
+    rng = np.random.default_rng(8)
+    findex_amd.set_layout(layout)
+    try:
+        for bwt, eof, counts in cases:
+            orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+            syms = [int(c) for c in np.nonzero(counts)[0]]
+            pats = []
+            for m in range(1, 45):
+                pats += lf_walk_patterns(orc, rng, 120, m, 0.35, alphabet=syms)
+            # walks that start at and around the EOF row, and ones that pass through it
+            for r0 in (orc.eof, max(orc.eof - 1, 0), min(orc.eof + 1, orc.n - 1), 0, orc.n - 1):
+                r, cs = r0, []
+                for _ in range(40):
+                    cs.append(orc.bwt_read(r))
+                    r = orc.getPrevI(r)
+                full = bytes(reversed(cs))
+                pats += [full[-m:] for m in (5, 9, 17, 25, 33, 40)]
+            pats += [bytes([syms[0]] * 12 + [0] + [syms[0]] * 12), bytes([syms[0]] * 20 + [250] + [syms[0]] * 3), b""] * 5
+            pats = [pats[i] for i in rng.permutation(len(pats))]
+            uniform = lf_walk_patterns(orc, rng, 4000, 36, 0.1, alphabet=syms)      # every wave jumps together
+            seen = []
+            for ktab in ("auto", "off"):
+                for jump in ("off", "auto"):
+                    findex_amd.set_ktab(ktab)
+                    findex_amd.set_jump(jump)
+                    try:
+                        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+                        check_search(hip, orc, pats)
+                        check_search(hip, orc, uniform)
+                        st = hip.stats()
+                        seen.append((jump, st["jump_bytes"], st["jump_lookups"]))
+                        if jump == "auto":
+                            assert st["jump_bytes"] == 16 * orc.n and st["jump_lookups"] > 2 * len(uniform)
+                            # the table itself: (BWT' along an 8-step LF walk, the row it ends on) -- spot-check through a
+                            # search of the walked characters from a one-row start is what check_search just did; the
+                            # executed steps equal the oracle's although fewer lines were requested
+                            assert st["search_requests"] < st["backward_steps"]
+                        else:
+                            assert st["jump_bytes"] == 0 and st["jump_lookups"] == 0
+                    finally:
+                        findex_amd.set_ktab("auto")
+                        findex_amd.set_jump("auto")
+    finally:
+        findex_amd.set_layout("auto")
+    # a block-mode handle (NaiveBWTSearcher) never has one
+    blk = findex_amd.HipFMSearcher.from_block(np.array([1, 2, 3, 1, 2], dtype=np.uint8), np.arange(256, dtype=np.int64) * 0, 2)
+    blk.search_batch(np.array([1, 2], dtype=np.uint8), np.array([0, 2], dtype=np.uint64))
+    assert blk.stats()["jump_bytes"] == 0
+
+
 def test_pipelined_host_batch_pageable_and_pinned():
     """Host-pointer batches of 128k patterns or more are cut into chunks over two streams (fmx_api.cpp): ragged
     lengths with empty patterns at chunk borders, offsets that do not start at 0, pageable and page-locked

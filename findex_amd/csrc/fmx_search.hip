@@ -19,7 +19,11 @@
 //   * a dynamic-refill variant that hands a group its next pattern as soon as one ends (at most 4 %
 //     faster than lockstep batches on lengths uniform in 1..64, slower otherwise);
 //   * forming the batches from patterns sorted by length (idle lanes issue no requests, and requests
-//     are the limit: ragged batches already run at 91 % of the uniform rate; the sort added its 90 us).
+//     are the limit: ragged batches already run at 91 % of the uniform rate; the sort added its 90 us);
+//   * with the row jump table (round 3): every lane group on its own step number, so that a group whose pattern
+//     differs from its row's text inside a jump does not make the fifteen that jumped wait for its eight steps
+//     (66 registers, per-group pattern cursors: 0.278 ms against 0.259 ms in lockstep on C3 -- with a jump table the
+//     kernel is bound by instruction issue, 88 % of the SIMDs' issue slots, not by waiting).
 #include <algorithm>
 #include <cstdlib>
 #include "fmx_device.h"

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench, findex_amd
-log2n, sigma, k, m, seed = bench.WORKLOADS["c3"]
+log2n, sigma, k, m, seed = bench.LITERAL["c3"]
 n = 1 << log2n
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream

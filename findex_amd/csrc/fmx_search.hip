@@ -32,6 +32,7 @@
 namespace fmx {
 
 constexpr int kSThreads = 256;
+constexpr uint64_t kDeferMark = 1ull << 63;      // ep_out of a pattern parked for k_search_defer (rows are < 2^38)
 
 // Bytes pat[pos-1], pat[pos-2], pat[pos-3], pat[pos-4] in byte lanes 0..3 (fewer when pos < 4).
 __device__ __forceinline__ uint32_t fetch4(const uint8_t *__restrict__ pat, uint64_t pos) {
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
       ch = pat_chunk(pat, own, end, len, KT / 4);              // the chunk step KT starts
     }
     uint32_t skip = 0;                                         // steps this group has jumped over and still sits out
+    bool deferred = false;                                     // this group's pattern was parked for k_search_defer
     for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
       const bool alive = it < len && sp < ep;
       if (!__builtin_amdgcn_ballot_w64(alive)) break;
@@ -227,9 +229,18 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
             const uint4 je = jtab[sp];
             jumped = je.x == ch && je.y == nx;
             if (jumped) { sp = ((uint64_t)je.w << 32) | je.z; ep = sp + 1; steps += 8; }
+            else {
+              // The pattern differs from its one row's text within these eight characters: it misses, and what is left
+              // to find is where -- the reference loop's values at the failing step.  Walking there here would hold up the
+              // whole wave (every lane executes the steps, the fifteen groups that jumped wait): the group parks its
+              // state in its output slots and retires; k_search_defer walks the parked patterns of 64 at a time, densely.
+              if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
+              deferred = true;
+              ep = sp;                                               // not alive any more
+            }
             if (t == 0) jtl++;
           }
-          if (!__builtin_amdgcn_ballot_w64(alive && !jumped)) {     // everybody jumped: go on eight steps further
+          if (!__builtin_amdgcn_ballot_w64(alive && !jumped && !deferred)) {     // everybody jumped: go on eight steps further
             it += 7;
             ch = ch2;
             nx = nx2;
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
           skip = jumped ? 8u : 0u;                                   // the others walk; this group waits for them
         }
       }
-      const bool stepping = alive && skip == 0u;
+      const bool stepping = alive && skip == 0u && !deferred;
       skip -= skip ? 1u : 0u;
       const bool wide_iv = stepping && (ep - sp) != 1;
       if (!__builtin_amdgcn_ballot_w64(wide_iv)) {
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         nx = pat_chunk(pat, own, end, len, (it >> 2) + 2);
       }
     }
-    if (act && t == 0) { sp_out[pid] = sp; ep_out[pid] = ep; }
+    if (act && t == 0 && !deferred) { sp_out[pid] = sp; ep_out[pid] = ep; }
     end0 = end1; len0 = len1; tail0 = tail1;
     end1 = end2; len1 = len2;
   }
@@ -326,6 +337,95 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
     if ((threadIdx.x & 63u) == 0 && lookups)
       atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 10, lookups);
   }
+}
+
+// The patterns k_search4 parked (a one-row search whose next eight characters differ from the row's jump-table entry):
+// sp_out[pid] = the row, ep_out[pid] = kDeferMark | the step number.  A wave looks at 128 consecutive patterns, hands the
+// parked ones to its lane groups and walks each to the step at which it fails -- at most eight one-row steps --
+// leaving the reference loop's final values and counting its steps.  One pattern in ten is parked at C3, so a wave
+// walks ~6 of them at once where the search kernel would have made 64 lanes execute the steps of one or two.
+template <bool WIDE, uint32_t LAYOUT>
+__global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
+                                                             uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
+                                                             unsigned long long *__restrict__ counters) {
+  constexpr int G = Lay<LAYOUT>::G;
+  constexpr uint32_t P = 64 / G;
+  constexpr uint32_t R = LAYOUT == kLayoutBytes ? 2u : 1u;
+  __shared__ uint4 s_tab[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) {
+    const uint64_t cf = ix.cf[c];
+    const uint16_t s = ix.slot[c];
+    uint64_t vb = 0;
+    if (s < kSlotEof) vb = LAYOUT == kLayoutBytes ? (uint64_t)s + 2 : (uint64_t)(uintptr_t)ix.bv + (uint64_t)s * ix.nblocks * kBlockBytes;
+    else if (s == kSlotEof) vb = 1;
+    s_tab[c] = make_uint4((uint32_t)cf, (uint32_t)(cf >> 32), (uint32_t)vb, (uint32_t)(vb >> 32));
+  }
+  __syncthreads();
+  const LaneConst lc = lane_const<G>();
+  const uint32_t t = lc.t, lane = threadIdx.x & 63u, grp = lane / G;
+  const uint32_t lane_off = t * 16;
+  const uint32_t wave = (blockIdx.x * kSThreads + threadIdx.x) >> 6, nwaves = gridDim.x * (kSThreads / 64);
+  uint32_t steps = 0, reqs = 0;
+  // 128 patterns per look: with one pattern in ten parked that fills most of a wave's lane groups, and the walks are
+  // chains of up to eight dependent requests -- the fewer rounds of them, the sooner the launch ends
+  for (uint64_t base = (uint64_t)wave * 128; base < k; base += (uint64_t)nwaves * 128) {
+    const uint64_t mine = base + lane;
+    const uint64_t e0 = mine < k ? ep_out[mine] : 0ull, e1 = mine + 64 < k ? ep_out[mine + 64] : 0ull;
+    unsigned long long m0 = __builtin_amdgcn_ballot_w64((e0 & kDeferMark) != 0ull);
+    unsigned long long m1 = __builtin_amdgcn_ballot_w64((e1 & kDeferMark) != 0ull);
+    while (m0 | m1) {
+      uint32_t pick = 128;                       // the grp-th parked pattern of this round
+      for (uint32_t j = 0; j < P && (m0 | m1); j++) {
+        uint32_t b;
+        if (m0) { b = (uint32_t)__builtin_ctzll(m0); m0 &= m0 - 1; }
+        else { b = 64u + (uint32_t)__builtin_ctzll(m1); m1 &= m1 - 1; }
+        if (grp == j) pick = b;
+      }
+      const bool act = pick < 128u;
+      const uint64_t pid = base + (act ? pick : 0u);
+      uint64_t sp = act ? sp_out[pid] : 0ull, ep = sp + (act ? 1u : 0u);
+      const uint32_t it = act ? (uint32_t)ep_out[pid] : 0u;
+      const uint64_t end = act ? off[pid + 1] : 8ull;
+      uint64_t chars = 0;                        // the eight characters from step `it` on, first one in the low byte
+      if (act) {
+        uint32_t lo, hi;                         // pat[end - it - 8 .. end - it): the pattern has them (len - it >= 8)
+        __builtin_memcpy(&lo, pat + (end - it - 8), 4);
+        __builtin_memcpy(&hi, pat + (end - it - 4), 4);
+        chars = ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
+      }
+      for (uint32_t s = 0; s < 8; s++) {
+        const bool stepping = sp < ep;
+        if (!__builtin_amdgcn_ballot_w64(stepping)) break;
+        if (stepping) {
+          const uint32_t c = (uint32_t)(chars >> (8u * s)) & 0xFFu;
+          const uint4 en = s_tab[c];
+          const uint64_t cfc = ((uint64_t)en.y << 32) | en.x;
+          const uint64_t vb = ((uint64_t)en.w << 32) | en.z;
+          if (vb > 1) {
+            if (LAYOUT == kLayoutBytes) {
+              const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), sp, lc);
+              sp = cfc + byte_rank_finish(q1, c, lc);
+              ep = sp + byte_match_bit(q1, c, lc);
+            } else {
+              uint32_t b1, m1;
+              split448(sp, b1, m1);
+              const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
+              sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+              ep = sp + payload_bit(w1, m1, lc);
+            }
+            reqs += R;
+          } else {
+            const uint64_t r1 = cfc + ((vb == 1 && sp > ix.eof) ? 1u : 0u);
+            ep = cfc + ((vb == 1 && ep > ix.eof) ? 1u : 0u);
+            sp = r1;
+          }
+          steps++;
+        }
+      }
+      if (act && t == 0) { sp_out[pid] = sp; ep_out[pid] = ep; }
+    }
+  }
+  counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
 }
 
 // generic kernel (fmx_kernels.hip)
@@ -361,6 +461,11 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
   k_search4<WIDE, LAYOUT, KT, JT><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, pat, off, sp,
                                                               ep, k, h->d_counters);
+  if (JT) {     // the patterns it parked (it reads the batch's ep_out once: 8 bytes per pattern; no state shared between calls)
+    const uint64_t wg = ((uint64_t)k + 2 * kSThreads - 1) / (2 * kSThreads);       // a wave looks at 128 patterns
+    const int g2 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 8);
+    k_search_defer<WIDE, LAYOUT><<<g2, kSThreads, 0, st>>>(h->dev, pat, off, sp, ep, k, h->d_counters);
+  }
   return hipGetLastError();
 }
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>

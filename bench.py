@@ -743,25 +743,26 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         # of a call hit L2 -- round 2 priced every load and came out above the PMC figure).
         n_states_batch = batch.info()["states"]
         rec_bytes = 32.0 * min(s1["frontier_records"], n_states_batch)
-        alg_bytes = (s1["frontier_requests"] * line_bytes + 16.0 * s1["ktab_lookups"] + rec_bytes +
+        alg_bytes = (s1["frontier_requests"] * line_bytes + 16.0 * s1["ktab_lookups"] + 8.0 * s1["jump_lookups"] + rec_bytes +
                      24.0 * (s1["frontier_queue_reads"] + s1["frontier_queue_writes"]) + 24.0 * s1["frontier_results"])
         achieved = alg_bytes / ksec / 1e9
         traffic = pmc_traffic(args.workload.replace("tiny", ""), "k_frontier")
-        all_req = s1["frontier_requests"] + s1["ktab_lookups"] + s1["frontier_records"]
+        all_req = s1["frontier_requests"] + s1["ktab_lookups"] + s1["jump_lookups"] + s1["frontier_records"]
         roof = {
             "bound": "hbm", "kernel": "k_frontier* (all device work of one fmx_regex_batch_match: HIP events around reset, start "
                                        "elements, the launch chain, result grouping and export)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d distinct state records x 32 B "
+            "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d row-table words x 8 B (one-row "
+                                 "elements) + %d distinct state records x 32 B "
                                  "(%d loads, L2-resident) + (%d + %d) queue entries x 24 B + %d results x 24 B"
-                                 % (s1["frontier_requests"], line_bytes, s1["ktab_lookups"], int(rec_bytes / 32),
+                                 % (s1["frontier_requests"], line_bytes, s1["ktab_lookups"], s1["jump_lookups"], int(rec_bytes / 32),
                                     s1["frontier_records"], s1["frontier_queue_reads"], s1["frontier_queue_writes"],
                                     s1["frontier_results"]),
             "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
             "requests_per_launch": int(all_req),
             "rank_line_requests": int(s1["frontier_requests"]), "ktab_lookups": int(s1["ktab_lookups"]),
-            "state_records": int(s1["frontier_records"]), "ktab_k": int(s1["ktab_k"]),
+            "state_records": int(s1["frontier_records"]), "ktab_k": int(s1["ktab_k"]), "row_table_lookups": int(s1["jump_lookups"]),
             "rank_queries_per_launch": ranks_per_step,
             "requests_G_per_s": all_req / ksec / 1e9,
             "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S,

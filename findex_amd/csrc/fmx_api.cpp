@@ -277,6 +277,7 @@ static void destroy(Index *h) {
   if (h->d_kt_dense) (void)hipFree(h->d_kt_dense);
   if (h->d_kt_levels) (void)hipFree(h->d_kt_levels);
   if (h->d_jump) (void)hipFree(h->d_jump);
+  if (h->d_row1) (void)hipFree(h->d_row1);
   if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
   if (h->d_sel_off) (void)hipFree(h->d_sel_off);
   if (h->d_sel_shift) (void)hipFree(h->d_sel_shift);
@@ -1032,9 +1033,9 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->backward_steps = cnt[1];
   out->launches = h->launches;
   out->last_kernel_ms = h->last_kernel_ms;
-  out->index_bytes = h->index_bytes + h->sel_bytes + h->kt_bytes + h->jump_bytes;
+  out->index_bytes = h->index_bytes + h->sel_bytes + h->kt_bytes + h->jump_bytes + h->row1_bytes;
   out->jump_lookups = cnt[10];
-  out->jump_bytes = h->jump_bytes;
+  out->jump_bytes = h->jump_bytes + h->row1_bytes;
   out->n_blocks = h->nblocks;
   out->n_symbols = h->nslots;
   out->block_bytes = h->layout == kLayoutBytes ? kByteBlock + 4 : kBlockBytes;

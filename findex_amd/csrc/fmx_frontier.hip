@@ -326,7 +326,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
   // the held element's state record; it stays while the element walks a literal stretch (meta bits 24..31)
   uint4 ra = make_uint4(0, 0, 0, 0);         // fol_off, cnt_c_emit, f[0], f[1]
   uint4 rb = make_uint4(0, 0, 0, 0);         // f[2], f[3], fc, regex
-  uint32_t n_reqs = 0, n_recs = 0, n_ktl = 0, n_writes = 0, n_emits = 0, n_reads = 0, stepped = 0, trunc = 0;
+  uint32_t n_reqs = 0, n_recs = 0, n_ktl = 0, n_jl = 0, n_writes = 0, n_emits = 0, n_reads = 0, stepped = 0, trunc = 0;
 
   // room for `cnt` entries in some slice's write buffer: slice, buffer, tag and first index (wave-uniform)
   struct Slot { uint64_t first; uint32_t tag; unsigned long long at; };
@@ -657,8 +657,14 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       }
     }
     const bool ranked = have && !cm;
-    // a rank query is needed unless the symbol is absent / EOF or the element is a start element
-    const bool query = ranked && len != 0 && slot < kSlotEof;
+    // a rank query is needed unless the symbol is absent / EOF or the element is a start element ...
+    const bool step_q = ranked && len != 0 && slot < kSlotEof;
+    // ... or holds one row and the handle has a row table: [r, r + 1) steps to [LF r, LF r + 1) if the state's byte is
+    // BWT'[r], to nothing otherwise -- one 8-byte load by the element's own lane, no lane group, no exchange slot
+    const bool row_q = kt.row1 != nullptr && step_q && (ep - sp) == 1;
+    unsigned long long r1e = 0;
+    if (row_q) { r1e = kt.row1[sp]; n_jl++; }
+    const bool query = step_q && !row_q;
     // The elements that have a query take the exchange slots 0, 1, 2 .. in lane order, so the lane groups serve
     // ceil(queries / (64/G)) sub-rounds, not all G: in a launch's thin end, and in rounds where most elements step
     // through the k-mer table, most sub-rounds have nothing to do and are skipped.
@@ -814,8 +820,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     pool_sync();
     }      // !narrow
     PH_MARK(ph2);
-    // the table entry is not needed before this point: keeps its load in flight beside the rank lines'
+    // the table entries are not needed before this point: keeps their loads in flight beside the rank lines'
     asm volatile("" : "+v"(ent.x), "+v"(ent.y), "+v"(ent.z), "+v"(ent.w));
+    asm volatile("" : "+v"(r1e));
     if (have) {
       if (from_tab) {
         sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
@@ -831,6 +838,9 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
           const uint64_t r2 = (slot == kSlotEof && ep > ix.eof) ? 1 : 0;
           sp = cfc + r1;
           ep = cfc + r2;
+        } else if (row_q) {
+          sp = r1e & ((1ull << 40) - 1);
+          ep = sp + (((uint32_t)(r1e >> 40) & 0xFFu) == c ? 1u : 0u);
         } else if (narrow) {
           sp = cfc + nsp;
           ep = cfc + nep;
@@ -1018,6 +1028,8 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
   {
     const unsigned long long lookups = wave_sum((unsigned long long)n_ktl);
     if (lane == 0 && lookups) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 9, lookups);
+    const unsigned long long rows = wave_sum((unsigned long long)n_jl);
+    if (lane == 0 && rows) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 10, rows);
   }
 }
 
@@ -1665,6 +1677,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
 
   KTab kt;
   HIP_TRY(ktab_get(h, st, &kt), "k-mer table");
+  HIP_TRY(row1_get(h, st, &kt.row1), "row table");
   // Generation tags are 16 bits wide; a buffer's tag advances at most once per launch.  Long before a tag can come
   // round to a value that an old entry still carries, the queue and the tags are zeroed (a 100 MB memset every few
   // thousand calls).

@@ -36,6 +36,8 @@ struct KTab {
                                              // stage them in LDS: indexing the by-value array would go through scratch)
   const uint8_t *dense = nullptr;   // [256] byte -> dense symbol id, 0xFF for bytes without a bit-vector
   uint32_t k = 0, sigma = 0;
+  // the regex frontier's row table (fmx_jump.hip, row1_get): per row BWT'[r] << 40 | LF r, or nullptr
+  const unsigned long long *row1 = nullptr;
 };
 
 // Host-resident rank dictionary of a (block-sized) index, for ONE dependent chain of rank queries (fmx_hostrank.cpp):
@@ -87,6 +89,11 @@ struct Index {
   mutable bool jt_ready = false;
   mutable void *d_jump = nullptr;
   mutable uint64_t jump_bytes = 0;
+  // row table of the regex frontier (fmx_jump.hip): (BWT'[r], LF r) per row, 8 bytes; built at the first regex match
+  mutable std::mutex r1_mu;
+  mutable bool r1_ready = false;
+  mutable void *d_row1 = nullptr;
+  mutable uint64_t row1_bytes = 0;
   mutable double tables_ms = 0.0;             // host time spent building the k-mer table and the select directory (under their mutexes)
   // select directory for Psi (fmx_select.hip), built on first use
   mutable std::mutex sel_mu;
@@ -122,6 +129,7 @@ bool ktab_enabled();                            // fmx_config_set("ktab", "auto"
 hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out);     // fmx_ktab.hip
 hipError_t select_prepare(const Index *h, hipStream_t st);          // fmx_select.hip: builds the select directory now
 hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out);   // fmx_jump.hip (nullptr: the handle has none)
+hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out);   // fmx_jump.hip (nullptr: none)
 void jump_set_enabled(bool on);                                     // fmx_config_set("jump", "auto" | "off")
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)

@@ -63,6 +63,29 @@ __global__ __launch_bounds__(kJThreads) void k_jump_double(const uint4 *__restri
   }
 }
 
+// The regex frontier's row table: R[r] = LF r | BWT'[r] << 40, one 8-byte word per row.  An element of the frontier whose
+// interval is one row [r, r + 1) steps with its state's byte c to [LF r, LF r + 1) if c == BWT'[r] and to nothing
+// otherwise (getPrevRange on one row) -- with R that is one 8-byte load by the element's own lane instead of a rank query
+// by a lane group (a 64-byte block through the LDS exchange, ~45 vector instructions): fmx_frontier.hip.  C4: 0.403 ->
+// 0.387 ms per call.  (Tried on top and dropped: a third byte BWT'[LF r], with which an element that stepped this way
+// drops those of its follows that cannot survive their own step, counting the reference's steps for them -- no gain on
+// C4: the follows that die there are pushed by elements that were still wider than one row, 0.388 vs 0.382 ms.)
+template <bool WIDE, uint32_t LAYOUT>
+__global__ __launch_bounds__(kJThreads) void k_row1_init(DevIndex ix, unsigned long long *__restrict__ out) {
+  __shared__ uint64_t s_cf[256];
+  __shared__ uint16_t s_slot[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  __syncthreads();
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
+  const uint64_t ngroups = (uint64_t)gridDim.x * (kJThreads / G);
+  for (uint64_t r = ((uint64_t)blockIdx.x * kJThreads + threadIdx.x) / G; r < ix.n; r += ngroups) {
+    const uint32_t c = r == ix.eof ? 0u : ix.bwt[r];
+    const uint64_t nxt = s_cf[c] + rank_excl<WIDE, LAYOUT>(ix, c, s_slot[c], r, lc);
+    if (lc.t == 0) out[r] = nxt | ((unsigned long long)c << 40);
+  }
+}
+
 static std::atomic<int> g_jump_enabled{1};
 void jump_set_enabled(bool on) { g_jump_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
 
@@ -125,6 +148,38 @@ hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out) {
     h->jt_ready = true;
   }
   *out = static_cast<const uint4 *>(h->d_jump);
+  return hipSuccess;
+}
+
+// The frontier's row table of a handle (nullptr: none), built at the first regex match: 8 n bytes.
+hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out) {
+  std::lock_guard<std::mutex> lk(h->r1_mu);
+  if (!h->r1_ready) {
+    const auto t0 = std::chrono::steady_clock::now();
+    static const int forced = getenv("FMX_ROW1") ? atoi(getenv("FMX_ROW1")) : -1;      // 0 = off
+    size_t free_b = 0, total_b = 0;
+    const uint64_t bytes = h->n * 8;
+    if (forced != 0 && g_jump_enabled.load(std::memory_order_relaxed) && !h->block_mode && h->n >= 2 && h->nslots >= 1 &&
+        hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes + (4ull << 30) <= free_b) {
+      void *p = nullptr;
+      hipError_t e = hipMalloc(&p, bytes);
+      if (e == hipSuccess) {
+        const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
+        const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
+#define CALL(W, L) k_row1_init<W, L><<<grid, kJThreads, 0, st>>>(h->dev, (unsigned long long *)p)
+        FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) { h->d_row1 = p; h->row1_bytes = bytes; }
+        else (void)hipFree(p);
+      }
+      if (e != hipSuccess) (void)hipGetLastError();      // no table: every element steps by rank query
+    }
+    h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->r1_ready = true;
+  }
+  *out = static_cast<const unsigned long long *>(h->d_row1);
   return hipSuccess;
 }
 

@@ -452,6 +452,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     requests_per_step = int(s1["search_requests"])
     lookups_per_step = int(s1["ktab_lookups"])
     jumps_per_step = int(s1["jump_lookups"])
+    rows_per_step = int(s1["row_lookups"])
     hits = int((sp < ep).sum().item())
     sp0, ep0 = sp.clone(), ep.clone()
     for _ in range(max(0, args.warmup - 1)):
@@ -499,8 +500,8 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     onehot = st["layout"] == 0
     line_bytes = 64.0 if onehot else 66.0        # bytes layout: a 128-B block and its 4-B checkpoint, one request each
     operand_bytes = k * m + 8 * (k + 1) + 16 * k
-    alg_bytes = requests_per_step * line_bytes + 16.0 * (lookups_per_step + jumps_per_step) + operand_bytes
-    all_requests = requests_per_step + lookups_per_step + jumps_per_step      # every one a dependent random request
+    alg_bytes = requests_per_step * line_bytes + 16.0 * (lookups_per_step + jumps_per_step) + 8.0 * rows_per_step + operand_bytes
+    all_requests = requests_per_step + lookups_per_step + jumps_per_step + rows_per_step      # every one a dependent random request
     ksec = kernel_ms * 1e-3
     achieved = alg_bytes / ksec / 1e9
     resident = "hbm" if st["index_bytes"] > INFINITY_CACHE_BYTES else "infinity-cache"
@@ -513,12 +514,13 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
                            ("committed profile profiles/%s (separate rocprofv3 --pmc passes of this very source; not "
                             "measured in this run)" % traffic[1]) if traffic else "no PMC profile of this workload committed"),
         "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_bytes": "%d rank-line requests x %g B + (%d k-mer table + %d row jump table) entries x 16 B + %d operand "
-                             "bytes (patterns, offsets, intervals)" % (requests_per_step, line_bytes, lookups_per_step,
-                                                                        jumps_per_step, operand_bytes),
+        "algorithmic_bytes": "%d rank-line requests x %g B + (%d k-mer table + %d row jump table) entries x 16 B + %d row "
+                             "table words x 8 B + %d operand bytes (patterns, offsets, intervals)"
+                             % (requests_per_step, line_bytes, lookups_per_step, jumps_per_step, rows_per_step, operand_bytes),
         "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
         "requests_per_launch": all_requests, "rank_line_requests": requests_per_step, "ktab_lookups": lookups_per_step,
         "jump_lookups": jumps_per_step, "jump_table_gib": s1["jump_bytes"] / 2**30,
+        "row_lookups": rows_per_step, "row_table_gib": s1["row_bytes"] / 2**30,
         "ktab_k": int(s1["ktab_k"]), "rank_queries_per_launch": ranks_per_step,
         "rank_queries_per_request": ranks_per_step / max(all_requests, 1),
         # SURVEY 8d's own pricing (its structure fetches 128/132 B per rank query; this layout does not): reported
@@ -566,9 +568,9 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
             "ranks_in_group": dist.get_world_size() if use_dist else 1,
             "index_gib": s1["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
             "tables_build_ms": s1["tables_build_ms"],
-            "tables_build_ms_is": "the k-mer jump table (K = %d) and the row jump table (%.1f GiB), built at the handle's first "
-                                  "search (or by fmx_prepare): paid once per open on top of index_build_ms"
-                                  % (int(s1["ktab_k"]), s1["jump_bytes"] / 2**30),
+            "tables_build_ms_is": "the k-mer jump table (K = %d), the row jump table (%.1f GiB) and the row table (%.1f GiB), built "
+                                  "at the handle's first search (or by fmx_prepare): paid once per open on top of index_build_ms"
+                                  % (int(s1["ktab_k"]), s1["jump_bytes"] / 2**30, s1["row_bytes"] / 2**30),
             "index_layout": "one-hot bit-vectors, 64-B blocks" if onehot else "BWT bytes + checkpoints",
         },
         "roofline": roof,
@@ -743,11 +745,11 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         # of a call hit L2 -- round 2 priced every load and came out above the PMC figure).
         n_states_batch = batch.info()["states"]
         rec_bytes = 32.0 * min(s1["frontier_records"], n_states_batch)
-        alg_bytes = (s1["frontier_requests"] * line_bytes + 16.0 * s1["ktab_lookups"] + 8.0 * s1["jump_lookups"] + rec_bytes +
+        alg_bytes = (s1["frontier_requests"] * line_bytes + 16.0 * s1["ktab_lookups"] + 8.0 * s1["row_lookups"] + rec_bytes +
                      24.0 * (s1["frontier_queue_reads"] + s1["frontier_queue_writes"]) + 24.0 * s1["frontier_results"])
         achieved = alg_bytes / ksec / 1e9
         traffic = pmc_traffic(args.workload.replace("tiny", ""), "k_frontier")
-        all_req = s1["frontier_requests"] + s1["ktab_lookups"] + s1["jump_lookups"] + s1["frontier_records"]
+        all_req = s1["frontier_requests"] + s1["ktab_lookups"] + s1["row_lookups"] + s1["frontier_records"]
         roof = {
             "bound": "hbm", "kernel": "k_frontier* (all device work of one fmx_regex_batch_match: HIP events around reset, start "
                                        "elements, the launch chain, result grouping and export)",
@@ -756,13 +758,13 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
             "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d row-table words x 8 B (one-row "
                                  "elements) + %d distinct state records x 32 B "
                                  "(%d loads, L2-resident) + (%d + %d) queue entries x 24 B + %d results x 24 B"
-                                 % (s1["frontier_requests"], line_bytes, s1["ktab_lookups"], s1["jump_lookups"], int(rec_bytes / 32),
+                                 % (s1["frontier_requests"], line_bytes, s1["ktab_lookups"], s1["row_lookups"], int(rec_bytes / 32),
                                     s1["frontier_records"], s1["frontier_queue_reads"], s1["frontier_queue_writes"],
                                     s1["frontier_results"]),
             "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
             "requests_per_launch": int(all_req),
             "rank_line_requests": int(s1["frontier_requests"]), "ktab_lookups": int(s1["ktab_lookups"]),
-            "state_records": int(s1["frontier_records"]), "ktab_k": int(s1["ktab_k"]), "row_table_lookups": int(s1["jump_lookups"]),
+            "state_records": int(s1["frontier_records"]), "ktab_k": int(s1["ktab_k"]), "row_table_lookups": int(s1["row_lookups"]),
             "rank_queries_per_launch": ranks_per_step,
             "requests_G_per_s": all_req / ksec / 1e9,
             "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S,

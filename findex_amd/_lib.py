@@ -50,7 +50,8 @@ class fmx_stats_t(ctypes.Structure):
                 ("frontier_queue_reads", ctypes.c_uint64), ("frontier_queue_writes", ctypes.c_uint64),
                 ("frontier_results", ctypes.c_uint64), ("frontier_records", ctypes.c_uint64),
                 ("ktab_lookups", ctypes.c_uint64), ("ktab_k", ctypes.c_uint32), ("reserved3", ctypes.c_uint32),
-                ("tables_build_ms", ctypes.c_double), ("jump_lookups", ctypes.c_uint64), ("jump_bytes", ctypes.c_uint64)]
+                ("tables_build_ms", ctypes.c_double), ("jump_lookups", ctypes.c_uint64), ("jump_bytes", ctypes.c_uint64),
+                ("row_lookups", ctypes.c_uint64), ("row_bytes", ctypes.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/fmx.h declares

@@ -352,7 +352,7 @@ __device__ __forceinline__ uint32_t single_row_step(const DevIndex &ix, uint32_t
 constexpr uint32_t kCounterSlots = 2048;
 constexpr uint32_t kCounterStride = 16;        // uint64 per slot: [0] rank queries, [1] backward steps, [2] search requests,
                                                // frontier kernels: [3] rank-line requests, [4] queue appends, [5] results,
-                                               // [6] elements stepped, [7] queue entries read, [8] state records loaded; [9] k-mer table lookups; [10] row jump table lookups
+                                               // [6] elements stepped, [7] queue entries read, [8] state records loaded; [9] k-mer table lookups; [10] row jump table lookups (16 B); [11] row table lookups (8 B)
 constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterStride * 8;
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {

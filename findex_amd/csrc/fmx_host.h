@@ -130,7 +130,7 @@ hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out);     // fmx_ktab.
 hipError_t select_prepare(const Index *h, hipStream_t st);          // fmx_select.hip: builds the select directory now
 hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out);   // fmx_jump.hip (nullptr: the handle has none)
 hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out);   // fmx_jump.hip (nullptr: none)
-void jump_set_enabled(bool on);                                     // fmx_config_set("jump", "auto" | "off")
+void jump_set_mode(int mode);      // fmx_config_set("jump", ..): bit 0 = the row table, bit 1 = the row jump table
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP

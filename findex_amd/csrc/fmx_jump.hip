@@ -86,13 +86,13 @@ __global__ __launch_bounds__(kJThreads) void k_row1_init(DevIndex ix, unsigned l
   }
 }
 
-static std::atomic<int> g_jump_enabled{1};
-void jump_set_enabled(bool on) { g_jump_enabled.store(on ? 1 : 0, std::memory_order_relaxed); }
+static std::atomic<int> g_jump_mode{3};      // bit 0: row table (R1), bit 1: row jump table (J8)
+void jump_set_mode(int mode) { g_jump_mode.store(mode & 3, std::memory_order_relaxed); }
 
 // Called under h->jt_mu by jump_get.  Leaves h->d_jump null when the table is not wanted or does not fit.
 static hipError_t build_jump(const Index *h, hipStream_t st) {
   static const int forced = getenv("FMX_JUMP") ? atoi(getenv("FMX_JUMP")) : -1;      // 0 = off, 1 = whenever it fits
-  if (forced == 0 || (forced < 0 && !g_jump_enabled.load(std::memory_order_relaxed))) return hipSuccess;
+  if (forced == 0 || (forced < 0 && !(g_jump_mode.load(std::memory_order_relaxed) & 2))) return hipSuccess;
   if (h->block_mode || h->n < 2 || h->nslots < 1) return hipSuccess;
   const uint64_t bytes = h->n * 16;
   size_t free_b = 0, total_b = 0;
@@ -159,7 +159,7 @@ hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **o
     static const int forced = getenv("FMX_ROW1") ? atoi(getenv("FMX_ROW1")) : -1;      // 0 = off
     size_t free_b = 0, total_b = 0;
     const uint64_t bytes = h->n * 8;
-    if (forced != 0 && g_jump_enabled.load(std::memory_order_relaxed) && !h->block_mode && h->n >= 2 && h->nslots >= 1 &&
+    if (forced != 0 && (g_jump_mode.load(std::memory_order_relaxed) & 1) && !h->block_mode && h->n >= 2 && h->nslots >= 1 &&
         hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes + (4ull << 30) <= free_b) {
       void *p = nullptr;
       hipError_t e = hipMalloc(&p, bytes);

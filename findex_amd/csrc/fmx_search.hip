@@ -85,7 +85,11 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // JT: the handle has a row jump table (fmx_jump.hip): once every stepping group of the wave holds one row, eight steps
 // at a time are ONE 16-byte lookup for every group whose next eight pattern characters are the ones its row's entry
 // names; the others walk those eight steps as before while the ones that jumped wait.
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT>
+// RW: the handle has a row table (fmx_jump.hip, row1_get): a group whose interval has become ONE ROW parks its pattern at
+// once -- sp_out = the row, ep_out = kDeferMark | step number -- and k_search_rows (below) finishes it with one LANE per
+// pattern, since from there on a search needs no rank query: this kernel then runs only the k-mer lookup and the few
+// steps on wide intervals.
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, bool RW>
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
                                                         uint32_t ksigma, const uint4 *__restrict__ jtab, const uint8_t *__restrict__ pat,
                                                         const uint64_t *__restrict__ off,
@@ -214,7 +218,13 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
     uint32_t skip = 0;                                         // steps this group has jumped over and still sits out
     bool deferred = false;                                     // this group's pattern was parked for k_search_defer
     for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
-      const bool alive = it < len && sp < ep;
+      bool alive = it < len && sp < ep;
+      if (RW && alive && (ep - sp) == 1) {                     // one row: the rest is k_search_rows'
+        if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
+        deferred = true;
+        ep = sp;
+        alive = false;
+      }
       if (!__builtin_amdgcn_ballot_w64(alive)) break;
       if (JT && (it & 3u) == 0u && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) != 1))) {
         // ---- every live group holds one row and starts a chunk of the pattern: the next eight characters are
@@ -339,11 +349,93 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   }
 }
 
-// The patterns k_search4 parked (a one-row search whose next eight characters differ from the row's jump-table entry):
-// sp_out[pid] = the row, ep_out[pid] = kDeferMark | the step number.  A wave looks at 128 consecutive patterns, hands the
-// parked ones to its lane groups and walks each to the step at which it fails -- at most eight one-row steps --
-// leaving the reference loop's final values and counting its steps.  One pattern in ten is parked at C3, so a wave
-// walks ~6 of them at once where the search kernel would have made 64 lanes execute the steps of one or two.
+// One-row searches, one LANE per pattern (k_search4<.., RW> parks a pattern as soon as its interval is a single row:
+// sp_out[pid] = the row, ep_out[pid] = kDeferMark | the step number).  From there a search is a comparison of the
+// pattern with the text in front of that row's suffix, and the two derived tables hold that text:
+//     J[r]  = (BWT'[r], BWT'[LF r], .., BWT'[LF^7 r] ; LF^8 r)     16 bytes (fmx_jump.hip), eight steps per lookup
+//     R1[r] = (BWT'[r] ; LF r)                                        8 bytes, one step per lookup
+// Neither needs a lane group (no rank query: nothing to popcount), so each lane walks its own pattern: 64 dependent
+// chains per wave where the lane groups of k_search4 keep 16 (8 in the bytes layout), and a dozen instructions per
+// lookup.  A pattern with eight or more characters left looks its row up in J; if they are not the entry's it fails
+// within these eight and finds where with R1, as does a pattern's tail of fewer than eight.  The step that FAILS is
+// not taken here: the reference loop's values at that step are a rank query (C[c] + rank(c, r) for a c that is not
+// BWT'[r]), so the pattern is parked again, at that step, for k_search_defer's lane groups -- one pattern in ten at C3.
+template <bool HAVE_J>
+__global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restrict__ jtab, const unsigned long long *__restrict__ row1,
+                                                            const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
+                                                            uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
+                                                            unsigned long long *__restrict__ counters) {
+  const uint64_t nth = (uint64_t)gridDim.x * kSThreads;
+  uint32_t steps = 0, looks = 0, rlooks = 0;      // lookups in J (counters[10]) and in R1 (counters[11])
+  for (uint64_t base = (uint64_t)blockIdx.x * kSThreads + (threadIdx.x & ~63u); base < k; base += nth) {      // wave-uniform
+    const uint64_t pid = base + (threadIdx.x & 63u);
+    const bool in = pid < k;
+    const uint64_t e0 = in ? ep_out[pid] : 0ull;
+    bool live = (e0 & kDeferMark) != 0ull;
+    uint64_t row = live ? sp_out[pid] : 0ull;
+    uint32_t it = (uint32_t)e0;
+    const uint64_t end = live ? off[pid + 1] : 0ull;
+    const uint32_t len = live ? (uint32_t)(end - off[pid]) : 0u;
+    uint32_t walk = 0;                           // steps still to be walked one by one after a lookup in J that did not agree
+    while (__builtin_amdgcn_ballot_w64(live)) {
+      const uint32_t rem = len - it;
+      const bool jm = HAVE_J && live && rem >= 8u && walk == 0u;
+      const bool rm = live && rem != 0u && !jm;
+      uint4 je = make_uint4(0, 0, 0, 0);
+      uint32_t lo = 0, hi = 0, c = 0;
+      unsigned long long re = 0;
+      if (jm) {                                  // pat[end - it - 8 .. end - it): the pattern has them
+        je = jtab[row];
+        __builtin_memcpy(&lo, pat + (end - it - 8), 4);
+        __builtin_memcpy(&hi, pat + (end - it - 4), 4);
+      }
+      if (rm) {
+        re = row1[row];
+        c = pat[end - it - 1];
+      }
+      if (jm) {
+        looks++;
+        if (je.x == __builtin_bswap32(hi) && je.y == __builtin_bswap32(lo)) {
+          row = ((uint64_t)je.w << 32) | je.z;
+          it += 8;
+          steps += 8;
+        } else {
+          walk = 8;
+        }
+      } else if (rm) {
+        rlooks++;
+        const uint32_t c2 = (uint32_t)(re >> 40) & 0xFFu;
+        if (c == c2 && c2 != 0u) {
+          row = re & ((1ull << 40) - 1);
+          it++;
+          steps++;
+          walk -= walk ? 1u : 0u;
+        } else {                                 // the failing step (or the end-of-text row): a rank query, k_search_defer's
+          sp_out[pid] = row;
+          ep_out[pid] = kDeferMark | it;
+          live = false;
+        }
+      } else if (live) {                         // the pattern is through
+        sp_out[pid] = row;
+        ep_out[pid] = row + 1;
+        live = false;
+      }
+    }
+  }
+  counters_add(counters, 2ull * steps, steps, 0);
+  const unsigned long long lookups = wave_sum((unsigned long long)looks);
+  if ((threadIdx.x & 63u) == 0 && lookups) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 10, lookups);
+  const unsigned long long rlookups = wave_sum((unsigned long long)rlooks);
+  if ((threadIdx.x & 63u) == 0 && rlookups) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 11, rlookups);
+}
+
+// The patterns still parked after that (sp_out[pid] = a row, ep_out[pid] = kDeferMark | the step number): with a row
+// table, the ones k_search_rows left at their failing step; without one, the ones whose lookup in J did not agree in
+// k_search4<.., JT> -- they fail within the next eight steps.  A wave looks at 128 consecutive patterns, hands the
+// parked ones to its lane groups and walks each with ordinary one-row steps until its interval is empty (or, should
+// it not fail after all, to its end), leaving the reference loop's final values and counting its steps.  One pattern
+// in ten is parked at C3, so a wave walks ~6 of them at once where the search kernel would have made 64 lanes execute
+// the steps of one or two.
 template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
                                                              uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
@@ -367,7 +459,7 @@ __global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const u
   const uint32_t wave = (blockIdx.x * kSThreads + threadIdx.x) >> 6, nwaves = gridDim.x * (kSThreads / 64);
   uint32_t steps = 0, reqs = 0;
   // 128 patterns per look: with one pattern in ten parked that fills most of a wave's lane groups, and the walks are
-  // chains of up to eight dependent requests -- the fewer rounds of them, the sooner the launch ends
+  // chains of dependent requests -- the fewer rounds of them, the sooner the launch ends
   for (uint64_t base = (uint64_t)wave * 128; base < k; base += (uint64_t)nwaves * 128) {
     const uint64_t mine = base + lane;
     const uint64_t e0 = mine < k ? ep_out[mine] : 0ull, e1 = mine + 64 < k ? ep_out[mine + 64] : 0ull;
@@ -384,43 +476,54 @@ __global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const u
       const bool act = pick < 128u;
       const uint64_t pid = base + (act ? pick : 0u);
       uint64_t sp = act ? sp_out[pid] : 0ull, ep = sp + (act ? 1u : 0u);
-      const uint32_t it = act ? (uint32_t)ep_out[pid] : 0u;
-      const uint64_t end = act ? off[pid + 1] : 8ull;
-      uint64_t chars = 0;                        // the eight characters from step `it` on, first one in the low byte
-      if (act) {
-        uint32_t lo, hi;                         // pat[end - it - 8 .. end - it): the pattern has them (len - it >= 8)
-        __builtin_memcpy(&lo, pat + (end - it - 8), 4);
-        __builtin_memcpy(&hi, pat + (end - it - 4), 4);
-        chars = ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
-      }
-      for (uint32_t s = 0; s < 8; s++) {
-        const bool stepping = sp < ep;
-        if (!__builtin_amdgcn_ballot_w64(stepping)) break;
-        if (stepping) {
-          const uint32_t c = (uint32_t)(chars >> (8u * s)) & 0xFFu;
-          const uint4 en = s_tab[c];
-          const uint64_t cfc = ((uint64_t)en.y << 32) | en.x;
-          const uint64_t vb = ((uint64_t)en.w << 32) | en.z;
-          if (vb > 1) {
-            if (LAYOUT == kLayoutBytes) {
-              const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), sp, lc);
-              sp = cfc + byte_rank_finish(q1, c, lc);
-              ep = sp + byte_match_bit(q1, c, lc);
-            } else {
-              uint32_t b1, m1;
-              split448(sp, b1, m1);
-              const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
-              sp = cfc + rank_finish<WIDE>(w1, m1, lc);
-              ep = sp + payload_bit(w1, m1, lc);
-            }
-            reqs += R;
+      uint32_t it = act ? (uint32_t)ep_out[pid] : 0u;
+      const uint64_t end = act ? off[pid + 1] : 0ull;
+      const uint32_t len = act ? (uint32_t)(end - off[pid]) : 0u;
+      for (;;) {                                 // eight steps at a time
+        const uint32_t rem = len - it;
+        if (!__builtin_amdgcn_ballot_w64(act && sp < ep && rem != 0u)) break;
+        const uint32_t nst = rem < 8u ? rem : 8u;
+        uint64_t chars = 0;                      // the next nst characters, the one of step `it` in the low byte
+        if (act && sp < ep) {
+          if (nst == 8u) {
+            uint32_t lo, hi;
+            __builtin_memcpy(&lo, pat + (end - it - 8), 4);
+            __builtin_memcpy(&hi, pat + (end - it - 4), 4);
+            chars = ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
           } else {
-            const uint64_t r1 = cfc + ((vb == 1 && sp > ix.eof) ? 1u : 0u);
-            ep = cfc + ((vb == 1 && ep > ix.eof) ? 1u : 0u);
-            sp = r1;
+            for (uint32_t s = 0; s < nst; s++) chars |= (uint64_t)pat[end - it - 1 - s] << (8u * s);
           }
-          steps++;
         }
+        for (uint32_t s = 0; s < 8; s++) {
+          const bool stepping = act && sp < ep && s < nst;
+          if (!__builtin_amdgcn_ballot_w64(stepping)) break;
+          if (stepping) {
+            const uint32_t c = (uint32_t)(chars >> (8u * s)) & 0xFFu;
+            const uint4 en = s_tab[c];
+            const uint64_t cfc = ((uint64_t)en.y << 32) | en.x;
+            const uint64_t vb = ((uint64_t)en.w << 32) | en.z;
+            if (vb > 1) {
+              if (LAYOUT == kLayoutBytes) {
+                const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), sp, lc);
+                sp = cfc + byte_rank_finish(q1, c, lc);
+                ep = sp + byte_match_bit(q1, c, lc);
+              } else {
+                uint32_t b1, m1;
+                split448(sp, b1, m1);
+                const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
+                sp = cfc + rank_finish<WIDE>(w1, m1, lc);
+                ep = sp + payload_bit(w1, m1, lc);
+              }
+              reqs += R;
+            } else {
+              const uint64_t r1 = cfc + ((vb == 1 && sp > ix.eof) ? 1u : 0u);
+              ep = cfc + ((vb == 1 && ep > ix.eof) ? 1u : 0u);
+              sp = r1;
+            }
+            steps++;
+          }
+        }
+        it += nst;                               // (meaningless once the interval is empty: the loop ends then)
       }
       if (act && t == 0) { sp_out[pid] = sp; ep_out[pid] = ep; }
     }
@@ -428,7 +531,6 @@ __global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const u
   counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
 }
 
-// generic kernel (fmx_kernels.hip)
 hipError_t launch_search_v1(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
                             hipStream_t st);
 
@@ -450,18 +552,24 @@ static int blocks_per_cu(K kernel) {
   return nb > 8 ? 8 : nb;
 }
 
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT>
-static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const uint8_t *pat, const uint64_t *off, uint64_t *sp,
-                              uint64_t *ep, uint32_t k, hipStream_t st) {
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, bool RW>
+static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
+                              const uint64_t *off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st) {
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
-  static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT>);
+  static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW>);
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search4<WIDE, LAYOUT, KT, JT><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, pat, off, sp,
-                                                              ep, k, h->d_counters);
-  if (JT) {     // the patterns it parked (it reads the batch's ep_out once: 8 bytes per pattern; no state shared between calls)
+  k_search4<WIDE, LAYOUT, KT, JT, RW><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, pat, off, sp,
+                                                                  ep, k, h->d_counters);
+  if (RW) {     // the one-row part of every search, a lane per pattern
+    const uint64_t wg = ((uint64_t)k + kSThreads - 1) / kSThreads;
+    const int g1 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 32);
+    if (jt) k_search_rows<true><<<g1, kSThreads, 0, st>>>(jt, r1, pat, off, sp, ep, k, h->d_counters);
+    else k_search_rows<false><<<g1, kSThreads, 0, st>>>(nullptr, r1, pat, off, sp, ep, k, h->d_counters);
+  }
+  if (JT || RW) {     // the patterns still parked (it reads the batch's ep_out once: 8 bytes per pattern; no state shared between calls)
     const uint64_t wg = ((uint64_t)k + 2 * kSThreads - 1) / (2 * kSThreads);       // a wave looks at 128 patterns
     const int g2 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 8);
     k_search_defer<WIDE, LAYOUT><<<g2, kSThreads, 0, st>>>(h->dev, pat, off, sp, ep, k, h->d_counters);
@@ -472,10 +580,18 @@ template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
 static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
                              uint32_t k, hipStream_t st) {
   const uint4 *jt = nullptr;
-  const hipError_t e = jump_get(h, st, &jt);
+  hipError_t e = jump_get(h, st, &jt);
   if (e != hipSuccess) return e;
-  return jt ? launch_v4kj<WIDE, LAYOUT, KT, true>(h, kt, jt, pat, off, sp, ep, k, st)
-            : launch_v4kj<WIDE, LAYOUT, KT, false>(h, kt, nullptr, pat, off, sp, ep, k, st);
+  // With a row jump table the lane groups finish the one-row part themselves, eight steps per lookup, in lockstep
+  // (C3: 0.240 ms; handing it to k_search_rows: 0.248 ms -- both run at ~37 G requests/s, and the hand-over costs two
+  // more launches: C2 0.129 -> 0.155 ms).  Without one (it does not fit: C5, n = 2^34) the row table alone, a third of
+  // the size, serves it with one lane per pattern: C5 49 -> 75 G rank queries/s.
+  const unsigned long long *r1 = nullptr;
+  static const int rows = getenv("FMX_ROWS") ? atoi(getenv("FMX_ROWS")) : -1;      // 0: never k_search_rows, 1: whenever there is a row table
+  if (rows != 0 && (!jt || rows == 1) && (e = row1_get(h, st, &r1)) != hipSuccess) return e;
+  if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, true>(h, kt, rows == 1 ? jt : nullptr, r1, pat, off, sp, ep, k, st);
+  return jt ? launch_v4kj<WIDE, LAYOUT, KT, true, false>(h, kt, jt, nullptr, pat, off, sp, ep, k, st)
+            : launch_v4kj<WIDE, LAYOUT, KT, false, false>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st);
 }
 
 template <bool WIDE, uint32_t LAYOUT>

@@ -456,7 +456,7 @@ def test_row_jump_table_on_and_off_agree(layout):
             uniform = lf_walk_patterns(orc, rng, 4000, 36, 0.1, alphabet=syms)      # every wave jumps together
             seen = []
             for ktab in ("auto", "off"):
-                for jump in ("off", "auto"):
+                for jump in ("off", "auto", "jumps", "rows"):
                     findex_amd.set_ktab(ktab)
                     findex_amd.set_jump(jump)
                     try:
@@ -465,7 +465,12 @@ def test_row_jump_table_on_and_off_agree(layout):
                         check_search(hip, orc, uniform)
                         st = hip.stats()
                         seen.append((jump, st["jump_bytes"], st["jump_lookups"]))
-                        if jump == "auto":
+                        # "auto" / "jumps": the lane groups of k_search4 walk the one-row part, eight steps per lookup where
+                        # the characters agree (a literal search builds no row table beside a jump table); "rows": one lane
+                        # per pattern walks it with the row table (k_search_rows), as on an index too large for a jump table
+                        assert st["row_bytes"] == (8 * orc.n if jump == "rows" else 0)
+                        assert (st["row_lookups"] > 0) == (jump == "rows")
+                        if jump in ("auto", "jumps"):
                             assert st["jump_bytes"] == 16 * orc.n and st["jump_lookups"] > 2 * len(uniform)
                             # the table itself: (BWT' along an 8-step LF walk, the row it ends on) -- spot-check through a
                             # search of the walked characters from a one-row start is what check_search just did; the

@@ -28,7 +28,7 @@ hip.stats_reset()
 rb.match_raw(max_steps=max_len)
 st = hip.stats()
 print({k: v for k, v in st.items() if k.startswith("frontier") or k in ("launches", "backward_steps", "ktab_lookups")})
-log = np.zeros((16, 1 << 15, 4), dtype=np.uint64)
+log = np.zeros((16, 1 << 15, 8), dtype=np.uint64)
 assert L.fmx_debug_wavelog(log.ctypes.data_as(ctypes.c_void_p), log.nbytes, 0) == 0
 print("kernel ms of the logged call: %.3f" % hip.last_kernel_ms())
 T = 0.01   # us per tick (100 MHz)
@@ -58,6 +58,24 @@ for p in range(16):
     late = np.argsort(t2)[-6:]
     print("         last waves to end (start us, first round us, end us, rounds, steps):",
           [(round((t0[i] - lo) * T, 1), round((t1[i] - lo) * T, 1), round((t2[i] - lo) * T, 1), int(rounds[i]), int(steps[i])) for i in late])
+    # who are the stragglers: waves by the time they end, in five groups
+    wr = (e[m, 4] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    rd = (e[m, 4] >> np.uint64(32)).astype(np.int64)
+    ap = (e[m, 5] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    gr = (e[m, 5] >> np.uint64(32)).astype(np.int64)
+    fan_t = (e[m, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    fan_r = (e[m, 6] >> np.uint64(32)).astype(np.int64)
+    if fan_r.sum():
+        print("         row loop: %d rounds in all, %.2f us per round; the ten waves with most of them: %s"
+              % (fan_r.sum(), fan_t.sum() * T / fan_r.sum(), [(int(fan_r[i]), round(fan_t[i] * T / max(1, fan_r[i]), 2)) for i in np.argsort(fan_r)[-10:]]))
+    order = np.argsort(t2)
+    for name, sel in (("first half", order[: len(order) // 2]), ("50-80 %", order[len(order) // 2: len(order) * 8 // 10]),
+                      ("80-95 %", order[len(order) * 8 // 10: len(order) * 95 // 100]), ("95-99 %", order[len(order) * 95 // 100: len(order) * 99 // 100]),
+                      ("last 1 %", order[len(order) * 99 // 100:])):
+        if len(sel):
+            print("         waves ending %-10s: end %6.1f us mean | rounds %5.1f  steps %6.0f  us/round %5.2f | queue appends %6.0f reads %6.0f  reservations %5.1f  looks %4.1f"
+                  % (name, ((t2[sel] - lo) * T).mean(), rounds[sel].mean(), steps[sel].mean(), (((t2 - t1)[sel] * T).sum() / max(1, rounds[sel].sum())),
+                     wr[sel].mean(), rd[sel].mean(), ap[sel].mean(), gr[sel].mean()))
     hist = np.bincount(np.minimum(rounds, 20), minlength=21)
     print("         waves by rounds (0..20+):", hist.tolist())
 

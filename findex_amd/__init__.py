@@ -38,8 +38,8 @@ def set_ktab(name):
 
 
 def set_jump(name):
-    """fmx_config_set("jump", ...): "auto" | "rows" | "jumps" | "off" -- the row table and the row jump table (handles that have not
-    searched yet)."""
+    """fmx_config_set("jump", ...): "auto" | "jumps" | "rows3" | "rows" | "off" -- the row jump table, the three-step row table and
+    the row table (handles that have not searched yet)."""
     from . import _lib
     _lib.check(_lib.load().fmx_config_set(b"jump", name.encode()))
 

@@ -278,6 +278,7 @@ static void destroy(Index *h) {
   if (h->d_kt_levels) (void)hipFree(h->d_kt_levels);
   if (h->d_jump) (void)hipFree(h->d_jump);
   if (h->d_row1) (void)hipFree(h->d_row1);
+  if (h->d_row3) (void)hipFree(h->d_row3);
   if (h->d_sel_dir) (void)hipFree(h->d_sel_dir);
   if (h->d_sel_off) (void)hipFree(h->d_sel_off);
   if (h->d_sel_shift) (void)hipFree(h->d_sel_shift);
@@ -460,11 +461,12 @@ int fmx_config_set(const char *key, const char *value) {
     return FMX_OK;
   }
   if (std::strcmp(key, "jump") == 0) {
-    if (std::strcmp(value, "auto") == 0) jump_set_mode(3);
+    if (std::strcmp(value, "auto") == 0) jump_set_mode(7);
     else if (std::strcmp(value, "off") == 0) jump_set_mode(0);
     else if (std::strcmp(value, "rows") == 0) jump_set_mode(1);
     else if (std::strcmp(value, "jumps") == 0) jump_set_mode(2);
-    else return arg_fail("jump must be auto, rows, jumps or off");
+    else if (std::strcmp(value, "rows3") == 0) jump_set_mode(4);
+    else return arg_fail("jump must be auto, rows, rows3, jumps or off");
     return FMX_OK;
   }
   if (std::strcmp(key, "threads") == 0) {
@@ -549,7 +551,8 @@ int fmx_prepare(const fmx_index *idx, unsigned what) {
   if (what & FMX_PREPARE_JUMP) {
     const uint4 *jt = nullptr;
     HIP_TRY(jump_get(h, lease.c->stream, &jt), "jump table");
-    const unsigned long long *r1 = nullptr;
+    const unsigned long long *r1 = nullptr, *r3 = nullptr;
+    if (!jt) HIP_TRY(row3_get(h, lease.c->stream, &r3), "three-step row table");      // what a literal search uses instead
     HIP_TRY(row1_get(h, lease.c->stream, &r1), "row table");
   }
   return FMX_OK;
@@ -1044,11 +1047,11 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->backward_steps = cnt[1];
   out->launches = h->launches;
   out->last_kernel_ms = h->last_kernel_ms;
-  out->index_bytes = h->index_bytes + h->sel_bytes + h->kt_bytes + h->jump_bytes + h->row1_bytes;
+  out->index_bytes = h->index_bytes + h->sel_bytes + h->kt_bytes + h->jump_bytes + h->row1_bytes + h->row3_bytes;
   out->jump_lookups = cnt[10];
   out->jump_bytes = h->jump_bytes;
   out->row_lookups = cnt[11];
-  out->row_bytes = h->row1_bytes;
+  out->row_bytes = h->row1_bytes + h->row3_bytes;
   out->n_blocks = h->nblocks;
   out->n_symbols = h->nslots;
   out->block_bytes = h->layout == kLayoutBytes ? kByteBlock + 4 : kBlockBytes;

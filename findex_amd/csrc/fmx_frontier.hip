@@ -191,16 +191,6 @@ constexpr uint32_t kGrab = FMX_GRAB;            // entries taken from the queue 
 #ifndef FMX_DEEP_PRIO
 #define FMX_DEEP_PRIO 1
 #endif
-#ifndef FMX_FAN
-#define FMX_FAN 1          // one-row elements are followed in their lanes, a whole follow list per row-table load (below)
-#endif
-#ifndef FMX_FAN_STRICT
-#define FMX_FAN_STRICT 0   // 1: entered only by a wave with nothing else to do (empty pool, share used up)
-#endif
-#ifndef FMX_FAN_LEAVE
-#define FMX_FAN_LEAVE 24u  // with other work waiting, a wave leaves that loop when fewer lanes than this are still busy
-#endif
-constexpr uint32_t kFanMax = 12;      // longest follow list matched in the lane (4 inline + 8 bytes fetched)
 #ifndef FMX_DEEP_SLACK
 #define FMX_DEEP_SLACK 4u
 #endif
@@ -276,8 +266,7 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
   constexpr int B = LAYOUT == kLayoutBytes ? 2 : FMX_FBATCH;     // sub-rounds whose lines are requested before any is consumed
 #ifdef FMX_WAVELOG
   const unsigned long long wl_t0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long wl_t1 = 0, wl_fan = 0;
-  uint32_t wl_fan_rounds = 0;
+  unsigned long long wl_t1 = 0;
 #endif
   const uint32_t lane = __lane_id();
   const uint32_t w = uni((blockIdx.x * kFThreads + threadIdx.x) >> 6);      // this wave (kept in scalar registers)
@@ -633,9 +622,8 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
 #endif
     PH_MARK(ph0);
     // ---- every element's state record and its step's lines are requested together
-    uint32_t run = meta >> 24;                // > 0: inside a literal stretch whose bytes the held record carries
-    const uint32_t c = (meta >> 16) & 0xFFu;
-    uint32_t len = meta & 0xFFFFu;
+    const uint32_t run = meta >> 24;          // > 0: inside a literal stretch whose bytes the held record carries
+    const uint32_t c = (meta >> 16) & 0xFFu, len = meta & 0xFFFFu;
     const uint16_t slot = s_slot[c];
     const uint64_t cfc = ix.cf[c];            // C[c]: needed only when the ranks are back, so its load rides along
     if (have && run == 0) {
@@ -863,126 +851,6 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       }
       stepped++;
     }
-#if FMX_FAN
-    // ---- ONE-ROW elements are followed in their lanes.  An element that has just been stepped to one row [r, r + 1)
-    // expands into its state's follows, and every one of them steps from that same row: to [LF r, LF r + 1) if its byte
-    // is BWT'[r], to nothing otherwise (getPrevRange on one row).  So the lane does not push them: it fetches the row
-    // table's word for r once, compares the follows' bytes with it -- each comparison is one of the reference's steps
-    // and is counted as one -- and goes on as the follow that survived, on row LF r, one length deeper.  A round of this
-    // loop is the state's record and one 8-byte word, requested together, and a few dozen instructions with no LDS, no
-    // pool, no exchange: the chains that a launch ends with (a starred class walking down the text one character per
-    // round, on a handful of lanes of a few waves) advance at one memory latency per character.
-    // The loop is entered when every stepped element of the wave holds one row, and left for the general bookkeeping
-    // below -- which finds the lanes exactly as a step leaves them -- when a lane meets something it does not do
-    // itself: a list longer than kFanMax, two follows with the surviving byte, the end-of-text row.
-    if (kt.row1 != nullptr) {
-      const bool post = have && sp < ep;
-      const bool rowable = (ep - sp) == 1 && !(from_tab && len + 1u < kt.k) && (run != 0u || (ra.y & 0xFFFFu) <= kFanMax);
-      if ((!FMX_FAN_STRICT || (pn == 0u && a_next >= a_end)) && __builtin_amdgcn_ballot_w64(post) != 0ull &&
-          __builtin_amdgcn_ballot_w64(post && !rowable) == 0ull && rounds + 2u < max_rounds) {
-        have = post;
-        from_tab = false;
-#ifdef FMX_WAVELOG
-        const unsigned long long fan_t0 = __builtin_amdgcn_s_memrealtime();
-        const uint32_t fan_r0 = rounds;
-#endif
-        bool fresh = run == 0u;                  // ra / rb are the state's own record already
-        bool moved = false;                      // left after a round was applied: the survivors' records are still to be read
-        run = 0;
-        for (;;) {
-          unsigned long long e = 0;
-          if (have) {
-            e = kt.row1[sp];
-            n_jl++;
-            if (!fresh) {
-              const uint4 *rp = reinterpret_cast<const uint4 *>(nfa.st + state);
-              ra = rp[0];
-              rb = rp[1];
-              n_recs++;
-            }
-          }
-          fresh = false;
-          len = meta & 0xFFFFu;
-          uint32_t fnf = have ? (ra.y & 0xFFFFu) : 0u;
-          const bool cut = fnf != 0u && len + 1u >= max_len;      // its follows would be too long: not expanded
-          if (cut) fnf = 0;
-          uint32_t xb0 = 0, xb1 = 0;             // bytes of the follows 4..7 and 8..11
-          if (fnf > kInlineFollows && fnf <= kFanMax) {
-            const uint8_t *fc = nfa.fol_c + ra.x;
-#pragma unroll
-            for (uint32_t q = 0; q < 4; q++) {
-              if (kInlineFollows + q < fnf) xb0 |= (uint32_t)fc[kInlineFollows + q] << (8u * q);
-              if (kInlineFollows + 4u + q < fnf) xb1 |= (uint32_t)fc[kInlineFollows + 4u + q] << (8u * q);
-            }
-          }
-          const uint32_t c2 = (uint32_t)(e >> 40) & 0xFFu;
-          uint32_t nmatch = 0, jm = 0;
-#pragma unroll
-          for (uint32_t q = 0; q < 4; q++) {
-            if (q < fnf && ((rb.z >> (8u * q)) & 0xFFu) == c2) { nmatch++; jm = q; }
-            if (4u + q < fnf && ((xb0 >> (8u * q)) & 0xFFu) == c2) { nmatch++; jm = 4u + q; }
-            if (8u + q < fnf && ((xb1 >> (8u * q)) & 0xFFu) == c2) { nmatch++; jm = 8u + q; }
-          }
-          const bool bail = have && (fnf > kFanMax || nmatch > 1u || (nmatch != 0u && c2 == 0u));
-          if (__builtin_amdgcn_ballot_w64(bail)) { moved = false; break; }      // nothing of this round has been used: the lanes are as the last step left them
-          // results
-          {
-            const bool emit_f = have && ((ra.y >> 24) & 1u) != 0u;
-            const unsigned long long em = __builtin_amdgcn_ballot_w64(emit_f);
-            if (em) {
-              const uint32_t cnt = (uint32_t)__builtin_popcountll(em);
-              if (rs_n + cnt > kRes64) flush_results();
-              if (emit_f) {
-                fmx_result r;
-                r.regex = rb.w;
-                r.len = len + 1;
-                r.sp = sp;
-                r.ep = ep;
-                rs.r[rs_n + (uint32_t)__builtin_popcountll(em & ((1ull << lane) - 1ull))] = r;
-              }
-              rs_n = uni(rs_n + cnt);
-            }
-          }
-          if (have) {
-            if (cut) trunc = 1;
-            stepped += fnf;                      // every follow is stepped once, from this row
-            if (nmatch) {
-              state = jm < kInlineFollows ? (jm == 0 ? ra.z : (jm == 1 ? ra.w : (jm == 2 ? rb.x : rb.y))) : nfa.fol[ra.x + jm];
-              meta = (len + 1u) | (c2 << 16);
-              sp = e & ((1ull << 40) - 1);
-              ep = sp + 1;
-            } else {
-              have = false;
-            }
-          }
-#ifdef FMX_WAVELOG
-          if (j == 0 && w < kLogWaves && rounds < 128u) {
-            const uint32_t nh = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(have));
-            uint32_t ml = have ? (meta & 0xFFFFu) : 0u;
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)ml, d, 64); ml = o > ml ? o : ml; }
-            if (lane == 0) g_wavetrace[w][rounds] = nh | (pn << 8) | ((ml > 255u ? 255u : ml) << 20) | (1u << 29);      // x1: a round of the row loop
-          }
-#endif
-          rounds++;
-          moved = true;
-          const unsigned long long live = __builtin_amdgcn_ballot_w64(have);
-          if (!live || rounds + 2u >= max_rounds) break;
-          if ((uint32_t)__builtin_popcountll(live) < FMX_FAN_LEAVE && (pn != 0u || a_next < a_end)) break;
-        }
-#ifdef FMX_WAVELOG
-        wl_fan += __builtin_amdgcn_s_memrealtime() - fan_t0;
-        wl_fan_rounds += rounds - fan_r0;
-#endif
-        if (moved && have) {
-          const uint4 *rp = reinterpret_cast<const uint4 *>(nfa.st + state);
-          ra = rp[0];
-          rb = rp[1];
-          n_recs++;
-        }
-        len = meta & 0xFFFFu;
-      }
-    }
-#endif
     const uint32_t cce = ra.y;
     uint32_t nf = 0, len1 = 0;
     bool emit = false;
@@ -1152,7 +1020,6 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
       e[0] = wl_t0; e[1] = wl_t1; e[2] = __builtin_amdgcn_s_memrealtime(); e[3] = rounds | (st_all << 32);
       e[4] = (unsigned long long)n_writes | ((unsigned long long)n_reads << 32);      // queue entries appended | read (lane 0's counts)
       e[5] = (unsigned long long)appends | ((unsigned long long)grabs << 32);         // reservations in the queue / result slices | looks for others' entries
-      e[6] = wl_fan | ((unsigned long long)wl_fan_rounds << 32);                      // ticks and rounds inside the row loop
     }
   }
 #endif

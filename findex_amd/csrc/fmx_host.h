@@ -94,6 +94,12 @@ struct Index {
   mutable bool r1_ready = false;
   mutable void *d_row1 = nullptr;
   mutable uint64_t row1_bytes = 0;
+  // three-step row table (fmx_jump.hip): (BWT'[r], BWT'[LF r], BWT'[LF^2 r]; LF^3 r) per row, 8 bytes; built at the first
+  // literal search of a handle whose row jump table does not fit
+  mutable std::mutex r3_mu;
+  mutable bool r3_ready = false;
+  mutable void *d_row3 = nullptr;
+  mutable uint64_t row3_bytes = 0;
   mutable double tables_ms = 0.0;             // host time spent building the k-mer table and the select directory (under their mutexes)
   // select directory for Psi (fmx_select.hip), built on first use
   mutable std::mutex sel_mu;
@@ -130,7 +136,8 @@ hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out);     // fmx_ktab.
 hipError_t select_prepare(const Index *h, hipStream_t st);          // fmx_select.hip: builds the select directory now
 hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out);   // fmx_jump.hip (nullptr: the handle has none)
 hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out);   // fmx_jump.hip (nullptr: none)
-void jump_set_mode(int mode);      // fmx_config_set("jump", ..): bit 0 = the row table, bit 1 = the row jump table
+hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out);   // fmx_jump.hip (nullptr: none)
+void jump_set_mode(int mode);      // fmx_config_set("jump", ..): bit 0 = the row table, bit 1 = the row jump table, bit 2 = the three-step row table
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP

@@ -86,8 +86,34 @@ __global__ __launch_bounds__(kJThreads) void k_row1_init(DevIndex ix, unsigned l
   }
 }
 
-static std::atomic<int> g_jump_mode{3};      // bit 0: row table (R1), bit 1: row jump table (J8)
-void jump_set_mode(int mode) { g_jump_mode.store(mode & 3, std::memory_order_relaxed); }
+// The three-step row table: R3[r] = LF^3 r | BWT'[r] << 40 | BWT'[LF r] << 48 | BWT'[LF^2 r] << 56, one 8-byte word per row --
+// what the row jump table is, at a third of its size, for an index whose 16 n bytes of J do not fit beside the dictionary
+// (n = 2^34: 256 GiB).  k_search_rows takes three steps of a one-row search with one load of it.  Built by walking:
+// three rank queries per row, the first of them on consecutive rows (neighbouring blocks), the others at random.
+template <bool WIDE, uint32_t LAYOUT>
+__global__ __launch_bounds__(kJThreads) void k_row3_init(DevIndex ix, unsigned long long *__restrict__ out) {
+  __shared__ uint64_t s_cf[256];
+  __shared__ uint16_t s_slot[256];
+  for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
+  __syncthreads();
+  constexpr int G = Lay<LAYOUT>::G;
+  const LaneConst lc = lane_const<G>();
+  const uint64_t ngroups = (uint64_t)gridDim.x * (kJThreads / G);
+  for (uint64_t r0 = ((uint64_t)blockIdx.x * kJThreads + threadIdx.x) / G; r0 < ix.n; r0 += ngroups) {
+    uint64_t r = r0;
+    unsigned long long chars = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < 3; s++) {
+      const uint32_t c = r == ix.eof ? 0u : ix.bwt[r];
+      chars |= (unsigned long long)c << (8u * s);
+      r = s_cf[c] + rank_excl<WIDE, LAYOUT>(ix, c, s_slot[c], r, lc);
+    }
+    if (lc.t == 0) out[r0] = r | (chars << 40);
+  }
+}
+
+static std::atomic<int> g_jump_mode{7};      // bit 0: row table (R1), bit 1: row jump table (J8), bit 2: three-step row table (R3)
+void jump_set_mode(int mode) { g_jump_mode.store(mode & 7, std::memory_order_relaxed); }
 
 // Called under h->jt_mu by jump_get.  Leaves h->d_jump null when the table is not wanted or does not fit.
 static hipError_t build_jump(const Index *h, hipStream_t st) {
@@ -180,6 +206,37 @@ hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **o
     h->r1_ready = true;
   }
   *out = static_cast<const unsigned long long *>(h->d_row1);
+  return hipSuccess;
+}
+
+// The three-step row table of a handle (nullptr: none), built at the first literal search that wants it: 8 n bytes.
+hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out) {
+  std::lock_guard<std::mutex> lk(h->r3_mu);
+  if (!h->r3_ready) {
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t free_b = 0, total_b = 0;
+    const uint64_t bytes = h->n * 8;
+    if ((g_jump_mode.load(std::memory_order_relaxed) & 4) && !h->block_mode && h->n >= 2 && h->nslots >= 1 &&
+        hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes + (8ull << 30) <= free_b) {
+      void *p = nullptr;
+      hipError_t e = hipMalloc(&p, bytes);
+      if (e == hipSuccess) {
+        const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
+        const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
+#define CALL(W, L) k_row3_init<W, L><<<grid, kJThreads, 0, st>>>(h->dev, (unsigned long long *)p)
+        FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) { h->d_row3 = p; h->row3_bytes = bytes; }
+        else (void)hipFree(p);
+      }
+      if (e != hipSuccess) (void)hipGetLastError();      // no table: the lane groups walk every step
+    }
+    h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->r3_ready = true;
+  }
+  *out = static_cast<const unsigned long long *>(h->d_row3);
   return hipSuccess;
 }
 

@@ -85,11 +85,12 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // JT: the handle has a row jump table (fmx_jump.hip): once every stepping group of the wave holds one row, eight steps
 // at a time are ONE 16-byte lookup for every group whose next eight pattern characters are the ones its row's entry
 // names; the others walk those eight steps as before while the ones that jumped wait.
-// RW: the handle has a row table (fmx_jump.hip, row1_get): a group whose interval has become ONE ROW parks its pattern at
-// once -- sp_out = the row, ep_out = kDeferMark | step number -- and k_search_rows (below) finishes it with one LANE per
-// pattern, since from there on a search needs no rank query: this kernel then runs only the k-mer lookup and the few
-// steps on wide intervals.
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, bool RW>
+// RW > 0: the handle has a row table (fmx_jump.hip, row1_get / row3_get): a group whose interval has become ONE ROW parks
+// its pattern -- sp_out = the row, ep_out = kDeferMark | step number -- and k_search_rows (below) finishes it with one
+// LANE per pattern, since from there on a search needs no rank query: this kernel then runs only the k-mer lookup and
+// the few steps on wide intervals.  RW = 1: parked at once; RW = 3 (the table takes three steps per word): parked when
+// the steps left are a multiple of three, after up to two more one-row steps here.
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW>
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
                                                         uint32_t ksigma, const uint4 *__restrict__ jtab, const uint8_t *__restrict__ pat,
                                                         const uint64_t *__restrict__ off,
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
     bool deferred = false;                                     // this group's pattern was parked for k_search_defer
     for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
       bool alive = it < len && sp < ep;
-      if (RW && alive && (ep - sp) == 1) {                     // one row: the rest is k_search_rows'
+      if (RW && alive && (ep - sp) == 1 && (RW == 1u || (len - it) % RW == 0u)) {      // one row: the rest is k_search_rows'
         if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
         deferred = true;
         ep = sp;
@@ -360,13 +361,16 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
 // within these eight and finds where with R1, as does a pattern's tail of fewer than eight.  The step that FAILS is
 // not taken here: the reference loop's values at that step are a rank query (C[c] + rank(c, r) for a c that is not
 // BWT'[r]), so the pattern is parked again, at that step, for k_search_defer's lane groups -- one pattern in ten at C3.
-template <bool HAVE_J>
+// MODE 0: R1 only; 1: J and R1; 2: R3, the three-step row table (fmx_jump.hip) -- R3[r] = (BWT'[r], BWT'[LF r], BWT'[LF^2 r] ;
+// LF^3 r) in 8 bytes, three steps per lookup, for an index whose J does not fit; k_search4<.., RW = 3> parks a pattern
+// with a multiple of three steps left, so only patterns that fail are parked again.
+template <int MODE>
 __global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restrict__ jtab, const unsigned long long *__restrict__ row1,
                                                             const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
                                                             uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
                                                             unsigned long long *__restrict__ counters) {
   const uint64_t nth = (uint64_t)gridDim.x * kSThreads;
-  uint32_t steps = 0, looks = 0, rlooks = 0;      // lookups in J (counters[10]) and in R1 (counters[11])
+  uint32_t steps = 0, looks = 0, rlooks = 0;      // lookups in J (counters[10]) and in R1 / R3 (counters[11])
   for (uint64_t base = (uint64_t)blockIdx.x * kSThreads + (threadIdx.x & ~63u); base < k; base += nth) {      // wave-uniform
     const uint64_t pid = base + (threadIdx.x & 63u);
     const bool in = pid < k;
@@ -379,7 +383,28 @@ __global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restri
     uint32_t walk = 0;                           // steps still to be walked one by one after a lookup in J that did not agree
     while (__builtin_amdgcn_ballot_w64(live)) {
       const uint32_t rem = len - it;
-      const bool jm = HAVE_J && live && rem >= 8u && walk == 0u;
+      if (MODE == 2) {
+        const bool tm = live && rem >= 3u;
+        unsigned long long re = 0;
+        uint32_t d = 0;
+        if (tm) {                                // pat[end - it - 3 .. end - it + 1): inside the pattern (it >= 1)
+          re = row1[row];
+          __builtin_memcpy(&d, pat + (end - it - 3), 4);
+        }
+        if (tm && (uint32_t)(re >> 40) == __builtin_bswap32(d << 8)) {
+          rlooks++;
+          row = re & ((1ull << 40) - 1);
+          it += 3;
+          steps += 3;
+        } else if (live) {
+          rlooks += tm ? 1u : 0u;
+          sp_out[pid] = row;                     // through (rem == 0), or k_search_defer's: the failing step, a tail of one or two
+          ep_out[pid] = rem == 0u ? row + 1 : (kDeferMark | it);
+          live = false;
+        }
+        continue;
+      }
+      const bool jm = MODE == 1 && live && rem >= 8u && walk == 0u;
       const bool rm = live && rem != 0u && !jm;
       uint4 je = make_uint4(0, 0, 0, 0);
       uint32_t lo = 0, hi = 0, c = 0;
@@ -552,7 +577,7 @@ static int blocks_per_cu(K kernel) {
   return nb > 8 ? 8 : nb;
 }
 
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, bool RW>
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
                               const uint64_t *off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st) {
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
@@ -566,8 +591,9 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   if (RW) {     // the one-row part of every search, a lane per pattern
     const uint64_t wg = ((uint64_t)k + kSThreads - 1) / kSThreads;
     const int g1 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 32);
-    if (jt) k_search_rows<true><<<g1, kSThreads, 0, st>>>(jt, r1, pat, off, sp, ep, k, h->d_counters);
-    else k_search_rows<false><<<g1, kSThreads, 0, st>>>(nullptr, r1, pat, off, sp, ep, k, h->d_counters);
+    if (RW == 3) k_search_rows<2><<<g1, kSThreads, 0, st>>>(nullptr, r1, pat, off, sp, ep, k, h->d_counters);
+    else if (jt) k_search_rows<1><<<g1, kSThreads, 0, st>>>(jt, r1, pat, off, sp, ep, k, h->d_counters);
+    else k_search_rows<0><<<g1, kSThreads, 0, st>>>(nullptr, r1, pat, off, sp, ep, k, h->d_counters);
   }
   if (JT || RW) {     // the patterns still parked (it reads the batch's ep_out once: 8 bytes per pattern; no state shared between calls)
     const uint64_t wg = ((uint64_t)k + 2 * kSThreads - 1) / (2 * kSThreads);       // a wave looks at 128 patterns
@@ -584,14 +610,26 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
   if (e != hipSuccess) return e;
   // With a row jump table the lane groups finish the one-row part themselves, eight steps per lookup, in lockstep
   // (C3: 0.240 ms; handing it to k_search_rows: 0.248 ms -- both run at ~37 G requests/s, and the hand-over costs two
-  // more launches: C2 0.129 -> 0.155 ms).  Without one (it does not fit: C5, n = 2^34) the row table alone, a third of
-  // the size, serves it with one lane per pattern: C5 49 -> 75 G rank queries/s.
-  const unsigned long long *r1 = nullptr;
-  static const int rows = getenv("FMX_ROWS") ? atoi(getenv("FMX_ROWS")) : -1;      // 0: never k_search_rows, 1: whenever there is a row table
-  if (rows != 0 && (!jt || rows == 1) && (e = row1_get(h, st, &r1)) != hipSuccess) return e;
-  if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, true>(h, kt, rows == 1 ? jt : nullptr, r1, pat, off, sp, ep, k, st);
-  return jt ? launch_v4kj<WIDE, LAYOUT, KT, true, false>(h, kt, jt, nullptr, pat, off, sp, ep, k, st)
-            : launch_v4kj<WIDE, LAYOUT, KT, false, false>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st);
+  // more launches: C2 0.129 -> 0.155 ms).  Without one (it does not fit: C5, n = 2^34) a table of a third of the size
+  // serves it with one lane per pattern: the three-step row table, or the regex frontier's one-step row table where
+  // the handle has that one already (C5: 49 -> 75 G rank queries/s with R1).
+  static const int rows = getenv("FMX_ROWS") ? atoi(getenv("FMX_ROWS")) : -1;      // 0: never k_search_rows, 1: R1 (and J) whenever there is a row table
+  if (rows == 1) {
+    const unsigned long long *r1 = nullptr;
+    if ((e = row1_get(h, st, &r1)) != hipSuccess) return e;
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, jt, r1, pat, off, sp, ep, k, st);
+  }
+  if (jt) return launch_v4kj<WIDE, LAYOUT, KT, true, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st);
+  if (rows != 0) {
+    const unsigned long long *r3 = nullptr, *r1 = nullptr;
+    bool have1;
+    { std::lock_guard<std::mutex> lk(h->r1_mu); have1 = h->d_row1 != nullptr; }
+    if (!have1 && (e = row3_get(h, st, &r3)) != hipSuccess) return e;
+    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, false, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st);
+    if ((e = row1_get(h, st, &r1)) != hipSuccess) return e;
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st);
+  }
+  return launch_v4kj<WIDE, LAYOUT, KT, false, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st);
 }
 
 template <bool WIDE, uint32_t LAYOUT>

@@ -69,15 +69,18 @@ int fmx_abi_version(void);
  * kernel and a synchronisation per call: a debugging aid; the host-pointer form always checks).  key "checkpoints": "auto" (default: the bytes layout keeps absolute
  * 32-bit checkpoints whenever every symbol occurs fewer than 2^32 times) or "superblock" (always the relative
  * checkpoints + 64-bit superblock counts that larger counts need; for tests).  Affects indexes opened afterwards.
- * key "jump": "auto" (default) / "rows" / "jumps" / "off": the two derived tables that serve searches whose interval
- * has narrowed to ONE ROW, where a backward step is a comparison with the text in front of that row's suffix.  The row
- * table -- per row BWT'[r] and LF r in 8 bytes, 8 n bytes in all -- turns such a step into one 8-byte load by a single
- * lane (fmx_search_batch*: the one-row part of every pattern is walked by one lane per pattern; the regex frontier
- * steps one-row elements with it).  The row jump table -- per row the eight BWT characters an LF walk from it reads and
- * the row it ends on, 16 n bytes -- takes eight such steps with one 16-byte lookup when the pattern's next eight
- * characters match.  Both are built on a handle's first use (or by fmx_prepare) when the memory is there (the jump
- * table: 32 n bytes + 8 GiB free while it is built); "rows" / "jumps" build only the one; fmx_stats_t.row_bytes,
- * .jump_bytes.  Results and executed-step counts are the same with and without them.
+ * key "jump": "auto" (default) / "jumps" / "rows3" / "rows" / "off": the derived tables that serve searches whose
+ * interval has narrowed to ONE ROW, where a backward step is a comparison with the text in front of that row's suffix:
+ *   - the row jump table: per row the eight BWT characters an LF walk from it reads and the row it ends on, 16 n
+ *     bytes -- eight steps of a literal search with one 16-byte lookup when the pattern's next eight characters match
+ *     (built at a handle's first literal search when 32 n bytes + 8 GiB of HBM are free);
+ *   - the three-step row table: the same with three characters, 8 n bytes -- built instead where the jump table does
+ *     not fit; the one-row part of every pattern is then walked by one lane per pattern;
+ *   - the row table: BWT'[r] and LF r in 8 bytes per row -- the regex frontier steps its one-row elements with it
+ *     (built at a handle's first regex match when 8 n bytes + 4 GiB are free); a literal search on a handle that has
+ *     it, and no jump table, uses it like the three-step table.
+ * "auto" builds what fits, at first use or in fmx_prepare; "jumps" / "rows3" / "rows" allow only the one; "off" none.
+ * fmx_stats_t.jump_bytes, .row_bytes.  Results and executed-step counts are the same with and without them.
  * key "threads": host threads the library's own parallel parts use (fmx_regex_compile_batch, making a regex batch
  * resident); "0" = detect (default). */
 int fmx_config_set(const char *key, const char *value);
@@ -419,9 +422,9 @@ typedef struct fmx_stats_t {
   uint64_t jump_lookups;        /* 16-byte row-jump-table entries fetched by fmx_search_batch[_dev]'s kernel (each stands
                                  * for 8 backward steps when the pattern's next 8 characters match it) */
   uint64_t jump_bytes;          /* device bytes of the row jump table (0: the handle has none); part of index_bytes */
-  uint64_t row_lookups;         /* 8-byte row-table words fetched (one backward step of a one-row interval each): by the
-                                 * one-row part of fmx_search_batch[_dev] and by the regex frontier */
-  uint64_t row_bytes;           /* device bytes of the row table (0: none); part of index_bytes */
+  uint64_t row_lookups;         /* 8-byte row-table words fetched (one or three backward steps of a one-row interval each):
+                                 * by the one-row part of fmx_search_batch[_dev] and by the regex frontier */
+  uint64_t row_bytes;           /* device bytes of the row table and the three-step row table (0: none); part of index_bytes */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 /* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */

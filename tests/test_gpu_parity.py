@@ -456,7 +456,7 @@ def test_row_jump_table_on_and_off_agree(layout):
             uniform = lf_walk_patterns(orc, rng, 4000, 36, 0.1, alphabet=syms)      # every wave jumps together
             seen = []
             for ktab in ("auto", "off"):
-                for jump in ("off", "auto", "jumps", "rows"):
+                for jump in ("off", "auto", "jumps", "rows", "rows3"):
                     findex_amd.set_ktab(ktab)
                     findex_amd.set_jump(jump)
                     try:
@@ -466,10 +466,11 @@ def test_row_jump_table_on_and_off_agree(layout):
                         st = hip.stats()
                         seen.append((jump, st["jump_bytes"], st["jump_lookups"]))
                         # "auto" / "jumps": the lane groups of k_search4 walk the one-row part, eight steps per lookup where
-                        # the characters agree (a literal search builds no row table beside a jump table); "rows": one lane
-                        # per pattern walks it with the row table (k_search_rows), as on an index too large for a jump table
-                        assert st["row_bytes"] == (8 * orc.n if jump == "rows" else 0)
-                        assert (st["row_lookups"] > 0) == (jump == "rows")
+                        # the characters agree (a literal search builds no row table beside a jump table); "rows3" / "rows":
+                        # one lane per pattern walks it (k_search_rows) with the three-step / one-step row table, as on an
+                        # index too large for a jump table
+                        assert st["row_bytes"] == (8 * orc.n if jump in ("rows", "rows3") else 0)
+                        assert (st["row_lookups"] > 0) == (jump in ("rows", "rows3"))
                         if jump in ("auto", "jumps"):
                             assert st["jump_bytes"] == 16 * orc.n and st["jump_lookups"] > 2 * len(uniform)
                             # the table itself: (BWT' along an 8-step LF walk, the row it ends on) -- spot-check through a

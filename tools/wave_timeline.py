@@ -63,11 +63,6 @@ for p in range(16):
     rd = (e[m, 4] >> np.uint64(32)).astype(np.int64)
     ap = (e[m, 5] & np.uint64(0xFFFFFFFF)).astype(np.int64)
     gr = (e[m, 5] >> np.uint64(32)).astype(np.int64)
-    fan_t = (e[m, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64)
-    fan_r = (e[m, 6] >> np.uint64(32)).astype(np.int64)
-    if fan_r.sum():
-        print("         row loop: %d rounds in all, %.2f us per round; the ten waves with most of them: %s"
-              % (fan_r.sum(), fan_t.sum() * T / fan_r.sum(), [(int(fan_r[i]), round(fan_t[i] * T / max(1, fan_r[i]), 2)) for i in np.argsort(fan_r)[-10:]]))
     order = np.argsort(t2)
     for name, sel in (("first half", order[: len(order) // 2]), ("50-80 %", order[len(order) // 2: len(order) * 8 // 10]),
                       ("80-95 %", order[len(order) * 8 // 10: len(order) * 95 // 100]), ("95-99 %", order[len(order) * 95 // 100: len(order) * 99 // 100]),

@@ -44,4 +44,10 @@ def set_jump(name):
     _lib.check(_lib.load().fmx_config_set(b"jump", name.encode()))
 
 
-__all__ = ["set_layout", "set_checkpoints", "set_ktab", "set_jump", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "CompiledRegexes", "FmxError", "MatchError", "Re2PostSyntax"]
+def set_pipeline(name):
+    """fmx_config_set("pipeline", ...): "off" | "on" -- large host batches in page-locked memory as overlapping chunks."""
+    from . import _lib
+    _lib.check(_lib.load().fmx_config_set(b"pipeline", name.encode()))
+
+
+__all__ = ["set_layout", "set_checkpoints", "set_ktab", "set_jump", "set_pipeline", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "CompiledRegexes", "FmxError", "MatchError", "Re2PostSyntax"]

@@ -435,6 +435,9 @@ extern "C" {
 const char *fmx_last_error(void) { return g_err.c_str(); }
 int fmx_abi_version(void) { return FMX_ABI_VERSION; }
 
+// fmx_config_set("pipeline", ..): large host batches in page-locked memory cut into chunks over three streams
+static std::atomic<int> g_pipeline{0};
+
 int fmx_config_set(const char *key, const char *value) {
   if (!key || !value) return arg_fail("null argument");
   if (std::strcmp(key, "layout") == 0) {
@@ -467,6 +470,12 @@ int fmx_config_set(const char *key, const char *value) {
     else if (std::strcmp(value, "jumps") == 0) jump_set_mode(2);
     else if (std::strcmp(value, "rows3") == 0) jump_set_mode(4);
     else return arg_fail("jump must be auto, rows, rows3, jumps or off");
+    return FMX_OK;
+  }
+  if (std::strcmp(key, "pipeline") == 0) {
+    if (std::strcmp(value, "on") == 0) g_pipeline.store(1, std::memory_order_relaxed);
+    else if (std::strcmp(value, "off") == 0) g_pipeline.store(0, std::memory_order_relaxed);
+    else return arg_fail("pipeline must be on or off");
     return FMX_OK;
   }
   if (std::strcmp(key, "threads") == 0) {
@@ -688,11 +697,15 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
     for (size_t q = 0; q <= k; q++) roff[q] = off[q] - lo;
     offp = roff.data();
   }
-  // Small batches: one copy each way through run_io.  Large batches in page-locked caller memory (fmx_host_alloc,
-  // or the caller's own hipHostMalloc / registered pages) are pipelined: the batch is cut into chunks of patterns,
-  // chunk j's bytes and offsets go up on one stream, are searched on a second and come back on a third, so the copies
-  // of one chunk run beside the kernels of another and both directions of the link are busy.  Offsets stay absolute:
-  // every chunk is copied to its own place of one device image of the batch.
+  // Small batches: one copy each way through run_io.  Large batches: whole arrays up with one synchronous copy each,
+  // one chain of kernels, whole arrays down (1.30 ms for 1M x 32 bytes here, from pageable and page-locked memory alike:
+  // the copies run at the link's 53 GB/s).  With fmx_config_set("pipeline", "on") large batches in page-locked caller
+  // memory (fmx_host_alloc, or the caller's own hipHostMalloc / registered pages) are pipelined instead: the batch is
+  // cut into chunks of patterns, chunk j's bytes and offsets go up on one stream, are searched on a second and come
+  // back on a third, so the copies of one chunk run beside the kernels of another and both directions of the link are
+  // busy.  Offsets stay absolute: every chunk is copied to its own place of one device image of the batch.  Off by
+  // default: on this platform asynchronous copies are slower than synchronous ones (one chunk, no overlap at all:
+  // 1.67 ms) and the overlap does not reliably win that back -- 1.08 to 1.7 ms with 4 chunks from box to box.
   if (k < kPipelineMin) {
     const HostIn ins[] = {{total ? pat + lo : nullptr, (size_t)total}, {offp, (k + 1) * 8}};
     const HostOut outs[] = {{sp, k * 8}, {ep, k * 8}};
@@ -716,7 +729,7 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
   auto pinned = [&](const void *p, size_t bytes) {
     return pinned1(p) && (bytes == 0 || pinned1(static_cast<const uint8_t *>(p) + bytes - 1));
   };
-  if (!(pinned(sp, k * 8) && pinned(ep, k * 8) && pinned(offp, (k + 1) * 8) && (!total || pinned(pat + lo, (size_t)total)))) {
+  if (!g_pipeline.load(std::memory_order_relaxed) || !(pinned(sp, k * 8) && pinned(ep, k * 8) && pinned(offp, (k + 1) * 8) && (!total || pinned(pat + lo, (size_t)total)))) {
     // Pageable caller memory: "asynchronous" copies of it are staged piecewise by the runtime and block the calling
     // thread (measured: 8 chunks, 0.37 ms each, nothing overlapped), while one synchronous copy per array runs at
     // link speed.  So: whole arrays up, one kernel, whole arrays down.

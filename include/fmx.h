@@ -81,6 +81,10 @@ int fmx_abi_version(void);
  *     it, and no jump table, uses it like the three-step table.
  * "auto" builds what fits, at first use or in fmx_prepare; "jumps" / "rows3" / "rows" allow only the one; "off" none.
  * fmx_stats_t.jump_bytes, .row_bytes.  Results and executed-step counts are the same with and without them.
+ * key "pipeline": "off" (default) / "on": fmx_search_batch with 128 k patterns or more in page-locked buffers cut into
+ * chunks whose uploads, searches and downloads overlap on three streams, instead of whole arrays up, one search, whole
+ * arrays down.  Same results; which is faster depends on how the platform's asynchronous copies compare with its
+ * synchronous ones (here: the synchronous form, hence the default).
  * key "threads": host threads the library's own parallel parts use (fmx_regex_compile_batch, making a regex batch
  * resident); "0" = detect (default). */
 int fmx_config_set(const char *key, const char *value);

@@ -491,7 +491,8 @@ def test_row_jump_table_on_and_off_agree(layout):
 
 
 def test_pipelined_host_batch_pageable_and_pinned():
-    """Host-pointer batches of 128k patterns or more are cut into chunks over two streams (fmx_api.cpp): ragged
+    """Host-pointer batches of 128k patterns or more travel as whole arrays or, with the "pipeline" setting on and
+    page-locked buffers, as chunks over three streams (fmx_api.cpp): ragged
     lengths with empty patterns at chunk borders, offsets that do not start at 0, pageable and page-locked
     (fmx_host_alloc) buffers -- every interval must equal the oracle's."""
     from findex_amd.searcher import PinnedArray
@@ -515,25 +516,32 @@ def test_pipelined_host_batch_pageable_and_pinned():
     pb, po = PinnedArray(buf.shape, np.uint8), PinnedArray(off.shape, np.uint64)
     psp, pep = PinnedArray((k,), np.uint64), PinnedArray((k,), np.uint64)
     pb.array[:] = buf
-    po.array[:] = off
-    hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
-    assert np.array_equal(psp.array, wsp) and np.array_equal(pep.array, wep)
-    # a decreasing offset is refused on both paths (large batches are checked beside / behind their uploads, not by a
-    # walk over the offsets before anything starts), and the handle stays usable
-    for q in (k // 3, k // 8):                   # inside a chunk; at a chunk's border
-        bad = off.copy()
-        bad[q] = bad[q + 1] + 1
-        with pytest.raises(findex_amd.FmxError) as e:
-            hip.search_batch(buf, bad)
-        assert e.value.code == 3
-        po.array[:] = bad
-        with pytest.raises(findex_amd.FmxError) as e:
+    for pipeline in ("off", "on"):               # whole arrays and one search / chunks over three streams
+        findex_amd.set_pipeline(pipeline)
+        try:
+            po.array[:] = off
+            psp.array[:] = 0
+            pep.array[:] = 0
             hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
-        assert e.value.code == 3
-    po.array[:] = off
-    psp.array[:] = 0
-    hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
-    assert np.array_equal(psp.array, wsp) and np.array_equal(pep.array, wep)
+            assert np.array_equal(psp.array, wsp) and np.array_equal(pep.array, wep)
+            # a decreasing offset is refused on every path (large batches are checked beside / behind their uploads, not
+            # by a walk over the offsets before anything starts), and the handle stays usable
+            for q in (k // 3, k // 8):                   # inside a chunk; at a chunk's border
+                bad = off.copy()
+                bad[q] = bad[q + 1] + 1
+                with pytest.raises(findex_amd.FmxError) as e:
+                    hip.search_batch(buf, bad)
+                assert e.value.code == 3
+                po.array[:] = bad
+                with pytest.raises(findex_amd.FmxError) as e:
+                    hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
+                assert e.value.code == 3
+            po.array[:] = off
+            psp.array[:] = 0
+            hip.search_batch(pb.array, po.array, out=(psp.array, pep.array))
+            assert np.array_equal(psp.array, wsp) and np.array_equal(pep.array, wep)
+        finally:
+            findex_amd.set_pipeline("off")
 
 
 def test_concurrent_calls_on_one_handle():

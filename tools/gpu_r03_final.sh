@@ -10,6 +10,7 @@ if [ $PART = all ] || [ $PART = bench ]; then
     timeout -k 10 400 python bench.py --workload $wl > $O/${wl}_bench.json 2> $O/${wl}_bench.log; echo "$wl rc=$?"
   done
   FMX_JUMP=0 timeout -k 10 400 python bench.py --workload c3 --no-cpu-baseline > $O/c3_nojump_bench.json 2> $O/c3_nojump_bench.log; echo "c3 (no jump table) rc=$?"
+  FMX_ROWS=0 timeout -k 10 400 python bench.py --workload c5 --no-cpu-baseline > $O/c5_norows_bench.json 2> $O/c5_norows_bench.log; echo "c5 (no row table) rc=$?"
   for wl in tiny c4tiny c4reftiny; do
     timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --workload $wl --steps 10 --warmup 2 > $O/${wl}_rccl1.json 2> $O/${wl}_rccl1.log; echo "$wl (1-rank RCCL) rc=$?"
   done
@@ -17,7 +18,7 @@ if [ $PART = all ] || [ $PART = bench ]; then
   timeout -k 10 300 python tools/measure_host_path.py c3 2>&1 | grep -v amdgpu.ids > $O/host_path.txt; tail -3 $O/host_path.txt
 fi
 if [ $PART = all ] || [ $PART = prof ]; then
-  for wl in c3 c4 c4ref; do
+  for wl in c3 c4 c4ref c5; do
     (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/bench_trace_$wl -- python3 $REPO/bench.py --workload $wl --no-cpu-baseline > $REPO/$O/${wl}_bench_under_rocprof.json 2> $REPO/$O/${wl}_bench_under_rocprof.err); echo "rocprof bench $wl exit $?"
     python - $O $wl <<'PY'
 import csv,glob,sys
@@ -31,6 +32,7 @@ with open("%s/%s_bench_kernel_stats.csv"%(O,wl),"w",newline="") as fo:
     for r in rows: w.writerow([r["Name"].split("(")[0].replace("fmx::",""),r["Calls"],r["TotalDurationNs"],r["AverageNs"],r["MinNs"],r["MaxNs"],r["StdDev"]])
 PY
     rm -rf $O/bench_trace_$wl
+    [ $wl = c5 ] && continue      # kernel times only; the PMC passes are taken on c3, c4, c4ref
     timeout -k 10 1000 bash tools/rocprof_passes.sh $O/prof_$wl $wl > $O/passes_$wl.log 2>&1; tail -1 $O/passes_$wl.log
     python tools/summarize_prof.py $O/prof_$wl $O/sum_$wl > /dev/null 2>&1 && echo "summarized $wl"
     rm -rf $O/prof_$wl

@@ -55,10 +55,13 @@ pp, po = PinnedArray(h_p.shape, np.uint8), PinnedArray(h_o.shape, np.uint64)
 psp, pep = PinnedArray((k,), np.uint64), PinnedArray((k,), np.uint64)
 pp.array[:] = h_p
 po.array[:] = h_o
-dtp = steady(lambda: hip.search_batch(pp.array, po.array, out=(psp.array, pep.array)))
-assert np.array_equal(psp.array, sp) and np.array_equal(pep.array, ep)
-print("host-pointer path %s, pinned buffers: %.3f ms per call, %.0f M rank-queries/s, %.1f M patterns/s PCIe-inclusive"
-      % (wl, dtp * 1e3, ranks / dtp / 1e6, k / dtp / 1e6))
+for pipeline in ("off", "on"):
+    findex_amd.set_pipeline(pipeline)
+    dtp = steady(lambda: hip.search_batch(pp.array, po.array, out=(psp.array, pep.array)))
+    assert np.array_equal(psp.array, sp) and np.array_equal(pep.array, ep)
+    print("host-pointer path %s, pinned buffers, pipeline %s: %.3f ms per call, %.0f M rank-queries/s, %.1f M patterns/s PCIe-inclusive"
+          % (wl, pipeline, dtp * 1e3, ranks / dtp / 1e6, k / dtp / 1e6))
+findex_amd.set_pipeline("off")
 
 # per-call latency of the single-query forms the Scala adapter's search()/getPrevRange() map to
 one_p = h_p.reshape(k, m)[0].copy()

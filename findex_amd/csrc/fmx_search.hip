@@ -90,9 +90,13 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // LANE per pattern, since from there on a search needs no rank query: this kernel then runs only the k-mer lookup and
 // the few steps on wide intervals.  RW = 1: parked at once; RW = 3 (the table takes three steps per word): parked when
 // the steps left are a multiple of three, after up to two more one-row steps here.
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW>
+// R3T (with JT): the handle also has the three-step row table (fmx_jump.hip): a one-row group that is not at a chunk
+// boundary, or has fewer than eight characters left, takes three steps with one 8-byte lookup instead of three rank
+// queries -- at C3 the three steps between the wide part of a search and its first aligned jump.
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T>
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
-                                                        uint32_t ksigma, const uint4 *__restrict__ jtab, const uint8_t *__restrict__ pat,
+                                                        uint32_t ksigma, const uint4 *__restrict__ jtab,
+                                                        const unsigned long long *__restrict__ r3tab, const uint8_t *__restrict__ pat,
                                                         const uint64_t *__restrict__ off,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
                                                         uint32_t k, unsigned long long *__restrict__ counters) {
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   Tail tail0;
   uint32_t ktl = 0;                 // k-mer table lookups (counters[9])
   uint32_t jtl = 0;                 // row jump table lookups (counters[10])
+  uint32_t r3l = 0;                 // three-step row table lookups (counters[11])
   load_off(wave, end0, len0);
   tail0 = load_tail(end0, len0);
   load_off((uint64_t)wave + nwaves, end1, len1);
@@ -260,6 +265,40 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
           skip = jumped ? 8u : 0u;                                   // the others walk; this group waits for them
         }
       }
+      if (JT && R3T) {
+        // ---- a group that holds one row and for which no aligned jump is at hand takes THREE steps with one word of the
+        // three-step row table -- when it stands one step behind a chunk boundary (the three steps end on the boundary),
+        // or has fewer than eight characters left beyond the next boundary anyway.  (Two or three steps behind a boundary
+        // with a jump to come, one or two single steps get there.)  The other groups step as usual meanwhile.
+        const uint32_t rem = len - it, a = it & 3u, to_align = (4u - a) & 3u;
+        const bool want3 = alive && skip == 0u && (ep - sp) == 1 && rem >= 3u && !(a == 0u && rem >= 8u) &&
+                           (to_align == 3u || to_align == 0u || rem < to_align + 8u);
+        if (__builtin_amdgcn_ballot_w64(want3)) {
+          const uint32_t valid = 4u - a;                                       // characters still in `ch` (wave-uniform)
+          const uint32_t three = (valid >= 3u ? ch : (ch | (nx << (8u * valid)))) & 0xFFFFFFu;
+          bool took = false;
+          if (want3) {
+            const unsigned long long re = r3tab[sp];
+            took = (uint32_t)(re >> 40) == three;
+            if (took) { sp = re & ((1ull << 40) - 1); ep = sp + 1; steps += 3; }
+            else {                                                             // it fails within these three: k_search_defer finds where
+              if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
+              deferred = true;
+              ep = sp;
+            }
+            if (t == 0) r3l++;
+          }
+          if (!__builtin_amdgcn_ballot_w64(alive && !took && !deferred) && !__builtin_amdgcn_ballot_w64(alive && skip != 0u)) {     // everybody took them: go on three steps further
+            for (uint32_t s3 = 0; s3 < 3u; s3++) {
+              ch >>= 8;
+              if ((it & 3u) == 3u) { ch = nx; nx = pat_chunk(pat, own, end, len, (it >> 2) + 2); }
+              if (s3 < 2u) it++;
+            }
+            continue;
+          }
+          skip = took ? 3u : skip;
+        }
+      }
       const bool stepping = alive && skip == 0u && !deferred;
       skip -= skip ? 1u : 0u;
       const bool wide_iv = stepping && (ep - sp) != 1;
@@ -347,6 +386,11 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
     const unsigned long long lookups = wave_sum((unsigned long long)jtl);
     if ((threadIdx.x & 63u) == 0 && lookups)
       atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 10, lookups);
+  }
+  if (JT && R3T) {
+    const unsigned long long lookups = wave_sum((unsigned long long)r3l);
+    if ((threadIdx.x & 63u) == 0 && lookups)
+      atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 11, lookups);
   }
 }
 
@@ -577,17 +621,17 @@ static int blocks_per_cu(K kernel) {
   return nb > 8 ? 8 : nb;
 }
 
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW>
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
                               const uint64_t *off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st) {
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
-  static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW>);
+  static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>);
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search4<WIDE, LAYOUT, KT, JT, RW><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, pat, off, sp,
-                                                                  ep, k, h->d_counters);
+  k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt,
+                                                                       R3T ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters);
   if (RW) {     // the one-row part of every search, a lane per pattern
     const uint64_t wg = ((uint64_t)k + kSThreads - 1) / kSThreads;
     const int g1 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 32);
@@ -619,7 +663,12 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
     if ((e = row1_get(h, st, &r1)) != hipSuccess) return e;
     if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, jt, r1, pat, off, sp, ep, k, st);
   }
-  if (jt) return launch_v4kj<WIDE, LAYOUT, KT, true, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st);
+  if (jt) {      // and the three-step table beside it, for the steps no aligned jump covers
+    const unsigned long long *r3 = nullptr;
+    if (rows != 0 && (e = row3_get(h, st, &r3)) != hipSuccess) return e;
+    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, true, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st)
+              : launch_v4kj<WIDE, LAYOUT, KT, true, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st);
+  }
   if (rows != 0) {
     const unsigned long long *r3 = nullptr, *r1 = nullptr;
     bool have1;

@@ -465,12 +465,12 @@ def test_row_jump_table_on_and_off_agree(layout):
                         check_search(hip, orc, uniform)
                         st = hip.stats()
                         seen.append((jump, st["jump_bytes"], st["jump_lookups"]))
-                        # "auto" / "jumps": the lane groups of k_search4 walk the one-row part, eight steps per lookup where
-                        # the characters agree (a literal search builds no row table beside a jump table); "rows3" / "rows":
-                        # one lane per pattern walks it (k_search_rows) with the three-step / one-step row table, as on an
-                        # index too large for a jump table
-                        assert st["row_bytes"] == (8 * orc.n if jump in ("rows", "rows3") else 0)
-                        assert (st["row_lookups"] > 0) == (jump in ("rows", "rows3"))
+                        # "auto": the lane groups of k_search4 walk the one-row part, eight steps per lookup in the row jump
+                        # table at chunk boundaries, three per lookup in the three-step table between them; "jumps": with
+                        # the jump table alone; "rows3" / "rows": one lane per pattern walks it (k_search_rows) with the
+                        # three-step / one-step row table, as on an index too large for a jump table
+                        assert st["row_bytes"] == (8 * orc.n if jump in ("auto", "rows", "rows3") else 0)
+                        assert (st["row_lookups"] > 0) == (jump in ("auto", "rows", "rows3"))
                         if jump in ("auto", "jumps"):
                             assert st["jump_bytes"] == 16 * orc.n and st["jump_lookups"] > 2 * len(uniform)
                             # the table itself: (BWT' along an 8-step LF walk, the row it ends on) -- spot-check through a

@@ -368,9 +368,15 @@ def cpu_baseline_literal(torch, orc, t_build, n, pats, off, sp, ep, sample, m, c
     if not ok:
         raise SystemExit("bench: GPU results differ from the CPU oracle on the baseline sample")
     ranks = 2 * int(steps.sum())
-    log(rank, "cpu_baseline: %d cores, %.2fs for %d patterns (%d rank queries), index build %.1fs, parity ok"
-        % (cores, dt, sample, ranks, t_build))
+    # the same on ONE core, over the first sample / cores patterns
+    s1 = max(1, sample // max(cores, 1))
+    t0 = time.time()
+    _, _, steps1 = orc.search_batch(h_pats[: s1 * m], h_off[: s1 + 1], threads=1)
+    dt1 = time.time() - t0
+    log(rank, "cpu_baseline: %d cores, %.2fs for %d patterns (%d rank queries), index build %.1fs, parity ok; one core: %.2fs for %d patterns"
+        % (cores, dt, sample, ranks, t_build, dt1, s1))
     return {"value": ranks / dt / 1e6, "unit": "M rank-queries/s", "cores": cores, "kind": "port",
+            "one_core_value": 2 * int(steps1.sum()) / dt1 / 1e6,
             "patterns_per_s": sample / dt, "index_build_s": t_build, "n": n,
             "sample": "%s; first %d of the timed batch's %d-char patterns; inverted lists + binary-search occ in C "
                       "with OpenMP; the GPU's (sp, ep) for them are bit-equal" % (note, sample, m)}

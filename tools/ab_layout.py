@@ -10,7 +10,7 @@ import bench, findex_amd
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 la = sys.argv[2] if len(sys.argv) > 2 else "onehot"
 lb = sys.argv[3] if len(sys.argv) > 3 else "bytes"
-log2n, sigma, k, m, seed = bench.WORKLOADS[wl]
+log2n, sigma, k, m, seed = bench.LITERAL[wl]
 n = 1 << log2n
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream

@@ -266,27 +266,42 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         }
       }
       if (JT && R3T) {
-        // ---- a group that holds one row and for which no aligned jump is at hand takes THREE steps with one word of the
+        // ---- a group whose interval is at most G rows and for which no aligned jump is at hand takes THREE steps with the
         // three-step row table -- when it stands one step behind a chunk boundary (the three steps end on the boundary),
         // or has fewer than eight characters left beyond the next boundary anyway.  (Two or three steps behind a boundary
-        // with a jump to come, one or two single steps get there.)  The other groups step as usual meanwhile.
+        // with a jump to come, one or two single steps get there.)  Lane t of the group looks up row sp + t: the rows whose
+        // three characters are the pattern's go on to LF^3 of themselves -- LF keeps the order of rows that carry the same
+        // character, so they land side by side: the new interval begins at the first survivor's image and has as many rows
+        // as there are survivors.  (At C3 one group in eight still holds two or three rows at step 5; stepping those the
+        // ordinary way kept their whole wave in the loop for three more iterations.)  The other groups step as usual.
         const uint32_t rem = len - it, a = it & 3u, to_align = (4u - a) & 3u;
-        const bool want3 = alive && skip == 0u && (ep - sp) == 1 && rem >= 3u && !(a == 0u && rem >= 8u) &&
+        const uint64_t width = ep - sp;
+        const bool want3 = alive && skip == 0u && width >= 1u && width <= (uint64_t)G && rem >= 3u && !(a == 0u && rem >= 8u && width == 1u) &&
                            (to_align == 3u || to_align == 0u || rem < to_align + 8u);
         if (__builtin_amdgcn_ballot_w64(want3)) {
           const uint32_t valid = 4u - a;                                       // characters still in `ch` (wave-uniform)
           const uint32_t three = (valid >= 3u ? ch : (ch | (nx << (8u * valid)))) & 0xFFFFFFu;
+          const bool mine = want3 && (uint64_t)t < width;
+          unsigned long long re = 0;
+          if (mine) re = r3tab[sp + t];
+          const bool hit = mine && (uint32_t)(re >> 40) == three;
+          const uint32_t lane64 = threadIdx.x & 63u, base = lane64 - t;
+          const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> base) & ((1u << G) - 1u);
+          const int first = (int)(base + (hm ? (uint32_t)__builtin_ctz(hm) : 0u));
+          const uint32_t lo3 = (uint32_t)__shfl((int)(uint32_t)re, first, 64), hi3 = (uint32_t)__shfl((int)(uint32_t)(re >> 32), first, 64);
           bool took = false;
           if (want3) {
-            const unsigned long long re = r3tab[sp];
-            took = (uint32_t)(re >> 40) == three;
-            if (took) { sp = re & ((1ull << 40) - 1); ep = sp + 1; steps += 3; }
-            else {                                                             // it fails within these three: k_search_defer finds where
+            took = hm != 0u;
+            if (took) {
+              sp = (((uint64_t)hi3 << 32) | lo3) & ((1ull << 40) - 1);
+              ep = sp + (uint32_t)__builtin_popcount(hm);
+              steps += 3;
+            } else if (width == 1u) {                                          // it fails within these three: k_search_defer finds where
               if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
               deferred = true;
               ep = sp;
-            }
-            if (t == 0) r3l++;
+            }                                                                  // (wider and no row agrees: it steps on and ends within three steps)
+            if (t == 0) r3l += (uint32_t)width;
           }
           if (!__builtin_amdgcn_ballot_w64(alive && !took && !deferred) && !__builtin_amdgcn_ballot_w64(alive && skip != 0u)) {     // everybody took them: go on three steps further
             for (uint32_t s3 = 0; s3 < 3u; s3++) {

@@ -372,8 +372,18 @@ JNIEXPORT jint JNICALL FN(calcGapsChain0)(JNIEnv *e, jobject self, jlong h, jbyt
   return (jint)done;
 }
 
-/* fmx_prepare: build the k-mer jump table (what & 1) / the select directory (what & 2) now, not at first use */
+/* fmx_prepare: build the k-mer jump table (what & 1) / the select directory (what & 2) / the row tables (what & 4) now, not at first use */
 JNIEXPORT void JNICALL FN(prepare0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_prepare(H(h), (unsigned)what)); }
+
+/* fmx_config_set: process-wide settings ("layout", "checkpoints", "ktab", "jump", "pipeline", "validate", "threads") */
+JNIEXPORT void JNICALL FN(configSet0)(JNIEnv *e, jobject self, jstring key, jstring value) {
+  const char *k = (*e)->GetStringUTFChars(e, key, 0);
+  const char *v = (*e)->GetStringUTFChars(e, value, 0);
+  int rc = (k && v) ? fmx_config_set(k, v) : FMX_ERR_NOMEM;
+  if (v) (*e)->ReleaseStringUTFChars(e, value, v);
+  if (k) (*e)->ReleaseStringUTFChars(e, key, k);
+  rethrow(e, rc);
+}
 
 JNIEXPORT jlong JNICALL FN(regexBatchCreate0)(JNIEnv *e, jobject self, jlong h, jlongArray regexes) {
   jsize k = (*e)->GetArrayLength(e, regexes);

@@ -45,6 +45,7 @@ object HipFM {
   @native def regexCompileBatch0(packed: Array[Byte], k: Int, lineOnly: Boolean, handles: Array[Long], status: Array[Int]): Unit
   @native def regexFreeBatch0(handles: Array[Long]): Unit
   @native def prepare0(h: Long, what: Int): Unit
+  @native def configSet0(key: String, value: String): Unit
   @native def occHost0(h: Long, c: Int, i: Long): Long
   @native def calcGapsChain0(h: Long, text: Array[Byte], from: Int, rank0: Long, lastChar: Int, rklst: Long, ranks: Array[Long]): Int
   @native def regexBatchCreate0(h: Long, regexes: Array[Long]): Long

@@ -124,3 +124,20 @@ def test_build_lists_cover_the_sources():
     have = set(os.listdir(build.CSRC))
     assert {f for f in have if f.endswith((".hip", ".cpp"))} == set(build.SOURCES)
     assert {f for f in have if f.endswith(".h")} == set(build.HEADERS)
+
+
+def test_config_keys_and_values():
+    """fmx_config_set (include/fmx.h): every documented key takes its documented values and refuses others with
+    FMX_ERR_ARG and a message -- no device needed."""
+    L = _lib.load()
+    ok = {b"layout": [b"onehot", b"bytes", b"auto"], b"checkpoints": [b"superblock", b"auto"], b"ktab": [b"off", b"auto"],
+          b"jump": [b"off", b"rows", b"rows3", b"jumps", b"auto"], b"pipeline": [b"on", b"off"], b"validate": [b"1", b"0"],
+          b"threads": [b"3", b"0"]}
+    for key, values in ok.items():
+        for v in values:                        # the last value of each list is the default: left in place
+            assert L.fmx_config_set(key, v) == 0, (key, v)
+        if key != b"validate":                  # ("validate" reads anything but "0" as on)
+            assert L.fmx_config_set(key, b"no-such-value") == 3, key
+            assert L.fmx_last_error().decode()
+    assert L.fmx_config_set(b"no-such-key", b"1") == 3
+    assert L.fmx_config_set(None, b"1") == 3 and L.fmx_config_set(b"jump", None) == 3

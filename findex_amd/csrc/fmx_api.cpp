@@ -561,7 +561,7 @@ int fmx_prepare(const fmx_index *idx, unsigned what) {
     const uint4 *jt = nullptr;
     HIP_TRY(jump_get(h, lease.c->stream, &jt), "jump table");
     const unsigned long long *r1 = nullptr, *r3 = nullptr;
-    if (!jt) HIP_TRY(row3_get(h, lease.c->stream, &r3), "three-step row table");      // what a literal search uses instead
+    HIP_TRY(row3_get(h, lease.c->stream, &r3), "three-step row table");      // beside the jump table, or instead of it
     HIP_TRY(row1_get(h, lease.c->stream, &r1), "row table");
   }
   return FMX_OK;

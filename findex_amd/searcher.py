@@ -309,9 +309,9 @@ class HipFMSearcher:
                                                _ptr(ranks), ctypes.byref(done)))
         return ranks[: text.size], int(done.value)
 
-    def prepare(self, ktab=True, select=False):
-        """fmx_prepare: build the k-mer jump table / the select directory now instead of at first use."""
-        _lib.check(self._L.fmx_prepare(self._h, (1 if ktab else 0) | (2 if select else 0)))
+    def prepare(self, ktab=True, select=False, jump=False):
+        """fmx_prepare: build the k-mer jump table / the select directory / the row tables now instead of at first use."""
+        _lib.check(self._L.fmx_prepare(self._h, (1 if ktab else 0) | (2 if select else 0) | (4 if jump else 0)))
 
     # ---- statistics
     def stats(self):

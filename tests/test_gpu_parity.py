@@ -490,6 +490,30 @@ def test_row_jump_table_on_and_off_agree(layout):
     assert blk.stats()["jump_bytes"] == 0
 
 
+def test_prepare_builds_every_table_up_front():
+    """fmx_prepare(KTAB | SELECT | JUMP): the k-mer table, the select directory and the three row tables are built by
+    the call, not by the first search / Psi / regex match after it (tables_build_ms does not move again), and the
+    answers are the oracle's."""
+    bwt, eof, counts = synth_bwt(300_000, 1, 20, 5)
+    hip, orc = pair_from_mem(bwt, eof, counts)
+    st0 = hip.stats()
+    assert st0["jump_bytes"] == 0 and st0["row_bytes"] == 0 and st0["ktab_k"] == 0
+    hip.prepare(ktab=True, select=True, jump=True)
+    st1 = hip.stats()
+    assert st1["ktab_k"] > 0 and st1["jump_bytes"] == 16 * orc.n and st1["row_bytes"] == 16 * orc.n      # R3 + R1: 8 n each
+    assert st1["tables_build_ms"] > 0
+    rng = np.random.default_rng(6)
+    pats = lf_walk_patterns(orc, rng, 3000, 30, 0.2, alphabet=list(range(1, 21)))
+    check_search(hip, orc, pats)
+    rows = rng.integers(0, orc.n, 500).astype(np.uint64)
+    assert hip.nextSubstr_batch(rows, 9) == [orc.nextSubstr(int(r), 9) for r in rows]
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(re, lineOnly=True)) for re in ("ab(c|d)*e", "a[b-d]+f")]
+    findex_amd.ReTree.matchSA_batch(hip, trees, mode="frontier", maxBranching=1 << 20, maxIterations=0)
+    st2 = hip.stats()
+    assert st2["tables_build_ms"] == st1["tables_build_ms"], "a table was built after fmx_prepare"
+    assert st2["jump_lookups"] > 0 and st2["row_lookups"] > 0
+
+
 def test_pipelined_host_batch_pageable_and_pinned():
     """Host-pointer batches of 128k patterns or more travel as whole arrays or, with the "pipeline" setting on and
     page-locked buffers, as chunks over three streams (fmx_api.cpp): ragged

@@ -401,7 +401,8 @@ typedef struct fmx_stats_t {
   uint64_t rank_queries;     /* occ evaluations the executed steps stand for (see above) */
   uint64_t backward_steps;   /* getPrevRange-equivalents executed (2 rank queries each) */
   uint64_t launches;         /* kernels launched by this handle */
-  double last_kernel_ms;     /* device time of the last host-pointer call's kernel(s), HIP events */
+  double last_kernel_ms;     /* device time of the last host-pointer call's kernel(s), HIP events (calls whose operands
+                              * and results fit in 2 KB are not timed: they leave it as it was) */
   uint64_t index_bytes;      /* device bytes held: rank dictionary + BWT + tables */
   uint64_t n_blocks;         /* rank-dictionary blocks per symbol */
   uint32_t n_symbols;        /* symbols that own a bit-vector */

@@ -490,6 +490,50 @@ def test_row_jump_table_on_and_off_agree(layout):
     assert blk.stats()["jump_bytes"] == 0
 
 
+@pytest.mark.parametrize("layout", ["onehot", "bytes"])
+def test_row_tables_on_repetitive_texts(layout):
+    """The three-step lookups take intervals of up to G rows (lane t looks up row sp + t): texts made of repeats, where
+    a pattern's interval stays a few rows wide for many steps and only SOME of its rows agree with the next three
+    characters -- every mode of the row tables against the oracle, intervals, misses' values and step counts."""
+    rng = np.random.default_rng(2024)
+    texts = []
+    unit = bytes(rng.integers(97, 100, 37).astype(np.uint8))
+    rep = bytearray(unit * 60)
+    for j in rng.integers(0, len(rep), 70):          # a few point mutations: the repeats split into families of 2..8 rows
+        rep[int(j)] = int(rng.integers(97, 101))
+    texts.append(bytes(rep))
+    texts.append(b"abracadabra" * 150 + b"abracadabrx" * 3 + b"cadabraabra" * 40)
+    texts.append(bytes(rng.integers(97, 99, 2500).astype(np.uint8)))      # two letters: wide intervals for a dozen steps
+    findex_amd.set_layout(layout)
+    try:
+        for text in texts:
+            bwt, eof, counts = bwt_of_text(text)
+            orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+            syms = [int(c) for c in np.nonzero(counts)[0]]
+            pats = []
+            for m in (3, 5, 6, 7, 8, 9, 11, 12, 16, 17, 19, 24, 31, 40):
+                pats += lf_walk_patterns(orc, rng, 150, m, 0.3, alphabet=syms)
+                for _ in range(40):                  # substrings of the text itself: hits with several occurrences
+                    a = int(rng.integers(0, len(text) - m))
+                    pats.append(text[a:a + m])
+            pats = [pats[i] for i in rng.permutation(len(pats))]
+            for ktab in ("auto", "off"):
+                for jump in ("off", "auto", "jumps", "rows", "rows3"):
+                    findex_amd.set_ktab(ktab)
+                    findex_amd.set_jump(jump)
+                    try:
+                        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+                        hits = check_search(hip, orc, pats)
+                        assert hits > len(pats) // 3
+                        if jump == "auto":
+                            assert hip.stats()["row_lookups"] > 0
+                    finally:
+                        findex_amd.set_ktab("auto")
+                        findex_amd.set_jump("auto")
+    finally:
+        findex_amd.set_layout("auto")
+
+
 def test_prepare_builds_every_table_up_front():
     """fmx_prepare(KTAB | SELECT | JUMP): the k-mer table, the select directory and the three row tables are built by
     the call, not by the first search / Psi / regex match after it (tables_build_ms does not move again), and the

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench, findex_amd
 from findex_amd.regex import RegexBatchMulti
-log2n, k, seed, max_len = bench.REGEX["c4"]
+log2n, k, seed, max_len = bench.REGEX["c4"][:4]
 n = 1 << log2n
 dev = torch.device("cuda", 0)
 bwt, eof = bench.make_bwt(torch, n, bench.C4_ALPHABET, seed, dev); torch.cuda.synchronize()

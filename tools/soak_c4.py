@@ -11,7 +11,7 @@ import bench, findex_amd
 from findex_amd.regex import RegexBatch
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 wl = sys.argv[2] if len(sys.argv) > 2 else "c4"
-log2n, k, seed, max_len = bench.REGEX[wl]
+log2n, k, seed, max_len = bench.REGEX[wl][:4]
 n = 1 << log2n
 dev = torch.device("cuda", 0)
 bwt, eof = bench.make_bwt(torch, n, bench.C4_ALPHABET, seed, dev); torch.cuda.synchronize()

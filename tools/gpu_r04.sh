@@ -1,0 +1,51 @@
+#!/bin/bash
+# round 4's GPU-box sessions, by part:  tools/gpu_r04.sh <tag> <part> [...]
+#   bound   : what binds k_search4: counters the box lists, the request-mix microbenchmark,
+#             the length / batch-size sweeps of the real kernel, PMC passes with the translation / latency counters
+O=gpurun_out/${1:-r04}; mkdir -p $O
+shift
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo build failed; tail -5 $O/build.log; exit 1; }
+for PART in "$@"; do
+case $PART in
+bound)
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 120 rocprofv3 -L > $REPO/$O/counters_avail.txt 2>&1); echo "list-avail rc=$?"
+  grep -o -i -E '\b(TCP_UTCL1|TCP_TCC|TCP_TCP|TCP_PENDING|TCC_EA0_RDREQ|TCC_TAG_STALL|TCC_BUBBLE|TCP_TA|TA_BUSY|TA_ADDR_STALL|TD_)[A-Z0-9_]*' $O/counters_avail.txt | sort -u > $O/counters_of_interest.txt; wc -l $O/counters_of_interest.txt
+  timeout -k 10 400 tools/ubench/mix > $O/ubench_mix.txt 2>&1; echo "mix rc=$?"; tail -3 $O/ubench_mix.txt
+  timeout -k 10 500 python tools/c3_bound.py 2>&1 | grep -v amdgpu.ids > $O/c3_bound.txt; echo "c3_bound rc=$?"; tail -4 $O/c3_bound.txt
+  ;;
+pmc_bound)
+  # translation / latency counters on the real kernel and on the microbenchmark's D-only and mixed programs
+  i=0
+  for grp in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_PERMISSION_MISS_sum" \
+             "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" \
+             "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum" \
+             "TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_STALL_MISSFIFO_FULL_sum" \
+             "GRBM_GUI_ACTIVE TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum"; do
+    i=$((i+1))
+    (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $REPO/$O/pmcb$i -- python3 $REPO/tools/prof_workload.py --workload c3 > $REPO/$O/pmcb$i.log 2>&1) || echo "pass $i failed: $grp"
+    (cd /tmp && export TMPDIR=/tmp && MIX_MODE=sep timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $REPO/$O/pmcm$i -- $REPO/tools/ubench/mix 77 64 32 4 D KDDRJJJ J > $REPO/$O/pmcm$i.log 2>&1) || echo "mix pass $i failed: $grp"
+    echo "pmc_bound pass $i done: $grp"
+  done
+  python - $O <<'PY'
+import csv,glob,sys,collections
+O=sys.argv[1]
+agg=collections.defaultdict(list)
+for f in sorted(glob.glob(O+"/pmc[bm]*/*/*_counter_collection.csv")):
+    tag="mix" if "/pmcm" in f else "c3"
+    for r in csv.DictReader(open(f)):
+        k=r["Kernel_Name"].split("(")[0].replace("fmx::","")
+        if tag=="c3" and not ("k_search4" in k or "k_occ" in k or "k_search_defer" in k): continue
+        agg[(tag,k,r["Counter_Name"])].append((int(r["Dispatch_Id"]),float(r["Counter_Value"])))
+with open(O+"/bound_counters.csv","w",newline="") as fo:
+    w=csv.writer(fo); w.writerow(["Run","Kernel","Counter","Dispatches","Values"])
+    for (t,k,c),v in sorted(agg.items()):
+        v.sort()
+        w.writerow([t,k,c,len(v)," ".join("%.6g"%x for _,x in v[:12])])
+print("bound_counters.csv written:",len(agg),"rows")
+PY
+  rm -rf $O/pmcb* $O/pmcm*.d 2>/dev/null
+  ;;
+*) echo "unknown part $PART";;
+esac
+done

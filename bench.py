@@ -155,15 +155,22 @@ def check_launch(args, rank, world):
             assert got.size == want.size and got.tobytes() == want.tobytes(), "regex exchange content"
     else:
         k = (LITERAL.get(args.workload) or (0, 0, 1000))[2]
-        gather = IntervalGather(k, torch.device("cpu"))
+        gather = IntervalGather(k, torch.device("cpu"), form=args.exchange, delivery=args.delivery)
         for i in range(args.steps):
             sp, ep = gather.slot(i)
             sp.copy_(torch.arange(k, dtype=torch.int64) * (rank + 1) + i)
             ep.copy_(sp + rank + 1)
+            if i == 1:
+                ep[5] = sp[5] + (1 << 30)       # a wide interval: travels through the escape list of the packed form
             out = gather.launch(i)
             gather.finish()
-            for r in range(world):
-                assert int(out[r, 0, 7]) == 7 * (r + 1) + i and int(out[r, 1, 7]) == 7 * (r + 1) + i + r + 1, "gather content"
+            if out is None:
+                assert args.delivery == "root" and rank != 0, "only the root receives"
+                continue
+            for r in range(world if use_dist else 1):
+                gsp, gep = gather.intervals(out, r)
+                assert int(gsp[7]) == 7 * (r + 1) + i and int(gep[7]) == 7 * (r + 1) + i + r + 1, "gather content"
+                assert int(gep[5] - gsp[5]) == ((1 << 30) if i == 1 else r + 1), "wide interval"
     dt = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
@@ -172,6 +179,7 @@ def check_launch(args, rank, world):
                           "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                           "config": {"workload": "launch check (%s shapes), gloo, no GPU work" % args.workload,
+                                     "exchange": "%s / %s" % (args.exchange, args.delivery),
                                      "ranks_in_group": dist.get_world_size() if use_dist else 1}}), flush=True)
     if use_dist:
         dist.destroy_process_group()
@@ -418,6 +426,89 @@ def cpu_baseline_regex(orc, t_build, n, res, trees, gpu_out, sample, max_len, re
                       "fmx_regex_compile_batch on the same cores) for the sample" % (note, sample, how)}
 
 
+def measure_exchange(args, torch, dist, hip, gather, k, device, stream, use_dist, reps=10):
+    """The exchange on its own (nothing else on the device), so that a scaling curve says which side of
+    max(search, gather) binds a step: per form (packed 8 B / pairs 16 B per pattern) and delivery (root only /
+    all-gather) the time from the pack kernel's launch to the collective's end, HIP events on the current stream around
+    `launch` + `finish` (the collective's own stream is joined by finish()).  None without a process group."""
+    if not use_dist:
+        return None
+    from findex_amd.distributed import IntervalGather
+    res = {}
+    for form in ("packed", "pairs"):
+        for delivery in ("root", "all"):
+            g = gather if (form == args.exchange and delivery == args.delivery) else \
+                IntervalGather(k, device, form=form, delivery=delivery, searcher=hip, depth=1)
+            sp, ep = g.slot(0)
+            if g is not gather:
+                sp.copy_(gather.mine[0][0])
+                ep.copy_(gather.mine[0][1])
+            ms = []
+            for i in range(reps + 2):
+                dist.barrier()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.launch(0, stream)
+                g.finish()
+                e1.record()
+                torch.cuda.synchronize()
+                if i >= 2:
+                    ms.append(e0.elapsed_time(e1))
+            t = torch.tensor([sum(ms) / len(ms)], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res["%s/%s" % (form, delivery)] = {"gather_ms": float(t.item()), "payload_bytes_per_rank": g.payload_bytes}
+            if g is not gather:
+                del g
+    mine = res["%s/%s" % (args.exchange, args.delivery)]
+    return {"form": args.exchange, "delivery": args.delivery, "gather_ms": mine["gather_ms"],
+            "payload_bytes_per_rank": mine["payload_bytes_per_rank"], "all_forms": res,
+            "gather_ms_is": "pack kernel + collective alone on the device (max over ranks, mean of %d); inside a step it runs "
+                            "beside the next step's search: a step costs max(search_ms, gather_ms)" % reps}
+
+
+def measure_host_path(torch, hip, pats, off, sp_dev, ep_dev, k, m, reps=5):
+    """The same batch through the HOST-pointer entry points (what findex's API hands over: JVM arrays,
+    findex.scala:15-31) -- PCIe-inclusive, never `value`: fmx_search_batch from pageable and page-locked buffers, and the
+    lean form (fmx_search_batch_ex: no offsets for equal-length patterns, intervals back in the 8-byte form)."""
+    import findex_amd
+    from findex_amd.searcher import PinnedArray
+    h_pat = pats.cpu().numpy()
+    h_off = off.cpu().numpy().astype(np.uint64)
+    want_sp = sp_dev.cpu().numpy().astype(np.uint64)
+    want_ep = ep_dev.cpu().numpy().astype(np.uint64)
+
+    def timed(fn):
+        fn()
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return r, sorted(ts)[len(ts) // 2]
+    out = {}
+    (gsp, gep), t = timed(lambda: hip.search_batch(h_pat, h_off))
+    assert np.array_equal(gsp, want_sp) and np.array_equal(gep, want_ep)
+    out["pageable"] = {"ms_per_call": t * 1e3, "patterns_per_s": k / t, "bytes_per_pattern": m + 8 + 16}
+    p_pat, p_off = PinnedArray(h_pat.shape, np.uint8), PinnedArray(h_off.shape, np.uint64)
+    p_sp, p_ep = PinnedArray((k,), np.uint64), PinnedArray((k,), np.uint64)
+    p_pat.array[:] = h_pat
+    p_off.array[:] = h_off
+    _, t = timed(lambda: hip.search_batch(p_pat.array, p_off.array, out=(p_sp.array, p_ep.array)))
+    assert np.array_equal(p_sp.array, want_sp) and np.array_equal(p_ep.array, want_ep)
+    out["page_locked"] = {"ms_per_call": t * 1e3, "patterns_per_s": k / t, "bytes_per_pattern": m + 8 + 16}
+    cap = max(16, k // 256)
+    pk, t = timed(lambda: hip.search_batch_ex(h_pat, fixed_len=m, packed=True, escape_cap=cap))
+    usp, uep = hip.unpack_intervals(pk, k, cap)
+    assert np.array_equal(usp, want_sp) and np.array_equal(uep, want_ep)
+    out["lean_pageable"] = {"ms_per_call": t * 1e3, "patterns_per_s": k / t, "bytes_per_pattern": m + 8,
+                            "what": "fmx_search_batch_ex: fixed_len = %d (no offsets travel), intervals back in the 8-byte form" % m}
+    out["what"] = ("fmx_search_batch on host arrays, median of %d calls after two warm-ups, results checked against the device-"
+                   "resident step's; the link moves ~53 GB/s each way on these boxes" % reps)
+    return out
+
+
 # ---------------------------------------------------------------- the two kinds of workload
 def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream):
     log2n, sigma, k, m, seed = LITERAL[args.workload]
@@ -438,14 +529,14 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     # the intervals land in the slots of a pipelined gather: with N > 1 the all-gather of step i (RCCL over
     # xGMI, 16 B per pattern) runs on the collective's stream while step i+1 is being searched
     from findex_amd.distributed import IntervalGather
-    gather = IntervalGather(k, device)
+    gather = IntervalGather(k, device, form=args.exchange, delivery=args.delivery, searcher=hip)
     step_no = [0]
 
     def step():
         sp, ep = gather.slot(step_no[0])
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
-        if use_dist:        # the path's one exchange: gather the hit intervals
-            gather.launch(step_no[0])
+        if use_dist:        # the path's one exchange: pack the hit intervals (8 B per pattern) and gather them
+            gather.launch(step_no[0], stream)
         step_no[0] += 1
         return sp, ep
 
@@ -476,7 +567,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp_i.data_ptr(), ep_i.data_ptr(), k, stream)
         b.record()
         if use_dist:
-            gather.launch(step_no[0])
+            gather.launch(step_no[0], stream)
         step_no[0] += 1
     gather.finish()         # every step's gather completes inside the timed region
     torch.cuda.synchronize()
@@ -485,6 +576,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     dt = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
 
+    exchange = measure_exchange(args, torch, dist, hip, gather, k, device, stream, use_dist)
     tot = torch.tensor([dt, float(ranks_per_step), float(hits), kernel_ms], dtype=torch.float64, device=device)
     if use_dist:
         mx = tot.clone()
@@ -499,6 +591,10 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         ranks_all, hits_all, kernel_ms_max = float(ranks_per_step), float(hits), kernel_ms
     if rank != 0:
         return None
+    if exchange is not None:
+        exchange["search_ms"] = kernel_ms_max
+        exchange["expected_step_ms"] = max(kernel_ms_max, exchange["gather_ms"])
+        exchange["step_is_bound_by"] = "gather" if exchange["gather_ms"] > kernel_ms_max else "search"
 
     # ---- roofline of the one kernel a step launches (k_search4).  Algorithmic bytes of THIS layout per launch:
     # every memory request for a rank-dictionary line the kernel issued (device counter), at the line's size, plus
@@ -559,6 +655,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "dtype": "u64",
         "data": "synthetic",
         "patterns_per_sec": world * k * args.steps / dt,
+        "exchange": exchange,
         "config": {
             "workload": "%s: %d x %d-char literal patterns per GPU, 2^%d-byte sigma=%d synthetic BWT resident "
                         "in HBM (rank dictionary replicated per GPU)" % (args.workload.upper(), k, m, log2n, sigma),
@@ -570,7 +667,9 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
                                 "with rank_queries_per_request per memory request (k-mer table for the first K steps, one "
                                 "row-jump-table entry per 8 steps once the interval is a row, shared blocks)",
             "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
-                           % (world, ", all_gather of (sp,ep) per step overlapped with the next step's search" if use_dist else ""),
+                           % (world, (", one gather of the hit intervals per step (%s form, delivered to %s), overlapped with the "
+                                      "next step's search" % (args.exchange, "rank 0" if args.delivery == "root" else "every rank"))
+                              if use_dist else ""),
             "ranks_in_group": dist.get_world_size() if use_dist else 1,
             "index_gib": s1["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
             "tables_build_ms": s1["tables_build_ms"],
@@ -581,6 +680,11 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         },
         "roofline": roof,
     }
+    if world == 1 and not args.no_host_path:
+        out["host_path"] = measure_host_path(torch, hip, pats, off, sp0, ep0, k, m)
+        log(rank, "host path: pageable %.3f ms, page-locked %.3f ms, lean (no offsets, 8-byte intervals) %.3f ms per call"
+            % (out["host_path"]["pageable"]["ms_per_call"], out["host_path"]["page_locked"]["ms_per_call"],
+               out["host_path"]["lean_pageable"]["ms_per_call"]))
     if want_cpu:
         cores = effective_cores()
         sample = min(k, 200_000)
@@ -840,6 +944,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(LITERAL) + sorted(REGEX))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive sub-record of the literal workloads")
+    ap.add_argument("--exchange", default="packed", choices=["packed", "pairs"],
+                    help="N > 1, literal workloads: the intervals travel as 8 bytes (default) or 16 bytes per pattern")
+    ap.add_argument("--delivery", default="root", choices=["root", "all"],
+                    help="N > 1, literal workloads: the gather is delivered to rank 0 only (default) or to every rank")
     ap.add_argument("--check-launch", action="store_true",
                     help="rendezvous + sharding + gather over gloo without any GPU work (tests the launcher)")
     args = ap.parse_args()

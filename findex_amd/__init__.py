@@ -50,4 +50,10 @@ def set_pipeline(name):
     _lib.check(_lib.load().fmx_config_set(b"pipeline", name.encode()))
 
 
-__all__ = ["set_layout", "set_checkpoints", "set_ktab", "set_jump", "set_pipeline", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "CompiledRegexes", "FmxError", "MatchError", "Re2PostSyntax"]
+def config_set(key, value):
+    """fmx_config_set(key, value): any of the library's process-wide options (include/fmx.h)."""
+    from . import _lib
+    _lib.check(_lib.load().fmx_config_set(key.encode(), str(value).encode()))
+
+
+__all__ = ["config_set", "set_layout", "set_checkpoints", "set_ktab", "set_jump", "set_pipeline", "HipFMSearcher", "REParser", "ReTree", "SAResult", "NFA", "DFA", "CompiledRegexes", "FmxError", "MatchError", "Re2PostSyntax"]

@@ -40,6 +40,10 @@ class fmx_result(ctypes.Structure):
                 ("ep", ctypes.c_uint64)]
 
 
+class fmx_search_opts(ctypes.Structure):
+    _fields_ = [("fixed_len", ctypes.c_uint32), ("packed", ctypes.c_uint32), ("escape_cap", ctypes.c_uint64)]
+
+
 class fmx_stats_t(ctypes.Structure):
     _fields_ = [("rank_queries", ctypes.c_uint64), ("backward_steps", ctypes.c_uint64),
                 ("launches", ctypes.c_uint64), ("last_kernel_ms", ctypes.c_double),
@@ -80,6 +84,12 @@ SYMBOLS = {
     "fmx_occ_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "fmx_search_batch": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz]),
     "fmx_search_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fmx_search_batch_ex": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _P(fmx_search_opts)]),
+    "fmx_search_batch_ex_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _P(fmx_search_opts), _vp]),
+    "fmx_packed_words": (_sz, [_sz, _sz]),
+    "fmx_pack_intervals_dev": (_i32, [_vp, _vp, _vp, _sz, _sz, _vp, _vp]),
+    "fmx_unpack_intervals_dev": (_i32, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "fmx_unpack_intervals": (_i32, [_vp, _sz, _sz, _vp, _vp]),
     "fmx_prev_range_batch": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "fmx_prev_range_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fmx_interval_prev_range": (_i32, [_vp, _u64, _u64, _i32, _i32, _vp, _vp, _vp, _P(_sz)]),
@@ -119,7 +129,8 @@ SYMBOLS = {
     "fmx_comm_create_all": (_i32, [_vp, _sz, _P(_vp)]),
     "fmx_comm_info": (_i32, [_vp, _P(_i32), _P(_i32)]),
     "fmx_comm_free": (_i32, [_vp]),
-    "fmx_allgather_dev": (_i32, [_vp, _vp, _vp, _sz]),
+    "fmx_allgather_dev": (_i32, [_vp, _vp, _vp, _sz, _vp]),
+    "fmx_gather_dev": (_i32, [_vp, _vp, _vp, _sz, _i32, _vp]),
     "fmx_stats": (_i32, [_vp, _P(fmx_stats_t)]),
     "fmx_stats_reset": (_i32, [_vp]),
     "fmx_last_kernel_ms": (_i32, [_vp, _P(ctypes.c_double)]),

@@ -365,7 +365,7 @@ static inline const Index *H(const fmx_index *p) { return reinterpret_cast<const
 // operands into one pinned staging buffer and travel as ONE copy each way; large calls copy each array
 // directly between the caller's memory and its own device buffer.
 struct HostIn { const void *src; size_t bytes; };
-struct HostOut { void *dst; size_t bytes; };
+struct HostOut { void *dst; size_t bytes; };      // dst == nullptr: device scratch of that size, nothing comes back
 constexpr size_t kSmallCall = 256u << 10;
 constexpr size_t kTinyCall = 2048;
 
@@ -425,7 +425,7 @@ static int run_io(const Index *h, const HostIn *ins, int nin, const HostOut *out
       if (rc != FMX_OK) return rc;
       oo = 0;
       for (int j = 0; j < nout; j++) {
-        if (outs[j].bytes) std::memcpy(outs[j].dst, hout + oo, outs[j].bytes);
+        if (outs[j].bytes && outs[j].dst) std::memcpy(outs[j].dst, hout + oo, outs[j].bytes);
         oo += up16(outs[j].bytes);
       }
       return FMX_OK;
@@ -441,7 +441,7 @@ static int run_io(const Index *h, const HostIn *ins, int nin, const HostOut *out
     if (rc != FMX_OK) return rc;
     oo = 0;
     for (int j = 0; j < nout; j++) {
-      if (outs[j].bytes) std::memcpy(outs[j].dst, hout + oo, outs[j].bytes);
+      if (outs[j].bytes && outs[j].dst) std::memcpy(outs[j].dst, hout + oo, outs[j].bytes);
       oo += up16(outs[j].bytes);
     }
     return FMX_OK;
@@ -456,7 +456,7 @@ static int run_io(const Index *h, const HostIn *ins, int nin, const HostOut *out
     HIP_TRY(launch(st, din, dout), "kernel launch");
     HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
     for (int j = 0; j < nout; j++)
-      if (outs[j].bytes) HIP_TRY(hipMemcpyAsync(outs[j].dst, dout[j], outs[j].bytes, hipMemcpyDeviceToHost, st), "D2H");
+      if (outs[j].bytes && outs[j].dst) HIP_TRY(hipMemcpyAsync(outs[j].dst, dout[j], outs[j].bytes, hipMemcpyDeviceToHost, st), "D2H");
     return (int)FMX_OK;
   });
 }
@@ -643,17 +643,67 @@ int fmx_occ_batch_dev(const fmx_index *idx, const void *d_c, const void *d_i, vo
   return FMX_OK;
 }
 
-int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, size_t k,
-                         void *stream) {
-  if (!idx || (k && (!d_off || !d_sp || !d_ep))) return arg_fail("null argument");
+int fmx_search_batch_ex_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, size_t k,
+                            const fmx_search_opts *opts, void *stream) {
+  const uint32_t fixed = opts ? opts->fixed_len : 0u;
+  if (!idx || (k && ((!d_off && !fixed) || !d_sp || !d_ep))) return arg_fail("null argument");
+  if (k && fixed && !d_pat) return arg_fail("pat is null");
   int rc = use_device(H(idx));
   if (rc) return rc;
-  if (k && validate_device_operands()) {
+  if (k && !fixed && validate_device_operands()) {
     bool ok = true;
     HIP_TRY(check_offsets(H(idx), d_off, k, (hipStream_t)stream, &ok), "k_check_offsets");
     if (!ok) return arg_fail("pattern offsets must be non-decreasing");
   }
-  HIP_TRY(launch_search(H(idx), d_pat, d_off, d_sp, d_ep, k, (hipStream_t)stream), "k_search");
+  HIP_TRY(launch_search(H(idx), d_pat, fixed ? nullptr : d_off, d_sp, d_ep, k, (hipStream_t)stream, fixed), "k_search");
+  if (opts && opts->packed)      // in place: d_sp's first k words become the packed words
+    HIP_TRY(launch_pack_intervals(H(idx), d_sp, d_ep, k, opts->escape_cap, d_sp, (hipStream_t)stream), "k_pack_intervals");
+  return FMX_OK;
+}
+
+int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, size_t k,
+                         void *stream) {
+  return fmx_search_batch_ex_dev(idx, d_pat, d_off, d_sp, d_ep, k, nullptr, stream);
+}
+
+size_t fmx_packed_words(size_t k, size_t escape_cap) { return k + 1 + 2 * escape_cap; }
+
+int fmx_pack_intervals_dev(const fmx_index *idx, const void *d_sp, const void *d_ep, size_t k, size_t escape_cap, void *d_packed,
+                           void *stream) {
+  if (!idx || !d_packed || (k && (!d_sp || !d_ep))) return arg_fail("null argument");
+  int rc = use_device(H(idx));
+  if (rc) return rc;
+  HIP_TRY(launch_pack_intervals(H(idx), d_sp, d_ep, k, escape_cap, d_packed, (hipStream_t)stream), "k_pack_intervals");
+  return FMX_OK;
+}
+
+int fmx_unpack_intervals_dev(const fmx_index *idx, const void *d_packed, size_t k, size_t escape_cap, void *d_sp, void *d_ep,
+                             void *stream) {
+  if (!idx || !d_packed || (k && (!d_sp || !d_ep))) return arg_fail("null argument");
+  int rc = use_device(H(idx));
+  if (rc) return rc;
+  HIP_TRY(launch_unpack_intervals(H(idx), d_packed, k, escape_cap, d_sp, d_ep, (hipStream_t)stream), "k_unpack_intervals");
+  return FMX_OK;
+}
+
+// Host-side decode of the 8-byte form (format arithmetic on the caller's own result buffer: no search happens here).
+int fmx_unpack_intervals(const uint64_t *packed, size_t k, size_t escape_cap, uint64_t *sp, uint64_t *ep) {
+  if (!packed || (k && (!sp || !ep))) return arg_fail("null argument");
+  for (size_t q = 0; q < k; q++) {
+    const uint64_t a = packed[q] & ((1ull << 40) - 1);
+    sp[q] = a;
+    ep[q] = a + (packed[q] >> 40);
+  }
+  const uint64_t cnt = packed[k];
+  for (uint64_t j = 0; j < cnt && j < escape_cap; j++) {
+    const uint64_t q = packed[k + 1 + 2 * j];
+    if (q >= k) { g_err = "packed intervals: escape entry names pattern " + std::to_string(q) + " of " + std::to_string(k); return FMX_ERR_FORMAT; }
+    ep[q] = packed[k + 2 + 2 * j];
+  }
+  if (cnt > escape_cap) {
+    g_err = std::to_string(cnt) + " intervals of 2^24 - 1 rows or more, the escape list holds " + std::to_string(escape_cap);
+    return FMX_ERR_OVERFLOW;
+  }
   return FMX_OK;
 }
 
@@ -707,10 +757,71 @@ int fmx_occ_batch(const fmx_index *idx, const uint8_t *c, const int64_t *i, uint
 
 int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
                      size_t k) {
-  if (!idx || (k && (!off || !sp || !ep))) return arg_fail("null argument");
+  return fmx_search_batch_ex(idx, pat, off, sp, ep, k, nullptr);
+}
+
+int fmx_search_batch_ex(const fmx_index *idx, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
+                        size_t k, const fmx_search_opts *opts) {
+  const uint32_t fixed = opts ? opts->fixed_len : 0u;
+  const bool packed = opts && opts->packed;
+  const size_t esc = packed ? (size_t)opts->escape_cap : 0;
+  if (!idx || (k && ((!off && !fixed) || !sp || (!ep && !packed)))) return arg_fail("null argument");
   const Index *h = H(idx);
   int rc = use_device(h);
-  if (rc || !k) return rc;
+  if (rc) return rc;
+  if (!k) { if (packed && sp) sp[0] = 0; return FMX_OK; }
+  if (fixed || packed) {
+    // ---- the lean forms of a host batch (round 4): equal-length patterns travel without offsets (8 B per pattern less
+    // up the link) and the intervals come back in the 8-byte form (8 B per pattern less down): 56 -> 40 B per
+    // 32-character pattern.  Whole arrays up, one chain of kernels, one array down, like the default path below.
+    uint64_t lo = 0, total = (uint64_t)fixed * k;
+    if (!fixed) {
+      unsigned bad = off[k] < off[0];
+      for (size_t q = 0; q < k; q++) bad |= off[q + 1] < off[q];
+      if (bad) return arg_fail("pattern offsets must be non-decreasing");
+      lo = off[0];
+      total = off[k] - off[0];
+    }
+    if (total && !pat) return arg_fail("pat is null");
+    const size_t out_words = packed ? fmx_packed_words(k, esc) : k;
+    if (k < (128u << 10) && !lo) {
+      HostIn ins[2] = {{total ? pat : nullptr, (size_t)total}, {off, fixed ? 0 : (k + 1) * 8}};
+      HostOut outs[2] = {{sp, out_words * 8}, {packed ? nullptr : ep, k * 8}};
+      return run_io(h, ins, 2, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
+        hipError_t e = launch_search(h, di[0], fixed ? nullptr : di[1], dout[0], dout[1], k, st, fixed);
+        if (e == hipSuccess && packed) e = launch_pack_intervals(h, dout[0], dout[1], k, esc, dout[0], st);
+        return e;
+      });
+    }
+    Call c0(h);
+    if ((rc = c0.init()) != FMX_OK) return rc;
+    DevBuf d_pat, d_off, d_sp, d_ep;
+    HIP_TRY(c0.alloc(d_pat, (size_t)total + 16), "hipMalloc");
+    HIP_TRY(c0.alloc(d_off, fixed ? 16 : (k + 1) * 8), "hipMalloc");
+    HIP_TRY(c0.alloc(d_sp, out_words * 8), "hipMalloc");
+    HIP_TRY(c0.alloc(d_ep, k * 8), "hipMalloc");
+    if (total) HIP_TRY(hipMemcpy(d_pat.p, pat + lo, (size_t)total, hipMemcpyHostToDevice), "H2D(patterns)");
+    if (!fixed) {
+      if (lo) {
+        std::vector<uint64_t> roff(k + 1);
+        for (size_t q = 0; q <= k; q++) roff[q] = off[q] - lo;
+        HIP_TRY(hipMemcpy(d_off.p, roff.data(), (k + 1) * 8, hipMemcpyHostToDevice), "H2D(offsets)");
+      } else {
+        HIP_TRY(hipMemcpy(d_off.p, off, (k + 1) * 8, hipMemcpyHostToDevice), "H2D(offsets)");
+      }
+    }
+    rc = c0.timed([&](hipStream_t st, EventPair &ev) {
+      HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
+      HIP_TRY(launch_search(h, d_pat.p, fixed ? nullptr : d_off.p, d_sp.p, d_ep.p, k, st, fixed), "k_search");
+      if (packed) HIP_TRY(launch_pack_intervals(h, d_sp.p, d_ep.p, k, esc, d_sp.p, st), "k_pack_intervals");
+      HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
+      return (int)FMX_OK;
+    });
+    if (rc != FMX_OK) return rc;
+    HIP_TRY(hipMemcpy(sp, d_sp.p, out_words * 8, hipMemcpyDeviceToHost), packed ? "D2H(packed)" : "D2H(sp)");
+    if (!packed) HIP_TRY(hipMemcpy(ep, d_ep.p, k * 8, hipMemcpyDeviceToHost), "D2H(ep)");
+    return FMX_OK;
+  }
   // Offsets must be non-decreasing (a kernel would read a "negative" pattern as 2^64 bytes).  Walking a million of
   // them on the host takes 0.37 ms -- a quarter of a large call -- so large batches are checked where it is free:
   // chunk by chunk on the host while the uploads run (page-locked buffers), or by a kernel on the uploaded copy.

@@ -9,6 +9,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <memory>
@@ -33,6 +34,8 @@ struct Rccl {
   int (*CommInitAll)(Comm *, int, const int *) = nullptr;
   int (*CommDestroy)(Comm) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
@@ -54,6 +57,8 @@ Rccl *rccl() {
     r.CommInitAll = reinterpret_cast<int (*)(Comm *, int, const int *)>(sym("ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<int (*)(Comm)>(sym("ncclCommDestroy"));
     r.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, Comm, hipStream_t)>(sym("ncclAllGather"));
+    r.Send = reinterpret_cast<int (*)(const void *, size_t, int, int, Comm, hipStream_t)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<int (*)(void *, size_t, int, int, Comm, hipStream_t)>(sym("ncclRecv"));
     r.GroupStart = reinterpret_cast<int (*)()>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<int (*)()>(sym("ncclGroupEnd"));
     r.GetErrorString = reinterpret_cast<const char *(*)(int)>(sym("ncclGetErrorString"));
@@ -77,12 +82,18 @@ struct CommSet {
   int n_ranks = 0;                     // ranks of the communicator
   std::vector<Comm> comm;              // this process's ranks (one per local device)
   std::vector<int> device;
+  std::vector<int> rank;               // the communicator rank of each local rank
   std::vector<hipStream_t> stream;     // one non-blocking stream per local rank for the collective
+  std::vector<hipEvent_t> event;       // per local rank: "the producer stream has reached the call"
+  // every per-rank vector has the communicator's local size from the start (null entries until made), so that a
+  // communicator whose initialisation failed half-way is destroyed like any other
+  explicit CommSet(size_t n_local) : comm(n_local, nullptr), device(n_local, 0), rank(n_local, 0), stream(n_local, nullptr), event(n_local, nullptr) {}
   ~CommSet() {
     Rccl *r = rccl();
     for (size_t i = 0; i < comm.size(); i++) {
       (void)hipSetDevice(device[i]);
       if (stream[i]) { (void)hipStreamSynchronize(stream[i]); (void)hipStreamDestroy(stream[i]); }
+      if (event[i]) (void)hipEventDestroy(event[i]);
       if (comm[i] && r->CommDestroy) (void)r->CommDestroy(comm[i]);
     }
   }
@@ -95,10 +106,37 @@ struct CommSet {
   } while (0)
 
 int add_streams(CommSet *c) {
-  c->stream.assign(c->comm.size(), nullptr);
   for (size_t i = 0; i < c->comm.size(); i++) {
     HIP_TRY(hipSetDevice(c->device[i]), "hipSetDevice");
     HIP_TRY(hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking), "hipStreamCreate");
+    HIP_TRY(hipEventCreateWithFlags(&c->event[i], hipEventDisableTiming), "hipEventCreate");
+  }
+  return FMX_OK;
+}
+
+// FMX_COMM_FAIL_INIT=1: the RCCL initialisation call is reported as failed without being made -- the error path of
+// fmx_comm_create_* (a communicator destroyed before its streams exist) under test without a broken fabric.
+bool fail_init_injected() {
+  const char *e = getenv("FMX_COMM_FAIL_INIT");
+  return e && e[0] == '1';
+}
+
+// The collective's stream of local rank i waits for the work the caller has enqueued on producer[i] so far (the
+// search that writes d_send, whatever last read d_recv); producer == nullptr: the caller vouches that both are idle.
+int order_after_producers(CommSet *s, void *const *producer) {
+  if (!producer) return FMX_OK;
+  for (size_t i = 0; i < s->comm.size(); i++) {
+    HIP_TRY(hipSetDevice(s->device[i]), "hipSetDevice");
+    HIP_TRY(hipEventRecord(s->event[i], static_cast<hipStream_t>(producer[i])), "hipEventRecord(producer stream)");
+    HIP_TRY(hipStreamWaitEvent(s->stream[i], s->event[i], 0), "hipStreamWaitEvent");
+  }
+  return FMX_OK;
+}
+
+int finish_collective(CommSet *s, const char *what) {
+  for (size_t i = 0; i < s->comm.size(); i++) {
+    HIP_TRY(hipSetDevice(s->device[i]), "hipSetDevice");
+    HIP_TRY(hipStreamSynchronize(s->stream[i]), what);
   }
   return FMX_OK;
 }
@@ -125,13 +163,13 @@ int fmx_comm_create_rank(const fmx_index *idx, int n_ranks, int rank, const void
   if (rc) return rc;
   const Index *h = reinterpret_cast<const Index *>(idx);
   HIP_TRY(hipSetDevice(h->device), "hipSetDevice");
-  std::unique_ptr<CommSet> c(new CommSet());
+  std::unique_ptr<CommSet> c(new CommSet(1));
   c->n_ranks = n_ranks;
-  c->comm.assign(1, nullptr);
-  c->device.assign(1, h->device);
+  c->device[0] = h->device;
+  c->rank[0] = rank;
   UniqueId uid;
   std::memcpy(&uid, id, sizeof uid);
-  const int e = rccl()->CommInitRank(&c->comm[0], n_ranks, uid, rank);
+  const int e = fail_init_injected() ? 1 : rccl()->CommInitRank(&c->comm[0], n_ranks, uid, rank);
   if (e) return nccl_fail(e, "ncclCommInitRank");
   if ((rc = add_streams(c.get())) != FMX_OK) return rc;
   *out = reinterpret_cast<fmx_comm *>(c.release());
@@ -143,17 +181,17 @@ int fmx_comm_create_all(fmx_index *const *idxs, size_t n_idx, fmx_comm **out) {
   *out = nullptr;
   int rc = rccl_ready();
   if (rc) return rc;
-  std::unique_ptr<CommSet> c(new CommSet());
+  std::unique_ptr<CommSet> c(new CommSet(n_idx));
   c->n_ranks = (int)n_idx;
   for (size_t r = 0; r < n_idx; r++) {
     if (!idxs[r]) { set_error("null index handle"); return FMX_ERR_ARG; }
     const int d = reinterpret_cast<const Index *>(idxs[r])->device;
-    for (int seen : c->device)
-      if (seen == d) { set_error("fmx_comm_create_all needs one handle per DEVICE (RCCL has one rank per GPU)"); return FMX_ERR_ARG; }
-    c->device.push_back(d);
+    for (size_t q = 0; q < r; q++)
+      if (c->device[q] == d) { set_error("fmx_comm_create_all needs one handle per DEVICE (RCCL has one rank per GPU)"); return FMX_ERR_ARG; }
+    c->device[r] = d;
+    c->rank[r] = (int)r;
   }
-  c->comm.assign(n_idx, nullptr);
-  const int e = rccl()->CommInitAll(c->comm.data(), (int)n_idx, c->device.data());
+  const int e = fail_init_injected() ? 1 : rccl()->CommInitAll(c->comm.data(), (int)n_idx, c->device.data());
   if (e) return nccl_fail(e, "ncclCommInitAll");
   if ((rc = add_streams(c.get())) != FMX_OK) return rc;
   *out = reinterpret_cast<fmx_comm *>(c.release());
@@ -173,7 +211,7 @@ int fmx_comm_info(const fmx_comm *c, int *n_ranks, int *n_local) {
   return FMX_OK;
 }
 
-int fmx_allgather_dev(fmx_comm *c, const void *const *d_send, void *const *d_recv, size_t bytes) {
+int fmx_allgather_dev(fmx_comm *c, const void *const *d_send, void *const *d_recv, size_t bytes, void *const *producer_streams) {
   if (!c || !d_send || !d_recv) { set_error("null argument"); return FMX_ERR_ARG; }
   CommSet *s = reinterpret_cast<CommSet *>(c);
   Rccl *r = rccl();
@@ -181,6 +219,8 @@ int fmx_allgather_dev(fmx_comm *c, const void *const *d_send, void *const *d_rec
   for (size_t i = 0; i < nl; i++)
     if (bytes && (!d_send[i] || !d_recv[i])) { set_error("null slice pointer"); return FMX_ERR_ARG; }
   if (!bytes) return FMX_OK;
+  int rc = order_after_producers(s, producer_streams);
+  if (rc) return rc;
   int e = r->GroupStart();                         // one process, several ranks: the calls must be fused
   if (e) return nccl_fail(e, "ncclGroupStart");
   for (size_t i = 0; i < nl && !e; i++) {
@@ -190,11 +230,37 @@ int fmx_allgather_dev(fmx_comm *c, const void *const *d_send, void *const *d_rec
   const int e2 = r->GroupEnd();
   if (e) return nccl_fail(e, "ncclAllGather");
   if (e2) return nccl_fail(e2, "ncclGroupEnd");
-  for (size_t i = 0; i < nl; i++) {
-    HIP_TRY(hipSetDevice(s->device[i]), "hipSetDevice");
-    HIP_TRY(hipStreamSynchronize(s->stream[i]), "hipStreamSynchronize(all-gather)");
+  return finish_collective(s, "hipStreamSynchronize(all-gather)");
+}
+
+// Root-only delivery: every rank sends its slice to `root`, which receives them in rank order -- what north_star's
+// "final RCCL gather of hit intervals" needs when one rank (the JVM's) consumes the answer: each of the root's links
+// carries one slice in, nothing lands on the other ranks.  ncclSend / ncclRecv inside one group (RCCL has no gather
+// primitive of its own; ncclGather in newer releases is this).
+int fmx_gather_dev(fmx_comm *c, const void *const *d_send, void *const *d_recv, size_t bytes, int root, void *const *producer_streams) {
+  if (!c || !d_send || !d_recv) { set_error("null argument"); return FMX_ERR_ARG; }
+  CommSet *s = reinterpret_cast<CommSet *>(c);
+  Rccl *r = rccl();
+  if (root < 0 || root >= s->n_ranks) { set_error("root is not a rank of the communicator"); return FMX_ERR_ARG; }
+  const size_t nl = s->comm.size();
+  for (size_t i = 0; i < nl; i++)
+    if (bytes && (!d_send[i] || (s->rank[i] == root && !d_recv[i]))) { set_error("null slice pointer"); return FMX_ERR_ARG; }
+  if (!bytes) return FMX_OK;
+  int rc = order_after_producers(s, producer_streams);
+  if (rc) return rc;
+  int e = r->GroupStart();
+  if (e) return nccl_fail(e, "ncclGroupStart");
+  for (size_t i = 0; i < nl && !e; i++) {
+    if (hipSetDevice(s->device[i]) != hipSuccess) { (void)r->GroupEnd(); set_error("hipSetDevice"); return FMX_ERR_HIP; }
+    e = r->Send(d_send[i], bytes, kNcclChar, root, s->comm[i], s->stream[i]);
+    if (!e && s->rank[i] == root)
+      for (int q = 0; q < s->n_ranks && !e; q++)
+        e = r->Recv(static_cast<uint8_t *>(d_recv[i]) + (size_t)q * bytes, bytes, kNcclChar, q, s->comm[i], s->stream[i]);
   }
-  return FMX_OK;
+  const int e2 = r->GroupEnd();
+  if (e) return nccl_fail(e, "ncclSend/ncclRecv");
+  if (e2) return nccl_fail(e2, "ncclGroupEnd");
+  return finish_collective(s, "hipStreamSynchronize(gather)");
 }
 
 }  // extern "C"

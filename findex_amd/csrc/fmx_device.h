@@ -70,6 +70,25 @@ struct DevIndex {
   uint32_t nslots;
 };
 
+constexpr unsigned long long kPackWide = 0xFFFFFFull;      // width field of a packed interval that stands for "look in the escape list"
+
+// Where pattern q of a batch lies in the pattern buffer: pat[b, e) -- from the caller's k + 1 offsets, or, for a batch of
+// equal-length patterns handed over WITHOUT offsets (fmx_search_opts.fixed_len), q * fixed.  Branch-free on purpose: the
+// two offsets are loaded in both forms (an implicit batch reads the same 16 readable bytes every time: `base` is then the
+// handle's C[] array) and a select picks -- a branch here would put a wait for the loads right behind them, and the
+// search kernel requests a batch's offsets two batches before it needs them.
+struct PatOff {
+  const uint64_t *base;
+  uint64_t fixed;          // 0: base[q], base[q + 1]; else pattern q = [q * fixed, (q + 1) * fixed)
+  __device__ __forceinline__ const uint64_t *at(uint64_t q) const { return base + (fixed ? 0ull : q); }
+  __device__ __forceinline__ void get(uint64_t q, uint64_t &b, uint64_t &e) const {
+    const uint64_t *p = at(q);
+    const uint64_t v0 = p[0], v1 = p[1];
+    b = fixed ? q * fixed : v0;
+    e = fixed ? (q + 1) * fixed : v1;
+  }
+};
+
 // ---- DPP helpers: reductions inside a group of 4 or 8 lanes stay in the VALU (no LDS crossbar).
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t v) {

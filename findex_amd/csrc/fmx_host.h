@@ -150,7 +150,12 @@ hipError_t launch_occ(const Index *h, const void *d_c, const void *d_i, void *d_
 hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep, const void *d_c, void *d_sp1,
                              void *d_ep1, uint64_t k, hipStream_t st);
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
-                         hipStream_t st);
+                         hipStream_t st, uint32_t fixed_len = 0);      // d_off == nullptr: k patterns of fixed_len bytes each
+// the 8-byte form of a batch's intervals (fmx.h: fmx_pack_intervals_dev); in place when d_packed == d_sp
+hipError_t launch_pack_intervals(const Index *h, const void *d_sp, const void *d_ep, uint64_t k, uint64_t escape_cap,
+                                 void *d_packed, hipStream_t st);
+hipError_t launch_unpack_intervals(const Index *h, const void *d_packed, uint64_t k, uint64_t escape_cap, void *d_sp,
+                                   void *d_ep, hipStream_t st);
 // fmx_config_set("validate", "1"): is d_off[0..k] non-decreasing?  Synchronises the stream.
 hipError_t check_offsets(const Index *h, const void *d_off, uint64_t k, hipStream_t st, bool *ok);
 hipError_t launch_lf_walk(const Index *h, const void *d_rows, uint64_t k, uint32_t len, void *d_out, void *d_end,

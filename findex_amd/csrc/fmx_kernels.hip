@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void k_prev_range(DevIndex ix, const uint
 // pattern byte are requested a step early; only the two rank lines are on the dependent chain.
 template <bool WIDE, uint32_t LAYOUT>
 __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t *__restrict__ pat,
-                                                      const uint64_t *__restrict__ off, uint64_t *__restrict__ sp_out,
+                                                      const PatOff off, uint64_t *__restrict__ sp_out,
                                                       uint64_t *__restrict__ ep_out, uint64_t k,
                                                       unsigned long long *__restrict__ counters) {
   __shared__ Tables tb;
@@ -151,10 +151,11 @@ __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t 
   uint64_t nb = 0, ne = 0; // offsets of the pattern this group takes next
   uint32_t steps = 0;
   if (active) {
-    base = off[p];
-    i = (int64_t)(off[p + 1] - base) - 1;
+    uint64_t e0;
+    off.get(p, base, e0);
+    i = (int64_t)(e0 - base) - 1;
     if (i >= 0) c = pat[base + i];
-    if (p + noct < k) { nb = off[p + noct]; ne = off[p + noct + 1]; }
+    if (p + noct < k) off.get(p + noct, nb, ne);
   }
   while (__builtin_amdgcn_ballot_w64(active)) {
     if (active) {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void k_search(DevIndex ix, const uint8_t 
           sp = 0;
           ep = ix.n;
           if (i >= 0) c = pat[base + i];
-          if (p + noct < k) { nb = off[p + noct]; ne = off[p + noct + 1]; }
+          if (p + noct < k) off.get(p + noct, nb, ne);
         }
       }
     }
@@ -311,14 +312,76 @@ hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep,
 
 // generic search kernel: one pattern per group, byte-at-a-time pattern reads (FMX_SEARCH_VARIANT=1,
 // and batches of 2^32 patterns or more)
-hipError_t launch_search_v1(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
+hipError_t launch_search_v1(const Index *h, const void *d_pat, PatOff po, void *d_sp, void *d_ep, uint64_t k,
                             hipStream_t st) {
   if (!k) return hipSuccess;
 #define CALL(W, L)                                                                                              \
   k_search<W, L><<<grid_for(h, k, kThreads / Lay<L>::G), kThreads, 0, st>>>(                                   \
-      h->dev, (const uint8_t *)d_pat, (const uint64_t *)d_off, (uint64_t *)d_sp, (uint64_t *)d_ep, k, h->d_counters)
+      h->dev, (const uint8_t *)d_pat, po, (uint64_t *)d_sp, (uint64_t *)d_ep, k, h->d_counters)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- the 8-byte form of a batch's intervals (fmx.h)
+// word q = sp | w << 40 with w = min(ep - sp, 0xFFFFFF); w == 0xFFFFFF: the interval is that wide or wider and its ep is
+// in the escape list behind the k words: word k counts the wide intervals, pairs (q, ep) follow (the first escape_cap of
+// them; their order is whatever the atomics made it, unpacking scatters by q).  In place when d_packed == d_sp: a thread
+// reads its own sp before it writes its word.
+__global__ __launch_bounds__(kThreads) void k_pack_intervals(const uint64_t *sp, const uint64_t *__restrict__ ep, uint64_t k,
+                                                             uint64_t escape_cap, unsigned long long *packed) {
+  const uint64_t nth = (uint64_t)gridDim.x * kThreads;
+  for (uint64_t q = (uint64_t)blockIdx.x * kThreads + threadIdx.x; q < k; q += nth) {
+    const uint64_t a = sp[q], b = ep[q];
+    const uint64_t w = b - a;                       // sp <= ep always (occ is monotone); a miss has w == 0
+    unsigned long long word = a | (kPackWide << 40);
+    if (w < kPackWide) word = a | (w << 40);
+    else {
+      const unsigned long long slot = atomicAdd(packed + k, 1ull);
+      if (slot < escape_cap) { packed[k + 1 + 2 * slot] = q; packed[k + 2 + 2 * slot] = b; }
+    }
+    packed[q] = word;
+  }
+}
+// (sp, ep) from the words, then the escape list's entries on top (pass 0 / pass 1: two launches, so that a wide
+// interval's ep is written after its word has been expanded)
+__global__ __launch_bounds__(kThreads) void k_unpack_intervals(const unsigned long long *__restrict__ packed, uint64_t k,
+                                                               uint64_t escape_cap, uint64_t *__restrict__ sp,
+                                                               uint64_t *__restrict__ ep, int pass) {
+  const uint64_t nth = (uint64_t)gridDim.x * kThreads;
+  if (pass == 0) {
+    for (uint64_t q = (uint64_t)blockIdx.x * kThreads + threadIdx.x; q < k; q += nth) {
+      const unsigned long long w = packed[q];
+      const uint64_t a = w & ((1ull << 40) - 1);
+      sp[q] = a;
+      ep[q] = a + (w >> 40);
+    }
+  } else {
+    const uint64_t cnt = packed[k] < escape_cap ? packed[k] : escape_cap;
+    for (uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x; j < cnt; j += nth) {
+      const uint64_t q = packed[k + 1 + 2 * j];
+      if (q < k) ep[q] = packed[k + 2 + 2 * j];
+    }
+  }
+}
+
+hipError_t launch_pack_intervals(const Index *h, const void *d_sp, const void *d_ep, uint64_t k, uint64_t escape_cap,
+                                 void *d_packed, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(static_cast<unsigned long long *>(d_packed) + k, 0, 8, st);
+  if (e != hipSuccess || !k) return e;
+  k_pack_intervals<<<grid_for(h, k, kThreads), kThreads, 0, st>>>((const uint64_t *)d_sp, (const uint64_t *)d_ep, k, escape_cap,
+                                                                   (unsigned long long *)d_packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_intervals(const Index *h, const void *d_packed, uint64_t k, uint64_t escape_cap, void *d_sp,
+                                   void *d_ep, hipStream_t st) {
+  if (!k) return hipSuccess;
+  k_unpack_intervals<<<grid_for(h, k, kThreads), kThreads, 0, st>>>((const unsigned long long *)d_packed, k, escape_cap,
+                                                                     (uint64_t *)d_sp, (uint64_t *)d_ep, 0);
+  if (escape_cap)
+    k_unpack_intervals<<<grid_for(h, escape_cap, kThreads), kThreads, 0, st>>>((const unsigned long long *)d_packed, k, escape_cap,
+                                                                                (uint64_t *)d_sp, (uint64_t *)d_ep, 1);
   return hipGetLastError();
 }
 

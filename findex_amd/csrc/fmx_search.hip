@@ -26,6 +26,7 @@
 //     kernel is bound by instruction issue, 88 % of the SIMDs' issue slots, not by waiting).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "fmx_device.h"
 #include "fmx_host.h"
 
@@ -97,7 +98,7 @@ template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
                                                         uint32_t ksigma, const uint4 *__restrict__ jtab,
                                                         const unsigned long long *__restrict__ r3tab, const uint8_t *__restrict__ pat,
-                                                        const uint64_t *__restrict__ off,
+                                                        const PatOff po,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
                                                         uint32_t k, unsigned long long *__restrict__ counters) {
   constexpr int G = Lay<LAYOUT>::G;              // lanes per pattern
@@ -126,49 +127,115 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   const uint32_t grp = (threadIdx.x & 63) / G;
   const uint32_t nbatch = (k + P - 1) / P;
   uint32_t steps = 0, reqs = 0;     // reqs: memory requests for rank-dictionary lines (counters[2])
-  // Pattern pipeline, three batches deep: (end, len, tail4) of the batch being searched; (end, len) of the
-  // next one, whose tail4 -- the last four pattern bytes, an address that depends on the offsets -- is
-  // requested when this batch starts; and the offsets of the batch after that.  Nothing of it sits on the
-  // search's dependent chain except in the wave's very first batch.
-  auto load_off = [&](uint64_t bt, uint64_t &e, uint32_t &len) {
+  // Pattern pipeline.  A wave's 16 (8) patterns lie one behind the other in the pattern buffer, so their bytes are ONE
+  // contiguous span: it is fetched with one coalesced wave-level load (16 bytes per lane, up to 1 KiB) while the batch
+  // before it is searched, parked in the wave's own LDS area, and every chunk of pattern bytes the search consumes is an
+  // LDS read.  Round 4 (profiles/r04_c3_bound.md): the memory system answers ~50 G cache-line requests per second that
+  // miss the CUs' own L1 / address-translation caches, whatever they ask for -- and the chunk loads of the former
+  // pipeline (a dword per group and four steps, two per row-jump lookup: ~35 line requests per batch beside its ~100
+  // table lookups) were a quarter of the kernel's requests.  A span of 1 KiB covers batches whose patterns average 63
+  // bytes; a longer one is read chunk by chunk from global memory as before (`staged` is wave-uniform).
+  // The offsets of a batch are requested two batches ahead and only LOOKED AT one batch later (raw values are carried
+  // over: any arithmetic on them here would put the wait for the load right behind it).
+  constexpr uint32_t kStageBytes = 1024, kStagePad = 16;
+  // two areas per wave: the batch being searched reads one while the next batch's span is parked in the other as soon as
+  // it has arrived (it arrives with the batch's first table lookup: no registers hold it across the search)
+  __shared__ __attribute__((aligned(16))) uint32_t s_pat[kSThreads / 64][2][(kStagePad + kStageBytes + 16) / 4];
+  uint32_t par = 0;                 // which area holds the current batch
+  const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t lane64 = threadIdx.x & 63u;
+  const uint64_t pat_addr = (uint64_t)(uintptr_t)pat;
+  auto load_off_raw = [&](uint64_t bt, uint64_t &v0, uint64_t &v1) {      // batches past the end read the last pattern's offsets
     const uint64_t pid = bt * P + grp;
-    e = 0; len = 0;
-    if (pid < k) {
-      const uint64_t b = off[pid];
-      e = off[pid + 1];
-      len = (uint32_t)(e - b);
-    }
+    const uint64_t *p = po.at(pid < k ? pid : (uint64_t)k - 1);
+    v0 = p[0];
+    v1 = p[1];
+  };
+  // (end, len) of group `grp` in batch bt from the raw offsets; groups past the end of the batch list get an empty
+  // pattern at the end of the last one, so that a wave's span is always [begin of its lane 0, end of its lane 63)
+  auto fix_off = [&](uint64_t bt, uint64_t v0, uint64_t v1, uint64_t &e, uint32_t &len) {
+    const uint64_t pid = bt * P + grp;
+    const uint64_t q = pid < k ? pid : (uint64_t)k - 1;
+    const uint64_t b = po.fixed ? q * po.fixed : v0;
+    e = po.fixed ? (q + 1) * po.fixed : v1;
+    len = pid < k ? (uint32_t)(e - b) : 0u;
+  };
+  struct Stage { uint4 w; uint64_t base; bool ok; };      // base: offset in the pattern buffer of LDS byte kStagePad (16-byte aligned address)
+  auto stage_issue = [&](uint64_t e, uint32_t len) {
+    const uint64_t b = e - len;
+    const uint64_t b0 = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    const uint64_t e1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, 63);
+    Stage st;
+    const uint64_t al = (pat_addr + b0) & ~15ull;
+    const uint64_t span = pat_addr + e1 - al;                 // bytes from the aligned start to the end of the last pattern
+    st.ok = span <= kStageBytes;
+    st.base = al - pat_addr;                                  // (wraps below zero when the buffer itself is unaligned: only differences are used)
+    st.w = make_uint4(0, 0, 0, 0);
+    if (st.ok && 16ull * lane64 < span) st.w = load_line16(al + 16u * lane64);      // the 16-byte block that holds the span's last byte is the last one read
+    return st;
+  };
+  auto stage_park = [&](const Stage &st, uint32_t area) {
+    if (st.ok) *reinterpret_cast<uint4 *>(s_pat[wave_in_wg][area] + (kStagePad + 16u * lane64) / 4) = st.w;
   };
   // the tail of a pattern: its first NT chunks (chunk i = the four bytes the search consumes at steps 4i .. 4i+3,
   // first one in byte lane 0); NT = 1 without the table, KT / 4 with it
   constexpr uint32_t NT = KT ? KT / 4 : 1;
   struct Tail { uint32_t c[NT]; };
-  auto load_tail = [&](uint64_t e, uint32_t len) {
-    Tail q;
-#pragma unroll
-    for (uint32_t i = 0; i < NT; i++) q.c[i] = len > 4u * i ? fetch4(pat, e - 4ull * i) : 0u;
-    return q;
-  };
-  uint64_t end0, end1, end2;
-  uint32_t len0, len1, len2;
-  Tail tail0;
-  uint32_t ktl = 0;                 // k-mer table lookups (counters[9])
-  uint32_t jtl = 0;                 // row jump table lookups (counters[10])
-  uint32_t r3l = 0;                 // three-step row table lookups (counters[11])
-  load_off(wave, end0, len0);
-  tail0 = load_tail(end0, len0);
-  load_off((uint64_t)wave + nwaves, end1, len1);
+  uint64_t end0, end1, raw2a, raw2b;
+  uint32_t len0, len1;
+  // lookups in the k-mer table (counters[9]), the row jump table (counters[10]) and the three-step row table (counters[11]):
+  // counted per wave in scalar registers (a ballot's population count), not per lane
+  uint32_t ktl = 0, jtl = 0, r3l = 0;
+  {
+    uint64_t a0, a1;
+    load_off_raw(wave, a0, a1);
+    fix_off(wave, a0, a1, end0, len0);
+    load_off_raw((uint64_t)wave + nwaves, a0, a1);
+    fix_off((uint64_t)wave + nwaves, a0, a1, end1, len1);
+  }
+  Stage cur = stage_issue(end0, len0);
+  stage_park(cur, par);
   for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
+    Stage nxt_stage;
+    // One batch, written once and compiled twice: STAGED = its bytes are in LDS; else (a span longer than the LDS area)
+    // they are read chunk by chunk from global memory.  Two copies of the code, so that no value of the staged path is
+    // ever a merge with the result of a global load -- the compiler waits for ALL outstanding loads (`vmcnt(0)`) where it
+    // meets such a value, and the next batch's loads issued below would be among them.
+    auto search_one_batch = [&](auto staged_tag) {
+    constexpr bool STAGED = decltype(staged_tag)::value;
     const uint32_t pid = batch * P + grp;
     const bool act = pid < k;
-    const uint64_t *own = off + (act ? pid : 0u);
+    const uint64_t *own = po.at(act ? pid : 0u);      // any valid address (pat_chunk)
     const uint64_t end = end0;
     const uint32_t len = act ? len0 : 0u;
-    const Tail tailq = tail0;
+    const uint64_t cur_base = cur.base;
+    const uint32_t *const spat = s_pat[wave_in_wg][par];
+    // chunk j of this group's pattern (see pat_chunk)
+    auto chunk = [&](uint32_t j) -> uint32_t {
+      if constexpr (!STAGED) {
+        return pat_chunk(pat, own, end, len, j);
+      } else {
+        const uint32_t have = len > 4u * j ? len - 4u * j : 0u;
+        const uint32_t o = have ? (uint32_t)(end - 4ull * j - cur_base) + (kStagePad - 4u) : 0u;      // LDS byte of the dword that ends where the chunk ends
+        const uint32_t lo = spat[o >> 2], hi = spat[(o >> 2) + 1];
+        const uint32_t r = __builtin_bswap32(__builtin_amdgcn_alignbyte(hi, lo, o & 3u));
+        return have >= 4u ? r : (r & ((1u << (8u * have)) - 1u));
+      }
+    };
+    Tail tailq;
+#pragma unroll
+    for (uint32_t i = 0; i < NT; i++) {
+      if constexpr (STAGED) tailq.c[i] = chunk(i);
+      else tailq.c[i] = len > 4u * i ? fetch4(pat, end - 4ull * i) : 0u;
+    }
     uint32_t ch = tailq.c[0];                                 // chunk 0
-    uint32_t nx = pat_chunk(pat, own, end, len, KT ? KT / 4 + 1 : 1);       // the chunk after the current one
-    const Tail tail1 = load_tail(end1, len1);                 // the next batch's tail
-    load_off((uint64_t)batch + 2ull * nwaves, end2, len2);
+    uint32_t nx = chunk(KT ? KT / 4 + 1 : 1);                 // the chunk after the current one
+    // the next batch's bytes and the offsets of the one after it: requested behind this batch's first lookup (below)
+    auto issue_ahead = [&]() {
+      nxt_stage = stage_issue(end1, len1);
+      load_off_raw((uint64_t)batch + 2ull * nwaves, raw2a, raw2b);
+    };
+    if (KT == 0) { issue_ahead(); stage_park(nxt_stage, par ^ 1u); }
     uint64_t sp = 0, ep = ix.n;
     // symbols without a vector: absent (x = 0) or the EOF symbol (x = 1)
     auto special = [&](uint64_t cfc, uint64_t vb, uint64_t x) { return cfc + ((vb == 1 && x > ix.eof) ? 1u : 0u); };
@@ -200,13 +267,17 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         elig = elig && d != 0xFFu;
         code = code * ksigma + d;
       }
+      // every lane loads (a group that is not eligible reads entry 0 and ignores it): a load under `if (elig)` is merged with
+      // a default value right behind it, and the compiler puts the wait for the load there -- before the loads below
+      const uint4 ent = ktab[elig ? code : 0u];
+      issue_ahead();
       if (elig) {
-        const uint4 ent = ktab[code];
         sp = (((uint64_t)ent.y << 32) | ent.x) & ((1ull << 56) - 1);
         ep = ((uint64_t)ent.w << 32) | ent.z;
         steps += ent.y >> 24;           // the reference's loop ran this many steps on these characters
-        ktl++;
       }
+      ktl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(elig && t == 0));
+      stage_park(nxt_stage, par ^ 1u);      // it was requested beside the entry and has arrived with it
       if (__builtin_amdgcn_ballot_w64(act && !elig)) {
         for (uint32_t j = 0; j < KT; j++) {
           const bool stepping = act && !elig && j < len && sp < ep;
@@ -219,13 +290,13 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
           }
         }
       }
-      ch = pat_chunk(pat, own, end, len, KT / 4);              // the chunk step KT starts
+      ch = chunk(KT / 4);              // the chunk step KT starts
     }
     uint32_t skip = 0;                                         // steps this group has jumped over and still sits out
     bool deferred = false;                                     // this group's pattern was parked for k_search_defer
     for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
       bool alive = it < len && sp < ep;
-      if (RW && alive && (ep - sp) == 1 && (RW == 1u || (len - it) % RW == 0u)) {      // one row: the rest is k_search_rows'
+      if (RW && alive && (ep - sp) == 1 && (RW == 1u || (len - it) % (RW ? RW : 1u) == 0u)) {      // one row: the rest is k_search_rows'
         if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
         deferred = true;
         ep = sp;
@@ -238,24 +309,29 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         // are done -- [r, r + 1) -> [LF^8 r, LF^8 r + 1).  The chunks behind them are requested beside the lookup.
         const bool can = alive && len - it >= 8u;
         if (__builtin_amdgcn_ballot_w64(can)) {
-          const uint32_t ch2 = pat_chunk(pat, own, end, len, (it >> 2) + 2);
-          const uint32_t nx2 = pat_chunk(pat, own, end, len, (it >> 2) + 3);
+          const uint32_t ch2 = chunk((it >> 2) + 2);
+          const uint32_t nx2 = chunk((it >> 2) + 3);
           bool jumped = false;
           if (can) {
+            // ONE 16-byte load: the entry's row is taken out of it unconditionally (selects below).  Written with the row used
+            // only under `if (jumped)`, the compiler sank that half of the load behind the comparison -- two dependent loads
+            // per lookup, the second a cache hit but a whole trip through the memory pipeline (round 4, profiles/r04_c3_bound.md).
             const uint4 je = jtab[sp];
+            const uint64_t row8 = ((uint64_t)je.w << 32) | je.z;
             jumped = je.x == ch && je.y == nx;
-            if (jumped) { sp = ((uint64_t)je.w << 32) | je.z; ep = sp + 1; steps += 8; }
-            else {
+            if (!jumped) {
               // The pattern differs from its one row's text within these eight characters: it misses, and what is left
               // to find is where -- the reference loop's values at the failing step.  Walking there here would hold up the
               // whole wave (every lane executes the steps, the fifteen groups that jumped wait): the group parks its
               // state in its output slots and retires; k_search_defer walks the parked patterns of 64 at a time, densely.
               if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
               deferred = true;
-              ep = sp;                                               // not alive any more
             }
-            if (t == 0) jtl++;
+            sp = jumped ? row8 : sp;
+            ep = jumped ? row8 + 1 : sp;                             // not jumped: not alive any more
+            steps += jumped ? 8u : 0u;
           }
+          jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(can && t == 0));
           if (!__builtin_amdgcn_ballot_w64(alive && !jumped && !deferred)) {     // everybody jumped: go on eight steps further
             it += 7;
             ch = ch2;
@@ -301,12 +377,12 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
               deferred = true;
               ep = sp;
             }                                                                  // (wider and no row agrees: it steps on and ends within three steps)
-            if (t == 0) r3l += (uint32_t)width;
           }
+          r3l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // a lane per row looked up
           if (!__builtin_amdgcn_ballot_w64(alive && !took && !deferred) && !__builtin_amdgcn_ballot_w64(alive && skip != 0u)) {     // everybody took them: go on three steps further
             for (uint32_t s3 = 0; s3 < 3u; s3++) {
               ch >>= 8;
-              if ((it & 3u) == 3u) { ch = nx; nx = pat_chunk(pat, own, end, len, (it >> 2) + 2); }
+              if ((it & 3u) == 3u) { ch = nx; nx = chunk((it >> 2) + 2); }
               if (s3 < 2u) it++;
             }
             continue;
@@ -384,26 +460,31 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
       ch >>= 8;
       if ((it & 3u) == 3u) {
         ch = nx;
-        nx = pat_chunk(pat, own, end, len, (it >> 2) + 2);
+        nx = chunk((it >> 2) + 2);
       }
     }
     if (act && t == 0 && !deferred) { sp_out[pid] = sp; ep_out[pid] = ep; }
-    end0 = end1; len0 = len1; tail0 = tail1;
-    end1 = end2; len1 = len2;
+    };      // search_one_batch
+    if (cur.ok) search_one_batch(std::true_type{});
+    else search_one_batch(std::false_type{});
+    cur = nxt_stage;
+    par ^= 1u;
+    end0 = end1; len0 = len1;
+    fix_off((uint64_t)batch + 2ull * nwaves, raw2a, raw2b, end1, len1);
   }
   counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
   if (KT) {
-    const unsigned long long lookups = wave_sum(t == 0 ? (unsigned long long)ktl : 0ull);
+    const unsigned long long lookups = ktl;
     if ((threadIdx.x & 63u) == 0 && lookups)
       atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 9, lookups);
   }
   if (JT) {
-    const unsigned long long lookups = wave_sum((unsigned long long)jtl);
+    const unsigned long long lookups = jtl;
     if ((threadIdx.x & 63u) == 0 && lookups)
       atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 10, lookups);
   }
   if (JT && R3T) {
-    const unsigned long long lookups = wave_sum((unsigned long long)r3l);
+    const unsigned long long lookups = r3l;
     if ((threadIdx.x & 63u) == 0 && lookups)
       atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 11, lookups);
   }
@@ -425,7 +506,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
 // with a multiple of three steps left, so only patterns that fail are parked again.
 template <int MODE>
 __global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restrict__ jtab, const unsigned long long *__restrict__ row1,
-                                                            const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
+                                                            const uint8_t *__restrict__ pat, const PatOff po,
                                                             uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
                                                             unsigned long long *__restrict__ counters) {
   const uint64_t nth = (uint64_t)gridDim.x * kSThreads;
@@ -437,8 +518,9 @@ __global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restri
     bool live = (e0 & kDeferMark) != 0ull;
     uint64_t row = live ? sp_out[pid] : 0ull;
     uint32_t it = (uint32_t)e0;
-    const uint64_t end = live ? off[pid + 1] : 0ull;
-    const uint32_t len = live ? (uint32_t)(end - off[pid]) : 0u;
+    uint64_t begin = 0, end = 0;
+    if (live) po.get(pid, begin, end);
+    const uint32_t len = (uint32_t)(end - begin);
     uint32_t walk = 0;                           // steps still to be walked one by one after a lookup in J that did not agree
     while (__builtin_amdgcn_ballot_w64(live)) {
       const uint32_t rem = len - it;
@@ -479,13 +561,12 @@ __global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restri
       }
       if (jm) {
         looks++;
-        if (je.x == __builtin_bswap32(hi) && je.y == __builtin_bswap32(lo)) {
-          row = ((uint64_t)je.w << 32) | je.z;
-          it += 8;
-          steps += 8;
-        } else {
-          walk = 8;
-        }
+        const bool agree = je.x == __builtin_bswap32(hi) && je.y == __builtin_bswap32(lo);
+        const uint64_t row8 = ((uint64_t)je.w << 32) | je.z;      // unconditional: keeps the entry ONE 16-byte load (k_search4)
+        row = agree ? row8 : row;
+        it += agree ? 8u : 0u;
+        steps += agree ? 8u : 0u;
+        walk = agree ? walk : 8u;
       } else if (rm) {
         rlooks++;
         const uint32_t c2 = (uint32_t)(re >> 40) & 0xFFu;
@@ -521,7 +602,7 @@ __global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restri
 // in ten is parked at C3, so a wave walks ~6 of them at once where the search kernel would have made 64 lanes execute
 // the steps of one or two.
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const uint8_t *__restrict__ pat, const uint64_t *__restrict__ off,
+__global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const uint8_t *__restrict__ pat, const PatOff po,
                                                              uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
                                                              unsigned long long *__restrict__ counters) {
   constexpr int G = Lay<LAYOUT>::G;
@@ -561,8 +642,9 @@ __global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const u
       const uint64_t pid = base + (act ? pick : 0u);
       uint64_t sp = act ? sp_out[pid] : 0ull, ep = sp + (act ? 1u : 0u);
       uint32_t it = act ? (uint32_t)ep_out[pid] : 0u;
-      const uint64_t end = act ? off[pid + 1] : 0ull;
-      const uint32_t len = act ? (uint32_t)(end - off[pid]) : 0u;
+      uint64_t begin = 0, end = 0;
+      if (act) po.get(pid, begin, end);
+      const uint32_t len = (uint32_t)(end - begin);
       for (;;) {                                 // eight steps at a time
         const uint32_t rem = len - it;
         if (!__builtin_amdgcn_ballot_w64(act && sp < ep && rem != 0u)) break;
@@ -615,7 +697,7 @@ __global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const u
   counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
 }
 
-hipError_t launch_search_v1(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
+hipError_t launch_search_v1(const Index *h, const void *d_pat, PatOff po, void *d_sp, void *d_ep, uint64_t k,
                             hipStream_t st);
 
 static int search_variant() {
@@ -638,7 +720,7 @@ static int blocks_per_cu(K kernel) {
 
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
-                              const uint64_t *off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st) {
+                              const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st) {
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
   static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>);
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
@@ -662,7 +744,7 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   return hipGetLastError();
 }
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
-static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
+static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
                              uint32_t k, hipStream_t st) {
   const uint4 *jt = nullptr;
   hipError_t e = jump_get(h, st, &jt);
@@ -697,7 +779,7 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
 }
 
 template <bool WIDE, uint32_t LAYOUT>
-static hipError_t launch_v4(const Index *h, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
+static hipError_t launch_v4(const Index *h, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
                             uint32_t k, hipStream_t st) {
   KTab kt;
   const hipError_t e = ktab_get(h, st, &kt);
@@ -710,12 +792,14 @@ static hipError_t launch_v4(const Index *h, const uint8_t *pat, const uint64_t *
 }
 
 // One launch per call: no scratch, nothing to own per stream, so concurrent calls on one handle need no lock.
+// d_off == nullptr: a batch of k patterns of fixed_len bytes each, one behind the other (fmx_search_opts.fixed_len).
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
-                         hipStream_t st) {
+                         hipStream_t st, uint32_t fixed_len) {
   if (!k) return hipSuccess;
-  if (search_variant() == 1 || k > 0xFFFFFFF0ull) return launch_search_v1(h, d_pat, d_off, d_sp, d_ep, k, st);
+  const PatOff po{d_off ? (const uint64_t *)d_off : (const uint64_t *)h->d_cf, d_off ? 0ull : (uint64_t)fixed_len};
+  if (search_variant() == 1 || k > 0xFFFFFFF0ull) return launch_search_v1(h, d_pat, po, d_sp, d_ep, k, st);
   hipError_t e = hipSuccess;
-#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, (const uint64_t *)d_off, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st)
+#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, po, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
   return e;

@@ -62,9 +62,76 @@ def all_gather_varlen(t, group=None):
     return [o[:s] for o, s in zip(out, sizes)]
 
 
-def search_batch_sharded(searcher, pat, off, group=None):
+PACK_WIDE = 0xFFFFFF      # width field of a packed interval that stands for "look in the escape list" (include/fmx.h)
+
+
+def packed_words(k, escape_cap):
+    return int(k) + 1 + 2 * int(escape_cap)
+
+
+def pack_intervals_np(sp, ep, escape_cap):
+    """The 8-byte form of a batch's intervals (include/fmx.h, fmx_pack_intervals_dev) on host arrays: word q = sp |
+    min(ep - sp, 0xFFFFFF) << 40; intervals of 0xFFFFFF rows or more leave their ep in the escape list behind the k words
+    (word k = how many there are, then (q, ep) pairs, the first escape_cap of them).  What the gloo ranks of the CPU
+    tests exchange; the device kernel's output differs at most in the ORDER of the escape entries."""
+    sp = np.ascontiguousarray(sp, dtype=np.uint64)
+    ep = np.ascontiguousarray(ep, dtype=np.uint64)
+    k = sp.size
+    w = ep - sp
+    out = np.zeros(packed_words(k, escape_cap), dtype=np.uint64)
+    out[:k] = sp | (np.minimum(w, np.uint64(PACK_WIDE)) << np.uint64(40))
+    wide = np.nonzero(w >= np.uint64(PACK_WIDE))[0]
+    out[k] = wide.size
+    keep = wide[: int(escape_cap)]
+    out[k + 1: k + 1 + 2 * keep.size: 2] = keep.astype(np.uint64)
+    out[k + 2: k + 2 + 2 * keep.size: 2] = ep[keep]
+    return out
+
+
+def unpack_intervals_np(packed, k, escape_cap):
+    """Inverse of pack_intervals_np; raises OverflowError when more intervals were wide than the escape list holds
+    (the caller then exchanges the 16-byte form)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint64)
+    k = int(k)
+    sp = packed[:k] & np.uint64((1 << 40) - 1)
+    ep = sp + (packed[:k] >> np.uint64(40))
+    cnt = int(packed[k])
+    if cnt > int(escape_cap):
+        raise OverflowError("%d intervals of 2^24 - 1 rows or more, the escape list holds %d" % (cnt, escape_cap))
+    q = packed[k + 1: k + 1 + 2 * cnt: 2].astype(np.int64)
+    ep = ep.copy()
+    ep[q] = packed[k + 2: k + 2 + 2 * cnt: 2]
+    return sp.copy(), ep
+
+
+def gather_varlen_to_root(t, root=0, group=None):
+    """Root-only delivery of 1-D tensors whose lengths differ per rank: the sizes are all-gathered (8 bytes per rank),
+    the payload padded to the longest goes to `root` alone (dist.gather: point-to-point sends under RCCL).  Returns the
+    list of per-rank tensors on the root, None elsewhere."""
+    rank, world = _group_info(group)
+    if world == 1:
+        return [t]
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes + [1])
+    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    out = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
+    dist.gather(pad, out, dst=dist.get_global_rank(group, root) if group is not None else root, group=group)
+    return [o[:s] for o, s in zip(out, sizes)] if rank == root else None
+
+
+def search_batch_sharded(searcher, pat, off, group=None, form="packed", delivery="all", root=0):
     """SuffixAlgo.search over a pattern batch sharded across the ranks of `group`.
-    Every rank passes the same (pat, off); every rank gets the full (sp, ep) back."""
+    Every rank passes the same (pat, off).  form = "packed" (default): the exchange carries the 8-byte form of each
+    interval (sp in 40 bits + the width in 24, wider intervals in an escape list: 8 bytes per pattern + 16 per escape);
+    "pairs": (sp, ep) as 16 bytes per pattern.  delivery = "all": every rank gets the full (sp, ep) back (all-gather);
+    "root": only rank `root` does (returns None elsewhere) -- the "final gather of hit intervals" when one rank
+    consumes the answer."""
+    if form not in ("packed", "pairs") or delivery not in ("all", "root"):
+        raise ValueError("form is packed or pairs, delivery is all or root")
     rank, world = _group_info(group)
     pat = np.ascontiguousarray(pat, dtype=np.uint8)
     off = np.ascontiguousarray(off, dtype=np.uint64)
@@ -73,18 +140,27 @@ def search_batch_sharded(searcher, pat, off, group=None):
     sp, ep = searcher.search_batch(pat, off[a:b + 1])
     if world == 1:
         return sp, ep
-    both = torch.from_numpy(np.concatenate([sp, ep]).astype(np.int64))      # same bits as uint64
-    dev = None
+    if form == "packed":
+        n_wide = int(((ep - sp) >= np.uint64(PACK_WIDE)).sum())
+        mine = pack_intervals_np(sp, ep, n_wide)              # exactly as long as it has to be: the lengths travel anyway
+    else:
+        mine = np.concatenate([sp, ep])
+    t = torch.from_numpy(mine.astype(np.int64))               # same bits as uint64
     if dist.get_backend(group) == "nccl":
-        dev = torch.device("cuda", torch.cuda.current_device())
-        both = both.to(dev)
-    parts = all_gather_varlen(both, group)
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    parts = all_gather_varlen(t, group) if delivery == "all" else gather_varlen_to_root(t, root, group)
+    if parts is None:
+        return None
     sps, eps = [], []
-    for p in parts:
-        h = p.numel() // 2
+    for r, p in enumerate(parts):
         q = p.cpu().numpy().astype(np.uint64)
-        sps.append(q[:h])
-        eps.append(q[h:])
+        kr = cuts[r + 1] - cuts[r]
+        if form == "packed":
+            s_, e_ = unpack_intervals_np(q, kr, (q.size - kr - 1) // 2)
+        else:
+            s_, e_ = q[:kr], q[kr:]
+        sps.append(s_)
+        eps.append(e_)
     return np.concatenate(sps), np.concatenate(eps)
 
 
@@ -188,7 +264,7 @@ def match_batch_sharded(sa, trees, group=None, match_fn=None, weights=None, **kw
 
 
 def gather_intervals_dev(sp, ep, group=None):
-    """Device form used by bench.py: equal-sized int64 device tensors sp, ep (k each) ->
+    """The 16-byte form in one call: equal-sized int64 device tensors sp, ep (k each) ->
     one all_gather_into_tensor of 16 B per pattern; returns a (world, 2, k) tensor."""
     rank, world = _group_info(group)
     mine = torch.stack([sp, ep])
@@ -201,22 +277,41 @@ def gather_intervals_dev(sp, ep, group=None):
 
 class IntervalGather:
     """Pipelined form of the path's one exchange, for callers that search batch after batch (bench.py): the
-    all-gather of batch i's intervals runs on the collective's own stream while batch i+1 is being searched.
+    gather of batch i's intervals runs on the collective's own stream while batch i+1 is being searched.
 
-    `depth` slots, each a (2, k) int64 tensor the search writes its sp / ep rows into (no staging copy) and a
-    (world, 2, k) tensor the gather fills.  Per batch: `sp, ep = slot(i)` (waits, on the current stream, for
-    the collective that last used the slot), search into them, `launch(i)`; `finish()` waits for everything
-    outstanding.  With the nccl backend (RCCL over xGMI) a batch then costs max(search, gather) instead of
-    their sum: 16 MB per rank and million patterns is ~0.4 ms on 8 GPUs against ~0.7 ms of search."""
+    `depth` slots, each a (2, k) int64 tensor the search writes its sp / ep rows into (no staging copy), a send buffer
+    and a receive buffer.  Per batch: `sp, ep = slot(i)` (waits, on the current stream, for the collective that last
+    used the slot), search into them, `launch(i)`; `finish()` waits for everything outstanding.
 
-    def __init__(self, k, device, group=None, depth=2):
+    form = "packed" (default): the send buffer is the 8-byte form of the intervals (include/fmx.h: k + 1 + 2 * escape_cap
+    words, packed by fmx_pack_intervals_dev on the current stream -- `searcher` must then be the rank's HipFMSearcher;
+    host tensors are packed with numpy), "pairs": the (2, k) tensor itself, 16 bytes per pattern.
+    delivery = "root" (default): every rank sends to rank `root`, which alone receives (world, words) -- one slice per
+    xGMI link into the root, nothing into the others; "all": all-gather, every rank receives everything.
+    With the nccl backend (RCCL over xGMI) a batch costs max(search, gather), not their sum.  What that is on 8 GPUs
+    for a million 32-character patterns per rank (C3): the search 0.2 ms; the payload 8 MB per rank packed (16 MB as
+    pairs), i.e. 8 MB over each of the root's seven links or, for the all-gather, 56 MB into every rank -- at ~50 GB/s per
+    link direction ~0.16 ms packed / ~0.33 ms as pairs before RCCL's own latencies.  bench.py measures it
+    (`exchange.gather_ms`)."""
+
+    def __init__(self, k, device, group=None, depth=2, form="packed", delivery="root", root=0, escape_cap=None, searcher=None):
+        if form not in ("packed", "pairs") or delivery not in ("all", "root"):
+            raise ValueError("form is packed or pairs, delivery is all or root")
         self.rank, self.world = _group_info(group)
-        self.group = group
+        self.group, self.k, self.form, self.delivery, self.root = group, int(k), form, delivery, int(root)
         self.live = dist is not None and dist.is_initialized()
-        self.mine = [torch.empty((2, k), dtype=torch.int64, device=device) for _ in range(depth)]
-        self.out = [torch.empty((self.world, 2, k), dtype=torch.int64, device=device) for _ in range(depth)]
+        self.cap = max(16, self.k // 256) if escape_cap is None else int(escape_cap)
+        self.searcher = searcher
+        self.words = packed_words(self.k, self.cap) if form == "packed" else 2 * self.k
+        self.mine = [torch.empty((2, self.k), dtype=torch.int64, device=device) for _ in range(depth)]
+        self.send = [torch.empty(self.words, dtype=torch.int64, device=device) if form == "packed" else self.mine[j].view(-1)
+                     for j in range(depth)]
+        recv_here = delivery == "all" or self.rank == self.root or not self.live
+        self.out = [torch.empty((self.world, self.words), dtype=torch.int64, device=device) if recv_here else None
+                    for _ in range(depth)]
         self.work = [None] * depth
         self.depth = depth
+        self.payload_bytes = 8 * self.words
 
     def slot(self, i):
         j = i % self.depth
@@ -225,13 +320,33 @@ class IntervalGather:
             self.work[j] = None
         return self.mine[j][0], self.mine[j][1]
 
-    def launch(self, i):
+    def pack(self, i, stream=0):
+        """The send buffer of slot i from its (sp, ep) rows (a no-op for form "pairs")."""
         j = i % self.depth
-        if self.live:
-            self.work[j] = dist.all_gather_into_tensor(self.out[j].view(-1), self.mine[j].view(-1), group=self.group,
-                                                       async_op=True)
+        if self.form != "packed":
+            return
+        sp, ep = self.mine[j][0], self.mine[j][1]
+        if sp.device.type == "cpu":
+            w = pack_intervals_np(sp.numpy().view(np.uint64), ep.numpy().view(np.uint64), self.cap)
+            self.send[j].copy_(torch.from_numpy(w.view(np.int64)))
         else:
-            self.out[j][0].copy_(self.mine[j])
+            if self.searcher is None:
+                raise ValueError("IntervalGather(form='packed') on device tensors needs searcher=")
+            self.searcher.pack_intervals_dev(sp.data_ptr(), ep.data_ptr(), self.k, self.send[j].data_ptr(), escape_cap=self.cap,
+                                             stream=stream)
+
+    def launch(self, i, stream=0, packed_already=False):
+        j = i % self.depth
+        if not packed_already:
+            self.pack(i, stream)
+        if not self.live:
+            self.out[j][0].copy_(self.send[j])
+        elif self.delivery == "all":
+            self.work[j] = dist.all_gather_into_tensor(self.out[j].view(-1), self.send[j], group=self.group, async_op=True)
+        else:
+            dst = dist.get_global_rank(self.group, self.root) if self.group is not None else self.root
+            outs = list(self.out[j].unbind(0)) if self.rank == self.root else None
+            self.work[j] = dist.gather(self.send[j], outs, dst=dst, group=self.group, async_op=True)
         return self.out[j]
 
     def finish(self):
@@ -239,3 +354,12 @@ class IntervalGather:
             if self.work[j] is not None:
                 self.work[j].wait()
                 self.work[j] = None
+
+    def intervals(self, out, r):
+        """(sp, ep) of rank r's batch as uint64 host arrays from a received buffer (None where nothing was delivered)."""
+        if out is None:
+            return None
+        row = out[r].cpu().numpy().view(np.uint64)
+        if self.form == "packed":
+            return unpack_intervals_np(row, self.k, self.cap)
+        return row[: self.k].copy(), row[self.k:].copy()

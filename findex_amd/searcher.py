@@ -242,6 +242,39 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_search_batch(self._h, _ptr(pat), _ptr(off), _ptr(sp), _ptr(ep), k))
         return sp, ep
 
+    def search_batch_ex(self, pat, off=None, fixed_len=0, packed=False, escape_cap=0):
+        """fmx_search_batch_ex: the lean forms of search_batch -- `fixed_len` > 0: k = len(pat) // fixed_len patterns of
+        that length, no offsets travel; `packed`: the intervals come back in the 8-byte form (one uint64 array of
+        fmx_packed_words(k, escape_cap) words: unpack_intervals).  Returns (sp, ep) or the packed array."""
+        pat = np.ascontiguousarray(pat, dtype=np.uint8)
+        if fixed_len:
+            if pat.size % int(fixed_len):
+                raise ValueError("the pattern buffer is not a whole number of patterns")
+            k, offp = pat.size // int(fixed_len), None
+        else:
+            off = np.ascontiguousarray(off, dtype=np.uint64)
+            k, offp = off.size - 1, _ptr(off)
+            if k and int(off[-1]) > pat.size:
+                raise ValueError("offsets run past the pattern buffer")
+        opts = _lib.fmx_search_opts(int(fixed_len), 1 if packed else 0, int(escape_cap))
+        if packed:
+            out = np.zeros(int(self._L.fmx_packed_words(k, int(escape_cap))), dtype=np.uint64)
+            _lib.check(self._L.fmx_search_batch_ex(self._h, _ptr(pat), offp, _ptr(out), None, k, ctypes.byref(opts)))
+            return out
+        sp = np.zeros(k, dtype=np.uint64)
+        ep = np.zeros(k, dtype=np.uint64)
+        _lib.check(self._L.fmx_search_batch_ex(self._h, _ptr(pat), offp, _ptr(sp), _ptr(ep), k, ctypes.byref(opts)))
+        return sp, ep
+
+    def unpack_intervals(self, packed, k, escape_cap=0):
+        """fmx_unpack_intervals (host): the 8-byte form -> (sp, ep); raises FMX_ERR_OVERFLOW when more intervals were wide
+        than the escape list holds."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        sp = np.zeros(int(k), dtype=np.uint64)
+        ep = np.zeros(int(k), dtype=np.uint64)
+        _lib.check(self._L.fmx_unpack_intervals(_ptr(packed) if packed.size else None, int(k), int(escape_cap), _ptr(sp), _ptr(ep)))
+        return sp, ep
+
     def prev_range_batch(self, sp, ep, c):
         sp = np.ascontiguousarray(sp, dtype=np.uint64)
         ep = np.ascontiguousarray(ep, dtype=np.uint64)
@@ -271,6 +304,22 @@ class HipFMSearcher:
     def search_batch_dev(self, d_pat, d_off, d_sp, d_ep, k, stream=0):
         _lib.check(self._L.fmx_search_batch_dev(self._h, _dp(d_pat), _dp(d_off), _dp(d_sp), _dp(d_ep), int(k),
                                                 _dp(stream)))
+
+    def search_batch_ex_dev(self, d_pat, d_off, d_sp, d_ep, k, stream=0, fixed_len=0, packed=False, escape_cap=0):
+        """fmx_search_batch_ex_dev: d_off may be 0 with fixed_len; with `packed` d_sp receives the packed words (it needs
+        fmx_packed_words(k, escape_cap) of them) and d_ep is k words of scratch."""
+        opts = _lib.fmx_search_opts(int(fixed_len), 1 if packed else 0, int(escape_cap))
+        _lib.check(self._L.fmx_search_batch_ex_dev(self._h, _dp(d_pat), _dp(d_off), _dp(d_sp), _dp(d_ep), int(k),
+                                                   ctypes.byref(opts), _dp(stream)))
+
+    def packed_words(self, k, escape_cap=0):
+        return int(self._L.fmx_packed_words(int(k), int(escape_cap)))
+
+    def pack_intervals_dev(self, d_sp, d_ep, k, d_packed, escape_cap=0, stream=0):
+        _lib.check(self._L.fmx_pack_intervals_dev(self._h, _dp(d_sp), _dp(d_ep), int(k), int(escape_cap), _dp(d_packed), _dp(stream)))
+
+    def unpack_intervals_dev(self, d_packed, k, d_sp, d_ep, escape_cap=0, stream=0):
+        _lib.check(self._L.fmx_unpack_intervals_dev(self._h, _dp(d_packed), int(k), int(escape_cap), _dp(d_sp), _dp(d_ep), _dp(stream)))
 
     def occ_batch_dev(self, d_c, d_i, d_out, k, stream=0):
         _lib.check(self._L.fmx_occ_batch_dev(self._h, _dp(d_c), _dp(d_i), _dp(d_out), int(k), _dp(stream)))

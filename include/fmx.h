@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 3
+#define FMX_ABI_VERSION 4
 
 enum {
   FMX_OK = 0,
@@ -159,6 +159,38 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
                      size_t k);
 int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep,
                          size_t k, void *stream);
+/* The lean forms of the same search (round 4; what the host link and the multi-GPU exchange carry):
+ *   fixed_len > 0 : every pattern has this many bytes and pattern q is pat[q * fixed_len ..): `off` is not read and may be
+ *                   NULL -- 8 bytes per pattern less up the link, and the kernels compute the offsets instead of loading them;
+ *   packed != 0   : the intervals come back in the 8-BYTE FORM, into `sp` (fmx_packed_words(k, escape_cap) words; `ep` is
+ *                   not written and may be NULL in the host form; in the device form d_ep is k words of scratch and d_sp's
+ *                   first k words are overwritten in place).
+ * The 8-byte form: word q = sp[q] | w << 40 with w = min(ep[q] - sp[q], 0xFFFFFF) -- rows are < 2^38, and a miss (sp == ep:
+ * None in the reference, findex.scala:30) keeps the loop's sp at its failing step with w = 0.  An interval of 2^24 - 1 rows
+ * or more (patterns of a character or two) has w = 0xFFFFFF and its ep in the ESCAPE LIST behind the k words: word k = the
+ * number of such intervals, then pairs (q, ep[q]) in no particular order, room for escape_cap of them.  When more than
+ * escape_cap intervals are that wide, word k still counts them all, fmx_unpack_intervals returns FMX_ERR_OVERFLOW and the
+ * caller asks for the 16-byte form instead (device side: compare word k with escape_cap).
+ * opts == NULL is fmx_search_batch[_dev] exactly. */
+typedef struct fmx_search_opts {
+  uint32_t fixed_len;
+  uint32_t packed;
+  uint64_t escape_cap;
+} fmx_search_opts;
+int fmx_search_batch_ex(const fmx_index *idx, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
+                        size_t k, const fmx_search_opts *opts);
+int fmx_search_batch_ex_dev(const fmx_index *idx, const void *d_pat, const void *d_off, void *d_sp, void *d_ep,
+                            size_t k, const fmx_search_opts *opts, void *stream);
+/* The 8-byte form on its own: pack device-resident (sp, ep) arrays (d_packed may be d_sp: in place), unpack them on the
+ * device (the first min(word k, escape_cap) escape entries are applied) or on the host (a decode of the caller's own
+ * buffer: FMX_ERR_OVERFLOW as above, FMX_ERR_FORMAT when an escape entry names a pattern >= k). */
+size_t fmx_packed_words(size_t k, size_t escape_cap);
+int fmx_pack_intervals_dev(const fmx_index *idx, const void *d_sp, const void *d_ep, size_t k, size_t escape_cap,
+                           void *d_packed, void *stream);
+int fmx_unpack_intervals_dev(const fmx_index *idx, const void *d_packed, size_t k, size_t escape_cap, void *d_sp,
+                             void *d_ep, void *stream);
+int fmx_unpack_intervals(const uint64_t *packed, size_t k, size_t escape_cap, uint64_t *sp, uint64_t *ep);
+
 /* One process, several GPUs: the batch is cut into contiguous slices balanced by pattern bytes, slice r is
  * searched on idxs[r] (one handle per device, every handle a replica of the same index) from its own host
  * thread, and each slice's intervals land in their range of sp / ep -- the single-process form of SURVEY.md 8e
@@ -376,11 +408,20 @@ int fmx_gather(fmx_index *const *idxs, size_t n_idx, const void *const *d_src, c
  *   one process per GPU : rank 0 calls fmx_comm_unique_id, ships the 128 bytes to the other ranks by its own
  *                         means, every rank calls fmx_comm_create_rank(its handle, n_ranks, rank, id).
  *   one process, N GPUs : fmx_comm_create_all(one handle per device) -- ncclCommInitAll.
- * fmx_allgather_dev(comm, d_send, d_recv, bytes): every rank contributes `bytes` bytes at d_send[i] and receives all
- * ranks' contributions, in rank order, at d_recv[i] (n_ranks * bytes); the arrays have one entry per LOCAL rank of
- * the communicator (1, or N for fmx_comm_create_all, in the order of `idxs`).  The call returns when the gather has
- * completed on every local rank.  Slices of different lengths (regex result lists): gather the counts first, then the
- * payload padded to the longest, as findex_amd/distributed.py all_gather_varlen does. */
+ * fmx_allgather_dev(comm, d_send, d_recv, bytes, producer_streams): every rank contributes `bytes` bytes at d_send[i] and
+ * receives all ranks' contributions, in rank order, at d_recv[i] (n_ranks * bytes); the arrays have one entry per LOCAL
+ * rank of the communicator (1, or N for fmx_comm_create_all, in the order of `idxs`).
+ * fmx_gather_dev(.., root, ..): the same exchange delivered to ONE rank -- every rank sends its slice to `root`, only the
+ * root's d_recv entry is written (the others may be NULL): the "final gather of hit intervals" when one rank consumes
+ * the answer; with the 8-byte interval form (fmx_search_opts.packed) it moves half of what the all-gather of (sp, ep) did
+ * per link and nothing at all into the other ranks.
+ * Ordering: the collective runs on the communicator's own streams.  producer_streams[i] (a hipStream_t; one per local
+ * rank) is the stream on which the caller enqueued the work that writes d_send[i] -- fmx_search_batch_dev is asynchronous --
+ * and that last touched d_recv[i]: the collective waits for everything enqueued there so far (an event, no host
+ * synchronisation).  producer_streams == NULL: the caller vouches that d_send and d_recv are idle (it has synchronised).
+ * Both calls return when the exchange has completed on every local rank, so anything enqueued afterwards may read d_recv.
+ * Slices of different lengths (regex result lists): gather the counts first, then the payload padded to the longest, as
+ * findex_amd/distributed.py all_gather_varlen does. */
 #define FMX_COMM_ID_BYTES 128
 typedef struct fmx_comm fmx_comm;
 int fmx_comm_unique_id(void *id /* FMX_COMM_ID_BYTES */);
@@ -388,7 +429,10 @@ int fmx_comm_create_rank(const fmx_index *idx, int n_ranks, int rank, const void
 int fmx_comm_create_all(fmx_index *const *idxs, size_t n_idx, fmx_comm **out);
 int fmx_comm_info(const fmx_comm *comm, int *n_ranks, int *n_local);
 int fmx_comm_free(fmx_comm *comm);
-int fmx_allgather_dev(fmx_comm *comm, const void *const *d_send, void *const *d_recv, size_t bytes);
+int fmx_allgather_dev(fmx_comm *comm, const void *const *d_send, void *const *d_recv, size_t bytes,
+                      void *const *producer_streams);
+int fmx_gather_dev(fmx_comm *comm, const void *const *d_send, void *const *d_recv, size_t bytes, int root,
+                   void *const *producer_streams);
 
 /* ---- statistics (since open or the last reset; device counters are read with a sync).
  * rank_queries counts occ(c,i) evaluations in the REFERENCE's terms: two per backward step (findex.scala:26-27,

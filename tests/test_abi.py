@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_device_count():
     L = _lib.load()
-    assert L.fmx_abi_version() == 3
+    assert L.fmx_abi_version() == 4
     n = ctypes.c_int(-1)
     assert L.fmx_device_count(ctypes.byref(n)) == 0 and n.value >= 0
 

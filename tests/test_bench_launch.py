@@ -50,12 +50,15 @@ def test_rank_count_must_match_gpus_flag():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("workload,ranks", [("c5", 2), ("c4", 3), ("c4ref", 2)])
-def test_driver_shapes_dry_run(workload, ranks):
-    """What the driver's scaling run launches, without GPUs: C5's per-rank batch (1M x 24: 16 MB of intervals per
-    rank through the pipelined all-gather) and the regex workloads' exchange -- result lists of unequal lengths with an
-    empty rank, ids made global, sizes then padded payload -- over gloo, three ranks for C4."""
-    p = run_bench(["--gpus", str(ranks)], workload=workload)
+@pytest.mark.parametrize("workload,ranks,extra", [("c5", 2, []), ("c3", 3, ["--delivery", "all"]),
+                                                  ("c3", 2, ["--exchange", "pairs", "--delivery", "all"]),
+                                                  ("tiny", 3, ["--exchange", "pairs"]), ("c4", 3, []), ("c4ref", 2, [])])
+def test_driver_shapes_dry_run(workload, ranks, extra):
+    """What the driver's scaling run launches, without GPUs: the literal workloads' per-rank batch (1M patterns: 8 MB of
+    packed intervals per rank -- a wide one through the escape list -- gathered to rank 0 through the pipelined
+    exchange; the other form and the other delivery by flag) and the regex workloads' exchange -- result lists of
+    unequal lengths with an empty rank, ids made global, sizes then padded payload -- over gloo, three ranks for C4."""
+    p = run_bench(["--gpus", str(ranks)] + extra, workload=workload)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
     assert out["n_gpus"] == ranks and out["config"]["ranks_in_group"] == ranks and workload in out["config"]["workload"]

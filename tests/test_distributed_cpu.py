@@ -63,6 +63,32 @@ def oracle_match(sa, res):
     return out
 
 
+class FakeSearcher:
+    """Answers made of the pattern's bytes: first byte 0 -> a miss (sp == ep), 1 -> an interval of 2^24 - 1 rows (the
+    narrowest that must use the escape list), 2 -> 2^24 - 2 rows (the widest that fits the word), 3 -> 2^37 rows,
+    else a few rows."""
+
+    def search_batch(self, pat, off):
+        k = off.size - 1
+        sp = np.zeros(k, dtype=np.uint64)
+        ep = np.zeros(k, dtype=np.uint64)
+        for q in range(k):
+            b = pat[int(off[q]):int(off[q + 1])]
+            sp[q] = int(b.sum()) * 1000003 % (1 << 38) if b.size else 0
+            c = int(b[0]) if b.size else 0
+            ep[q] = int(sp[q]) + {0: 0, 1: (1 << 24) - 1, 2: (1 << 24) - 2, 3: 1 << 37}.get(c, c)
+        return sp, ep
+
+
+def fake_workload():
+    rng = np.random.default_rng(12)
+    pats = [bytes(rng.integers(0, 9, int(rng.integers(1, 6)), dtype=np.uint8)) for _ in range(40)]
+    pats.insert(20, bytes(rng.integers(0, 9, 400, dtype=np.uint8)))      # one pattern holds most of the bytes
+    off = np.zeros(len(pats) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in pats])
+    return np.frombuffer(b"".join(pats), dtype=np.uint8).copy(), off
+
+
 def _rank_main(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -86,29 +112,46 @@ def _rank_main(rank, world, port, q):
             kw_refused = True
         t = torch.arange(3 + 2 * rank, dtype=torch.int64) + 100 * rank
         parts = D.all_gather_varlen(t)
-        # the pipelined gather bench.py uses: 5 batches through 2 slots, gather i overlapping batch i+1
-        g = D.IntervalGather(4, torch.device("cpu"))
-        seen = []
-        outs = []
-        for i in range(5):
-            a, b = g.slot(i)
-            a.copy_(torch.arange(4) + 10 * i + 1000 * rank)
-            b.copy_(torch.arange(4) + 10 * i + 1000 * rank + 5)
-            outs.append(g.launch(i))
-            if i >= 1:                      # batch i-1's gather has had a batch to finish; wait and read it
-                g.work[(i - 1) % g.depth].wait()
-                seen.append(outs[i - 1].clone().tolist())
-        g.finish()
-        seen.append(outs[4].clone().tolist())
-        q.put((rank, sp, ep, res, cuts, [p.tolist() for p in parts], seen, ex1.tolist(), ex2.tolist(), kw_refused))
+        # the pipelined gather bench.py uses: 5 batches through 2 slots, gather i overlapping batch i+1 -- in both
+        # forms (packed 8 B / pairs 16 B per pattern; batch 3 holds a wide interval and a miss) and both deliveries
+        seen = {}
+        for form in ("packed", "pairs"):
+            for delivery in ("all", "root"):
+                g = D.IntervalGather(4, torch.device("cpu"), form=form, delivery=delivery, escape_cap=2)
+                outs, got = [], []
+                for i in range(5):
+                    a, b = g.slot(i)
+                    a.copy_(torch.arange(4) + 10 * i + 1000 * rank)
+                    b.copy_(torch.arange(4) + 10 * i + 1000 * rank + 5)
+                    if i == 3:
+                        b[1] = a[1] + (1 << 33)          # wide: through the escape list
+                        b[2] = a[2]                      # a miss: sp == ep
+                    outs.append(g.launch(i))
+                    if i >= 1:                      # batch i-1's gather has had a batch to finish; wait and read it
+                        g.work[(i - 1) % g.depth].wait()
+                        got.append(None if outs[i - 1] is None else [[x.tolist() for x in g.intervals(outs[i - 1], r)] for r in range(world)])
+                g.finish()
+                got.append(None if outs[4] is None else [[x.tolist() for x in g.intervals(outs[4], r)] for r in range(world)])
+                seen[form + "/" + delivery] = (got, g.payload_bytes)
+        # the one-call form: every (form, delivery), a searcher whose answers include wide intervals and misses, and a
+        # byte distribution that leaves the middle rank of three without a pattern
+        fake = FakeSearcher()
+        fbuf, foff = fake_workload()
+        sharded = {}
+        for form in ("packed", "pairs"):
+            for delivery in ("all", "root"):
+                r_ = D.search_batch_sharded(fake, fbuf, foff, form=form, delivery=delivery, root=world - 1)
+                sharded[form + "/" + delivery] = None if r_ is None else (r_[0].tolist(), r_[1].tolist())
+        fcuts = D.shard_bounds(foff, world)
+        q.put((rank, sp, ep, res, cuts, [p.tolist() for p in parts], seen, ex1.tolist(), ex2.tolist(), kw_refused, sharded, fcuts))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_matches_single_process():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_match_single_process(world):
     port = free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -130,22 +173,65 @@ def test_two_rank_gloo_matches_single_process():
     wres = oracle_match(s, REGEXES)
     want1 = [(j + 7 * r, 5 + j + r, 1000 * r + j, 1000 * r + j + 3) for r in range(world) for j in range(2 + 3 * r)]
     want2 = [w for w in want1 if w[2] >= 1000]                 # rank 0 contributed nothing in the second round
-    for rank, sp, ep, res, cuts, parts, seen, ex1, ex2, kw_refused in got:
+    fbuf, foff = fake_workload()
+    fsp, fep = FakeSearcher().search_batch(fbuf, foff)
+    assert int(((fep - fsp) >= np.uint64(0xFFFFFF)).sum()) >= 3 and int((fep == fsp).sum()) >= 3
+    for rank, sp, ep, res, cuts, parts, seen, ex1, ex2, kw_refused, sharded, fcuts in got:
         assert [tuple(x) for x in ex1] == want1 and [tuple(x) for x in ex2] == want2
         assert kw_refused
-        for i, batch in enumerate(seen):    # (world, 2, k): every rank sees every rank's rows of batch i
-            for r in range(world):
-                assert batch[r][0] == [j + 10 * i + 1000 * r for j in range(4)]
-                assert batch[r][1] == [j + 10 * i + 1000 * r + 5 for j in range(4)]
+        for key, (batches, payload) in seen.items():
+            form, delivery = key.split("/")
+            assert payload == (8 * (4 + 1 + 2 * 2) if form == "packed" else 16 * 4)
+            for i, batch in enumerate(batches):    # every receiving rank sees every rank's rows of batch i
+                if delivery == "root" and rank != 0:
+                    assert batch is None
+                    continue
+                for r in range(world):
+                    a = [j + 10 * i + 1000 * r for j in range(4)]
+                    b = [x + 5 for x in a]
+                    if i == 3:
+                        b[1], b[2] = a[1] + (1 << 33), a[2]
+                    assert batch[r] == [a, b], (key, i, r)
+        for key, val in sharded.items():
+            if key.endswith("/root") and rank != world - 1:
+                assert val is None
+            else:
+                assert val == (fsp.tolist(), fep.tolist()), key
+        if world == 3:
+            assert fcuts[1] == fcuts[2] or fcuts[2] - fcuts[1] <= 1      # the heavy pattern leaves a rank (nearly) empty
         assert np.array_equal(sp, wsp) and np.array_equal(ep, wep)
         assert [sorted(r) for r in res] == wres
         assert cuts[0] == 0 and cuts[-1] == off.size - 1 and cuts == sorted(cuts)
-        assert parts == [[0, 1, 2], [100, 101, 102, 103, 104]]
-    # byte balance of the shards
-    cuts = got[0][4]
-    b0 = int(off[cuts[1]] - off[cuts[0]])
-    b1 = int(off[cuts[2]] - off[cuts[1]])
-    assert abs(b0 - b1) <= 20
+        assert parts == [[100 * r + j for j in range(3 + 2 * r)] for r in range(world)]
+    if world == 2:      # byte balance of the shards
+        cuts = got[0][4]
+        b0 = int(off[cuts[1]] - off[cuts[0]])
+        b1 = int(off[cuts[2]] - off[cuts[1]])
+        assert abs(b0 - b1) <= 20
+
+
+def test_packed_interval_form_round_trips():
+    """pack_intervals_np / unpack_intervals_np (the host twin of fmx_pack_intervals_dev): misses, the two widths either
+    side of the escape threshold, rows near 2^38, an escape list that is exactly full, one entry too short, and empty."""
+    rng = np.random.default_rng(1)
+    sp = rng.integers(0, 1 << 38, 1000, dtype=np.int64).astype(np.uint64)
+    w = rng.integers(0, 50, 1000, dtype=np.int64).astype(np.uint64)
+    w[::97] = np.uint64(0xFFFFFF)
+    w[5::97] = np.uint64(0xFFFFFE)
+    w[9::97] = np.uint64(1 << 37)
+    w[3::50] = 0
+    ep = sp + w
+    n_wide = int((w >= np.uint64(0xFFFFFF)).sum())
+    pk = D.pack_intervals_np(sp, ep, n_wide)
+    assert pk.size == D.packed_words(1000, n_wide) and int(pk[1000]) == n_wide
+    a, b = D.unpack_intervals_np(pk, 1000, n_wide)
+    assert np.array_equal(a, sp) and np.array_equal(b, ep)
+    short = D.pack_intervals_np(sp, ep, n_wide - 1)
+    assert int(short[1000]) == n_wide
+    with pytest.raises(OverflowError):
+        D.unpack_intervals_np(short, 1000, n_wide - 1)
+    e = D.pack_intervals_np(sp[:0], ep[:0], 4)
+    assert e.size == 9 and D.unpack_intervals_np(e, 0, 4)[0].size == 0
 
 
 def test_work_bounds_balance_by_weight():

@@ -1168,14 +1168,18 @@ def test_match_batch_sharded_device_exchange():
     assert got.tobytes() == want.tobytes() and want.size > 100
 
 
-def test_allgather_dev_rccl_in_the_library():
-    """fmx_comm_* / fmx_allgather_dev: the exchange as an RCCL call inside libfmx.so (what a JVM caller uses).  One
-    GPU here, so the communicators have one rank -- created both ways (ncclCommInitAll over the handles of one
+def test_allgather_dev_rccl_in_the_library(monkeypatch):
+    """fmx_comm_* / fmx_allgather_dev / fmx_gather_dev: the exchange as an RCCL call inside libfmx.so (what a JVM caller
+    uses).  One GPU here, so the communicators have one rank -- created both ways (ncclCommInitAll over the handles of one
     process; unique id + ncclCommInitRank as one process per GPU does) -- and the gather of the intervals of a real
-    search must reproduce them; with two or more GPUs a second handle joins and every rank receives both slices."""
+    search must reproduce them; with two or more GPUs a second handle joins and every rank receives both slices.  The
+    search is NOT synchronised before the exchange: the collective is ordered behind the producer streams by the
+    library.  Both payloads: (sp, ep) as 16 bytes per pattern and the packed 8-byte form; both deliveries: to every
+    rank and to the root only.  A failed RCCL initialisation is a status, not a crash."""
     import ctypes
     torch = _torch()
     from findex_amd import _lib
+    from findex_amd.distributed import pack_intervals_np
     L = _lib.load()
     ndev = min(torch.cuda.device_count(), 2)
     bwt, eof, counts = synth_bwt(200_000, 97, 100, 5)
@@ -1185,7 +1189,16 @@ def test_allgather_dev_rccl_in_the_library():
     buf, off = pack_patterns(lf_walk_patterns(orc, rng, 1000 * ndev, 6, 0.2, alphabet=[97, 98, 99, 100]))
     wsp, wep, _ = orc.search_batch(buf, off)
     k = 1000
-    sends, recvs = [], []
+    for hip in hips:
+        hip.prepare(ktab=True, jump=True)               # no table is built (and no stream synchronised) by the searches below
+    comm = ctypes.c_void_p()
+    idxs = (ctypes.c_void_p * ndev)(*[h.handle for h in hips])
+    _lib.check(L.fmx_comm_create_all(idxs, ndev, ctypes.byref(comm)))
+    nr, nl = ctypes.c_int(), ctypes.c_int()
+    _lib.check(L.fmx_comm_info(comm, ctypes.byref(nr), ctypes.byref(nl)))
+    assert nr.value == ndev and nl.value == ndev
+    sends, recvs, packs, precvs, streams, keep = [], [], [], [], [], []
+    pw = hips[0].packed_words(k, 8)
     for d, hip in enumerate(hips):                      # rank d searches patterns [d*k, (d+1)*k) on its own GPU
         dev = torch.device("cuda", d)
         with torch.cuda.device(dev):
@@ -1193,37 +1206,62 @@ def test_allgather_dev_rccl_in_the_library():
             d_pat = torch.from_numpy(buf[lo:int(off[(d + 1) * k])].copy()).to(dev)
             d_off = torch.from_numpy((off[d * k:(d + 1) * k + 1] - np.uint64(lo)).astype(np.int64)).to(dev)
             both = torch.empty(2 * k, dtype=torch.int64, device=dev)
-            hip.search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), both.data_ptr(), both.data_ptr() + 8 * k, k, 0)
-            torch.cuda.synchronize(dev)
-            sends.append(both)
+            pk = torch.empty(pw, dtype=torch.int64, device=dev)
             recvs.append(torch.zeros(2 * k * ndev, dtype=torch.int64, device=dev))
-    comm = ctypes.c_void_p()
-    idxs = (ctypes.c_void_p * ndev)(*[h.handle for h in hips])
-    _lib.check(L.fmx_comm_create_all(idxs, ndev, ctypes.byref(comm)))
-    nr, nl = ctypes.c_int(), ctypes.c_int()
-    _lib.check(L.fmx_comm_info(comm, ctypes.byref(nr), ctypes.byref(nl)))
-    assert nr.value == ndev and nl.value == ndev
+            precvs.append(torch.zeros(pw * ndev, dtype=torch.int64, device=dev))
+            torch.cuda.synchronize(dev)
+            st = torch.cuda.Stream(device=dev)
+            hip.search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), both.data_ptr(), both.data_ptr() + 8 * k, k, st.cuda_stream)
+            hip.pack_intervals_dev(both.data_ptr(), both.data_ptr() + 8 * k, k, pk.data_ptr(), escape_cap=8, stream=st.cuda_stream)
+            sends.append(both)
+            packs.append(pk)
+            streams.append(st)
+            keep += [d_pat, d_off]
     sp_ = (ctypes.c_void_p * ndev)(*[t.data_ptr() for t in sends])
     rp_ = (ctypes.c_void_p * ndev)(*[t.data_ptr() for t in recvs])
-    _lib.check(L.fmx_allgather_dev(comm, sp_, rp_, 16 * k))
+    pp_ = (ctypes.c_void_p * ndev)(*[t.data_ptr() for t in packs])
+    pr_ = (ctypes.c_void_p * ndev)(*[t.data_ptr() for t in precvs])
+    st_ = (ctypes.c_void_p * ndev)(*[s_.cuda_stream for s_ in streams])
+    _lib.check(L.fmx_allgather_dev(comm, sp_, rp_, 16 * k, st_))          # ordered behind the searches by the library
     for d in range(ndev):
         got = recvs[d].cpu().numpy().astype(np.uint64).reshape(ndev, 2, k)
         for r in range(ndev):
             assert np.array_equal(got[r, 0], wsp[r * k:(r + 1) * k]) and np.array_equal(got[r, 1], wep[r * k:(r + 1) * k])
+    root = ndev - 1
+    _lib.check(L.fmx_gather_dev(comm, pp_, pr_, 8 * pw, root, st_))       # the packed form, delivered to the root only
+    got = precvs[root].cpu().numpy().astype(np.uint64).reshape(ndev, pw)
+    for r in range(ndev):
+        assert np.array_equal(got[r], pack_intervals_np(wsp[r * k:(r + 1) * k], wep[r * k:(r + 1) * k], 8))
+        usp, uep = hips[0].unpack_intervals(got[r], k, 8)
+        assert np.array_equal(usp, wsp[r * k:(r + 1) * k]) and np.array_equal(uep, wep[r * k:(r + 1) * k])
+    for d in range(ndev):
+        if d != root:
+            assert int(precvs[d].abs().sum().item()) == 0                 # nothing lands on the other ranks
+    assert L.fmx_gather_dev(comm, pp_, pr_, 8 * pw, ndev, st_) == 3       # no such root
     _lib.check(L.fmx_comm_free(comm))
     # the one-process-per-GPU bootstrap with a single rank: unique id -> ncclCommInitRank
     uid = ctypes.create_string_buffer(128)
     _lib.check(L.fmx_comm_unique_id(uid))
     _lib.check(L.fmx_comm_create_rank(hips[0].handle, 1, 0, uid, ctypes.byref(comm)))
     recvs[0].zero_()
+    torch.cuda.synchronize()
     one_s = (ctypes.c_void_p * 1)(sends[0].data_ptr())
     one_r = (ctypes.c_void_p * 1)(recvs[0].data_ptr())
-    _lib.check(L.fmx_allgather_dev(comm, one_s, one_r, 16 * k))
+    _lib.check(L.fmx_allgather_dev(comm, one_s, one_r, 16 * k, None))     # idle buffers: no producer streams
     assert torch.equal(recvs[0][: 2 * k], sends[0])
     _lib.check(L.fmx_comm_free(comm))
     # refused: two handles on one device (RCCL has one rank per GPU)
     twice = (ctypes.c_void_p * 2)(hips[0].handle, hips[0].handle)
     assert L.fmx_comm_create_all(twice, 2, ctypes.byref(comm)) == 3
+    # a failed initialisation (injected) returns FMX_ERR_HIP with a message and leaves nothing behind
+    monkeypatch.setenv("FMX_COMM_FAIL_INIT", "1")
+    comm = ctypes.c_void_p()
+    assert L.fmx_comm_create_rank(hips[0].handle, 1, 0, uid, ctypes.byref(comm)) == 5 and not comm.value
+    assert b"ncclCommInitRank" in L.fmx_last_error()
+    assert L.fmx_comm_create_all(idxs, ndev, ctypes.byref(comm)) == 5 and not comm.value
+    monkeypatch.delenv("FMX_COMM_FAIL_INIT")
+    _lib.check(L.fmx_comm_create_all(idxs, ndev, ctypes.byref(comm)))     # and the library still makes communicators
+    _lib.check(L.fmx_comm_free(comm))
 
 
 def _nccl_rank(rank, world, port, q):
@@ -1699,3 +1737,139 @@ def test_c4_full_size_regex_batch():
             assert rows.size == 1 and rows[0]["len"] == len(res[j]) and rows[0]["sp"] == sp[i] and rows[0]["ep"] == ep[i]
         else:
             assert rows.size == 0
+
+
+# ---------------------------------------------------------------- round 4: staged pattern spans, lean batch forms
+def _dev_search(hip, torch, buf, off, shift=0, fixed_len=0, packed=False, escape_cap=0):
+    """fmx_search_batch_ex_dev on device copies of (buf, off); the pattern bytes start `shift` bytes into their tensor so
+    that the buffer the kernel sees is not 16-byte aligned."""
+    dev = torch.device("cuda", 0)
+    k = (buf.size // fixed_len) if fixed_len else off.size - 1
+    d_pat = torch.zeros(buf.size + shift + 64, dtype=torch.uint8, device=dev)
+    d_pat[shift:shift + buf.size] = torch.from_numpy(buf).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev) if not fixed_len else None
+    words = hip.packed_words(k, escape_cap) if packed else k
+    d_sp = torch.zeros(max(words, 1), dtype=torch.int64, device=dev)
+    d_ep = torch.zeros(max(k, 1), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    hip.search_batch_ex_dev(d_pat.data_ptr() + shift, d_off.data_ptr() if d_off is not None else 0, d_sp.data_ptr(), d_ep.data_ptr(),
+                            k, torch.cuda.current_stream().cuda_stream, fixed_len=fixed_len, packed=packed, escape_cap=escape_cap)
+    torch.cuda.synchronize()
+    if packed:
+        return d_sp.cpu().numpy().astype(np.uint64)
+    return d_sp[:k].cpu().numpy().astype(np.uint64), d_ep[:k].cpu().numpy().astype(np.uint64)
+
+
+@pytest.mark.parametrize("layout", ["onehot", "bytes"])
+def test_staged_pattern_spans_edges(layout):
+    """k_search4 reads a wave's patterns from LDS, staged as ONE contiguous span of up to 1 KiB per batch (16 patterns; 8
+    in the bytes layout), and from global memory when the span is longer: batches on both sides of that limit inside one
+    call, spans that end exactly at 1024 bytes behind every alignment of the buffer, patterns that start inside the
+    span's first dword, empty patterns between long ones, a last batch with one pattern -- each against the oracle,
+    steps counted, with the row tables on and off."""
+    torch = _torch()
+    findex_amd.set_layout(layout)
+    try:
+        bwt, eof, counts = synth_bwt(250_000, 1, 6, 41)
+        orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+        rng = np.random.default_rng(11)
+        per = 8 if layout == "bytes" else 16
+        for jump in ("auto", "off"):
+            findex_amd.config_set("jump", jump)
+            hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+            groups = []
+            for m in (1, 3, 4, 5, 31, 32, 33, 60, 63, 64, 65, 70, 128, 200):      # whole batches of one length: spans of per * m bytes
+                groups.append(lf_walk_patterns(orc, rng, 3 * per, m, 0.2, alphabet=[1, 2, 3, 4, 5, 6]))
+            mixed = []
+            for _ in range(40 * per):                                             # ragged: spans between 0 and ~2 KiB
+                m = int(rng.choice([0, 1, 2, 3, 7, 16, 40, 64, 90, 130]))
+                mixed += lf_walk_patterns(orc, rng, 1, m, 0.2, alphabet=[1, 2, 3, 4, 5, 6]) if m else [b""]
+            pats = [p for g in groups for p in g] + mixed + lf_walk_patterns(orc, rng, 1, 9, 0.0)
+            buf, off = pack_patterns(pats)
+            wsp, wep, wsteps = orc.search_batch(buf, off)
+            for shift in (0, 1, 7, 15):
+                hip.stats_reset()
+                gsp, gep = _dev_search(hip, torch, buf, off, shift=shift)
+                assert np.array_equal(gsp, wsp) and np.array_equal(gep, wep), (layout, jump, shift)
+                assert hip.stats()["backward_steps"] == int(wsteps.sum())
+            # spans that end exactly on the limit: `per` patterns of 1024 / per bytes behind a buffer start of every alignment
+            m = 1024 // per
+            exact = lf_walk_patterns(orc, rng, 4 * per, m, 0.1, alphabet=[1, 2, 3, 4, 5, 6])
+            buf, off = pack_patterns(exact)
+            wsp, wep, _ = orc.search_batch(buf, off)
+            for shift in range(0, 16, 3):
+                gsp, gep = _dev_search(hip, torch, buf, off, shift=shift)
+                assert np.array_equal(gsp, wsp) and np.array_equal(gep, wep), (layout, jump, "exact", shift)
+            hip.close()
+    finally:
+        findex_amd.set_layout("auto")
+        findex_amd.config_set("jump", "auto")
+
+
+def test_search_ex_fixed_length_and_packed_forms():
+    """fmx_search_batch_ex[_dev]: a batch of equal-length patterns without offsets, and the intervals in the 8-byte form --
+    host and device entry points, small (one staged copy) and large (whole arrays) batches, against the plain call; wide
+    intervals (empty and one-character patterns over 40 M rows) through the escape list, in place on the device, and
+    the overflow status when the list is too short."""
+    torch = _torch()
+    from findex_amd.distributed import pack_intervals_np, unpack_intervals_np
+    bwt, eof, counts = synth_bwt(40_000_000, 1, 2, 8)
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(3)
+    for k, m in ((1, 5), (17, 1), (1000, 12), (150_000, 26), (140_000, 3)):
+        buf = rng.integers(1, 3, size=k * m, dtype=np.uint8)
+        off = np.arange(k + 1, dtype=np.uint64) * np.uint64(m)
+        wsp, wep = hip.search_batch(buf, off)
+        hip.stats_reset()
+        gsp, gep = hip.search_batch_ex(buf, fixed_len=m)
+        assert np.array_equal(gsp, wsp) and np.array_equal(gep, wep), (k, m, "fixed")
+        dsp, dep = _dev_search(hip, torch, buf, off, shift=5, fixed_len=m)
+        assert np.array_equal(dsp, wsp) and np.array_equal(dep, wep), (k, m, "fixed dev")
+        cap = 64
+        for fixed in (0, m):
+            pk = hip.search_batch_ex(buf, off, fixed_len=fixed, packed=True, escape_cap=cap)
+            assert pk.size == k + 1 + 2 * cap
+            usp, uep = hip.unpack_intervals(pk, k, cap)
+            assert np.array_equal(usp, wsp) and np.array_equal(uep, wep), (k, m, fixed, "packed")
+            nsp, nep = unpack_intervals_np(pk, k, cap)
+            assert np.array_equal(nsp, wsp) and np.array_equal(nep, wep)
+        pk = _dev_search(hip, torch, buf, off, fixed_len=m, packed=True, escape_cap=cap)
+        assert np.array_equal(pk[:k + 1], pack_intervals_np(wsp, wep, cap)[:k + 1])
+    # wide intervals: lengths 0 and 1 among longer ones
+    pats = [b"", b"\x01", b"\x02", b"\x01\x02"] * 10 + [bytes(rng.integers(1, 3, 30, dtype=np.uint8)) for _ in range(100)]
+    pats = [pats[i] for i in rng.permutation(len(pats))]
+    buf, off = pack_patterns(pats)
+    k = len(pats)
+    wsp, wep = hip.search_batch(buf, off)
+    n_wide = int(((wep - wsp) >= np.uint64(0xFFFFFF)).sum())
+    assert n_wide == 30
+    pk = hip.search_batch_ex(buf, off, packed=True, escape_cap=40)
+    assert int(pk[k]) == n_wide
+    usp, uep = hip.unpack_intervals(pk, k, 40)
+    assert np.array_equal(usp, wsp) and np.array_equal(uep, wep)
+    ref = pack_intervals_np(wsp, wep, 40)
+    assert np.array_equal(pk[:k + 1], ref[:k + 1])
+    assert sorted(zip(pk[k + 1:k + 1 + 2 * n_wide:2].tolist(), pk[k + 2:k + 2 + 2 * n_wide:2].tolist())) == \
+        sorted(zip(ref[k + 1:k + 1 + 2 * n_wide:2].tolist(), ref[k + 2:k + 2 + 2 * n_wide:2].tolist()))
+    # the device round trip: pack, unpack into fresh arrays
+    dev = torch.device("cuda", 0)
+    d_sp = torch.from_numpy(wsp.astype(np.int64)).to(dev)
+    d_ep = torch.from_numpy(wep.astype(np.int64)).to(dev)
+    d_pk = torch.zeros(k + 1 + 80, dtype=torch.int64, device=dev)
+    d_a = torch.zeros(k, dtype=torch.int64, device=dev)
+    d_b = torch.zeros(k, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    hip.pack_intervals_dev(d_sp.data_ptr(), d_ep.data_ptr(), k, d_pk.data_ptr(), escape_cap=40, stream=st)
+    hip.unpack_intervals_dev(d_pk.data_ptr(), k, d_a.data_ptr(), d_b.data_ptr(), escape_cap=40, stream=st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_a.cpu().numpy().astype(np.uint64), wsp) and np.array_equal(d_b.cpu().numpy().astype(np.uint64), wep)
+    # an escape list that is too short: the count says so, the host decode refuses
+    pk = hip.search_batch_ex(buf, off, packed=True, escape_cap=7)
+    assert int(pk[k]) == n_wide
+    with pytest.raises(findex_amd.FmxError) as e:
+        hip.unpack_intervals(pk, k, 7)
+    assert e.value.code == 9
+    with pytest.raises(OverflowError):
+        unpack_intervals_np(pk, k, 7)
+    hip.close()

@@ -46,6 +46,24 @@ print("bound_counters.csv written:",len(agg),"rows")
 PY
   rm -rf $O/pmcb* $O/pmcm*.d 2>/dev/null
   ;;
+tests)
+  timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest -m gpu rc=$?"; tail -5 $O/pytest_gpu.log
+  ;;
+c3bound)
+  timeout -k 10 500 python tools/c3_bound.py 2>&1 | grep -v amdgpu.ids > $O/c3_bound.txt; echo "c3_bound rc=$?"; grep "^fit\|m  32  miss 0.10" $O/c3_bound.txt
+  ;;
+bench:*)
+  wl=${PART#bench:}
+  timeout -k 10 500 python bench.py --workload $wl > $O/${wl}_bench.json 2> $O/${wl}_bench.log; echo "bench $wl rc=$?"
+  python - $O/${wl}_bench.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d["roofline"]
+    print("value %.0f M rq/s  ms/step %.4f  kernel_ms %.4f  frac %.3f  req/s %s" % (d["value"], d["ms_per_step"], r["kernel_ms"], r["frac"], r.get("requests_G_per_s")))
+except Exception as e:
+    print("no result:", e)
+PY
+  ;;
 *) echo "unknown part $PART";;
 esac
 done

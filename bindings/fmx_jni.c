@@ -143,6 +143,36 @@ JNIEXPORT void JNICALL FN(searchBatchDirect0)(JNIEnv *e, jobject self, jlong h, 
   rethrow(e, fmx_search_batch(H(h), p, o, r, r + k, (size_t)k));
 }
 
+/* ---- the lean form (fmx_search_batch_ex): k = pat.length / len equal-length patterns, no offsets; out = long[2k] */
+JNIEXPORT void JNICALL FN(searchBatchFixed0)(JNIEnv *e, jobject self, jlong h, jbyteArray pat, jint len, jlongArray out) {
+  jsize nb = (*e)->GetArrayLength(e, pat);
+  if (len <= 0 || nb % len != 0 || (*e)->GetArrayLength(e, out) < 2 * (nb / len)) { rethrow(e, FMX_ERR_ARG); return; }
+  jsize k = nb / len;
+  jbyte *p = in_bytes(e, pat, nb);
+  jlong *r = malloc(sizeof(jlong) * (size_t)(k > 0 ? 2 * k : 1));
+  fmx_search_opts opts = {(uint32_t)len, 0, 0};
+  int rc = (p && r) ? fmx_search_batch_ex(H(h), (const uint8_t *)p, 0, (uint64_t *)r, (uint64_t *)r + k, (size_t)k, &opts) : FMX_ERR_NOMEM;
+  if (rc == FMX_OK && k > 0) (*e)->SetLongArrayRegion(e, out, 0, 2 * k, r);
+  free(r);
+  free(p);
+  rethrow(e, rc);
+}
+
+/* the same over direct ByteBuffers (fmx_host_alloc memory) with the intervals back in the 8-byte form: `out` holds
+ * fmx_packed_words(k, escapeCap) longs; HipFM.unpack decodes them (word q = sp | width << 40, escape list behind) */
+JNIEXPORT void JNICALL FN(searchBatchPackedDirect0)(JNIEnv *e, jobject self, jlong h, jobject pat, jint len, jobject out, jlong k,
+                                                    jlong escapeCap) {
+  uint8_t *p = (*e)->GetDirectBufferAddress(e, pat);
+  uint64_t *r = (*e)->GetDirectBufferAddress(e, out);
+  if (!p || !r || k < 0 || len <= 0 || escapeCap < 0 || (*e)->GetDirectBufferCapacity(e, pat) < k * (jlong)len ||
+      (*e)->GetDirectBufferCapacity(e, out) < 8 * (jlong)fmx_packed_words((size_t)k, (size_t)escapeCap)) {
+    rethrow(e, FMX_ERR_ARG);
+    return;
+  }
+  fmx_search_opts opts = {(uint32_t)len, 1, (uint64_t)escapeCap};
+  rethrow(e, fmx_search_batch_ex(H(h), p, 0, r, 0, (size_t)k, &opts));
+}
+
 /* ---- getPrevRange for k (sp, ep, c) triples: out = long[2k] (sp1[0..k) then ep1[0..k)) */
 JNIEXPORT void JNICALL FN(prevRangeBatch0)(JNIEnv *e, jobject self, jlong h, jlongArray sp, jlongArray ep, jbyteArray c,
                                            jlongArray out) {
@@ -375,7 +405,10 @@ JNIEXPORT jint JNICALL FN(calcGapsChain0)(JNIEnv *e, jobject self, jlong h, jbyt
 /* fmx_prepare: build the k-mer jump table (what & 1) / the select directory (what & 2) / the row tables (what & 4) now, not at first use */
 JNIEXPORT void JNICALL FN(prepare0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_prepare(H(h), (unsigned)what)); }
 
-/* fmx_config_set: process-wide settings ("layout", "checkpoints", "ktab", "jump", "pipeline", "validate", "threads") */
+/* fmx_drop_tables: free the row tables again (what & 4) */
+JNIEXPORT void JNICALL FN(dropTables0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_drop_tables(H(h), (unsigned)what)); }
+
+/* fmx_config_set: process-wide settings ("layout", "checkpoints", "ktab", "jump", "tables_after", "pipeline", "validate", "threads") */
 JNIEXPORT void JNICALL FN(configSet0)(JNIEnv *e, jobject self, jstring key, jstring value) {
   const char *k = (*e)->GetStringUTFChars(e, key, 0);
   const char *v = (*e)->GetStringUTFChars(e, value, 0);

@@ -44,6 +44,9 @@ object HipFM {
   @native def regexFree0(r: Long): Unit
   @native def regexCompileBatch0(packed: Array[Byte], k: Int, lineOnly: Boolean, handles: Array[Long], status: Array[Int]): Unit
   @native def regexFreeBatch0(handles: Array[Long]): Unit
+  @native def searchBatchFixed0(h: Long, pat: Array[Byte], len: Int, out: Array[Long]): Unit
+  @native def searchBatchPackedDirect0(h: Long, pat: ByteBuffer, len: Int, out: ByteBuffer, k: Long, escapeCap: Long): Unit
+  @native def dropTables0(h: Long, what: Int): Unit
   @native def prepare0(h: Long, what: Int): Unit
   @native def configSet0(key: String, value: String): Unit
   @native def occHost0(h: Long, c: Int, i: Long): Long
@@ -153,11 +156,39 @@ class HipFMSearcher(filename: String, bigEndian: Boolean = true, device: Int = 0
     * search.  `pat` = pattern bytes, `off` = k+1 longs, `out` receives sp[0..k) then ep[0..k) as longs. */
   def searchBatchDirect(pat: ByteBuffer, off: ByteBuffer, out: ByteBuffer, k: Long): Unit =
     searchBatchDirect0(h, pat, off, out, k)
+
+  /** A batch of equal-length patterns (flat: k * len bytes) without an offsets array (fmx_search_batch_ex, fixed_len). */
+  def searchBatchFixed(flat: Array[Byte], len: Int): Array[(Long, Long)] = {
+    val k = flat.length / len
+    val out = new Array[Long](2 * k)
+    searchBatchFixed0(h, flat, len, out)
+    Array.tabulate(k)(j => (out(j), out(k + j)))
+  }
+
+  /** The same over page-locked direct buffers with the intervals back in the 8-byte form (`out`: k + 1 + 2 * escapeCap
+    * longs, little-endian; HipFMSearcher.unpack decodes): 40 bytes per 32-character pattern cross the link instead of 56. */
+  def searchBatchPackedDirect(pat: ByteBuffer, len: Int, out: ByteBuffer, k: Long, escapeCap: Long): Unit =
+    searchBatchPackedDirect0(h, pat, len, out, k, escapeCap)
+
+  /** Build the derived tables now (fmx_prepare: 1 = k-mer table, 2 = select directory, 4 = row tables) / free the row tables. */
+  def prepare(what: Int): Unit = prepare0(h, what)
+  def dropTables(): Unit = dropTables0(h, 4)
 }
 
 object HipFMSearcher {
   /** A page-locked direct buffer for batches (free with HipFM.hostFree0 when done). */
   def pinned(bytes: Long): ByteBuffer = HipFM.hostAlloc0(bytes).order(ByteOrder.LITTLE_ENDIAN)
+
+  /** Decode of the 8-byte interval form (include/fmx.h): word q = sp | min(ep - sp, 0xFFFFFF) << 40, wider intervals in the
+    * escape list behind word k (their count), as (q, ep) pairs.  Throws when more intervals were wide than the list holds. */
+  def unpack(words: java.nio.LongBuffer, k: Int, escapeCap: Int): Array[(Long, Long)] = {
+    val out = Array.tabulate(k) { q => val w = words.get(q); val sp = w & ((1L << 40) - 1); (sp, sp + (w >>> 40)) }
+    val cnt = words.get(k)
+    if (cnt > escapeCap) throw new Exception(cnt + " intervals of 2^24 - 1 rows or more, the escape list holds " + escapeCap)
+    var j = 0
+    while (j < cnt) { val q = words.get(k + 1 + 2 * j).toInt; out(q) = (out(q)._1, words.get(k + 2 + 2 * j)); j += 1 }
+    out
+  }
 }
 
 /** NaiveBWTSearcher(bwt, bucketStarts, rk0) (findex.scala:459-506): the searcher BWTMerger2.calcGaps uses. */

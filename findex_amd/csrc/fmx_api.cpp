@@ -507,6 +507,14 @@ int fmx_config_set(const char *key, const char *value) {
     else return arg_fail("jump must be auto, rows, rows3, jumps or off");
     return FMX_OK;
   }
+  if (std::strcmp(key, "tables_after") == 0) {
+    if (std::strcmp(value, "auto") == 0) { tables_set_after(-1); return FMX_OK; }
+    char *end = nullptr;
+    const long long v = std::strtoll(value, &end, 10);
+    if (end == value || *end || v < 0) return arg_fail("tables_after must be auto or a non-negative number of patterns");
+    tables_set_after(v);
+    return FMX_OK;
+  }
   if (std::strcmp(key, "pipeline") == 0) {
     if (std::strcmp(value, "on") == 0) g_pipeline.store(1, std::memory_order_relaxed);
     else if (std::strcmp(value, "off") == 0) g_pipeline.store(0, std::memory_order_relaxed);
@@ -588,11 +596,13 @@ int fmx_prepare(const fmx_index *idx, unsigned what) {
   CtxLease lease(h);
   if (!lease.c) return FMX_ERR_HIP;
   if (what & FMX_PREPARE_KTAB) {
+    h->prepared.store(true, std::memory_order_relaxed);
     KTab kt;
     HIP_TRY(ktab_get(h, lease.c->stream, &kt), "k-mer table");
   }
   if (what & FMX_PREPARE_SELECT) HIP_TRY(select_prepare(h, lease.c->stream), "select directory");
   if (what & FMX_PREPARE_JUMP) {
+    h->prepared.store(true, std::memory_order_relaxed);      // from now on searches use (and may build) the row tables
     const uint4 *jt = nullptr;
     HIP_TRY(jump_get(h, lease.c->stream, &jt), "jump table");
     const unsigned long long *r1 = nullptr, *r3 = nullptr;
@@ -600,6 +610,16 @@ int fmx_prepare(const fmx_index *idx, unsigned what) {
     HIP_TRY(row1_get(h, lease.c->stream, &r1), "row table");
   }
   return FMX_OK;
+}
+
+int fmx_drop_tables(fmx_index *idx, unsigned what) {
+  if (!idx) return arg_fail("null argument");
+  if (what & ~(unsigned)FMX_PREPARE_JUMP) return arg_fail("fmx_drop_tables frees the row tables only (FMX_PREPARE_JUMP)");
+  Index *h = H(idx);
+  int rc = use_device(h);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize(), "hipDeviceSynchronize");
+  return drop_tables(h, what);
 }
 
 int fmx_close(fmx_index *idx) {
@@ -1226,6 +1246,8 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->ktab_k = h->kt.k;
   out->build_ms = h->build_ms;
   out->tables_build_ms = h->tables_ms;
+  out->peak_table_build_bytes = h->peak_table_build_bytes.load(std::memory_order_relaxed);
+  out->patterns_seen = h->patterns_seen.load(std::memory_order_relaxed);
   return FMX_OK;
 }
 

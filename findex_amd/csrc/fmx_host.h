@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -101,6 +102,10 @@ struct Index {
   mutable void *d_row3 = nullptr;
   mutable uint64_t row3_bytes = 0;
   mutable double tables_ms = 0.0;             // host time spent building the k-mer table and the select directory (under their mutexes)
+  // when the derived tables are built (fmx_jump.hip, tables_due): patterns searched so far, fmx_prepare seen
+  mutable std::atomic<uint64_t> patterns_seen{0};
+  mutable std::atomic<bool> prepared{false};
+  mutable std::atomic<uint64_t> peak_table_build_bytes{0};      // most device memory a table build held at once (table + its scratch)
   // select directory for Psi (fmx_select.hip), built on first use
   mutable std::mutex sel_mu;
   mutable bool sel_ready = false;
@@ -132,11 +137,17 @@ struct CtxLease {            // scope guard around ctx_acquire / ctx_release
   CtxLease &operator=(const CtxLease &) = delete;
 };
 bool ktab_enabled();                            // fmx_config_set("ktab", "auto" | "off")
-hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out);     // fmx_ktab.hip
+// The derived tables are built when they have a chance to pay: by fmx_prepare, or at the search that brings the patterns a
+// handle has been asked for to `threshold` (fmx_config_set("tables_after", ..)); `build` = false only looks.
+bool tables_due(const Index *h, uint64_t k, bool small_table);      // fmx_jump.hip: counts k, then decides
+void tables_set_after(long long patterns);                          // fmx_config_set("tables_after", "auto" | N)
+void note_table_build(const Index *h, uint64_t bytes_held);
+hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out, bool build = true);     // fmx_ktab.hip
 hipError_t select_prepare(const Index *h, hipStream_t st);          // fmx_select.hip: builds the select directory now
-hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out);   // fmx_jump.hip (nullptr: the handle has none)
-hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out);   // fmx_jump.hip (nullptr: none)
-hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out);   // fmx_jump.hip (nullptr: none)
+hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out, bool build = true);   // fmx_jump.hip (nullptr: the handle has none)
+hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build = true);   // fmx_jump.hip (nullptr: none)
+hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build = true);   // fmx_jump.hip (nullptr: none)
+int drop_tables(Index *h, unsigned what);       // fmx_jump.hip: fmx_drop_tables
 void jump_set_mode(int mode);      // fmx_config_set("jump", ..): bit 0 = the row table, bit 1 = the row jump table, bit 2 = the three-step row table
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)

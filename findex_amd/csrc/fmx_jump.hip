@@ -13,11 +13,13 @@
 // misses return the reference loop's values and count its steps, as with the k-mer table at the other end of the
 // pattern (fmx_ktab.hip).
 //
-// Built on the device at a handle's first literal search (or by fmx_prepare), by doubling: J1[r] = (BWT'[r], LF r)
-// from one rank query per row, then J2 = J1 o J1, J4 = J2 o J2, J8 = J4 o J4 -- three passes of random 16-byte
-// gathers.  16 n bytes (64 GiB at C3, beside the 77 GiB dictionary), twice that while it is built; when the memory is
-// not there (C5: n = 2^34) the handle simply has no jump table.  Not for fmx_open_block handles (their skipped row
-// and first-byte rule are not properties of an LF walk).
+// Built on the device when it has a chance to pay (tables_due below: fmx_prepare, or the search that brings the handle's
+// patterns to the threshold), into ONE allocation of 16 n bytes (64 GiB at C3, beside the 77 GiB dictionary): a lane group
+// per row walks the eight steps -- with the three-step row table R3 (built first: it is kept anyway) two lookups of it
+// give six of them and two rank queries the rest; without it eight rank queries.  (Rounds 3 built J by doubling, J1 -> J2 ->
+// J4 -> J8 through a second 16 n-byte buffer: 0.45 s of kernels and 3.5-4 s for the two 64 GiB hipMallocs.)  When the
+// memory is not there (C5: n = 2^34) the handle simply has no jump table.  Not for fmx_open_block handles (their skipped
+// row and first-byte rule are not properties of an LF walk).
 #include "fmx_device.h"
 #include "fmx_host.h"
 
@@ -31,9 +33,10 @@ namespace fmx {
 
 constexpr int kJThreads = 256;
 
-// J1[r] = (BWT'[r]; LF r) for r in [lo, hi): one lane group per row, LF r = C[c] + rank(c, r)
+// J[r] = (BWT'[r], .., BWT'[LF^7 r]; LF^8 r): one lane group per row.  r3 != nullptr: R3[r] and R3[LF^3 r] give six steps
+// (one 8-byte word each, read by the group's first lane), two rank queries the last two; else eight rank queries.
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kJThreads) void k_jump_init(DevIndex ix, uint4 *__restrict__ out, uint64_t lo, uint64_t hi) {
+__global__ __launch_bounds__(kJThreads) void k_jump_build(DevIndex ix, const unsigned long long *__restrict__ r3, uint4 *__restrict__ out) {
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
@@ -41,25 +44,23 @@ __global__ __launch_bounds__(kJThreads) void k_jump_init(DevIndex ix, uint4 *__r
   constexpr int G = Lay<LAYOUT>::G;
   const LaneConst lc = lane_const<G>();
   const uint64_t ngroups = (uint64_t)gridDim.x * (kJThreads / G);
-  for (uint64_t r = lo + ((uint64_t)blockIdx.x * kJThreads + threadIdx.x) / G; r < hi; r += ngroups) {
-    const uint32_t c = r == ix.eof ? 0u : ix.bwt[r];
-    const uint64_t nxt = s_cf[c] + rank_excl<WIDE, LAYOUT>(ix, c, s_slot[c], r, lc);
-    if (lc.t == 0) out[r] = make_uint4(c, 0u, (uint32_t)nxt, (uint32_t)(nxt >> 32));
-  }
-}
-
-// J(2m) = Jm o Jm: the m characters of row r, then the m characters of the row they lead to
-__global__ __launch_bounds__(kJThreads) void k_jump_double(const uint4 *__restrict__ in, uint4 *__restrict__ out, uint64_t n, uint32_t m) {
-  const uint64_t nth = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += nth) {
-    const uint4 a = in[r];
-    const uint4 b = in[((uint64_t)a.w << 32) | a.z];
-    uint4 o;
-    o.x = m == 4 ? a.x : (a.x | (b.x << (8u * m)));
-    o.y = m == 4 ? b.x : 0u;
-    o.z = b.z;
-    o.w = b.w;
-    out[r] = o;
+  for (uint64_t r0 = ((uint64_t)blockIdx.x * kJThreads + threadIdx.x) / G; r0 < ix.n; r0 += ngroups) {
+    uint64_t r = r0;
+    unsigned long long chars = 0;
+    uint32_t first = 0;
+    if (r3) {
+      const unsigned long long a = r3[r];                       // every lane of the group: one request (same address)
+      const unsigned long long b = r3[a & ((1ull << 40) - 1)];
+      chars = (a >> 40) | ((b >> 40) << 24);
+      r = b & ((1ull << 40) - 1);
+      first = 6;
+    }
+    for (uint32_t s = first; s < 8; s++) {
+      const uint32_t c = r == ix.eof ? 0u : ix.bwt[r];
+      chars |= (unsigned long long)c << (8u * s);
+      r = s_cf[c] + rank_excl<WIDE, LAYOUT>(ix, c, s_slot[c], r, lc);
+    }
+    if (lc.t == 0) out[r0] = make_uint4((uint32_t)chars, (uint32_t)(chars >> 32), (uint32_t)r, (uint32_t)(r >> 32));
   }
 }
 
@@ -115,93 +116,79 @@ __global__ __launch_bounds__(kJThreads) void k_row3_init(DevIndex ix, unsigned l
 static std::atomic<int> g_jump_mode{7};      // bit 0: row table (R1), bit 1: row jump table (J8), bit 2: three-step row table (R3)
 void jump_set_mode(int mode) { g_jump_mode.store(mode & 7, std::memory_order_relaxed); }
 
-// Called under h->jt_mu by jump_get.  Leaves h->d_jump null when the table is not wanted or does not fit.
-static hipError_t build_jump(const Index *h, hipStream_t st) {
-  static const int forced = getenv("FMX_JUMP") ? atoi(getenv("FMX_JUMP")) : -1;      // 0 = off, 1 = whenever it fits
-  if (forced == 0 || (forced < 0 && !(g_jump_mode.load(std::memory_order_relaxed) & 2))) return hipSuccess;
-  if (h->block_mode || h->n < 2 || h->nslots < 1) return hipSuccess;
-  const uint64_t bytes = h->n * 16;
-  size_t free_b = 0, total_b = 0;
-  hipError_t e = hipMemGetInfo(&free_b, &total_b);
-  if (e != hipSuccess) return e;
-  // twice the table while it is built, and a margin for the callers' batches; never more than half of what is free
-  // once it stands (the dictionary and the k-mer table are resident already)
-  if (2 * bytes + (8ull << 30) > free_b && !(forced == 1 && 2 * bytes + (1ull << 28) <= free_b)) return hipSuccess;
-  static const bool trace = getenv("FMX_TRACE") != nullptr;
-  const auto t0 = std::chrono::steady_clock::now();
-  auto mark = [&](const char *what) {
-    if (trace) { (void)hipStreamSynchronize(st); fprintf(stderr, "[fmx] jump table %-12s +%.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
-  };
-  void *a = nullptr, *b = nullptr;
-  e = hipMalloc(&a, bytes);
-  if (e == hipSuccess) e = hipMalloc(&b, bytes);
-  if (e != hipSuccess) { if (a) (void)hipFree(a); (void)hipGetLastError(); return hipSuccess; }      // no table, no error
-  mark("allocated");
-  {
-    const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
-    const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
-#define CALL(W, L) k_jump_init<W, L><<<grid, kJThreads, 0, st>>>(h->dev, (uint4 *)a, (uint64_t)0, h->n)
-    FMX_LAYOUT_DISPATCH(h, CALL);
-#undef CALL
-    e = hipGetLastError();
-  }
-  mark("J1");
-  void *src = a, *dst = b;
-  for (uint32_t m = 1; m < 8 && e == hipSuccess; m *= 2) {
-    const int grid = (int)std::min<uint64_t>((h->n + kJThreads - 1) / kJThreads, (uint64_t)h->cu_count * 16);
-    k_jump_double<<<grid, kJThreads, 0, st>>>((const uint4 *)src, (uint4 *)dst, h->n, m);
-    e = hipGetLastError();
-    std::swap(src, dst);
-    mark("doubled");
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(dst);                  // the buffer the last pass read
-  mark("freed");
-  if (e != hipSuccess) { (void)hipFree(src); return e; }
-  h->d_jump = src;
-  h->jump_bytes = bytes;
-  return hipSuccess;
+// ---- when the derived tables are built.  Round 3 built all of them at a handle's FIRST search, whatever it was: a
+// single getPrevRange-sized query on a C3-size handle waited 6 s and left 96 GiB behind.  Now a table is built by
+// fmx_prepare, or by the search that brings the patterns the handle has been asked for to a threshold -- "auto": n / 64
+// patterns (at least 65536) for the row tables, whose build is O(n) rank queries, i.e. when the searches themselves have
+// done work of that order; 1024 patterns for the k-mer table (milliseconds to build).  fmx_config_set("tables_after", N):
+// N patterns for both (0: at the first search, round 3's behaviour -- the tests use it).
+static std::atomic<long long> g_tables_after{-1};
+void tables_set_after(long long patterns) { g_tables_after.store(patterns, std::memory_order_relaxed); }
+bool tables_due(const Index *h, uint64_t k, bool small_table) {
+  // a search asks twice (k-mer table, then row tables): its patterns are counted by the second question
+  const uint64_t seen = (small_table ? h->patterns_seen.load(std::memory_order_relaxed) : h->patterns_seen.fetch_add(k, std::memory_order_relaxed)) + k;
+  if (h->prepared.load(std::memory_order_relaxed)) return true;
+  const long long after = g_tables_after.load(std::memory_order_relaxed);
+  const uint64_t need = after >= 0 ? (uint64_t)after : (small_table ? 1024ull : std::max<uint64_t>(65536, h->n / 64));
+  return seen >= need;
+}
+void note_table_build(const Index *h, uint64_t bytes_held) {
+  uint64_t cur = h->peak_table_build_bytes.load(std::memory_order_relaxed);
+  while (bytes_held > cur && !h->peak_table_build_bytes.compare_exchange_weak(cur, bytes_held, std::memory_order_relaxed)) {}
 }
 
-// The jump table of a handle (nullptr: none), built on first use.
-hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out) {
-  std::lock_guard<std::mutex> lk(h->jt_mu);
-  if (!h->jt_ready) {
-    const auto t0 = std::chrono::steady_clock::now();
-    const hipError_t e = build_jump(h, st);
-    if (e != hipSuccess) { (void)hipGetLastError(); h->d_jump = nullptr; h->jump_bytes = 0; }      // searches walk every step
-    h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    h->jt_ready = true;
+// 8 n bytes of row words by `launch`; leaves *slot null when the table is not wanted or does not fit (no error).
+template <class Launch>
+static void build_row_words(const Index *h, hipStream_t st, uint64_t margin, void **slot, uint64_t *slot_bytes, Launch launch) {
+  size_t free_b = 0, total_b = 0;
+  const uint64_t bytes = h->n * 8;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes + margin > free_b) { (void)hipGetLastError(); return; }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e == hipSuccess) {
+    const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
+    const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
+    launch(grid, static_cast<unsigned long long *>(p));
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) { *slot = p; *slot_bytes = bytes; note_table_build(h, bytes); }
+    else (void)hipFree(p);
   }
-  *out = static_cast<const uint4 *>(h->d_jump);
+  if (e != hipSuccess) (void)hipGetLastError();
+}
+
+static bool rows_eligible(const Index *h) { return !h->block_mode && h->n >= 2 && h->nslots >= 1; }
+
+// The three-step row table of a handle (nullptr: none yet / none at all): 8 n bytes.
+hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build) {
+  std::lock_guard<std::mutex> lk(h->r3_mu);
+  if (!h->r3_ready && build) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((g_jump_mode.load(std::memory_order_relaxed) & 4) && rows_eligible(h))
+      build_row_words(h, st, 8ull << 30, &h->d_row3, &h->row3_bytes, [&](int grid, unsigned long long *p) {
+#define CALL(W, L) k_row3_init<W, L><<<grid, kJThreads, 0, st>>>(h->dev, p)
+        FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
+      });
+    h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->r3_ready = true;
+  }
+  *out = static_cast<const unsigned long long *>(h->d_row3);
   return hipSuccess;
 }
 
 // The frontier's row table of a handle (nullptr: none), built at the first regex match: 8 n bytes.
-hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out) {
+hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build) {
   std::lock_guard<std::mutex> lk(h->r1_mu);
-  if (!h->r1_ready) {
+  if (!h->r1_ready && build) {
     const auto t0 = std::chrono::steady_clock::now();
     static const int forced = getenv("FMX_ROW1") ? atoi(getenv("FMX_ROW1")) : -1;      // 0 = off
-    size_t free_b = 0, total_b = 0;
-    const uint64_t bytes = h->n * 8;
-    if (forced != 0 && (g_jump_mode.load(std::memory_order_relaxed) & 1) && !h->block_mode && h->n >= 2 && h->nslots >= 1 &&
-        hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes + (4ull << 30) <= free_b) {
-      void *p = nullptr;
-      hipError_t e = hipMalloc(&p, bytes);
-      if (e == hipSuccess) {
-        const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
-        const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
-#define CALL(W, L) k_row1_init<W, L><<<grid, kJThreads, 0, st>>>(h->dev, (unsigned long long *)p)
+    if (forced != 0 && (g_jump_mode.load(std::memory_order_relaxed) & 1) && rows_eligible(h))
+      build_row_words(h, st, 4ull << 30, &h->d_row1, &h->row1_bytes, [&](int grid, unsigned long long *p) {
+#define CALL(W, L) k_row1_init<W, L><<<grid, kJThreads, 0, st>>>(h->dev, p)
         FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e == hipSuccess) { h->d_row1 = p; h->row1_bytes = bytes; }
-        else (void)hipFree(p);
-      }
-      if (e != hipSuccess) (void)hipGetLastError();      // no table: every element steps by rank query
-    }
+      });
     h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     h->r1_ready = true;
   }
@@ -209,35 +196,74 @@ hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **o
   return hipSuccess;
 }
 
-// The three-step row table of a handle (nullptr: none), built at the first literal search that wants it: 8 n bytes.
-hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out) {
-  std::lock_guard<std::mutex> lk(h->r3_mu);
-  if (!h->r3_ready) {
-    const auto t0 = std::chrono::steady_clock::now();
-    size_t free_b = 0, total_b = 0;
-    const uint64_t bytes = h->n * 8;
-    if ((g_jump_mode.load(std::memory_order_relaxed) & 4) && !h->block_mode && h->n >= 2 && h->nslots >= 1 &&
-        hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes + (8ull << 30) <= free_b) {
-      void *p = nullptr;
-      hipError_t e = hipMalloc(&p, bytes);
-      if (e == hipSuccess) {
-        const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
-        const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
-#define CALL(W, L) k_row3_init<W, L><<<grid, kJThreads, 0, st>>>(h->dev, (unsigned long long *)p)
-        FMX_LAYOUT_DISPATCH(h, CALL);
+// Called under h->jt_mu by jump_get.  Leaves h->d_jump null when the table is not wanted or does not fit.
+static hipError_t build_jump(const Index *h, hipStream_t st) {
+  static const int forced = getenv("FMX_JUMP") ? atoi(getenv("FMX_JUMP")) : -1;      // 0 = off, 1 = whenever it fits
+  if (forced == 0 || (forced < 0 && !(g_jump_mode.load(std::memory_order_relaxed) & 2))) return hipSuccess;
+  if (!rows_eligible(h)) return hipSuccess;
+  const uint64_t bytes = h->n * 16;
+  // the three-step table first: the search kernel uses it beside J, and J is built from it (two lookups instead of six
+  // of the eight rank queries per row)
+  const unsigned long long *r3 = nullptr;
+  (void)row3_get(h, st, &r3, true);
+  size_t free_b = 0, total_b = 0;
+  hipError_t e = hipMemGetInfo(&free_b, &total_b);
+  if (e != hipSuccess) return e;
+  // the table and a margin for the callers' batches (the dictionary, the k-mer table and R3 are resident already)
+  if (bytes + (8ull << 30) > free_b && !(forced == 1 && bytes + (1ull << 28) <= free_b)) return hipSuccess;
+  static const bool trace = getenv("FMX_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (trace) { (void)hipStreamSynchronize(st); fprintf(stderr, "[fmx] jump table %-12s +%.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+  };
+  void *a = nullptr;
+  e = hipMalloc(&a, bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no table, no error
+  mark("allocated");
+  {
+    const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
+    const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
+#define CALL(W, L) k_jump_build<W, L><<<grid, kJThreads, 0, st>>>(h->dev, r3, (uint4 *)a)
+    FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e == hipSuccess) { h->d_row3 = p; h->row3_bytes = bytes; }
-        else (void)hipFree(p);
-      }
-      if (e != hipSuccess) (void)hipGetLastError();      // no table: the lane groups walk every step
-    }
-    h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    h->r3_ready = true;
+    e = hipGetLastError();
   }
-  *out = static_cast<const unsigned long long *>(h->d_row3);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  mark(r3 ? "built (R3)" : "built (walk)");
+  if (e != hipSuccess) { (void)hipFree(a); return e; }
+  h->d_jump = a;
+  h->jump_bytes = bytes;
+  note_table_build(h, bytes);
   return hipSuccess;
+}
+
+// The jump table of a handle (nullptr: none yet / none at all).
+hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out, bool build) {
+  std::lock_guard<std::mutex> lk(h->jt_mu);
+  if (!h->jt_ready && build) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const double ms_before = h->tables_ms;
+    const hipError_t e = build_jump(h, st);
+    if (e != hipSuccess) { (void)hipGetLastError(); h->d_jump = nullptr; h->jump_bytes = 0; }      // searches walk every step
+    // (row3_get, called inside build_jump, has added its share already: the whole span counts once)
+    h->tables_ms = ms_before + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->jt_ready = true;
+  }
+  *out = static_cast<const uint4 *>(h->d_jump);
+  return hipSuccess;
+}
+
+// fmx_drop_tables: frees derived tables (the caller guarantees that no call is using the handle).  They are built
+// again by fmx_prepare or when the threshold is met anew.
+int drop_tables(Index *h, unsigned what) {
+  if (what & 4u) {
+    { std::lock_guard<std::mutex> lk(h->jt_mu); if (h->d_jump) (void)hipFree(h->d_jump); h->d_jump = nullptr; h->jump_bytes = 0; h->jt_ready = false; }
+    { std::lock_guard<std::mutex> lk(h->r3_mu); if (h->d_row3) (void)hipFree(h->d_row3); h->d_row3 = nullptr; h->row3_bytes = 0; h->r3_ready = false; }
+    { std::lock_guard<std::mutex> lk(h->r1_mu); if (h->d_row1) (void)hipFree(h->d_row1); h->d_row1 = nullptr; h->row1_bytes = 0; h->r1_ready = false; }
+    h->prepared.store(false, std::memory_order_relaxed);
+    h->patterns_seen.store(0, std::memory_order_relaxed);
+  }
+  return 0;
 }
 
 }  // namespace fmx

@@ -130,12 +130,18 @@ static hipError_t build_ktab(const Index *h, hipStream_t st) {
   h->kt.tab = h->kt.level[k - 1];
   h->kt.dense = static_cast<const uint8_t *>(d_dense);
   h->kt_bytes = all * 16 + 256;
+  note_table_build(h, h->kt_bytes);
   return hipSuccess;
 }
 
 // The table of a handle (k == 0: none), built on first use.
-hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out) {
+hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out, bool build) {
   std::lock_guard<std::mutex> lk(h->kt_mu);
+  if (!h->kt_ready && !build) {      // not yet: this search walks its first steps on the rank dictionary
+    *out = KTab{};
+    out->sigma = h->nslots;
+    return hipSuccess;
+  }
   if (!h->kt_ready) {
     const auto t0 = std::chrono::steady_clock::now();
     const hipError_t e = build_ktab(h, st);

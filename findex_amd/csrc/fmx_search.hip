@@ -746,8 +746,11 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
 static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
                              uint32_t k, hipStream_t st) {
+  // the row tables are built by fmx_prepare or by the search that brings the handle's patterns to the threshold
+  // (fmx_jump.hip, tables_due); until then -- a per-call adapter's single queries -- every step is walked on the dictionary
+  const bool due = tables_due(h, k, false);
   const uint4 *jt = nullptr;
-  hipError_t e = jump_get(h, st, &jt);
+  hipError_t e = jump_get(h, st, &jt, due);
   if (e != hipSuccess) return e;
   // With a row jump table the lane groups finish the one-row part themselves, eight steps per lookup, in lockstep
   // (C3: 0.240 ms; handing it to k_search_rows: 0.248 ms -- both run at ~37 G requests/s, and the hand-over costs two
@@ -757,12 +760,12 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
   static const int rows = getenv("FMX_ROWS") ? atoi(getenv("FMX_ROWS")) : -1;      // 0: never k_search_rows, 1: R1 (and J) whenever there is a row table
   if (rows == 1) {
     const unsigned long long *r1 = nullptr;
-    if ((e = row1_get(h, st, &r1)) != hipSuccess) return e;
+    if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
     if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, jt, r1, pat, off, sp, ep, k, st);
   }
   if (jt) {      // and the three-step table beside it, for the steps no aligned jump covers
     const unsigned long long *r3 = nullptr;
-    if (rows != 0 && (e = row3_get(h, st, &r3)) != hipSuccess) return e;
+    if (rows != 0 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
     return r3 ? launch_v4kj<WIDE, LAYOUT, KT, true, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st)
               : launch_v4kj<WIDE, LAYOUT, KT, true, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st);
   }
@@ -770,9 +773,9 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
     const unsigned long long *r3 = nullptr, *r1 = nullptr;
     bool have1;
     { std::lock_guard<std::mutex> lk(h->r1_mu); have1 = h->d_row1 != nullptr; }
-    if (!have1 && (e = row3_get(h, st, &r3)) != hipSuccess) return e;
+    if (!have1 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
     if (r3) return launch_v4kj<WIDE, LAYOUT, KT, false, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st);
-    if ((e = row1_get(h, st, &r1)) != hipSuccess) return e;
+    if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
     if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st);
   }
   return launch_v4kj<WIDE, LAYOUT, KT, false, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st);
@@ -782,7 +785,7 @@ template <bool WIDE, uint32_t LAYOUT>
 static hipError_t launch_v4(const Index *h, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
                             uint32_t k, hipStream_t st) {
   KTab kt;
-  const hipError_t e = ktab_get(h, st, &kt);
+  const hipError_t e = ktab_get(h, st, &kt, tables_due(h, k, true));
   if (e != hipSuccess) return e;
   // the search uses the table's levels in steps of four characters (all levels are kept: fmx_ktab.hip)
   if (kt.k >= 12) return launch_v4k<WIDE, LAYOUT, 12>(h, kt, pat, off, sp, ep, k, st);

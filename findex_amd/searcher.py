@@ -362,6 +362,10 @@ class HipFMSearcher:
         """fmx_prepare: build the k-mer jump table / the select directory / the row tables now instead of at first use."""
         _lib.check(self._L.fmx_prepare(self._h, (1 if ktab else 0) | (2 if select else 0) | (4 if jump else 0)))
 
+    def drop_tables(self):
+        """fmx_drop_tables: free the row jump table, the three-step row table and the row table."""
+        _lib.check(self._L.fmx_drop_tables(self._h, 4))
+
     # ---- statistics
     def stats(self):
         s = _lib.fmx_stats_t()

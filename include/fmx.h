@@ -73,7 +73,7 @@ int fmx_abi_version(void);
  * interval has narrowed to ONE ROW, where a backward step is a comparison with the text in front of that row's suffix:
  *   - the row jump table: per row the eight BWT characters an LF walk from it reads and the row it ends on, 16 n
  *     bytes -- eight steps of a literal search with one 16-byte lookup when the pattern's next eight characters match
- *     (built at a handle's first literal search when 32 n bytes + 8 GiB of HBM are free);
+ *     (built when 16 n bytes + 8 GiB of HBM are free -- one allocation: key "tables_after" says when);
  *   - the three-step row table: the same with three characters, 8 n bytes -- built instead where the jump table does
  *     not fit; the one-row part of every pattern is then walked by one lane per pattern;
  *   - the row table: BWT'[r] and LF r in 8 bytes per row -- the regex frontier steps its one-row elements with it
@@ -81,6 +81,13 @@ int fmx_abi_version(void);
  *     it, and no jump table, uses it like the three-step table.
  * "auto" builds what fits, at first use or in fmx_prepare; "jumps" / "rows3" / "rows" allow only the one; "off" none.
  * fmx_stats_t.jump_bytes, .row_bytes.  Results and executed-step counts are the same with and without them.
+ * key "tables_after": "auto" (default) / N: WHEN a handle's derived tables are built.  A table pays only for a caller that
+ * searches much: at C3 (n = 2^32) the row tables take ~1.5 s and 96 GiB and save 0.4 ms per million patterns.  So they are
+ * built by fmx_prepare, or by the search that brings the patterns the handle has been asked for to the threshold -- auto:
+ * n / 64 patterns (at least 65536) for the row tables, 1024 patterns for the k-mer table; N: that many for both (0: at the
+ * first search).  A per-call adapter's single queries never build one.  (The regex frontier builds the k-mer table and its
+ * row table at a handle's first match: a frontier is thousands of steps.)  fmx_stats_t.patterns_seen,
+ * .peak_table_build_bytes; fmx_drop_tables frees them again.
  * key "pipeline": "off" (default) / "on": fmx_search_batch with 128 k patterns or more in page-locked buffers cut into
  * chunks whose uploads, searches and downloads overlap on three streams, instead of whole arrays up, one search, whole
  * arrays down.  Same results; which is faster depends on how the platform's asynchronous copies compare with its
@@ -133,6 +140,10 @@ int fmx_close(fmx_index *idx);
  * fmx_stats_t.tables_build_ms. */
 enum { FMX_PREPARE_KTAB = 1, FMX_PREPARE_SELECT = 2, FMX_PREPARE_JUMP = 4 };
 int fmx_prepare(const fmx_index *idx, unsigned what);
+/* Frees the row tables again (what = FMX_PREPARE_JUMP: the row jump table, the three-step row table, the row table --
+ * 16 n + 8 n + 8 n bytes) and forgets the handle's pattern count, so that they come back only by fmx_prepare or when
+ * the threshold is met anew.  No other call may be using the handle. */
+int fmx_drop_tables(fmx_index *idx, unsigned what);
 
 /* ---- scalars: SuffixAlgo.n / cf, findex.scala:10-12; NaiveFMSearcher.cf bwtmerger.scala:346-352 */
 int fmx_n(const fmx_index *idx, uint64_t *n);
@@ -474,6 +485,9 @@ typedef struct fmx_stats_t {
   uint64_t row_lookups;         /* 8-byte row-table words fetched (one or three backward steps of a one-row interval each):
                                  * by the one-row part of fmx_search_batch[_dev] and by the regex frontier */
   uint64_t row_bytes;           /* device bytes of the row table and the three-step row table (0: none); part of index_bytes */
+  uint64_t peak_table_build_bytes;   /* most device memory one derived table's build held at once: since round 4 the table
+                                      * itself (the row jump table was built through a second buffer of its size before) */
+  uint64_t patterns_seen;       /* patterns this handle's literal searches have been asked for (what "tables_after" counts) */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 /* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */

@@ -23,3 +23,17 @@ def testdata():
 @pytest.fixture(scope="session")
 def golden():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def tables_at_first_search():
+    """The library builds a handle's derived tables only when they can pay (fmx_config_set("tables_after"): after
+    n / 64 patterns, or by fmx_prepare).  The parity tests search a few thousand patterns per handle and want every
+    table-served code path exercised, so for the test session the threshold is 0 -- tables at the first search, as in
+    round 3; test_tables_are_built_lazily sets "auto" itself."""
+    try:
+        import findex_amd
+        findex_amd.config_set("tables_after", "0")
+    except Exception:
+        pass            # no library built: the tests that need it fail on their own
+    yield

@@ -558,6 +558,62 @@ def test_prepare_builds_every_table_up_front():
     assert st2["jump_lookups"] > 0 and st2["row_lookups"] > 0
 
 
+def test_tables_are_built_lazily():
+    """The default policy ("tables_after" = auto): a handle's derived tables are built by fmx_prepare or by the search
+    that brings its patterns to the threshold -- 1024 for the k-mer table, max(65536, n / 64) for the row tables -- never
+    by a per-call adapter's single queries; fmx_drop_tables frees the row tables and resets the count; the row jump
+    table is built in ONE allocation (peak_table_build_bytes = its own size).  Answers are the oracle's throughout."""
+    import time
+    bwt, eof, counts = synth_bwt(2_000_000, 1, 20, 6)
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(8)
+    findex_amd.config_set("tables_after", "auto")
+    try:
+        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+        t0 = time.perf_counter()
+        assert hip.search(b"\x01\x02\x03") == orc.search(b"\x01\x02\x03")
+        dt = time.perf_counter() - t0
+        st = hip.stats()
+        assert st["jump_bytes"] == 0 and st["row_bytes"] == 0 and st["ktab_k"] == 0 and st["patterns_seen"] == 1
+        assert st["tables_build_ms"] == 0 and dt < 0.1
+        pats = lf_walk_patterns(orc, rng, 600, 30, 0.2, alphabet=list(range(1, 21)))
+        check_search(hip, orc, pats)                         # 601 patterns so far: still nothing
+        assert hip.stats()["ktab_k"] == 0
+        check_search(hip, orc, pats)                         # 1201: the k-mer table, not the row tables
+        st = hip.stats()
+        assert st["ktab_k"] > 0 and st["jump_bytes"] == 0 and st["row_bytes"] == 0
+        big = pats * 54                                       # 32400 patterns per call
+        check_search(hip, orc, big)
+        assert hip.stats()["jump_bytes"] == 0
+        check_search(hip, orc, big)                          # 66001 >= 65536: this search builds and uses them
+        st = hip.stats()
+        assert st["jump_bytes"] == 16 * orc.n and st["row_bytes"] == 8 * orc.n and st["jump_lookups"] > 0
+        assert st["peak_table_build_bytes"] == 16 * orc.n, "the row jump table is built in one allocation"
+        assert st["patterns_seen"] == 1 + 2 * 600 + 2 * 32400
+        hip.drop_tables()
+        st = hip.stats()
+        assert st["jump_bytes"] == 0 and st["row_bytes"] == 0 and st["patterns_seen"] == 0 and st["ktab_k"] > 0
+        check_search(hip, orc, pats)
+        assert hip.stats()["jump_bytes"] == 0
+        hip.prepare(ktab=False, jump=True)
+        assert hip.stats()["jump_bytes"] == 16 * orc.n
+        hip.stats_reset()
+        check_search(hip, orc, pats)
+        assert hip.stats()["jump_lookups"] > 0
+        hip.close()
+        # "jumps" alone: no three-step table to build from -- eight rank queries per row, same table
+        findex_amd.config_set("jump", "jumps")
+        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+        hip.prepare(ktab=True, jump=True)
+        st = hip.stats()
+        assert st["jump_bytes"] == 16 * orc.n and st["row_bytes"] == 0
+        check_search(hip, orc, pats)
+        hip.close()
+    finally:
+        findex_amd.config_set("tables_after", "0")
+        findex_amd.config_set("jump", "auto")
+
+
 def test_pipelined_host_batch_pageable_and_pinned():
     """Host-pointer batches of 128k patterns or more travel as whole arrays or, with the "pipeline" setting on and
     page-locked buffers, as chunks over three streams (fmx_api.cpp): ragged

@@ -35,6 +35,7 @@ n = 1 << log2n
 bwt, eof = bench.make_bwt(torch, n, sigma, seed, dev)
 torch.cuda.synchronize()
 hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=0, stream=stream)
+hip.prepare(ktab=True, jump=True)
 del bwt
 torch.cuda.empty_cache()
 

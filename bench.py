@@ -50,9 +50,12 @@ def survey_bytes_per_rank(sigma):
     return 128 if sigma <= 4 else 132
 
 
-# Ceiling of the memory system for dependent random 64-byte requests, measured with tools/ubench/chain.hip on
-# MI355X (16 chains per wave, full occupancy).  Quoted for HBM-resident workloads only.
-REQUEST_CEILING_G_PER_S = 53.0
+# Ceiling of the memory system for dependent random requests of the search kernel's own MIX (64-byte dictionary blocks,
+# 16-byte row-jump and k-mer entries, 8-byte row words, from four tables of 177 GiB), measured with tools/ubench/mix.hip on
+# MI355X: 46.5 G requests/s for every kind and every mix (profiles/r04_ubench_mix.txt; chain.hip, whose chains carry
+# less arithmetic, reaches 51-54 on one table).  What the memory system counts is cache-line requests that miss the
+# CU's L1 / translation cache, whatever they ask for (profiles/r04_c3_bound.md).  Quoted for HBM-resident workloads only.
+REQUEST_CEILING_G_PER_S = 46.5
 INFINITY_CACHE_BYTES = 256 << 20
 
 LITERAL = {
@@ -68,6 +71,16 @@ REGEX = {
     "c4tiny": (22, 5_000, 4, 64, False),
     "c4ref": (30, 100_000, 4, 0, True),
     "c4reftiny": (22, 5_000, 4, 0, True),
+}
+# The same two shapes over the BWT of a TEXT with natural repeats (tools/text_bwt.py: words.txt's words drawn with
+# replacement, index over the reversed text like findex's) -- beside the i.i.d. inputs SURVEY 8d prescribes, which are the
+# best case for the derived tables and have LF cycles no text has.  Never the headline.
+TEXT = {
+    # name: (log2 n, patterns or regexes per GPU, pattern length / max match length (0: none), seed#)
+    "c3text": (30, 1_000_000, 32, 13),
+    "c4text": (30, 100_000, 0, 14),
+    "c3texttiny": (20, 50_000, 32, 13),
+    "c4texttiny": (20, 3_000, 0, 14),
 }
 REF_LIMITS = (1024, 1000)      # ReTree.matchSA's defaults, re2/retree.scala:570
 C4_ALPHABET = "abcdefghijklmnopqrstuvwxyz \n"
@@ -204,6 +217,20 @@ def make_bwt(torch, n, symbols, seed, device):
     return bwt, n // 3
 
 
+def make_text_bwt(torch, n, seed, device, rank=0):
+    """BWT of a seeded natural-language-like text of n - 1 bytes (tools/text_bwt.py), suffix-sorted on the device."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import text_bwt
+    t0 = time.time()
+    text = text_bwt.make_text(torch, n - 1, seed, device)
+    bwt, eof = text_bwt.bwt_of_reversed_text(torch, text, lambda m: log(rank, m))
+    sample = text[: min(n - 1, 1 << 24)].cpu().numpy()          # a stretch of the text: where the regex workload takes its literals
+    del text
+    torch.cuda.empty_cache()
+    log(rank, "text: %d bytes, BWT by prefix doubling in %.1fs; begins %r" % (n - 1, time.time() - t0, sample[:60].tobytes()))
+    return bwt, eof, sample
+
+
 def make_patterns(torch, hip, n, sigma, k, m, seed, device, stream):
     """90 % hit patterns by LF walk (every backward step keeps a non-empty interval), 10 % with one byte
     replaced (early-exit path), SURVEY 8d.  Generated on the device with the library's own LF-walk kernel;
@@ -218,17 +245,22 @@ def make_patterns(torch, hip, n, sigma, k, m, seed, device, stream):
     pats = torch.flip(walk, dims=[1]).contiguous()
     mut = torch.rand(k, generator=g, device=device) < 0.10
     pos = torch.randint(0, m, (k,), generator=g, device=device)
-    sym = torch.randint(1, sigma + 1, (k,), generator=g, device=device, dtype=torch.uint8)
+    if isinstance(sigma, int):
+        sym = torch.randint(1, sigma + 1, (k,), generator=g, device=device, dtype=torch.uint8)
+    else:       # a string: the alphabet's characters
+        alpha = torch.tensor([ord(c) for c in sigma], dtype=torch.uint8, device=device)
+        sym = alpha[torch.randint(0, alpha.numel(), (k,), generator=g, device=device)]
     idx = torch.nonzero(mut).squeeze(1)
     pats[idx, pos[idx]] = sym[idx]
     off = torch.arange(0, (k + 1) * m, m, dtype=torch.int64, device=device)
     return pats.reshape(-1), off
 
 
-def make_regexes(k, seed):
+def make_regexes(k, seed, text_sample=None):
     """The seeded C4 grammar (tools/regex_workload.py); only shapes the reference's ReTree.apply accepts are kept:
     the candidate stream is compiled in chunks with fmx_regex_compile_batch and the first k that compile are the
-    batch (the same list tools/regex_workload.generate draws one by one).
+    batch (the same list tools/regex_workload.generate draws one by one).  text_sample (the text workloads): a
+    regex's literal characters are a stretch of that text instead of random letters, so that it has matches.
     Returns (regex strings, CompiledRegexes holding their handles)."""
     import random
     import findex_amd
@@ -236,8 +268,16 @@ def make_regexes(k, seed):
     import regex_workload
     rng = random.Random(seed)
     res, sets = [], []
+    literal = None
+    if text_sample is not None:
+        def literal(r, nlit):
+            while True:
+                a = r.randrange(0, text_sample.size - nlit)
+                w = text_sample[a:a + nlit].tobytes().decode("latin-1")
+                if w[0] not in " \n":              # (the grammar's extras are inserted behind the first character)
+                    return w
     while len(res) < k:
-        cand = [regex_workload.gen_one(rng) for _ in range(k - len(res) + 64)]
+        cand = [regex_workload.gen_one(rng, literal=literal) for _ in range(k - len(res) + 64)]
         cs = findex_amd.ReTree.compile_batch(cand)
         ok = np.nonzero(cs.ok())[0][: k - len(res)]
         res += [cand[i] for i in ok]
@@ -511,16 +551,25 @@ def measure_host_path(torch, hip, pats, off, sp_dev, ep_dev, k, m, reps=5):
 
 # ---------------------------------------------------------------- the two kinds of workload
 def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream):
-    log2n, sigma, k, m, seed = LITERAL[args.workload]
+    is_text = args.workload in TEXT
+    if is_text:
+        log2n, k, m, seed = TEXT[args.workload]
+        sigma = C4_ALPHABET
+    else:
+        log2n, sigma, k, m, seed = LITERAL[args.workload]
     n = 1 << log2n
     t0 = time.time()
-    bwt, eof = make_bwt(torch, n, sigma, seed, device)          # same seed on every rank: replicas
+    if is_text:
+        bwt, eof, _ = make_text_bwt(torch, n, seed, device, rank)
+    else:
+        bwt, eof = make_bwt(torch, n, sigma, seed, device)          # same seed on every rank: replicas
     torch.cuda.synchronize()
     hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=local, stream=stream)
     hip.prepare(ktab=True, jump=True)      # a serving handle: its derived tables up front (tables_build_ms), not at the threshold
     st = hip.stats()
+    n_sigma = sigma if isinstance(sigma, int) else len(sigma)
     log(rank, "index: n=2^%d sigma=%d, %.1f GiB in HBM (%d symbols x %d blocks x %d B), built in %.1f ms (+%.1fs setup)"
-        % (log2n, sigma, st["index_bytes"] / 2**30, st["n_symbols"], st["n_blocks"], st["block_bytes"],
+        % (log2n, n_sigma, st["index_bytes"] / 2**30, st["n_symbols"], st["n_blocks"], st["block_bytes"],
            st["build_ms"], time.time() - t0))
     want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline
     if not want_cpu:
@@ -628,15 +677,15 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "rank_queries_per_request": ranks_per_step / max(all_requests, 1),
         # SURVEY 8d's own pricing (its structure fetches 128/132 B per rank query; this layout does not): reported
         # for comparison only, it is not a fraction of anything
-        "survey_equiv_GBps": ranks_per_step * survey_bytes_per_rank(sigma) / ksec / 1e9,
+        "survey_equiv_GBps": ranks_per_step * survey_bytes_per_rank(n_sigma) / ksec / 1e9,
         "index_resident_in": resident,
     }
     if resident == "hbm":
         # the limit that binds this access pattern: distinct dependent memory requests per second
         roof["requests_G_per_s"] = all_requests / ksec / 1e9
         roof["request_ceiling_G_per_s"] = REQUEST_CEILING_G_PER_S
-        roof["request_ceiling_source"] = ("tools/ubench/chain.hip (dependent 64-byte requests, 16 chains per wave, full occupancy): "
-                                          "profiles/r02_ubench_chain_sizes.txt -- 54 G/s over 8 GiB, 51 G/s over a 77 GiB table")
+        roof["request_ceiling_source"] = ("tools/ubench/mix.hip (dependent chains with this kernel's mix of 64 / 16 / 8-byte requests over "
+                                          "four tables of 177 GiB, 16 chains per wave): profiles/r04_ubench_mix.txt, profiles/r04_c3_bound.md")
         roof["request_frac"] = roof["requests_G_per_s"] / REQUEST_CEILING_G_PER_S
     else:
         roof["note"] = ("the rank dictionary (%.0f MB) stays in the 256 MiB Infinity Cache: bytes are served on die, the "
@@ -654,13 +703,14 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u64",
-        "data": "synthetic",
+        "data": "synthetic" if not is_text else "synthetic text with natural repeats (words.txt's words drawn with replacement), its true BWT",
         "patterns_per_sec": world * k * args.steps / dt,
         "exchange": exchange,
         "config": {
-            "workload": "%s: %d x %d-char literal patterns per GPU, 2^%d-byte sigma=%d synthetic BWT resident "
-                        "in HBM (rank dictionary replicated per GPU)" % (args.workload.upper(), k, m, log2n, sigma),
-            "n": n, "sigma": sigma, "patterns_per_gpu": k, "pattern_len": m,
+            "workload": "%s: %d x %d-char literal patterns per GPU, 2^%d-byte sigma=%d %s resident "
+                        "in HBM (rank dictionary replicated per GPU)"
+                        % (args.workload.upper(), k, m, log2n, n_sigma, "BWT of a text with natural repeats" if is_text else "synthetic BWT"),
+            "n": n, "sigma": n_sigma, "patterns_per_gpu": k, "pattern_len": m,
             "hit_patterns_fraction": hits_all / (world * k),
             "rank_queries_per_step": ranks_all,
             "rank_queries_are": "occ evaluations of the reference's loop on these inputs (2 per backward step, early "
@@ -716,10 +766,19 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
 
 
 def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream):
-    log2n, k, seed, max_len, ref_mode = REGEX[args.workload]
+    is_text = args.workload in TEXT
+    text_sample = None
+    if is_text:
+        log2n, k, max_len, seed = TEXT[args.workload]
+        ref_mode = False
+    else:
+        log2n, k, seed, max_len, ref_mode = REGEX[args.workload]
     n = 1 << log2n
     t0 = time.time()
-    bwt, eof = make_bwt(torch, n, C4_ALPHABET, seed, device)
+    if is_text:
+        bwt, eof, text_sample = make_text_bwt(torch, n, seed, device, rank)
+    else:
+        bwt, eof = make_bwt(torch, n, C4_ALPHABET, seed, device)
     torch.cuda.synchronize()
     hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=local, stream=stream)
     st = hip.stats()
@@ -730,7 +789,7 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         del bwt
         torch.cuda.empty_cache()
     t0 = time.time()
-    res, trees = make_regexes(k, seed * 1000 + rank)           # weak scaling: every rank its own k regexes
+    res, trees = make_regexes(k, seed * 1000 + rank, text_sample)           # weak scaling: every rank its own k regexes
     t_gen = time.time() - t0
     cap = 1 << 22
     lim = dict(mode="reference", maxBranching=REF_LIMITS[0], maxIterations=REF_LIMITS[1]) if ref_mode else dict(max_steps=max_len)
@@ -882,12 +941,14 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
             "rank_queries_per_launch": ranks_per_step,
             "requests_G_per_s": all_req / ksec / 1e9,
             "request_ceiling_G_per_s": REQUEST_CEILING_G_PER_S,
-            "request_ceiling_source": "tools/ubench/chain.hip, profiles/r02_ubench_chain_sizes.txt",
+            "request_ceiling_source": "tools/ubench/mix.hip, profiles/r04_ubench_mix.txt",
             "request_frac": all_req / ksec / 1e9 / REQUEST_CEILING_G_PER_S,
             "device_rank_queries_G_per_s": ranks_per_step / ksec / 1e9,
-            "note": "the synthetic BWT is an i.i.d. string, not the BWT of a text: a handful of starred classes sit on LF "
-                    "cycles and never die, so the launch's critical path is %d dependent rounds cut by max_match_len "
-                    "(truncated_at_max_len); on a real text a frontier dies by itself" % max_len,
+            "note": ("the index is the BWT of a text: every frontier dies by itself, no match length limit is set"
+                     if is_text else
+                     "the synthetic BWT is an i.i.d. string, not the BWT of a text: a handful of starred classes sit on LF "
+                     "cycles and never die, so the launch's critical path is %d dependent rounds cut by max_match_len "
+                     "(truncated_at_max_len); on a real text a frontier dies by itself (workload c4text)" % max_len),
         }
     roof["traffic"] = traffic[0] if traffic else None
     roof["traffic_source"] = (traffic[1] if traffic and traffic[0] is None else
@@ -905,15 +966,16 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u64",
-        "data": "synthetic",
+        "data": "synthetic" if not is_text else "synthetic text with natural repeats (words.txt's words drawn with replacement), its true BWT; regex literals are stretches of the text",
         "regexes_per_sec": world * k * args.steps / dt,
         "regexes_per_sec_is": "a RESIDENT batch (compiled and on the device) matched again and again; a batch given as "
                               "strings and matched once runs at fresh_batch.regexes_per_s",
         "fresh_batch": fresh_batch,
         "host_delivered": host_delivered,
         "config": {
-            "workload": ("%s: %d seeded regexes (<= 32 Glushkov positions) per GPU, 2^%d-byte sigma=%d synthetic BWT "
-                         "resident in HBM, " % (args.workload.upper(), k, log2n, len(C4_ALPHABET))) +
+            "workload": ("%s: %d seeded regexes (<= 32 Glushkov positions) per GPU, 2^%d-byte sigma=%d %s "
+                         "resident in HBM, " % (args.workload.upper(), k, log2n, len(C4_ALPHABET),
+                                                "BWT of a text with natural repeats" if is_text else "synthetic BWT")) +
                         ("ReTree.matchSA in the reference's own pop order under its default limits (maxBranching %d, "
                          "maxIterations %d), result lists delivered to the host" % REF_LIMITS if ref_mode else
                          "SA-interval frontier expansion, results (grouped by regex, ordered) left in HBM"),
@@ -946,7 +1008,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=sorted(LITERAL) + sorted(REGEX))
+    ap.add_argument("--workload", default="c3", choices=sorted(LITERAL) + sorted(REGEX) + sorted(TEXT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive sub-record of the literal workloads")
     ap.add_argument("--exchange", default="packed", choices=["packed", "pairs"],
@@ -983,7 +1045,7 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=device)
     stream = torch.cuda.current_stream().cuda_stream
-    run = run_regex if args.workload in REGEX else run_literal
+    run = run_regex if (args.workload in REGEX or args.workload.startswith("c4text")) else run_literal
     out = run(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -402,10 +402,11 @@ JNIEXPORT jint JNICALL FN(calcGapsChain0)(JNIEnv *e, jobject self, jlong h, jbyt
   return (jint)done;
 }
 
-/* fmx_prepare: build the k-mer jump table (what & 1) / the select directory (what & 2) / the row tables (what & 4) now, not at first use */
+/* fmx_prepare: build the k-mer jump table (what & 1) / the select directory (what & 2) / the literal search's row tables (what & 4) /
+ * the regex frontier's row table (what & 8) now, not at the threshold or at first use */
 JNIEXPORT void JNICALL FN(prepare0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_prepare(H(h), (unsigned)what)); }
 
-/* fmx_drop_tables: free the row tables again (what & 4) */
+/* fmx_drop_tables: free the row tables again (what & 4: J and R3, what & 8: the frontier's) */
 JNIEXPORT void JNICALL FN(dropTables0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_drop_tables(H(h), (unsigned)what)); }
 
 /* fmx_config_set: process-wide settings ("layout", "checkpoints", "ktab", "jump", "tables_after", "pipeline", "validate", "threads") */

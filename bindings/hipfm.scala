@@ -170,9 +170,9 @@ class HipFMSearcher(filename: String, bigEndian: Boolean = true, device: Int = 0
   def searchBatchPackedDirect(pat: ByteBuffer, len: Int, out: ByteBuffer, k: Long, escapeCap: Long): Unit =
     searchBatchPackedDirect0(h, pat, len, out, k, escapeCap)
 
-  /** Build the derived tables now (fmx_prepare: 1 = k-mer table, 2 = select directory, 4 = row tables) / free the row tables. */
+  /** Build the derived tables now (fmx_prepare: 1 = k-mer table, 2 = select directory, 4 = the literal search's row tables, 8 = the regex frontier's) / free the row tables. */
   def prepare(what: Int): Unit = prepare0(h, what)
-  def dropTables(): Unit = dropTables0(h, 4)
+  def dropTables(): Unit = dropTables0(h, 4 | 8)
 }
 
 object HipFMSearcher {

@@ -589,7 +589,7 @@ int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[2
 
 int fmx_prepare(const fmx_index *idx, unsigned what) {
   if (!idx) return arg_fail("null argument");
-  if (what & ~(unsigned)(FMX_PREPARE_KTAB | FMX_PREPARE_SELECT | FMX_PREPARE_JUMP)) return arg_fail("unknown fmx_prepare flag");
+  if (what & ~(unsigned)(FMX_PREPARE_KTAB | FMX_PREPARE_SELECT | FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER)) return arg_fail("unknown fmx_prepare flag");
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
@@ -605,8 +605,11 @@ int fmx_prepare(const fmx_index *idx, unsigned what) {
     h->prepared.store(true, std::memory_order_relaxed);      // from now on searches use (and may build) the row tables
     const uint4 *jt = nullptr;
     HIP_TRY(jump_get(h, lease.c->stream, &jt), "jump table");
-    const unsigned long long *r1 = nullptr, *r3 = nullptr;
+    const unsigned long long *r3 = nullptr;
     HIP_TRY(row3_get(h, lease.c->stream, &r3), "three-step row table");      // beside the jump table, or instead of it
+  }
+  if (what & FMX_PREPARE_FRONTIER) {
+    const unsigned long long *r1 = nullptr;
     HIP_TRY(row1_get(h, lease.c->stream, &r1), "row table");
   }
   return FMX_OK;
@@ -614,7 +617,7 @@ int fmx_prepare(const fmx_index *idx, unsigned what) {
 
 int fmx_drop_tables(fmx_index *idx, unsigned what) {
   if (!idx) return arg_fail("null argument");
-  if (what & ~(unsigned)FMX_PREPARE_JUMP) return arg_fail("fmx_drop_tables frees the row tables only (FMX_PREPARE_JUMP)");
+  if (!what || (what & ~(unsigned)(FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER))) return arg_fail("fmx_drop_tables frees the row tables only (FMX_PREPARE_JUMP, FMX_PREPARE_FRONTIER)");
   Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;

@@ -259,9 +259,13 @@ int drop_tables(Index *h, unsigned what) {
   if (what & 4u) {
     { std::lock_guard<std::mutex> lk(h->jt_mu); if (h->d_jump) (void)hipFree(h->d_jump); h->d_jump = nullptr; h->jump_bytes = 0; h->jt_ready = false; }
     { std::lock_guard<std::mutex> lk(h->r3_mu); if (h->d_row3) (void)hipFree(h->d_row3); h->d_row3 = nullptr; h->row3_bytes = 0; h->r3_ready = false; }
-    { std::lock_guard<std::mutex> lk(h->r1_mu); if (h->d_row1) (void)hipFree(h->d_row1); h->d_row1 = nullptr; h->row1_bytes = 0; h->r1_ready = false; }
     h->prepared.store(false, std::memory_order_relaxed);
     h->patterns_seen.store(0, std::memory_order_relaxed);
+  }
+  if (what & 8u) {
+    std::lock_guard<std::mutex> lk(h->r1_mu);
+    if (h->d_row1) (void)hipFree(h->d_row1);
+    h->d_row1 = nullptr; h->row1_bytes = 0; h->r1_ready = false;
   }
   return 0;
 }

@@ -358,13 +358,14 @@ class HipFMSearcher:
                                                _ptr(ranks), ctypes.byref(done)))
         return ranks[: text.size], int(done.value)
 
-    def prepare(self, ktab=True, select=False, jump=False):
-        """fmx_prepare: build the k-mer jump table / the select directory / the row tables now instead of at first use."""
-        _lib.check(self._L.fmx_prepare(self._h, (1 if ktab else 0) | (2 if select else 0) | (4 if jump else 0)))
+    def prepare(self, ktab=True, select=False, jump=False, frontier=False):
+        """fmx_prepare: build the k-mer jump table / the select directory / the literal search's row tables (J, R3) / the
+        regex frontier's row table now instead of at the threshold or at first use."""
+        _lib.check(self._L.fmx_prepare(self._h, (1 if ktab else 0) | (2 if select else 0) | (4 if jump else 0) | (8 if frontier else 0)))
 
-    def drop_tables(self):
-        """fmx_drop_tables: free the row jump table, the three-step row table and the row table."""
-        _lib.check(self._L.fmx_drop_tables(self._h, 4))
+    def drop_tables(self, jump=True, frontier=True):
+        """fmx_drop_tables: free the row jump table and the three-step row table / the frontier's row table."""
+        _lib.check(self._L.fmx_drop_tables(self._h, (4 if jump else 0) | (8 if frontier else 0)))
 
     # ---- statistics
     def stats(self):

@@ -131,17 +131,19 @@ int fmx_open_dev(const void *d_bwt, uint64_t n, uint64_t eof, const int64_t *cou
 int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[256], uint64_t rk0, int device,
                    fmx_index **out);
 int fmx_close(fmx_index *idx);
-/* Builds now what a handle otherwise builds at first use -- FMX_PREPARE_KTAB: the k-mer jump table (first search or
- * regex match; up to min(16 GiB, a quarter of the free HBM)), FMX_PREPARE_SELECT: the select directory (first Psi /
- * nextSubstr; at most ~n bytes), FMX_PREPARE_JUMP: the row table and the row jump table (first literal search / regex
- * match; 8 n + 16 n bytes, the latter twice while it is built; each skipped when that much HBM is not free) -- so that no later call allocates device memory or synchronises a stream: for a
- * caller that captures its stream, or that times its first search.  A table that cannot be built (no memory) is
- * left out: searches then walk every step on the rank dictionary, with the same results.  The time spent is reported as
- * fmx_stats_t.tables_build_ms. */
-enum { FMX_PREPARE_KTAB = 1, FMX_PREPARE_SELECT = 2, FMX_PREPARE_JUMP = 4 };
+/* Builds now what a handle otherwise builds when its searches reach the "tables_after" threshold (literal search) or
+ * at first use (Psi, regex match) -- FMX_PREPARE_KTAB: the k-mer jump table (up to min(16 GiB, a quarter of the free
+ * HBM)); FMX_PREPARE_SELECT: the select directory (first Psi / nextSubstr; at most ~n bytes); FMX_PREPARE_JUMP: the
+ * tables of the literal search's one-row part -- the three-step row table and the row jump table (8 n + 16 n bytes, one
+ * allocation each; each skipped when that much HBM is not free); FMX_PREPARE_FRONTIER: the regex frontier's row table
+ * (8 n bytes, otherwise built at the first regex match) -- so that no later call allocates device memory or synchronises
+ * a stream: for a caller that captures its stream, or that times its first search.  A table that cannot be built (no
+ * memory) is left out: searches then walk every step on the rank dictionary, with the same results.  The time spent is
+ * reported as fmx_stats_t.tables_build_ms. */
+enum { FMX_PREPARE_KTAB = 1, FMX_PREPARE_SELECT = 2, FMX_PREPARE_JUMP = 4, FMX_PREPARE_FRONTIER = 8 };
 int fmx_prepare(const fmx_index *idx, unsigned what);
-/* Frees the row tables again (what = FMX_PREPARE_JUMP: the row jump table, the three-step row table, the row table --
- * 16 n + 8 n + 8 n bytes) and forgets the handle's pattern count, so that they come back only by fmx_prepare or when
+/* Frees the row tables again (what = FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER in any combination: the row jump table and
+ * the three-step row table, 16 n + 8 n bytes / the frontier's row table, 8 n bytes) and forgets the handle's pattern count, so that they come back only by fmx_prepare or when
  * the threshold is met anew.  No other call may be using the handle. */
 int fmx_drop_tables(fmx_index *idx, unsigned what);
 

@@ -46,6 +46,25 @@ def check_search(hip, orc, pats):
     return int((wsp < wep).sum())
 
 
+def reference_loop_by_prev_range(hip, pats2d):
+    """SuffixAlgo.search (findex.scala:15-31) restated over fmx_prev_range_batch -- K4, one plain getPrevRange per
+    pattern and step, no derived table -- for k equal-length patterns: (sp, ep, steps) of the reference's loop.  K4 is
+    verified against the oracle up to 2^32 rows and against brute-force prefix counts above, so this is the at-size
+    check for what the table-served search kernels return where the oracle's 32-bit lists cannot follow."""
+    k, m = pats2d.shape
+    sp = np.zeros(k, dtype=np.uint64)
+    ep = np.full(k, hip.n, dtype=np.uint64)
+    steps = np.zeros(k, dtype=np.int64)
+    for i in range(m - 1, -1, -1):
+        act = np.nonzero(sp < ep)[0]
+        if act.size == 0:
+            break
+        a, b = hip.prev_range_batch(sp[act], ep[act], pats2d[act, i])
+        sp[act], ep[act] = a, b
+        steps[act] += 1
+    return sp, ep, steps
+
+
 # ---------------------------------------------------------------- reference fixtures
 @pytest.mark.parametrize("name,be", FIXTURES)
 def test_fixture_files_occ_search_step(testdata, name, be):
@@ -542,7 +561,7 @@ def test_prepare_builds_every_table_up_front():
     hip, orc = pair_from_mem(bwt, eof, counts)
     st0 = hip.stats()
     assert st0["jump_bytes"] == 0 and st0["row_bytes"] == 0 and st0["ktab_k"] == 0
-    hip.prepare(ktab=True, select=True, jump=True)
+    hip.prepare(ktab=True, select=True, jump=True, frontier=True)
     st1 = hip.stats()
     assert st1["ktab_k"] > 0 and st1["jump_bytes"] == 16 * orc.n and st1["row_bytes"] == 16 * orc.n      # R3 + R1: 8 n each
     assert st1["tables_build_ms"] > 0
@@ -1287,7 +1306,7 @@ def test_allgather_dev_rccl_in_the_library(monkeypatch):
     _lib.check(L.fmx_gather_dev(comm, pp_, pr_, 8 * pw, root, st_))       # the packed form, delivered to the root only
     got = precvs[root].cpu().numpy().astype(np.uint64).reshape(ndev, pw)
     for r in range(ndev):
-        assert np.array_equal(got[r], pack_intervals_np(wsp[r * k:(r + 1) * k], wep[r * k:(r + 1) * k], 8))
+        assert np.array_equal(got[r][:k + 1], pack_intervals_np(wsp[r * k:(r + 1) * k], wep[r * k:(r + 1) * k], 8)[:k + 1])      # (no escapes: the list's slots are not written)
         usp, uep = hips[0].unpack_intervals(got[r], k, 8)
         assert np.array_equal(usp, wsp[r * k:(r + 1) * k]) and np.array_equal(uep, wep[r * k:(r + 1) * k])
     for d in range(ndev):
@@ -1573,6 +1592,17 @@ def test_bytes_layout_c5_shape(checkpoints):
     bad[np.arange(50_000), rng.integers(0, m, 50_000)] = 200
     bsp, bep = hip.search_batch(bad.reshape(-1), off[:50_001])
     assert (bsp == bep).all()
+    # misses INSIDE the alphabet: the failing step is a rank query on rows past 2^32 (k_search_rows<2> parks the pattern,
+    # k_search_defer<true, bytes> finds the reference loop's (sp, ep) there) -- values and step counts against the loop
+    # restated over getPrevRange
+    inalpha = pats[:100_000].copy()
+    inalpha[np.arange(100_000), rng.integers(0, m, 100_000)] = rng.integers(1, 129, 100_000).astype(np.uint8)
+    hip.stats_reset()
+    isp, iep = hip.search_batch(inalpha.reshape(-1), off[:100_001])
+    isteps = hip.stats()["backward_steps"]
+    wsp, wep, wsteps = reference_loop_by_prev_range(hip, inalpha)
+    assert np.array_equal(isp, wsp) and np.array_equal(iep, wep) and isteps == int(wsteps.sum())
+    assert int((wsp == wep).sum()) > 90_000 and int((wsp[wsp == wep] > np.uint64(1 << 32)).sum()) > 50_000
     # the same patterns cut into ragged pieces: a prefix of a hit pattern hits an interval that contains the full hit
     cut = rng.integers(1, m + 1, 100_000)
     pieces = [pats[j, :cut[j]].tobytes() for j in range(100_000)]
@@ -1688,6 +1718,18 @@ def test_full_size_properties(log2n, extra, sigma):
         w1, w2 = orc.prev_range_batch(a_sp, a_ep, qc)
         assert np.array_equal(g1, w1) and np.array_equal(g2, w2)
         orc.close()
+    # hits and in-alphabet misses (one byte replaced), (sp, ep) and executed steps against the reference loop restated
+    # over getPrevRange calls -- the value check that still works where the oracle's 32-bit lists stop (n > 2^32)
+    kk = min(k, 100_000)
+    mixed = pats[:kk].copy()
+    mut = rng.random(kk) < 0.5
+    mixed[mut, rng.integers(0, m, int(mut.sum()))] = rng.integers(1, sigma + 1, int(mut.sum())).astype(np.uint8)
+    hip.stats_reset()
+    msp, mep = hip.search_batch(mixed.reshape(-1), np.arange(kk + 1, dtype=np.uint64) * m)
+    msteps = hip.stats()["backward_steps"]
+    wsp, wep, wsteps = reference_loop_by_prev_range(hip, mixed)
+    assert np.array_equal(msp, wsp) and np.array_equal(mep, wep) and msteps == int(wsteps.sum())
+    assert 0 < int((wsp == wep).sum()) < kk
     # partition property of one step
     for a, bnd in ((0, n), (int(sp[0]), int(ep[0])), (n // 2, n // 2 + 100000)):
         parts = hip.getIntervalPrevRange(a, bnd, 0, 255)
@@ -1929,3 +1971,69 @@ def test_search_ex_fixed_length_and_packed_forms():
     with pytest.raises(OverflowError):
         unpack_intervals_np(pk, k, 7)
     hip.close()
+
+
+def test_text_index_parity_literals_and_regexes():
+    """An index over a TEXT with natural repeats (tools/text_bwt.py: words drawn with replacement, suffix-sorted on the
+    device, reversed like findex's) -- where intervals stay wide for many characters and no frontier needs a length
+    cap: the generator's BWT equals the naive sort's on a small text; on 2^20 bytes, literal patterns (stretches of the
+    text, a fifth of them with one byte replaced; ragged lengths) and the text workload's regexes (literals cut from
+    the text) against the oracle, bit for bit, steps counted, no truncation."""
+    import random
+    import sys
+    torch = _torch()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import regex_workload
+    import text_bwt
+    dev = torch.device("cuda", 0)
+    small = text_bwt.make_text(torch, 3000, 5, dev)
+    sb, se = text_bwt.bwt_of_reversed_text(torch, small)
+    wb, we, _ = bwt_of_text(small.cpu().numpy()[::-1].tobytes())
+    assert se == we and np.array_equal(sb.cpu().numpy(), wb)
+    n = 1 << 20
+    text = text_bwt.make_text(torch, n - 1, 7, dev)
+    d_bwt, eof = text_bwt.bwt_of_reversed_text(torch, text)
+    bwt = d_bwt.cpu().numpy()
+    h_text = text.cpu().numpy()
+    counts = np.bincount(h_text, minlength=256).astype(np.int64)
+    hip, orc = pair_from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(17)
+    alpha = [c for c in range(256) if counts[c]]
+    pats = []
+    for m in (1, 2, 3, 5, 8, 13, 21, 32, 47, 80):
+        for a in rng.integers(0, n - 1 - m, 400):
+            p = bytearray(h_text[a:a + m].tobytes())
+            if rng.random() < 0.2:
+                p[int(rng.integers(0, m))] = int(rng.choice(alpha))
+            pats.append(bytes(p))
+    pats = [pats[i] for i in rng.permutation(len(pats))]
+    hits = check_search(hip, orc, pats)
+    assert hits > 3000
+    assert hip.search(h_text[1000:1012].tobytes()) is not None      # a stretch of the text is found reading forward
+    st = hip.stats()
+    assert st["jump_lookups"] > 0 and st["row_lookups"] > 0
+    prng = random.Random(3)
+
+    def literal(r, nlit):
+        while True:
+            a = r.randrange(0, h_text.size - nlit)
+            w = h_text[a:a + nlit].tobytes().decode("latin-1")
+            if w[0] not in " \n":
+                return w
+    res = []
+    while len(res) < 400:
+        re_ = regex_workload.gen_one(prng, literal=literal)
+        try:
+            R.ReTree(R.re2post(re_)).tables()
+            res.append(re_)
+        except (R.MatchError, R.Re2PostSyntax):
+            pass
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(r_)) for r_ in res]
+    batch = findex_amd.ReTree.prepare_batch(hip, trees)
+    got, _ = batch.match_raw(cap=1 << 20)
+    assert not batch.truncated                                      # the frontier died by itself
+    want, pops, trunc = orc.match_tables_batch([R.ReTree(R.re2post(r_)).tables() for r_ in res])
+    assert got.size == want.size and got.size > 400
+    for f in ("regex", "len", "sp", "ep"):
+        assert np.array_equal(got[f], want[f]), f

@@ -64,6 +64,30 @@ except Exception as e:
     print("no result:", e)
 PY
   ;;
+trace:*)
+  wl=${PART#trace:}
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/trace_$wl -- python3 $REPO/bench.py --workload $wl --no-cpu-baseline --no-host-path > $REPO/$O/${wl}_bench_under_rocprof.json 2> $REPO/$O/${wl}_bench_under_rocprof.err); echo "rocprof bench $wl exit $?"
+  python - $O $wl <<'PY'
+import csv,glob,sys
+O,wl=sys.argv[1],sys.argv[2]
+rows=[]
+for f in glob.glob("%s/trace_%s/*/*_kernel_stats.csv"%(O,wl)):
+    for r in csv.DictReader(open(f)):
+        if "fmx::" in r["Name"]: rows.append(r)
+with open("%s/%s_bench_kernel_stats.csv"%(O,wl),"w",newline="") as fo:
+    w=csv.writer(fo); w.writerow(["Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs","StdDev"])
+    for r in rows: w.writerow([r["Name"].split("(")[0].replace("fmx::",""),r["Calls"],r["TotalDurationNs"],r["AverageNs"],r["MinNs"],r["MaxNs"],r["StdDev"]])
+for r in rows:
+    if int(r["Calls"])>=5: print("%-60s calls %4s avg %9.1f us min %9.1f" % (r["Name"].split("(")[0].replace("fmx::","")[:60], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3))
+PY
+  rm -rf $O/trace_$wl
+  ;;
+prof:*)
+  wl=${PART#prof:}
+  timeout -k 10 1100 bash tools/rocprof_passes.sh $O/prof_$wl $wl > $O/passes_$wl.log 2>&1; tail -1 $O/passes_$wl.log
+  python tools/summarize_prof.py $O/prof_$wl $O/sum_$wl > /dev/null 2>&1 && echo "summarized $wl"
+  rm -rf $O/prof_$wl
+  ;;
 *) echo "unknown part $PART";;
 esac
 done

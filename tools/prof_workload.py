@@ -43,7 +43,7 @@ else:
     bwt, eof = bench.make_bwt(torch, n, sigma, seed, dev)
 torch.cuda.synchronize()
 hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=0, stream=stream)
-hip.prepare(ktab=True, jump=not regex)
+hip.prepare(ktab=True, jump=not regex, frontier=regex)
 del bwt
 torch.cuda.empty_cache()
 if regex:

@@ -9,9 +9,11 @@ import random
 ALPHABET = "abcdefghijklmnopqrstuvwxyz \n"
 
 
-def gen_one(rng, letters="abcdefghijklmnopqrstuvwxyz"):
+def gen_one(rng, letters="abcdefghijklmnopqrstuvwxyz", literal=None):
+    """literal(rng, nlit) -> nlit characters: where the literal part comes from (default: random letters; the text
+    workloads pass a function that cuts a stretch out of their text, so that the regexes have matches there)."""
     nlit = rng.randint(4, 12)
-    toks = [rng.choice(letters) for _ in range(nlit)]
+    toks = list(literal(rng, nlit)) if literal else [rng.choice(letters) for _ in range(nlit)]
     extras = []
     for _ in range(rng.randint(0, 2)):
         extras.append("[" + "".join(rng.sample(letters, rng.randint(2, 3))) + "]")

@@ -716,7 +716,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
             "rank_queries_are": "occ evaluations of the reference's loop on these inputs (2 per backward step, early "
                                 "exits counted) -- a reference-equivalent count, not executed popcounts: the kernel serves them "
                                 "with rank_queries_per_request per memory request (k-mer table for the first K steps, one "
-                                "row-jump-table entry per 8 steps once the interval is a row, shared blocks)",
+                                "row-jump-table entry per %d steps once the interval is a row, shared blocks)" % max(int(s1["jump_chars"]), 1),
             "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
                            % (world, (", one gather of the hit intervals per step (%s form, delivered to %s), overlapped with the "
                                       "next step's search" % (args.exchange, "rank 0" if args.delivery == "root" else "every rank"))

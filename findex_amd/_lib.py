@@ -53,7 +53,7 @@ class fmx_stats_t(ctypes.Structure):
                 ("frontier_requests", ctypes.c_uint64), ("frontier_elements", ctypes.c_uint64),
                 ("frontier_queue_reads", ctypes.c_uint64), ("frontier_queue_writes", ctypes.c_uint64),
                 ("frontier_results", ctypes.c_uint64), ("frontier_records", ctypes.c_uint64),
-                ("ktab_lookups", ctypes.c_uint64), ("ktab_k", ctypes.c_uint32), ("reserved3", ctypes.c_uint32),
+                ("ktab_lookups", ctypes.c_uint64), ("ktab_k", ctypes.c_uint32), ("jump_chars", ctypes.c_uint32),
                 ("tables_build_ms", ctypes.c_double), ("jump_lookups", ctypes.c_uint64), ("jump_bytes", ctypes.c_uint64),
                 ("row_lookups", ctypes.c_uint64), ("row_bytes", ctypes.c_uint64),
                 ("peak_table_build_bytes", ctypes.c_uint64), ("patterns_seen", ctypes.c_uint64)]

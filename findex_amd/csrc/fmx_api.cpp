@@ -507,6 +507,13 @@ int fmx_config_set(const char *key, const char *value) {
     else return arg_fail("jump must be auto, rows, rows3, jumps or off");
     return FMX_OK;
   }
+  if (std::strcmp(key, "jump_chars") == 0) {
+    char *end = nullptr;
+    const long v = std::strtol(value, &end, 10);
+    if (end == value || *end || v < 8 || v > 11) return arg_fail("jump_chars must be 8, 9, 10 or 11");
+    jump_set_chars((int)v);
+    return FMX_OK;
+  }
   if (std::strcmp(key, "tables_after") == 0) {
     if (std::strcmp(value, "auto") == 0) { tables_set_after(-1); return FMX_OK; }
     char *end = nullptr;
@@ -1247,6 +1254,7 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->frontier_records = cnt[8];
   out->ktab_lookups = cnt[9];
   out->ktab_k = h->kt.k;
+  out->jump_chars = h->jump_bytes ? h->jump_chars : 0;
   out->build_ms = h->build_ms;
   out->tables_build_ms = h->tables_ms;
   out->peak_table_build_bytes = h->peak_table_build_bytes.load(std::memory_order_relaxed);

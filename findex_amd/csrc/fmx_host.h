@@ -90,6 +90,7 @@ struct Index {
   mutable bool jt_ready = false;
   mutable void *d_jump = nullptr;
   mutable uint64_t jump_bytes = 0;
+  mutable uint32_t jump_chars = 0;              // characters (backward steps) one entry of the row jump table stands for: 8 .. 11
   // row table of the regex frontier (fmx_jump.hip): (BWT'[r], LF r) per row, 8 bytes; built at the first regex match
   mutable std::mutex r1_mu;
   mutable bool r1_ready = false;
@@ -148,6 +149,7 @@ hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out, bool buil
 hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build = true);   // fmx_jump.hip (nullptr: none)
 hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build = true);   // fmx_jump.hip (nullptr: none)
 int drop_tables(Index *h, unsigned what);       // fmx_jump.hip: fmx_drop_tables
+void jump_set_chars(int chars);     // fmx_config_set("jump_chars", "8" .. "11")
 void jump_set_mode(int mode);      // fmx_config_set("jump", ..): bit 0 = the row table, bit 1 = the row jump table, bit 2 = the three-step row table
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)

@@ -7,8 +7,11 @@
 // -- the pattern is being compared, one character per dependent rank query, with the text that precedes suffix r.
 // At C3 (n = 2^32, sigma = 128, 32-character patterns) that is 26 of a pattern's 28 memory requests.  The text before
 // a row does not depend on the pattern, so it can be laid down once:
-//     J[r] = ( BWT'[r], BWT'[LF r], .., BWT'[LF^7 r] ;  LF^8 r )                   8 bytes + a row number = 16 bytes
-// and a one-row search whose next eight characters equal J[r]'s lands on row LF^8 r with ONE request instead of eight
+//     J[r] = ( BWT'[r], BWT'[LF r], .., BWT'[LF^(jc-1) r] ;  LF^jc r )          jc <= 11 characters + a 40-bit row = 16 bytes
+// (bytes 0 .. 10 the characters, unused ones 0; bytes 11 .. 15 the row; jc = 9 by default, fmx_config_set("jump_chars"):
+// round 3's entries held eight characters and an 8-byte row because its lookups were tied to the pattern's 4-byte chunks;
+// with the pattern staged in LDS any offset is as good as another, and nine characters make C3's 27 one-row steps three
+// lookups flat) and a one-row search whose next jc characters equal J[r]'s lands on row LF^jc r with ONE request instead of jc
 // (k_search4, fmx_search.hip).  A pattern that differs somewhere in those eight walks them the ordinary way -- so
 // misses return the reference loop's values and count its steps, as with the k-mer table at the other end of the
 // pattern (fmx_ktab.hip).
@@ -33,10 +36,10 @@ namespace fmx {
 
 constexpr int kJThreads = 256;
 
-// J[r] = (BWT'[r], .., BWT'[LF^7 r]; LF^8 r): one lane group per row.  r3 != nullptr: R3[r] and R3[LF^3 r] give six steps
-// (one 8-byte word each, read by the group's first lane), two rank queries the last two; else eight rank queries.
+// J[r]: one lane group per row walks the jc steps.  r3 != nullptr: floor(jc / 3) lookups of the three-step table R3 (one
+// 8-byte word each, every lane of the group the same address) and jc mod 3 rank queries; else jc rank queries.
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kJThreads) void k_jump_build(DevIndex ix, const unsigned long long *__restrict__ r3, uint4 *__restrict__ out) {
+__global__ __launch_bounds__(kJThreads) void k_jump_build(DevIndex ix, const unsigned long long *__restrict__ r3, uint4 *__restrict__ out, uint32_t jc) {
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
@@ -46,21 +49,26 @@ __global__ __launch_bounds__(kJThreads) void k_jump_build(DevIndex ix, const uns
   const uint64_t ngroups = (uint64_t)gridDim.x * (kJThreads / G);
   for (uint64_t r0 = ((uint64_t)blockIdx.x * kJThreads + threadIdx.x) / G; r0 < ix.n; r0 += ngroups) {
     uint64_t r = r0;
-    unsigned long long chars = 0;
-    uint32_t first = 0;
-    if (r3) {
-      const unsigned long long a = r3[r];                       // every lane of the group: one request (same address)
-      const unsigned long long b = r3[a & ((1ull << 40) - 1)];
-      chars = (a >> 40) | ((b >> 40) << 24);
-      r = b & ((1ull << 40) - 1);
-      first = 6;
+    unsigned long long lo = 0;      // characters 0 .. 7
+    uint32_t hi = 0;                // characters 8 .. 10
+    uint32_t s = 0;                 // characters walked so far
+    const uint32_t threes = r3 ? jc / 3u : 0u;
+    for (uint32_t q = 0; q < threes; q++) {
+      const unsigned long long a = r3[r];
+      const unsigned long long c3 = a >> 40;                 // three characters
+      if (s < 8u) lo |= c3 << (8u * s);                      // (a shift of 8 s <= 56 bits: what runs over the top is in hi)
+      if (s == 6u) hi |= (uint32_t)(c3 >> 16);
+      if (s >= 8u) hi |= (uint32_t)c3 << (8u * (s - 8u));
+      s += 3u;
+      r = a & ((1ull << 40) - 1);
     }
-    for (uint32_t s = first; s < 8; s++) {
+    for (; s < jc; s++) {
       const uint32_t c = r == ix.eof ? 0u : ix.bwt[r];
-      chars |= (unsigned long long)c << (8u * s);
+      if (s < 8u) lo |= (unsigned long long)c << (8u * s);
+      else hi |= c << (8u * (s - 8u));
       r = s_cf[c] + rank_excl<WIDE, LAYOUT>(ix, c, s_slot[c], r, lc);
     }
-    if (lc.t == 0) out[r0] = make_uint4((uint32_t)chars, (uint32_t)(chars >> 32), (uint32_t)r, (uint32_t)(r >> 32));
+    if (lc.t == 0) out[r0] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), hi | ((uint32_t)(r & 0xFFu) << 24), (uint32_t)(r >> 8));
   }
 }
 
@@ -115,6 +123,8 @@ __global__ __launch_bounds__(kJThreads) void k_row3_init(DevIndex ix, unsigned l
 
 static std::atomic<int> g_jump_mode{7};      // bit 0: row table (R1), bit 1: row jump table (J8), bit 2: three-step row table (R3)
 void jump_set_mode(int mode) { g_jump_mode.store(mode & 7, std::memory_order_relaxed); }
+static std::atomic<int> g_jump_chars{9};
+void jump_set_chars(int chars) { g_jump_chars.store(chars, std::memory_order_relaxed); }
 
 // ---- when the derived tables are built.  Round 3 built all of them at a handle's FIRST search, whatever it was: a
 // single getPrevRange-sized query on a C3-size handle waited 6 s and left 96 GiB behind.  Now a table is built by
@@ -216,6 +226,7 @@ static hipError_t build_jump(const Index *h, hipStream_t st) {
   auto mark = [&](const char *what) {
     if (trace) { (void)hipStreamSynchronize(st); fprintf(stderr, "[fmx] jump table %-12s +%.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
   };
+  const uint32_t jc = (uint32_t)std::min(11, std::max(8, g_jump_chars.load(std::memory_order_relaxed)));
   void *a = nullptr;
   e = hipMalloc(&a, bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no table, no error
@@ -223,7 +234,7 @@ static hipError_t build_jump(const Index *h, hipStream_t st) {
   {
     const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
     const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
-#define CALL(W, L) k_jump_build<W, L><<<grid, kJThreads, 0, st>>>(h->dev, r3, (uint4 *)a)
+#define CALL(W, L) k_jump_build<W, L><<<grid, kJThreads, 0, st>>>(h->dev, r3, (uint4 *)a, jc)
     FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
     e = hipGetLastError();
@@ -233,6 +244,7 @@ static hipError_t build_jump(const Index *h, hipStream_t st) {
   if (e != hipSuccess) { (void)hipFree(a); return e; }
   h->d_jump = a;
   h->jump_bytes = bytes;
+  h->jump_chars = jc;
   note_table_build(h, bytes);
   return hipSuccess;
 }

@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // queries -- at C3 the three steps between the wide part of a search and its first aligned jump.
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T>
 __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
-                                                        uint32_t ksigma, const uint4 *__restrict__ jtab,
+                                                        uint32_t ksigma, const uint4 *__restrict__ jtab, const uint32_t jc,
                                                         const unsigned long long *__restrict__ r3tab, const uint8_t *__restrict__ pat,
                                                         const PatOff po,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
@@ -137,10 +137,14 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   // bytes; a longer one is read chunk by chunk from global memory as before (`staged` is wave-uniform).
   // The offsets of a batch are requested two batches ahead and only LOOKED AT one batch later (raw values are carried
   // over: any arithmetic on them here would put the wait for the load right behind it).
+  // The bytes layout keeps the former pipeline (chunks from global memory, the next batch's tail requested a batch
+  // ahead): its waves hold 8 patterns, not 16, so the staging costs the same instructions and registers for half the
+  // lines saved -- C5's share of this kernel went from 0.181 to 0.217 ms with it (62 -> 70 registers, 8 -> 7 waves).
+  constexpr bool kStage = LAYOUT != kLayoutBytes;
   constexpr uint32_t kStageBytes = 1024, kStagePad = 16;
   // two areas per wave: the batch being searched reads one while the next batch's span is parked in the other as soon as
   // it has arrived (it arrives with the batch's first table lookup: no registers hold it across the search)
-  __shared__ __attribute__((aligned(16))) uint32_t s_pat[kSThreads / 64][2][(kStagePad + kStageBytes + 16) / 4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pat[kSThreads / 64][2][kStage ? (kStagePad + kStageBytes + 16) / 4 : 4];
   uint32_t par = 0;                 // which area holds the current batch
   const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane64 = threadIdx.x & 63u;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
     Stage st;
     const uint64_t al = (pat_addr + b0) & ~15ull;
     const uint64_t span = pat_addr + e1 - al;                 // bytes from the aligned start to the end of the last pattern
-    st.ok = span <= kStageBytes;
+    st.ok = kStage && span <= kStageBytes;
     st.base = al - pat_addr;                                  // (wraps below zero when the buffer itself is unaligned: only differences are used)
     st.w = make_uint4(0, 0, 0, 0);
     if (st.ok && 16ull * lane64 < span) st.w = load_line16(al + 16u * lane64);      // the 16-byte block that holds the span's last byte is the last one read
@@ -195,6 +199,11 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   }
   Stage cur = stage_issue(end0, len0);
   stage_park(cur, par);
+  // without staging (the bytes layout) a batch's tail -- the chunks its k-mer lookup is made of -- is requested while the
+  // batch before it is searched; a staging kernel's rare unstaged batch (a span over 1 KiB) fetches it when it starts
+  Tail tail_ahead;
+#pragma unroll
+  for (uint32_t i = 0; i < NT; i++) tail_ahead.c[i] = (!kStage && len0 > 4u * i) ? fetch4(pat, end0 - 4ull * i) : 0u;
   for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
     Stage nxt_stage;
     // One batch, written once and compiled twice: STAGED = its bytes are in LDS; else (a span longer than the LDS area)
@@ -222,17 +231,43 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         return have >= 4u ? r : (r & ((1u << (8u * have)) - 1u));
       }
     };
+    // the four characters that steps at .. at + 3 consume, the first in byte lane 0, zeros behind the pattern's start -- for
+    // any `at` (chunk(j) = chars4(4 j)): what a row-jump lookup compares, and where the cursor is set again behind one
+    auto chars4 = [&](uint32_t at) -> uint32_t {
+      const uint32_t have = len > at ? len - at : 0u;
+      if constexpr (STAGED) {
+        const uint32_t o = have ? (uint32_t)(end - at - cur_base) + (kStagePad - 4u) : 0u;
+        const uint32_t lo = spat[o >> 2], hi = spat[(o >> 2) + 1];
+        const uint32_t r = __builtin_bswap32(__builtin_amdgcn_alignbyte(hi, lo, o & 3u));
+        return have >= 4u ? r : (r & ((1u << (8u * have)) - 1u));
+      } else {
+        uint32_t r = 0;
+        if (have >= 4u) {
+          uint32_t d;
+          __builtin_memcpy(&d, pat + (end - at - 4), 4);
+          r = __builtin_bswap32(d);
+        } else {
+          for (uint32_t j = 0; j < have; j++) r |= (uint32_t)pat[end - at - 1 - j] << (8u * j);
+        }
+        return r;
+      }
+    };
     Tail tailq;
 #pragma unroll
     for (uint32_t i = 0; i < NT; i++) {
       if constexpr (STAGED) tailq.c[i] = chunk(i);
-      else tailq.c[i] = len > 4u * i ? fetch4(pat, end - 4ull * i) : 0u;
+      else if constexpr (kStage) tailq.c[i] = len > 4u * i ? fetch4(pat, end - 4ull * i) : 0u;
+      else tailq.c[i] = act ? tail_ahead.c[i] : 0u;
     }
     uint32_t ch = tailq.c[0];                                 // chunk 0
     uint32_t nx = chunk(KT ? KT / 4 + 1 : 1);                 // the chunk after the current one
     // the next batch's bytes and the offsets of the one after it: requested behind this batch's first lookup (below)
     auto issue_ahead = [&]() {
       nxt_stage = stage_issue(end1, len1);
+      if constexpr (!kStage) {
+#pragma unroll
+        for (uint32_t i = 0; i < NT; i++) tail_ahead.c[i] = len1 > 4u * i ? fetch4(pat, end1 - 4ull * i) : 0u;
+      }
       load_off_raw((uint64_t)batch + 2ull * nwaves, raw2a, raw2b);
     };
     if (KT == 0) { issue_ahead(); stage_park(nxt_stage, par ^ 1u); }
@@ -303,57 +338,71 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         alive = false;
       }
       if (!__builtin_amdgcn_ballot_w64(alive)) break;
-      if (JT && (it & 3u) == 0u && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) != 1))) {
-        // ---- every live group holds one row and starts a chunk of the pattern: the next eight characters are
-        // `ch` and `nx`.  A group with eight or more left looks its row up; if the characters agree the eight steps
-        // are done -- [r, r + 1) -> [LF^8 r, LF^8 r + 1).  The chunks behind them are requested beside the lookup.
-        const bool can = alive && len - it >= 8u;
+      // the cursor (`ch`: what is left of the current chunk, `nx`: the next chunk) set for step ni
+      auto cursor_to = [&](uint32_t ni) {
+        const uint32_t c0 = chars4(ni), a = ni & 3u;
+        ch = a ? (c0 & ((1u << (8u * (4u - a))) - 1u)) : c0;
+        nx = chunk((ni >> 2) + 1);
+      };
+      if (JT && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) > (uint64_t)G))) {
+        // ---- every live group holds at most G rows (one, as a rule: sigma = 128, n = 2^32 -- from the 6th step on) and none
+        // is sitting out: a group with jc or more characters left looks its rows up in the row jump table, lane t row
+        // sp + t -- J[r] = the jc characters an LF walk from r reads and the row it ends on (fmx_jump.hip).  The rows whose
+        // characters are the pattern's next jc go on to LF^jc of themselves; LF keeps the order of rows that carry the same
+        // character, so they land side by side: the new interval begins at the first survivor's image and has as many
+        // rows as there are survivors.  The pattern's characters come from the staged span at any offset (round 3's
+        // lookups had to start on a chunk boundary of the pattern and held eight characters; nine fit C3's 32 - 5 = 27
+        // one-row steps exactly: three lookups where there were three and a three-step word).
+        const bool can = alive && len - it >= jc;
         if (__builtin_amdgcn_ballot_w64(can)) {
-          const uint32_t ch2 = chunk((it >> 2) + 2);
-          const uint32_t nx2 = chunk((it >> 2) + 3);
+          const uint32_t p0 = chars4(it), p1 = chars4(it + 4u), p2 = chars4(it + 8u);
+          const uint32_t m2 = jc > 8u ? ((1u << (8u * (jc - 8u))) - 1u) : 0u;
+          const uint64_t width = ep - sp;
+          const bool mine = can && (uint64_t)t < width;
+          // ONE 16-byte load, everything taken out of it unconditionally: with the row used only under `if (hit)`, the
+          // compiler sank that half of the load behind the comparison -- two dependent loads per lookup (round 4,
+          // profiles/r04_c3_bound.md)
+          uint4 je = make_uint4(0, 0, 0, 0);
+          if (mine) je = jtab[sp + t];
+          const bool hit = mine && je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
+          const uint32_t lane64g = threadIdx.x & 63u, gbase = lane64g - t;
+          const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> gbase) & ((1u << G) - 1u);
+          const int first = (int)(gbase + (hm ? (uint32_t)__builtin_ctz(hm) : 0u));
+          const uint32_t rlo = (uint32_t)__shfl((int)((je.z >> 24) | (je.w << 8)), first, 64), rhi = (uint32_t)__shfl((int)(je.w >> 24), first, 64);
           bool jumped = false;
           if (can) {
-            // ONE 16-byte load: the entry's row is taken out of it unconditionally (selects below).  Written with the row used
-            // only under `if (jumped)`, the compiler sank that half of the load behind the comparison -- two dependent loads
-            // per lookup, the second a cache hit but a whole trip through the memory pipeline (round 4, profiles/r04_c3_bound.md).
-            const uint4 je = jtab[sp];
-            const uint64_t row8 = ((uint64_t)je.w << 32) | je.z;
-            jumped = je.x == ch && je.y == nx;
-            if (!jumped) {
-              // The pattern differs from its one row's text within these eight characters: it misses, and what is left
-              // to find is where -- the reference loop's values at the failing step.  Walking there here would hold up the
-              // whole wave (every lane executes the steps, the fifteen groups that jumped wait): the group parks its
-              // state in its output slots and retires; k_search_defer walks the parked patterns of 64 at a time, densely.
+            jumped = hm != 0u;
+            if (!jumped && width == 1u) {
+              // The pattern differs from its one row's text within these characters: it misses, and what is left to find is
+              // where -- the reference loop's values at the failing step.  Walking there here would hold up the whole wave
+              // (every lane executes the steps, the groups that jumped wait): the group parks its state in its output
+              // slots and retires; k_search_defer walks the parked patterns of 64 at a time, densely.
               if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
               deferred = true;
-            }
-            sp = jumped ? row8 : sp;
-            ep = jumped ? row8 + 1 : sp;                             // not jumped: not alive any more
-            steps += jumped ? 8u : 0u;
+            }                                                          // (wider and no row agrees: it steps on and ends within jc steps)
+            const uint64_t rowj = ((uint64_t)rhi << 32) | rlo;
+            const uint64_t spn = jumped ? rowj : sp;
+            ep = jumped ? rowj + (uint32_t)__builtin_popcount(hm) : (deferred ? sp : ep);      // parked: not alive any more
+            sp = spn;
+            steps += jumped ? jc : 0u;
           }
-          jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(can && t == 0));
-          if (!__builtin_amdgcn_ballot_w64(alive && !jumped && !deferred)) {     // everybody jumped: go on eight steps further
-            it += 7;
-            ch = ch2;
-            nx = nx2;
+          jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // an entry per row looked up
+          if (!__builtin_amdgcn_ballot_w64(alive && !jumped && !deferred)) {     // everybody jumped: go on jc steps further
+            cursor_to(it + jc);
+            it += jc - 1u;
             continue;
           }
-          skip = jumped ? 8u : 0u;                                   // the others walk; this group waits for them
+          skip = jumped ? jc : 0u;                                   // the others walk; this group waits for them
         }
       }
       if (JT && R3T) {
-        // ---- a group whose interval is at most G rows and for which no aligned jump is at hand takes THREE steps with the
-        // three-step row table -- when it stands one step behind a chunk boundary (the three steps end on the boundary),
-        // or has fewer than eight characters left beyond the next boundary anyway.  (Two or three steps behind a boundary
-        // with a jump to come, one or two single steps get there.)  Lane t of the group looks up row sp + t: the rows whose
-        // three characters are the pattern's go on to LF^3 of themselves -- LF keeps the order of rows that carry the same
-        // character, so they land side by side: the new interval begins at the first survivor's image and has as many rows
-        // as there are survivors.  (At C3 one group in eight still holds two or three rows at step 5; stepping those the
-        // ordinary way kept their whole wave in the loop for three more iterations.)  The other groups step as usual.
-        const uint32_t rem = len - it, a = it & 3u, to_align = (4u - a) & 3u;
+        // ---- a group that holds at most G rows and has not just jumped -- fewer than jc characters left, or other groups of
+        // the wave are still wide or sitting out -- takes THREE steps with the three-step row table, lane t row sp + t as
+        // above (at C3: the last three of a pattern's 32 steps for the one group in eight that came to the row tables a
+        // step late).  The other groups step as usual.
+        const uint32_t rem = len - it, a = it & 3u;
         const uint64_t width = ep - sp;
-        const bool want3 = alive && skip == 0u && width >= 1u && width <= (uint64_t)G && rem >= 3u && !(a == 0u && rem >= 8u && width == 1u) &&
-                           (to_align == 3u || to_align == 0u || rem < to_align + 8u);
+        const bool want3 = alive && skip == 0u && !deferred && width >= 1u && width <= (uint64_t)G && rem >= 3u;
         if (__builtin_amdgcn_ballot_w64(want3)) {
           const uint32_t valid = 4u - a;                                       // characters still in `ch` (wave-uniform)
           const uint32_t three = (valid >= 3u ? ch : (ch | (nx << (8u * valid)))) & 0xFFFFFFu;
@@ -380,11 +429,8 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
           }
           r3l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // a lane per row looked up
           if (!__builtin_amdgcn_ballot_w64(alive && !took && !deferred) && !__builtin_amdgcn_ballot_w64(alive && skip != 0u)) {     // everybody took them: go on three steps further
-            for (uint32_t s3 = 0; s3 < 3u; s3++) {
-              ch >>= 8;
-              if ((it & 3u) == 3u) { ch = nx; nx = chunk((it >> 2) + 2); }
-              if (s3 < 2u) it++;
-            }
+            cursor_to(it + 3u);
+            it += 2u;
             continue;
           }
           skip = took ? 3u : skip;
@@ -465,8 +511,12 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
     }
     if (act && t == 0 && !deferred) { sp_out[pid] = sp; ep_out[pid] = ep; }
     };      // search_one_batch
-    if (cur.ok) search_one_batch(std::true_type{});
-    else search_one_batch(std::false_type{});
+    if constexpr (kStage) {
+      if (cur.ok) search_one_batch(std::true_type{});
+      else search_one_batch(std::false_type{});
+    } else {
+      search_one_batch(std::false_type{});
+    }
     cur = nxt_stage;
     par ^= 1u;
     end0 = end1; len0 = len1;
@@ -505,7 +555,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
 // LF^3 r) in 8 bytes, three steps per lookup, for an index whose J does not fit; k_search4<.., RW = 3> parks a pattern
 // with a multiple of three steps left, so only patterns that fail are parked again.
 template <int MODE>
-__global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restrict__ jtab, const unsigned long long *__restrict__ row1,
+__global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restrict__ jtab, const uint32_t jc, const unsigned long long *__restrict__ row1,
                                                             const uint8_t *__restrict__ pat, const PatOff po,
                                                             uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
                                                             unsigned long long *__restrict__ counters) {
@@ -545,15 +595,19 @@ __global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restri
         }
         continue;
       }
-      const bool jm = MODE == 1 && live && rem >= 8u && walk == 0u;
+      const bool jm = MODE == 1 && live && rem >= jc && walk == 0u;
       const bool rm = live && rem != 0u && !jm;
       uint4 je = make_uint4(0, 0, 0, 0);
-      uint32_t lo = 0, hi = 0, c = 0;
+      uint32_t p0 = 0, p1 = 0, p2 = 0, c = 0;
       unsigned long long re = 0;
-      if (jm) {                                  // pat[end - it - 8 .. end - it): the pattern has them
+      if (jm) {                                  // the pattern's next jc (8 .. 11) characters, the first in byte lane 0 of p0
         je = jtab[row];
-        __builtin_memcpy(&lo, pat + (end - it - 8), 4);
-        __builtin_memcpy(&hi, pat + (end - it - 4), 4);
+        uint32_t d0, d1;
+        __builtin_memcpy(&d0, pat + (end - it - 4), 4);
+        __builtin_memcpy(&d1, pat + (end - it - 8), 4);
+        p0 = __builtin_bswap32(d0);
+        p1 = __builtin_bswap32(d1);
+        for (uint32_t j = 8; j < jc; j++) p2 |= (uint32_t)pat[end - it - 1 - j] << (8u * (j - 8u));
       }
       if (rm) {
         re = row1[row];
@@ -561,12 +615,13 @@ __global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restri
       }
       if (jm) {
         looks++;
-        const bool agree = je.x == __builtin_bswap32(hi) && je.y == __builtin_bswap32(lo);
-        const uint64_t row8 = ((uint64_t)je.w << 32) | je.z;      // unconditional: keeps the entry ONE 16-byte load (k_search4)
-        row = agree ? row8 : row;
-        it += agree ? 8u : 0u;
-        steps += agree ? 8u : 0u;
-        walk = agree ? walk : 8u;
+        const uint32_t m2 = jc > 8u ? ((1u << (8u * (jc - 8u))) - 1u) : 0u;
+        const bool agree = je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
+        const uint64_t rowj = (uint64_t)(je.z >> 24) | ((uint64_t)je.w << 8);      // unconditional: keeps the entry ONE 16-byte load (k_search4)
+        row = agree ? rowj : row;
+        it += agree ? jc : 0u;
+        steps += agree ? jc : 0u;
+        walk = agree ? walk : jc;
       } else if (rm) {
         rlooks++;
         const uint32_t c2 = (uint32_t)(re >> 40) & 0xFFu;
@@ -727,14 +782,14 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt,
+  k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
                                                                        R3T ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters);
   if (RW) {     // the one-row part of every search, a lane per pattern
     const uint64_t wg = ((uint64_t)k + kSThreads - 1) / kSThreads;
     const int g1 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 32);
-    if (RW == 3) k_search_rows<2><<<g1, kSThreads, 0, st>>>(nullptr, r1, pat, off, sp, ep, k, h->d_counters);
-    else if (jt) k_search_rows<1><<<g1, kSThreads, 0, st>>>(jt, r1, pat, off, sp, ep, k, h->d_counters);
-    else k_search_rows<0><<<g1, kSThreads, 0, st>>>(nullptr, r1, pat, off, sp, ep, k, h->d_counters);
+    if (RW == 3) k_search_rows<2><<<g1, kSThreads, 0, st>>>(nullptr, 0u, r1, pat, off, sp, ep, k, h->d_counters);
+    else if (jt) k_search_rows<1><<<g1, kSThreads, 0, st>>>(jt, h->jump_chars, r1, pat, off, sp, ep, k, h->d_counters);
+    else k_search_rows<0><<<g1, kSThreads, 0, st>>>(nullptr, 0u, r1, pat, off, sp, ep, k, h->d_counters);
   }
   if (JT || RW) {     // the patterns still parked (it reads the batch's ep_out once: 8 bytes per pattern; no state shared between calls)
     const uint64_t wg = ((uint64_t)k + 2 * kSThreads - 1) / (2 * kSThreads);       // a wave looks at 128 patterns

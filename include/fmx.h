@@ -71,8 +71,9 @@ int fmx_abi_version(void);
  * checkpoints + 64-bit superblock counts that larger counts need; for tests).  Affects indexes opened afterwards.
  * key "jump": "auto" (default) / "jumps" / "rows3" / "rows" / "off": the derived tables that serve searches whose
  * interval has narrowed to ONE ROW, where a backward step is a comparison with the text in front of that row's suffix:
- *   - the row jump table: per row the eight BWT characters an LF walk from it reads and the row it ends on, 16 n
- *     bytes -- eight steps of a literal search with one 16-byte lookup when the pattern's next eight characters match
+ *   - the row jump table: per row the nine BWT characters an LF walk from it reads and the row it ends on, 16 n
+ *     bytes -- nine steps of a literal search with one 16-byte lookup when the pattern's next nine characters match
+ *     (key "jump_chars": "8" .. "11" characters per entry for tables built afterwards; 9 is the default)
  *     (built when 16 n bytes + 8 GiB of HBM are free -- one allocation: key "tables_after" says when);
  *   - the three-step row table: the same with three characters, 8 n bytes -- built instead where the jump table does
  *     not fit; the one-row part of every pattern is then walked by one lane per pattern;
@@ -477,12 +478,12 @@ typedef struct fmx_stats_t {
   uint64_t frontier_records;    /* 32-byte state records loaded (none inside a literal stretch) */
   uint64_t ktab_lookups;        /* 16-byte k-mer table entries fetched (each stands for up to ktab_k backward steps) */
   uint32_t ktab_k;              /* K of the k-mer jump table (0: none, or not built yet) */
-  uint32_t reserved3;           /* 0 */
+  uint32_t jump_chars;          /* characters (backward steps) one row-jump-table entry stands for (0: no such table) */
   double tables_build_ms;       /* host time spent building the k-mer table, the row jump table and the select directory
                                  * (at first use or in fmx_prepare): what a handle's first search / first Psi pays on top
                                  * of build_ms */
   uint64_t jump_lookups;        /* 16-byte row-jump-table entries fetched by fmx_search_batch[_dev]'s kernel (each stands
-                                 * for 8 backward steps when the pattern's next 8 characters match it) */
+                                 * for jump_chars backward steps when the pattern's next jump_chars characters match it) */
   uint64_t jump_bytes;          /* device bytes of the row jump table (0: the handle has none); part of index_bytes */
   uint64_t row_lookups;         /* 8-byte row-table words fetched (one or three backward steps of a one-row interval each):
                                  * by the one-row part of fmx_search_batch[_dev] and by the regex frontier */

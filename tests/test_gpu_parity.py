@@ -491,7 +491,7 @@ def test_row_jump_table_on_and_off_agree(layout):
                         assert st["row_bytes"] == (8 * orc.n if jump in ("auto", "rows", "rows3") else 0)
                         assert (st["row_lookups"] > 0) == (jump in ("auto", "rows", "rows3"))
                         if jump in ("auto", "jumps"):
-                            assert st["jump_bytes"] == 16 * orc.n and st["jump_lookups"] > 2 * len(uniform)
+                            assert st["jump_bytes"] == 16 * orc.n and st["jump_lookups"] > 2 * len(uniform) and st["jump_chars"] == 9
                             # the table itself: (BWT' along an 8-step LF walk, the row it ends on) -- spot-check through a
                             # search of the walked characters from a one-row start is what check_search just did; the
                             # executed steps equal the oracle's although fewer lines were requested
@@ -500,6 +500,20 @@ def test_row_jump_table_on_and_off_agree(layout):
                             assert st["jump_bytes"] == 0 and st["jump_lookups"] == 0
                     finally:
                         findex_amd.set_ktab("auto")
+                        findex_amd.set_jump("auto")
+            # every entry width: 8 .. 11 characters per lookup (9 above), with and without the three-step table beside it
+            for jc in (8, 10, 11):
+                for jump in ("auto", "jumps"):
+                    findex_amd.config_set("jump_chars", jc)
+                    findex_amd.set_jump(jump)
+                    try:
+                        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+                        check_search(hip, orc, pats)
+                        check_search(hip, orc, uniform)
+                        st = hip.stats()
+                        assert st["jump_chars"] == jc and st["jump_lookups"] > len(uniform)
+                    finally:
+                        findex_amd.config_set("jump_chars", 9)
                         findex_amd.set_jump("auto")
     finally:
         findex_amd.set_layout("auto")
@@ -549,6 +563,14 @@ def test_row_tables_on_repetitive_texts(layout):
                     finally:
                         findex_amd.set_ktab("auto")
                         findex_amd.set_jump("auto")
+            for jc in (8, 11):                           # intervals of a few rows through the row jump table, lane t row sp + t
+                findex_amd.config_set("jump_chars", jc)
+                try:
+                    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+                    check_search(hip, orc, pats)
+                    assert hip.stats()["jump_lookups"] > 0
+                finally:
+                    findex_amd.config_set("jump_chars", 9)
     finally:
         findex_amd.set_layout("auto")
 
@@ -1977,8 +1999,10 @@ def test_text_index_parity_literals_and_regexes():
     """An index over a TEXT with natural repeats (tools/text_bwt.py: words drawn with replacement, suffix-sorted on the
     device, reversed like findex's) -- where intervals stay wide for many characters and no frontier needs a length
     cap: the generator's BWT equals the naive sort's on a small text; on 2^20 bytes, literal patterns (stretches of the
-    text, a fifth of them with one byte replaced; ragged lengths) and the text workload's regexes (literals cut from
-    the text) against the oracle, bit for bit, steps counted, no truncation."""
+    text -- REVERSED: SuffixAlgo.search on an index over reverse(T) finds p in reverse(T), SURVEY section 0.2 -- a fifth of
+    them with one byte replaced; ragged lengths) and the text workload's regexes (literals cut from the text, read
+    forward: the regex engines walk a regex forward with getPrevRange) against the oracle, bit for bit, steps
+    counted, no truncation."""
     import random
     import sys
     torch = _torch()
@@ -2003,14 +2027,14 @@ def test_text_index_parity_literals_and_regexes():
     pats = []
     for m in (1, 2, 3, 5, 8, 13, 21, 32, 47, 80):
         for a in rng.integers(0, n - 1 - m, 400):
-            p = bytearray(h_text[a:a + m].tobytes())
+            p = bytearray(h_text[a:a + m][::-1].tobytes())
             if rng.random() < 0.2:
                 p[int(rng.integers(0, m))] = int(rng.choice(alpha))
             pats.append(bytes(p))
     pats = [pats[i] for i in rng.permutation(len(pats))]
     hits = check_search(hip, orc, pats)
     assert hits > 3000
-    assert hip.search(h_text[1000:1012].tobytes()) is not None      # a stretch of the text is found reading forward
+    assert hip.search(h_text[1000:1012][::-1].tobytes()) is not None      # a stretch of the text, reversed, is found
     st = hip.stats()
     assert st["jump_lookups"] > 0 and st["row_lookups"] > 0
     prng = random.Random(3)

@@ -344,68 +344,65 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         ch = a ? (c0 & ((1u << (8u * (4u - a))) - 1u)) : c0;
         nx = chunk((ni >> 2) + 1);
       };
-      if (JT && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) > (uint64_t)G))) {
-        // ---- every live group holds at most G rows (one, as a rule: sigma = 128, n = 2^32 -- from the 6th step on) and none
-        // is sitting out: a group with jc or more characters left looks its rows up in the row jump table, lane t row
-        // sp + t -- J[r] = the jc characters an LF walk from r reads and the row it ends on (fmx_jump.hip).  The rows whose
-        // characters are the pattern's next jc go on to LF^jc of themselves; LF keeps the order of rows that carry the same
-        // character, so they land side by side: the new interval begins at the first survivor's image and has as many
-        // rows as there are survivors.  The pattern's characters come from the staged span at any offset (round 3's
-        // lookups had to start on a chunk boundary of the pattern and held eight characters; nine fit C3's 32 - 5 = 27
-        // one-row steps exactly: three lookups where there were three and a three-step word).
-        const bool can = alive && len - it >= jc;
+      // `it` is the wave's clock; a group that has taken several steps with one lookup sits out (`skip`) until the clock
+      // has caught up with it, and when no group is stepping the clock is simply moved to the first group that is free
+      // again (below) -- so the groups of a wave go through the row tables independently of each other.
+      const uint32_t rem = len - it;
+      bool lookedup = false;                                   // this group has taken steps by table lookup in this iteration
+      if (JT) {
+        // ---- a group that holds ONE row (sigma = 128, n = 2^32: from the 6th step on) and has jc or more characters left
+        // looks the row up in the row jump table: J[r] = the jc characters an LF walk from r reads and the row it ends on
+        // (fmx_jump.hip).  The pattern's characters come from the staged span at any offset (round 3's lookups had to
+        // start on a chunk boundary of the pattern and held eight characters; nine fit C3's 32 - 5 = 27 one-row steps
+        // exactly: three lookups where there were three and a three-step word).
+        const bool can = alive && skip == 0u && (ep - sp) == 1u && rem >= jc;
         if (__builtin_amdgcn_ballot_w64(can)) {
-          const uint32_t p0 = chars4(it), p1 = chars4(it + 4u), p2 = chars4(it + 8u);
+          uint32_t p0, p1, p2;
+          if constexpr (STAGED) {      // the 12 bytes that end where step `it` reads, in one burst: (p0, p1, p2) = steps it .. it + 11
+            const uint32_t o = can ? (uint32_t)(end - it - cur_base) + (kStagePad - 12u) : 0u;
+            const uint32_t w0 = o >> 2, sh = o & 3u;
+            const uint32_t d0 = spat[w0], d1 = spat[w0 + 1], d2 = spat[w0 + 2], d3 = spat[w0 + 3];
+            p0 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d3, d2, sh));
+            p1 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d2, d1, sh));
+            p2 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, sh));
+          } else {
+            p0 = chars4(it); p1 = chars4(it + 4u); p2 = chars4(it + 8u);
+          }
           const uint32_t m2 = jc > 8u ? ((1u << (8u * (jc - 8u))) - 1u) : 0u;
-          const uint64_t width = ep - sp;
-          const bool mine = can && (uint64_t)t < width;
-          // ONE 16-byte load, everything taken out of it unconditionally: with the row used only under `if (hit)`, the
-          // compiler sank that half of the load behind the comparison -- two dependent loads per lookup (round 4,
-          // profiles/r04_c3_bound.md)
-          uint4 je = make_uint4(0, 0, 0, 0);
-          if (mine) je = jtab[sp + t];
-          const bool hit = mine && je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
-          const uint32_t lane64g = threadIdx.x & 63u, gbase = lane64g - t;
-          const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> gbase) & ((1u << G) - 1u);
-          const int first = (int)(gbase + (hm ? (uint32_t)__builtin_ctz(hm) : 0u));
-          const uint32_t rlo = (uint32_t)__shfl((int)((je.z >> 24) | (je.w << 8)), first, 64), rhi = (uint32_t)__shfl((int)(je.w >> 24), first, 64);
-          bool jumped = false;
           if (can) {
-            jumped = hm != 0u;
-            if (!jumped && width == 1u) {
+            // ONE 16-byte load (every lane of the group the same entry), everything taken out of it unconditionally: with
+            // the row used only under `if (jumped)`, the compiler sank that half of the load behind the comparison -- two
+            // dependent loads per lookup (round 4, profiles/r04_c3_bound.md)
+            const uint4 je = jtab[sp];
+            const bool jumped = je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
+            const uint64_t rowj = (uint64_t)(je.z >> 24) | ((uint64_t)je.w << 8);
+            if (!jumped) {
               // The pattern differs from its one row's text within these characters: it misses, and what is left to find is
               // where -- the reference loop's values at the failing step.  Walking there here would hold up the whole wave
               // (every lane executes the steps, the groups that jumped wait): the group parks its state in its output
               // slots and retires; k_search_defer walks the parked patterns of 64 at a time, densely.
               if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
               deferred = true;
-            }                                                          // (wider and no row agrees: it steps on and ends within jc steps)
-            const uint64_t rowj = ((uint64_t)rhi << 32) | rlo;
-            const uint64_t spn = jumped ? rowj : sp;
-            ep = jumped ? rowj + (uint32_t)__builtin_popcount(hm) : (deferred ? sp : ep);      // parked: not alive any more
-            sp = spn;
+            }
+            ep = jumped ? rowj + 1 : sp;                             // parked: not alive any more
+            sp = jumped ? rowj : sp;
             steps += jumped ? jc : 0u;
+            skip = jumped ? jc : 0u;
+            lookedup = jumped;
           }
-          jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // an entry per row looked up
-          if (!__builtin_amdgcn_ballot_w64(alive && !jumped && !deferred)) {     // everybody jumped: go on jc steps further
-            cursor_to(it + jc);
-            it += jc - 1u;
-            continue;
-          }
-          skip = jumped ? jc : 0u;                                   // the others walk; this group waits for them
+          jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(can && t == 0));
         }
       }
       if (JT && R3T) {
-        // ---- a group that holds at most G rows and has not just jumped -- fewer than jc characters left, or other groups of
-        // the wave are still wide or sitting out -- takes THREE steps with the three-step row table, lane t row sp + t as
-        // above (at C3: the last three of a pattern's 32 steps for the one group in eight that came to the row tables a
-        // step late).  The other groups step as usual.
-        const uint32_t rem = len - it, a = it & 3u;
+        // ---- a group that holds two to G rows, or one row and fewer than jc characters (the tail of its pattern), takes
+        // THREE steps with the three-step row table, lane t row sp + t: the rows whose three characters are the pattern's
+        // go on to LF^3 of themselves -- LF keeps the order of rows that carry the same character, so they land side by
+        // side: the new interval begins at the first survivor's image and has as many rows as there are survivors.  (No
+        // row table, or one or two characters left: single steps.)
         const uint64_t width = ep - sp;
-        const bool want3 = alive && skip == 0u && !deferred && width >= 1u && width <= (uint64_t)G && rem >= 3u;
+        const bool want3 = alive && skip == 0u && !deferred && !lookedup && width >= 1u && width <= (uint64_t)G && rem >= 3u && (width != 1u || rem < jc);
         if (__builtin_amdgcn_ballot_w64(want3)) {
-          const uint32_t valid = 4u - a;                                       // characters still in `ch` (wave-uniform)
-          const uint32_t three = (valid >= 3u ? ch : (ch | (nx << (8u * valid)))) & 0xFFFFFFu;
+          const uint32_t three = chars4(it) & 0xFFFFFFu;
           const bool mine = want3 && (uint64_t)t < width;
           unsigned long long re = 0;
           if (mine) re = r3tab[sp + t];
@@ -414,13 +411,14 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
           const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> base) & ((1u << G) - 1u);
           const int first = (int)(base + (hm ? (uint32_t)__builtin_ctz(hm) : 0u));
           const uint32_t lo3 = (uint32_t)__shfl((int)(uint32_t)re, first, 64), hi3 = (uint32_t)__shfl((int)(uint32_t)(re >> 32), first, 64);
-          bool took = false;
           if (want3) {
-            took = hm != 0u;
+            const bool took = hm != 0u;
             if (took) {
               sp = (((uint64_t)hi3 << 32) | lo3) & ((1ull << 40) - 1);
               ep = sp + (uint32_t)__builtin_popcount(hm);
               steps += 3;
+              skip = 3u;
+              lookedup = true;
             } else if (width == 1u) {                                          // it fails within these three: k_search_defer finds where
               if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
               deferred = true;
@@ -428,13 +426,24 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
             }                                                                  // (wider and no row agrees: it steps on and ends within three steps)
           }
           r3l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // a lane per row looked up
-          if (!__builtin_amdgcn_ballot_w64(alive && !took && !deferred) && !__builtin_amdgcn_ballot_w64(alive && skip != 0u)) {     // everybody took them: go on three steps further
-            cursor_to(it + 3u);
-            it += 2u;
-            continue;
-          }
-          skip = took ? 3u : skip;
         }
+      }
+      if ((JT || R3T) && !__builtin_amdgcn_ballot_w64(alive && skip == 0u && !deferred)) {
+        // ---- nobody steps in this iteration: every live group has jumped or is sitting out.  The clock goes to the first
+        // group that is free again (1 .. 11 steps on), and every cursor with it.
+        bool cand = alive && !deferred && skip != 0u;      // the smallest `skip` among them, a bit at a time
+        uint32_t adv = 0;
+#pragma unroll
+        for (int bit = 3; bit >= 0; bit--) {
+          const bool z = cand && ((skip >> bit) & 1u) == 0u;
+          if (__builtin_amdgcn_ballot_w64(z)) cand = z;
+          else adv |= 1u << bit;
+        }
+        if (!__builtin_amdgcn_ballot_w64(cand)) adv = 1u;                       // (everybody parked: the loop ends at the top)
+        skip -= skip >= adv ? adv : skip;
+        cursor_to(it + adv);
+        it += adv - 1u;
+        continue;
       }
       const bool stepping = alive && skip == 0u && !deferred;
       skip -= skip ? 1u : 0u;

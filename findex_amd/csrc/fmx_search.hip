@@ -146,6 +146,18 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   // it has arrived (it arrives with the batch's first table lookup: no registers hold it across the search)
   __shared__ __attribute__((aligned(16))) uint32_t s_pat[kSThreads / 64][2][kStage ? (kStagePad + kStageBytes + 16) / 4 : 4];
   uint32_t par = 0;                 // which area holds the current batch
+  // Patterns that are found to MISS by a table lookup (their one row's text differs from the pattern within the
+  // lookup's characters) still owe the reference loop's values at the failing step: a few one-row rank steps.  Taking
+  // them where they arise would make the whole wave execute them while the groups that jumped wait; a kernel with a
+  // row jump table (and no hand-over to k_search_rows) therefore parks them in a list in LDS and walks them densely, a
+  // lane group each, when 48 have come together and before the wave ends (walk_parked below) -- round 3 parked them in
+  // the output arrays for a second launch, k_search_defer: 26-30 us behind the 150 of this one at C3.
+  constexpr bool kFold = JT && RW == 0u;
+  constexpr uint32_t kParkCap = 64;
+  __shared__ uint64_t s_park_row[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
+  __shared__ uint32_t s_park_pid[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
+  __shared__ uint32_t s_park_it[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
+  uint32_t npark = 0;               // entries in this wave's list (wave-uniform)
   const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane64 = threadIdx.x & 63u;
   const uint64_t pat_addr = (uint64_t)(uintptr_t)pat;
@@ -204,6 +216,70 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   Tail tail_ahead;
 #pragma unroll
   for (uint32_t i = 0; i < NT; i++) tail_ahead.c[i] = (!kStage && len0 > 4u * i) ? fetch4(pat, end0 - 4ull * i) : 0u;
+  // The parked patterns, P at a time, a lane group each: one-row steps (one rank query + one bit test, as in the step
+  // loop) from the row and step they were parked with until the interval is empty -- or, should one not fail after all,
+  // to its end -- leaving the reference loop's final values in the output arrays and counting its steps.
+  auto walk_parked = [&]() {
+    while (npark) {                                            // wave-uniform
+      const uint32_t take = npark < P ? npark : P;
+      const bool actw = grp < take;
+      const uint32_t slot = npark - take + (actw ? grp : 0u);
+      npark -= take;
+      const uint32_t wpid = actw ? s_park_pid[wave_in_wg][slot] : 0u;
+      uint32_t wit = actw ? s_park_it[wave_in_wg][slot] : 0u;
+      uint64_t wsp = actw ? s_park_row[wave_in_wg][slot] : 0ull, wep = wsp + (actw ? 1u : 0u);
+      uint64_t wbegin = 0, wend = 0;
+      if (actw) po.get(wpid, wbegin, wend);
+      const uint32_t wlen = (uint32_t)(wend - wbegin);
+      for (;;) {                                               // eight steps at a time
+        const uint32_t wrem = wlen - wit;
+        if (!__builtin_amdgcn_ballot_w64(actw && wsp < wep && wrem != 0u)) break;
+        const uint32_t nst = wrem < 8u ? wrem : 8u;
+        uint64_t chars = 0;                                    // the next nst characters, the one of step `wit` in the low byte
+        if (actw && wsp < wep) {
+          if (nst == 8u) {
+            uint32_t lo, hi;
+            __builtin_memcpy(&lo, pat + (wend - wit - 8), 4);
+            __builtin_memcpy(&hi, pat + (wend - wit - 4), 4);
+            chars = ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
+          } else {
+            for (uint32_t s8 = 0; s8 < nst; s8++) chars |= (uint64_t)pat[wend - wit - 1 - s8] << (8u * s8);
+          }
+        }
+        for (uint32_t s8 = 0; s8 < 8; s8++) {
+          const bool stepping = actw && wsp < wep && s8 < nst;
+          if (!__builtin_amdgcn_ballot_w64(stepping)) break;
+          if (stepping) {
+            const uint32_t c = (uint32_t)(chars >> (8u * s8)) & 0xFFu;
+            const uint4 en = s_tab[c];
+            const uint64_t cfc = ((uint64_t)en.y << 32) | en.x;
+            const uint64_t vb = ((uint64_t)en.w << 32) | en.z;
+            if (vb > 1) {
+              if (LAYOUT == kLayoutBytes) {
+                const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), wsp, lc);
+                wsp = cfc + byte_rank_finish(q1, c, lc);
+                wep = wsp + byte_match_bit(q1, c, lc);
+              } else {
+                uint32_t b1, m1;
+                split448(wsp, b1, m1);
+                const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
+                wsp = cfc + rank_finish<WIDE>(w1, m1, lc);
+                wep = wsp + payload_bit(w1, m1, lc);
+              }
+              reqs += R;
+            } else {
+              const uint64_t r1 = cfc + ((vb == 1 && wsp > ix.eof) ? 1u : 0u);
+              wep = cfc + ((vb == 1 && wep > ix.eof) ? 1u : 0u);
+              wsp = r1;
+            }
+            steps++;
+          }
+        }
+        wit += nst;                                            // (meaningless once the interval is empty: the loop ends then)
+      }
+      if (actw && t == 0) { sp_out[wpid] = wsp; ep_out[wpid] = wep; }
+    }
+  };
   for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
     Stage nxt_stage;
     // One batch, written once and compiled twice: STAGED = its bytes are in LDS; else (a span longer than the LDS area)
@@ -328,6 +404,8 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
       ch = chunk(KT / 4);              // the chunk step KT starts
     }
     uint32_t skip = 0;                                         // steps this group has jumped over and still sits out
+    uint32_t p0 = 0, p1 = 0, p2 = 0, pit = ~0u;               // the pattern's characters for a row-jump lookup at step pit, fetched ahead
+    uint32_t cursor_it = KT ? KT : 1u;                         // the step (ch, nx) stand for
     bool deferred = false;                                     // this group's pattern was parked for k_search_defer
     for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
       bool alive = it < len && sp < ep;
@@ -338,69 +416,104 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         alive = false;
       }
       if (!__builtin_amdgcn_ballot_w64(alive)) break;
-      // the cursor (`ch`: what is left of the current chunk, `nx`: the next chunk) set for step ni
+      // the cursor (`ch`: what is left of the current chunk, `nx`: the next chunk) set for step ni; it is maintained step by
+      // step while groups step and set afresh (cursor_it says for which step it stands) after the clock has jumped
       auto cursor_to = [&](uint32_t ni) {
         const uint32_t c0 = chars4(ni), a = ni & 3u;
         ch = a ? (c0 & ((1u << (8u * (4u - a))) - 1u)) : c0;
         nx = chunk((ni >> 2) + 1);
+        cursor_it = ni;
       };
-      // `it` is the wave's clock; a group that has taken several steps with one lookup sits out (`skip`) until the clock
-      // has caught up with it, and when no group is stepping the clock is simply moved to the first group that is free
-      // again (below) -- so the groups of a wave go through the row tables independently of each other.
+      // the twelve characters steps at .. at + 11 consume (p0 first): what a lookup in the row jump table compares
+      auto chars12 = [&](uint32_t at, bool want, uint32_t &q0, uint32_t &q1, uint32_t &q2) {
+        if constexpr (STAGED) {        // the 12 bytes that end where step `at` reads, in one burst of four LDS dwords
+          const uint32_t o = want ? (uint32_t)(end - at - cur_base) + (kStagePad - 12u) : 0u;
+          const uint32_t w0 = o >> 2, sh = o & 3u;
+          const uint32_t d0 = spat[w0], d1 = spat[w0 + 1], d2 = spat[w0 + 2], d3 = spat[w0 + 3];
+          q0 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d3, d2, sh));
+          q1 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d2, d1, sh));
+          q2 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, sh));
+        } else {
+          q0 = chars4(at); q1 = chars4(at + 4u); q2 = chars4(at + 8u);
+        }
+      };
       const uint32_t rem = len - it;
       bool lookedup = false;                                   // this group has taken steps by table lookup in this iteration
-      if (JT) {
-        // ---- a group that holds ONE row (sigma = 128, n = 2^32: from the 6th step on) and has jc or more characters left
-        // looks the row up in the row jump table: J[r] = the jc characters an LF walk from r reads and the row it ends on
-        // (fmx_jump.hip).  The pattern's characters come from the staged span at any offset (round 3's lookups had to
-        // start on a chunk boundary of the pattern and held eight characters; nine fit C3's 32 - 5 = 27 one-row steps
-        // exactly: three lookups where there were three and a three-step word).
-        const bool can = alive && skip == 0u && (ep - sp) == 1u && rem >= jc;
+      bool park_now = false;                                   // ... or was found to miss by one: it is parked below
+      if (JT && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) > (uint64_t)G))) {
+        // ---- every live group holds at most G rows (one, as a rule: sigma = 128, n = 2^32 -- from the 6th step on) and none
+        // is sitting out: a group with jc or more characters left looks its rows up in the row jump table -- J[r] = the
+        // jc characters an LF walk from r reads and the row it ends on (fmx_jump.hip).  The pattern's characters come from
+        // the staged span at any offset (round 3's lookups had to start on a chunk boundary of the pattern and held
+        // eight characters; nine fit C3's 32 - 5 = 27 one-row steps exactly: three lookups where there were three and a
+        // three-step word), and the characters of the NEXT lookup are fetched from LDS while the entries are on their way:
+        // between an entry's arrival and the next entry's request stand a comparison and a select.
+        const bool can = alive && rem >= jc;
         if (__builtin_amdgcn_ballot_w64(can)) {
-          uint32_t p0, p1, p2;
-          if constexpr (STAGED) {      // the 12 bytes that end where step `it` reads, in one burst: (p0, p1, p2) = steps it .. it + 11
-            const uint32_t o = can ? (uint32_t)(end - it - cur_base) + (kStagePad - 12u) : 0u;
-            const uint32_t w0 = o >> 2, sh = o & 3u;
-            const uint32_t d0 = spat[w0], d1 = spat[w0 + 1], d2 = spat[w0 + 2], d3 = spat[w0 + 3];
-            p0 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d3, d2, sh));
-            p1 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d2, d1, sh));
-            p2 = __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, sh));
-          } else {
-            p0 = chars4(it); p1 = chars4(it + 4u); p2 = chars4(it + 8u);
-          }
+          if (pit != it) chars12(it, can, p0, p1, p2);
           const uint32_t m2 = jc > 8u ? ((1u << (8u * (jc - 8u))) - 1u) : 0u;
+          const uint64_t width = ep - sp;
+          bool jumped = false;
+          uint64_t rowj = 0;
+          uint32_t nrows = 1;
+          uint32_t q0 = 0, q1 = 0, q2 = 0;
+          // ONE 16-byte load per row, everything taken out of it unconditionally: with the row used only under `if (hit)`,
+          // the compiler sank that half of the load behind the comparison -- two dependent loads per lookup (round 4,
+          // profiles/r04_c3_bound.md)
+          if (!__builtin_amdgcn_ballot_w64(can && width != 1u)) {
+            // one row per group: every lane of the group loads the same entry, the row comes straight out of it
+            uint4 je = make_uint4(0, 0, 0, 0);
+            if (can) je = jtab[sp];
+            chars12(it + jc, can && rem >= 2u * jc, q0, q1, q2);
+            jumped = can && je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
+            rowj = (uint64_t)(je.z >> 24) | ((uint64_t)je.w << 8);
+            jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(can && t == 0));
+          } else {
+            // two to G rows somewhere: lane t looks up row sp + t; the rows whose characters are the pattern's go on to
+            // LF^jc of themselves -- LF keeps the order of rows that carry the same character, so they land side by side:
+            // the new interval begins at the first survivor's image and has as many rows as there are survivors
+            const bool mine = can && (uint64_t)t < width;
+            uint4 je = make_uint4(0, 0, 0, 0);
+            if (mine) je = jtab[sp + t];
+            chars12(it + jc, can && rem >= 2u * jc, q0, q1, q2);
+            const bool hit = mine && je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
+            const uint32_t lane64g = threadIdx.x & 63u, gbase = lane64g - t;
+            const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> gbase) & ((1u << G) - 1u);
+            const int first = (int)(gbase + (hm ? (uint32_t)__builtin_ctz(hm) : 0u));
+            const uint32_t rlo = (uint32_t)__shfl((int)((je.z >> 24) | (je.w << 8)), first, 64), rhi = (uint32_t)__shfl((int)(je.w >> 24), first, 64);
+            jumped = can && hm != 0u;
+            rowj = ((uint64_t)rhi << 32) | rlo;
+            nrows = (uint32_t)__builtin_popcount(hm);
+            jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // an entry per row looked up
+          }
+          p0 = q0; p1 = q1; p2 = q2;
+          pit = it + jc;
           if (can) {
-            // ONE 16-byte load (every lane of the group the same entry), everything taken out of it unconditionally: with
-            // the row used only under `if (jumped)`, the compiler sank that half of the load behind the comparison -- two
-            // dependent loads per lookup (round 4, profiles/r04_c3_bound.md)
-            const uint4 je = jtab[sp];
-            const bool jumped = je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
-            const uint64_t rowj = (uint64_t)(je.z >> 24) | ((uint64_t)je.w << 8);
-            if (!jumped) {
+            if (!jumped && width == 1u) {
               // The pattern differs from its one row's text within these characters: it misses, and what is left to find is
               // where -- the reference loop's values at the failing step.  Walking there here would hold up the whole wave
               // (every lane executes the steps, the groups that jumped wait): the group parks its state in its output
               // slots and retires; k_search_defer walks the parked patterns of 64 at a time, densely.
-              if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
+              park_now = true;
               deferred = true;
-            }
-            ep = jumped ? rowj + 1 : sp;                             // parked: not alive any more
+            }                                                        // (wider and no row agrees: it steps on and ends within jc steps)
+            ep = jumped ? rowj + nrows : (deferred ? sp : ep);       // parked: not alive any more
             sp = jumped ? rowj : sp;
             steps += jumped ? jc : 0u;
             skip = jumped ? jc : 0u;
             lookedup = jumped;
           }
-          jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(can && t == 0));
         }
       }
       if (JT && R3T) {
-        // ---- a group that holds two to G rows, or one row and fewer than jc characters (the tail of its pattern), takes
-        // THREE steps with the three-step row table, lane t row sp + t: the rows whose three characters are the pattern's
-        // go on to LF^3 of themselves -- LF keeps the order of rows that carry the same character, so they land side by
-        // side: the new interval begins at the first survivor's image and has as many rows as there are survivors.  (No
-        // row table, or one or two characters left: single steps.)
+        // ---- a group that holds at most G rows and has not just jumped takes THREE steps with the three-step row table,
+        // lane t row sp + t as above: the tail of its pattern (fewer than jc characters left) at any step; with more left
+        // -- it waits for the other groups of the wave to become narrow, or free, too -- only at every third step, so that
+        // the groups that wait this way come free together (taken at any step, their three-step rests would interleave
+        // and the row jump table, which wants every group free at once, would never be reached).
         const uint64_t width = ep - sp;
-        const bool want3 = alive && skip == 0u && !deferred && !lookedup && width >= 1u && width <= (uint64_t)G && rem >= 3u && (width != 1u || rem < jc);
+        const bool want3 = alive && skip == 0u && !deferred && !lookedup && width >= 1u && width <= (uint64_t)G && rem >= 3u &&
+                           (rem < jc || it % 3u == 0u);
         if (__builtin_amdgcn_ballot_w64(want3)) {
           const uint32_t three = chars4(it) & 0xFFFFFFu;
           const bool mine = want3 && (uint64_t)t < width;
@@ -419,8 +532,8 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
               steps += 3;
               skip = 3u;
               lookedup = true;
-            } else if (width == 1u) {                                          // it fails within these three: k_search_defer finds where
-              if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
+            } else if (width == 1u) {                                          // it fails within these three: the walk finds where
+              park_now = true;
               deferred = true;
               ep = sp;
             }                                                                  // (wider and no row agrees: it steps on and ends within three steps)
@@ -428,9 +541,21 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
           r3l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // a lane per row looked up
         }
       }
+      if (JT && __builtin_amdgcn_ballot_w64(park_now)) {
+        // (sp is still the row the lookup was made with: a parked group's sp is not touched again)
+        if constexpr (kFold) {
+          const unsigned long long pm = __builtin_amdgcn_ballot_w64(park_now && t == 0);
+          const uint32_t lane64p = threadIdx.x & 63u;
+          const uint32_t slot = npark + (uint32_t)__builtin_popcountll(pm & ((1ull << lane64p) - 1ull));
+          if (park_now && t == 0) { s_park_row[wave_in_wg][slot] = sp; s_park_pid[wave_in_wg][slot] = pid; s_park_it[wave_in_wg][slot] = it; }
+          npark += (uint32_t)__builtin_popcountll(pm);
+        } else {
+          if (park_now && t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
+        }
+      }
       if ((JT || R3T) && !__builtin_amdgcn_ballot_w64(alive && skip == 0u && !deferred)) {
         // ---- nobody steps in this iteration: every live group has jumped or is sitting out.  The clock goes to the first
-        // group that is free again (1 .. 11 steps on), and every cursor with it.
+        // group that is free again (1 .. 11 steps on).
         bool cand = alive && !deferred && skip != 0u;      // the smallest `skip` among them, a bit at a time
         uint32_t adv = 0;
 #pragma unroll
@@ -441,10 +566,10 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         }
         if (!__builtin_amdgcn_ballot_w64(cand)) adv = 1u;                       // (everybody parked: the loop ends at the top)
         skip -= skip >= adv ? adv : skip;
-        cursor_to(it + adv);
         it += adv - 1u;
         continue;
       }
+      if (cursor_it != it) cursor_to(it);                                       // (wave-uniform)
       const bool stepping = alive && skip == 0u && !deferred;
       skip -= skip ? 1u : 0u;
       const bool wide_iv = stepping && (ep - sp) != 1;
@@ -517,6 +642,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         ch = nx;
         nx = chunk((it >> 2) + 2);
       }
+      cursor_it = it + 1u;
     }
     if (act && t == 0 && !deferred) { sp_out[pid] = sp; ep_out[pid] = ep; }
     };      // search_one_batch
@@ -526,11 +652,13 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
     } else {
       search_one_batch(std::false_type{});
     }
+    if (kFold && npark > kParkCap - P) walk_parked();      // room for a whole batch's groups
     cur = nxt_stage;
     par ^= 1u;
     end0 = end1; len0 = len1;
     fix_off((uint64_t)batch + 2ull * nwaves, raw2a, raw2b, end1, len1);
   }
+  if (kFold) walk_parked();
   counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
   if (KT) {
     const unsigned long long lookups = ktl;
@@ -800,7 +928,7 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
     else if (jt) k_search_rows<1><<<g1, kSThreads, 0, st>>>(jt, h->jump_chars, r1, pat, off, sp, ep, k, h->d_counters);
     else k_search_rows<0><<<g1, kSThreads, 0, st>>>(nullptr, 0u, r1, pat, off, sp, ep, k, h->d_counters);
   }
-  if (JT || RW) {     // the patterns still parked (it reads the batch's ep_out once: 8 bytes per pattern; no state shared between calls)
+  if (RW) {     // the patterns k_search_rows left at their failing step (it reads the batch's ep_out once: 8 bytes per pattern; no state shared between calls)
     const uint64_t wg = ((uint64_t)k + 2 * kSThreads - 1) / (2 * kSThreads);       // a wave looks at 128 patterns
     const int g2 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 8);
     k_search_defer<WIDE, LAYOUT><<<g2, kSThreads, 0, st>>>(h->dev, pat, off, sp, ep, k, h->d_counters);

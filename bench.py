@@ -489,7 +489,7 @@ def measure_exchange(args, torch, dist, hip, gather, k, device, stream, use_dist
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                g.launch(0, stream)
+                g.launch(0, stream, packed_already=(form == "packed" and g is gather))      # the configured form arrives packed by the search
                 g.finish()
                 e1.record()
                 torch.cuda.synchronize()
@@ -583,17 +583,29 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     step_no = [0]
 
     def step():
-        sp, ep = gather.slot(step_no[0])
-        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
-        if use_dist:        # the path's one exchange: pack the hit intervals (8 B per pattern) and gather them
-            gather.launch(step_no[0], stream)
+        i = step_no[0]
         step_no[0] += 1
+        if use_dist:        # the intervals are written in the exchange's form by the search itself, then gathered: the path's one exchange
+            gather.search_into(i, hip, pats.data_ptr(), off.data_ptr(), stream)
+            gather.launch(i, stream, packed_already=True)
+            return None, None
+        sp, ep = gather.slot(i)
+        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
         return sp, ep
 
     # rank queries one step executes (device counter; identical every step)
     hip.stats_reset()
     sp, ep = step()
+    gather.finish()
     torch.cuda.synchronize()
+    if sp is None:          # the packed form went to the exchange: the intervals themselves, for the hit count
+        sp, ep = gather.mine[0][0], gather.mine[0][1]
+        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
+        torch.cuda.synchronize()
+        hip.stats_reset()
+        step()
+        gather.finish()
+        torch.cuda.synchronize()
     s1 = hip.stats()
     ranks_per_step = int(s1["rank_queries"])
     requests_per_step = int(s1["search_requests"])
@@ -612,13 +624,19 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for a, b in ev:
-        sp_i, ep_i = gather.slot(step_no[0])
-        a.record()          # torch's current stream == the stream the kernel is launched on
-        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp_i.data_ptr(), ep_i.data_ptr(), k, stream)
-        b.record()
-        if use_dist:
-            gather.launch(step_no[0], stream)
+        i = step_no[0]
         step_no[0] += 1
+        if use_dist:
+            gather.slot(i)      # (waits for the collective that last used the slot, outside the search's events)
+            a.record()          # torch's current stream == the stream the kernel is launched on
+            gather.search_into(i, hip, pats.data_ptr(), off.data_ptr(), stream)
+            b.record()
+            gather.launch(i, stream, packed_already=True)
+        else:
+            sp_i, ep_i = gather.slot(i)
+            a.record()
+            hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp_i.data_ptr(), ep_i.data_ptr(), k, stream)
+            b.record()
     gather.finish()         # every step's gather completes inside the timed region
     torch.cuda.synchronize()
     if use_dist:
@@ -1043,7 +1061,15 @@ def main():
     # under torch.distributed.run (RANK/MASTER_* set) the RCCL path runs even for one rank
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
-        dist.init_process_group("nccl", device_id=device)
+        # the collective's stream at high priority: its kernels are few workgroups that must find room beside a search
+        # kernel that fills the device (FMX_BENCH_NCCL_PRIO=0: default priority)
+        opts = None
+        if os.environ.get("FMX_BENCH_NCCL_PRIO", "1") != "0":
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                opts = None
+        dist.init_process_group("nccl", device_id=device, pg_options=opts)
     stream = torch.cuda.current_stream().cuda_stream
     run = run_regex if (args.workload in REGEX or args.workload.startswith("c4text")) else run_literal
     out = run(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream)

@@ -685,9 +685,9 @@ int fmx_search_batch_ex_dev(const fmx_index *idx, const void *d_pat, const void 
     HIP_TRY(check_offsets(H(idx), d_off, k, (hipStream_t)stream, &ok), "k_check_offsets");
     if (!ok) return arg_fail("pattern offsets must be non-decreasing");
   }
-  HIP_TRY(launch_search(H(idx), d_pat, fixed ? nullptr : d_off, d_sp, d_ep, k, (hipStream_t)stream, fixed), "k_search");
-  if (opts && opts->packed)      // in place: d_sp's first k words become the packed words
-    HIP_TRY(launch_pack_intervals(H(idx), d_sp, d_ep, k, opts->escape_cap, d_sp, (hipStream_t)stream), "k_pack_intervals");
+  // packed: by the search kernel itself where it finishes every pattern, else in place behind it (d_sp's first k words)
+  HIP_TRY(launch_search(H(idx), d_pat, fixed ? nullptr : d_off, d_sp, d_ep, k, (hipStream_t)stream, fixed,
+                        (opts && opts->packed) ? (uint64_t)opts->escape_cap : ~0ull), "k_search");
   return FMX_OK;
 }
 
@@ -818,9 +818,7 @@ int fmx_search_batch_ex(const fmx_index *idx, const uint8_t *pat, const uint64_t
       HostIn ins[2] = {{total ? pat : nullptr, (size_t)total}, {off, fixed ? 0 : (k + 1) * 8}};
       HostOut outs[2] = {{sp, out_words * 8}, {packed ? nullptr : ep, k * 8}};
       return run_io(h, ins, 2, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
-        hipError_t e = launch_search(h, di[0], fixed ? nullptr : di[1], dout[0], dout[1], k, st, fixed);
-        if (e == hipSuccess && packed) e = launch_pack_intervals(h, dout[0], dout[1], k, esc, dout[0], st);
-        return e;
+        return launch_search(h, di[0], fixed ? nullptr : di[1], dout[0], dout[1], k, st, fixed, packed ? (uint64_t)esc : ~0ull);
       });
     }
     Call c0(h);
@@ -842,8 +840,7 @@ int fmx_search_batch_ex(const fmx_index *idx, const uint8_t *pat, const uint64_t
     }
     rc = c0.timed([&](hipStream_t st, EventPair &ev) {
       HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
-      HIP_TRY(launch_search(h, d_pat.p, fixed ? nullptr : d_off.p, d_sp.p, d_ep.p, k, st, fixed), "k_search");
-      if (packed) HIP_TRY(launch_pack_intervals(h, d_sp.p, d_ep.p, k, esc, d_sp.p, st), "k_pack_intervals");
+      HIP_TRY(launch_search(h, d_pat.p, fixed ? nullptr : d_off.p, d_sp.p, d_ep.p, k, st, fixed, packed ? (uint64_t)esc : ~0ull), "k_search");
       HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
       return (int)FMX_OK;
     });

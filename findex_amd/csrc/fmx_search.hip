@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
                                                         const unsigned long long *__restrict__ r3tab, const uint8_t *__restrict__ pat,
                                                         const PatOff po,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
-                                                        uint32_t k, unsigned long long *__restrict__ counters) {
+                                                        uint32_t k, unsigned long long *__restrict__ counters, const uint64_t pk_cap) {
   constexpr int G = Lay<LAYOUT>::G;              // lanes per pattern
   constexpr uint32_t P = 64 / G;                 // patterns per wave
   constexpr uint32_t R = LAYOUT == kLayoutBytes ? 2u : 1u;    // memory requests per rank query
@@ -158,6 +158,23 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
   __shared__ uint32_t s_park_pid[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
   __shared__ uint32_t s_park_it[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
   uint32_t npark = 0;               // entries in this wave's list (wave-uniform)
+  // A pattern's final interval (a group's first lane calls).  pk_cap != ~0 (only a kernel that finishes every pattern
+  // itself is launched that way): straight into the 8-byte form (fmx.h) -- word q of sp_out, wide intervals appended to
+  // the escape list behind word k -- instead of a pass of k_pack_intervals over both arrays behind the search.
+  auto emit = [&](uint32_t q, uint64_t a, uint64_t b) {
+    if (kFold && pk_cap != ~0ull) {
+      unsigned long long *pk = reinterpret_cast<unsigned long long *>(sp_out);
+      const uint64_t w = b - a;
+      if (w >= kPackWide) {
+        const unsigned long long slot = atomicAdd(pk + k, 1ull);
+        if (slot < pk_cap) { pk[(uint64_t)k + 1 + 2 * slot] = q; pk[(uint64_t)k + 2 + 2 * slot] = b; }
+      }
+      pk[q] = a | ((w < kPackWide ? w : kPackWide) << 40);
+    } else {
+      sp_out[q] = a;
+      ep_out[q] = b;
+    }
+  };
   const uint32_t wave_in_wg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t lane64 = threadIdx.x & 63u;
   const uint64_t pat_addr = (uint64_t)(uintptr_t)pat;
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         }
         wit += nst;                                            // (meaningless once the interval is empty: the loop ends then)
       }
-      if (actw && t == 0) { sp_out[wpid] = wsp; ep_out[wpid] = wep; }
+      if (actw && t == 0) emit(wpid, wsp, wep);
     }
   };
   for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
@@ -644,7 +661,7 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
       }
       cursor_it = it + 1u;
     }
-    if (act && t == 0 && !deferred) { sp_out[pid] = sp; ep_out[pid] = ep; }
+    if (act && t == 0 && !deferred) emit(pid, sp, ep);
     };      // search_one_batch
     if constexpr (kStage) {
       if (cur.ok) search_one_batch(std::true_type{});
@@ -912,7 +929,7 @@ static int blocks_per_cu(K kernel) {
 
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
-                              const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st) {
+                              const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st, uint64_t pk_cap) {
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
   static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>);
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
@@ -920,7 +937,8 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
   k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
-                                                                       R3T ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters);
+                                                                       R3T ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters,
+                                                                       (JT && RW == 0u) ? pk_cap : ~0ull);
   if (RW) {     // the one-row part of every search, a lane per pattern
     const uint64_t wg = ((uint64_t)k + kSThreads - 1) / kSThreads;
     const int g1 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 32);
@@ -933,11 +951,14 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
     const int g2 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 8);
     k_search_defer<WIDE, LAYOUT><<<g2, kSThreads, 0, st>>>(h->dev, pat, off, sp, ep, k, h->d_counters);
   }
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  // the 8-byte form was asked for and this set of kernels leaves (sp, ep): packed in place behind them
+  if (e == hipSuccess && pk_cap != ~0ull && !(JT && RW == 0u)) e = launch_pack_intervals(h, sp, ep, k, pk_cap, sp, st);
+  return e;
 }
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
 static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
-                             uint32_t k, hipStream_t st) {
+                             uint32_t k, hipStream_t st, uint64_t pk_cap) {
   // the row tables are built by fmx_prepare or by the search that brings the handle's patterns to the threshold
   // (fmx_jump.hip, tables_due); until then -- a per-call adapter's single queries -- every step is walked on the dictionary
   const bool due = tables_due(h, k, false);
@@ -953,48 +974,59 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
   if (rows == 1) {
     const unsigned long long *r1 = nullptr;
     if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
-    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, jt, r1, pat, off, sp, ep, k, st);
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, jt, r1, pat, off, sp, ep, k, st, pk_cap);
   }
   if (jt) {      // and the three-step table beside it, for the steps no aligned jump covers
     const unsigned long long *r3 = nullptr;
     if (rows != 0 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
-    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, true, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st)
-              : launch_v4kj<WIDE, LAYOUT, KT, true, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st);
+    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, true, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap)
+              : launch_v4kj<WIDE, LAYOUT, KT, true, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap);
   }
   if (rows != 0) {
     const unsigned long long *r3 = nullptr, *r1 = nullptr;
     bool have1;
     { std::lock_guard<std::mutex> lk(h->r1_mu); have1 = h->d_row1 != nullptr; }
     if (!have1 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
-    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, false, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st);
+    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, false, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st, pk_cap);
     if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
-    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st);
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st, pk_cap);
   }
-  return launch_v4kj<WIDE, LAYOUT, KT, false, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st);
+  return launch_v4kj<WIDE, LAYOUT, KT, false, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st, pk_cap);
 }
 
 template <bool WIDE, uint32_t LAYOUT>
 static hipError_t launch_v4(const Index *h, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
-                            uint32_t k, hipStream_t st) {
+                            uint32_t k, hipStream_t st, uint64_t pk_cap) {
   KTab kt;
   const hipError_t e = ktab_get(h, st, &kt, tables_due(h, k, true));
   if (e != hipSuccess) return e;
   // the search uses the table's levels in steps of four characters (all levels are kept: fmx_ktab.hip)
-  if (kt.k >= 12) return launch_v4k<WIDE, LAYOUT, 12>(h, kt, pat, off, sp, ep, k, st);
-  if (kt.k >= 8) return launch_v4k<WIDE, LAYOUT, 8>(h, kt, pat, off, sp, ep, k, st);
-  if (kt.k >= 4) return launch_v4k<WIDE, LAYOUT, 4>(h, kt, pat, off, sp, ep, k, st);
-  return launch_v4k<WIDE, LAYOUT, 0>(h, kt, pat, off, sp, ep, k, st);
+  if (kt.k >= 12) return launch_v4k<WIDE, LAYOUT, 12>(h, kt, pat, off, sp, ep, k, st, pk_cap);
+  if (kt.k >= 8) return launch_v4k<WIDE, LAYOUT, 8>(h, kt, pat, off, sp, ep, k, st, pk_cap);
+  if (kt.k >= 4) return launch_v4k<WIDE, LAYOUT, 4>(h, kt, pat, off, sp, ep, k, st, pk_cap);
+  return launch_v4k<WIDE, LAYOUT, 0>(h, kt, pat, off, sp, ep, k, st, pk_cap);
 }
 
 // One launch per call: no scratch, nothing to own per stream, so concurrent calls on one handle need no lock.
 // d_off == nullptr: a batch of k patterns of fixed_len bytes each, one behind the other (fmx_search_opts.fixed_len).
+// pack_cap != ~0: the intervals in the 8-byte form (fmx.h) with room for pack_cap escape entries -- d_sp receives the
+// packed words (its first k words double as the kernels' sp array where a set of kernels cannot pack by itself), d_ep is
+// scratch.
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
-                         hipStream_t st, uint32_t fixed_len) {
+                         hipStream_t st, uint32_t fixed_len, uint64_t pack_cap) {
+  if (pack_cap != ~0ull) {       // the count of wide intervals (word k): zero before anything appends to the list
+    const hipError_t e0 = hipMemsetAsync(static_cast<unsigned long long *>(d_sp) + k, 0, 8, st);
+    if (e0 != hipSuccess) return e0;
+  }
   if (!k) return hipSuccess;
   const PatOff po{d_off ? (const uint64_t *)d_off : (const uint64_t *)h->d_cf, d_off ? 0ull : (uint64_t)fixed_len};
-  if (search_variant() == 1 || k > 0xFFFFFFF0ull) return launch_search_v1(h, d_pat, po, d_sp, d_ep, k, st);
+  if (search_variant() == 1 || k > 0xFFFFFFF0ull) {
+    hipError_t e1 = launch_search_v1(h, d_pat, po, d_sp, d_ep, k, st);
+    if (e1 == hipSuccess && pack_cap != ~0ull) e1 = launch_pack_intervals(h, d_sp, d_ep, k, pack_cap, d_sp, st);
+    return e1;
+  }
   hipError_t e = hipSuccess;
-#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, po, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st)
+#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, po, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st, pack_cap)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
   return e;

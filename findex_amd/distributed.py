@@ -320,6 +320,18 @@ class IntervalGather:
             self.work[j] = None
         return self.mine[j][0], self.mine[j][1]
 
+    def search_into(self, i, searcher, d_pat, d_off, stream=0, fixed_len=0):
+        """Slot i's search, written where the exchange sends from: in the packed form the search kernels emit the 8-byte
+        words themselves (fmx_search_batch_ex_dev, packed) -- no (sp, ep) arrays, no packing pass behind the search; call
+        launch(i, stream, packed_already=True) behind it.  Waits for the slot like slot(i)."""
+        sp, ep = self.slot(i)
+        j = i % self.depth
+        if self.form == "packed":
+            searcher.search_batch_ex_dev(d_pat, d_off, self.send[j].data_ptr(), ep.data_ptr(), self.k, stream, fixed_len=fixed_len,
+                                         packed=True, escape_cap=self.cap)
+        else:
+            searcher.search_batch_ex_dev(d_pat, d_off, sp.data_ptr(), ep.data_ptr(), self.k, stream, fixed_len=fixed_len)
+
     def pack(self, i, stream=0):
         """The send buffer of slot i from its (sp, ep) rows (a no-op for form "pairs")."""
         j = i % self.depth

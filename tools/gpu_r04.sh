@@ -64,6 +64,34 @@ except Exception as e:
     print("no result:", e)
 PY
   ;;
+overlap)
+  # does the exchange run beside the next step's search?  one-rank RCCL (its gather is a device kernel like any rank's),
+  # the collective's stream at default / high priority, the search kernel on all / fewer workgroups per CU
+  for prio in 0 1; do for wgs in 0 4 3 2; do
+    FMX_BENCH_NCCL_PRIO=$prio FMX_SEARCH_WGS=$( [ $wgs = 0 ] && echo 8 || echo $wgs ) timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --workload c3 --steps 20 --warmup 3 --no-cpu-baseline > $O/overlap_p${prio}_w${wgs}.json 2> $O/overlap_p${prio}_w${wgs}.log
+    python - $O/overlap_p${prio}_w${wgs}.json $prio $wgs <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); x=d["exchange"]
+    print("nccl prio %s search wgs/CU %s: ms/step %.4f search_ms %.4f gather_ms %.4f sum %.4f" % (sys.argv[2], sys.argv[3], d["ms_per_step"], x["search_ms"], x["gather_ms"], x["search_ms"]+x["gather_ms"]))
+except Exception as e:
+    print("no result:", e)
+PY
+  done; done
+  ;;
+rccl1:*)
+  wl=${PART#rccl1:}
+  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --workload $wl --steps 10 --warmup 2 --no-cpu-baseline > $O/${wl}_one_rank_rccl.json 2> $O/${wl}_one_rank_rccl.log; echo "$wl (1-rank RCCL) rc=$?"
+  python - $O/${wl}_one_rank_rccl.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); x=d.get("exchange")
+    print("value %.0f ms/step %.4f exchange %s" % (d["value"], d["ms_per_step"], {k:x[k] for k in ("form","delivery","gather_ms","payload_bytes_per_rank","search_ms")} if x else None))
+    if x: print("  all forms:", {k:round(v["gather_ms"],4) for k,v in x["all_forms"].items()})
+except Exception as e:
+    print("no result:", e)
+PY
+  ;;
 trace:*)
   wl=${PART#trace:}
   (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/trace_$wl -- python3 $REPO/bench.py --workload $wl --no-cpu-baseline --no-host-path > $REPO/$O/${wl}_bench_under_rocprof.json 2> $REPO/$O/${wl}_bench_under_rocprof.err); echo "rocprof bench $wl exit $?"

@@ -586,7 +586,9 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         it += adv - 1u;
         continue;
       }
-      if (cursor_it != it) cursor_to(it);                                       // (wave-uniform)
+      if constexpr (JT || R3T) {
+        if (cursor_it != it) cursor_to(it);                                     // (wave-uniform; the clock only jumps with a row table)
+      }
       const bool stepping = alive && skip == 0u && !deferred;
       skip -= skip ? 1u : 0u;
       const bool wide_iv = stepping && (ep - sp) != 1;

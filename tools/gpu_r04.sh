@@ -64,6 +64,15 @@ except Exception as e:
     print("no result:", e)
 PY
   ;;
+ab:*)
+  # A/B of library variants on one box:  ab:<workload>:<tag>[,<tag>..]   ("-" = the product build)
+  spec=${PART#ab:}; wl=${spec%%:*}; tags=${spec#*:}
+  for rep in 1 2; do for tag in ${tags//,/ }; do
+    lib=""; [ "$tag" != "-" ] && lib="FMX_LIB=$PWD/findex_amd/lib/variants/libfmx_$tag.so"
+    echo -n "$wl $tag: "
+    env $lib timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-path --steps 20 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('ms/step %.4f kernel %.4f value %.0f'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))"
+  done; done
+  ;;
 overlap)
   # does the exchange run beside the next step's search?  one-rank RCCL (its gather is a device kernel like any rank's),
   # the collective's stream at default / high priority, the search kernel on all / fewer workgroups per CU

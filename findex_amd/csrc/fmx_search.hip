@@ -94,8 +94,11 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // R3T (with JT): the handle also has the three-step row table (fmx_jump.hip): a one-row group that is not at a chunk
 // boundary, or has fewer than eight characters left, takes three steps with one 8-byte lookup instead of three rank
 // queries -- at C3 the three steps between the wide part of a search and its first aligned jump.
+#ifndef FMX_SEARCH_WAVES
+#define FMX_SEARCH_WAVES 6      // waves per SIMD the search kernel is compiled for (register budget 512 / waves, in eights)
+#endif
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T>
-__global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
+__global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_SEARCH_WAVES, 8))) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
                                                         uint32_t ksigma, const uint4 *__restrict__ jtab, const uint32_t jc,
                                                         const unsigned long long *__restrict__ r3tab, const uint8_t *__restrict__ pat,
                                                         const PatOff po,
@@ -421,7 +424,6 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
       ch = chunk(KT / 4);              // the chunk step KT starts
     }
     uint32_t skip = 0;                                         // steps this group has jumped over and still sits out
-    uint32_t p0 = 0, p1 = 0, p2 = 0, pit = ~0u;               // the pattern's characters for a row-jump lookup at step pit, fetched ahead
     uint32_t cursor_it = KT ? KT : 1u;                         // the step (ch, nx) stand for
     bool deferred = false;                                     // this group's pattern was parked for k_search_defer
     for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
@@ -463,17 +465,16 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
         // jc characters an LF walk from r reads and the row it ends on (fmx_jump.hip).  The pattern's characters come from
         // the staged span at any offset (round 3's lookups had to start on a chunk boundary of the pattern and held
         // eight characters; nine fit C3's 32 - 5 = 27 one-row steps exactly: three lookups where there were three and a
-        // three-step word), and the characters of the NEXT lookup are fetched from LDS while the entries are on their way:
-        // between an entry's arrival and the next entry's request stand a comparison and a select.
+        // three-step word); between an entry's arrival and the next entry's request stand a comparison and a select.
         const bool can = alive && rem >= jc;
         if (__builtin_amdgcn_ballot_w64(can)) {
-          if (pit != it) chars12(it, can, p0, p1, p2);
+          uint32_t p0, p1, p2;
+          chars12(it, can, p0, p1, p2);      // (LDS: they arrive long before the entries requested below)
           const uint32_t m2 = jc > 8u ? ((1u << (8u * (jc - 8u))) - 1u) : 0u;
           const uint64_t width = ep - sp;
           bool jumped = false;
           uint64_t rowj = 0;
           uint32_t nrows = 1;
-          uint32_t q0 = 0, q1 = 0, q2 = 0;
           // ONE 16-byte load per row, everything taken out of it unconditionally: with the row used only under `if (hit)`,
           // the compiler sank that half of the load behind the comparison -- two dependent loads per lookup (round 4,
           // profiles/r04_c3_bound.md)
@@ -481,7 +482,6 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
             // one row per group: every lane of the group loads the same entry, the row comes straight out of it
             uint4 je = make_uint4(0, 0, 0, 0);
             if (can) je = jtab[sp];
-            chars12(it + jc, can && rem >= 2u * jc, q0, q1, q2);
             jumped = can && je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
             rowj = (uint64_t)(je.z >> 24) | ((uint64_t)je.w << 8);
             jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(can && t == 0));
@@ -492,7 +492,6 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
             const bool mine = can && (uint64_t)t < width;
             uint4 je = make_uint4(0, 0, 0, 0);
             if (mine) je = jtab[sp + t];
-            chars12(it + jc, can && rem >= 2u * jc, q0, q1, q2);
             const bool hit = mine && je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
             const uint32_t lane64g = threadIdx.x & 63u, gbase = lane64g - t;
             const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> gbase) & ((1u << G) - 1u);
@@ -503,8 +502,6 @@ __global__ __launch_bounds__(kSThreads) void k_search4(DevIndex ix, const uint4 
             nrows = (uint32_t)__builtin_popcount(hm);
             jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // an entry per row looked up
           }
-          p0 = q0; p1 = q1; p2 = q2;
-          pit = it + jc;
           if (can) {
             if (!jumped && width == 1u) {
               // The pattern differs from its one row's text within these characters: it misses, and what is left to find is

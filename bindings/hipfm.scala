@@ -227,6 +227,10 @@ object HipRegex {
                  maxIterations: Int, cap: Int = 1 << 20, maxFrontier: Long = 0): Array[List[SAResult]] = {
     // one native call compiles the whole batch on all host cores (fmx_regex_compile_batch); a regex the reference
     // would refuse raises what it raises there: "re2post syntax" (status 7) or a MatchError (status 8)
+    // (the packed form is 0-terminated: a regex that contains the character 0 would be split in two silently -- the
+    // one-regex entry point passes it through, here it is refused; the reference's readers escape byte 0 anyway)
+    val zero = res.indexWhere(_.indexOf(0.toChar) >= 0)
+    if (zero >= 0) throw new IllegalArgumentException("regex " + zero + " of the batch contains the character 0")
     val packed = res.flatMap(r => latin1(r) :+ 0.toByte)
     val handles = new Array[Long](res.length)
     val st = new Array[Int](res.length)

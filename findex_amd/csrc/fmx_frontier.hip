@@ -1990,14 +1990,14 @@ int fmx_regex_compile_batch(const char *const *res, size_t k, int line_only, fmx
   }
   std::atomic<size_t> first_bad{k};
   std::atomic<int> nomem{0};
-  parallel_for(k, 256, [&](size_t a, size_t b) {
+  auto compile_range = [&](size_t a, size_t b) {
     for (size_t i = a; i < b; i++) {
       int rc = FMX_OK;
       try {
         out[i] = reinterpret_cast<fmx_regex *>(new Regex(compile_regex(res[i], line_only != 0)));
       } catch (const RegexError &e) {
         rc = e.code;
-      } catch (const std::bad_alloc &) {
+      } catch (...) {       // bad_alloc, length_error ..: nothing may leave a worker thread (std::terminate) or this extern "C" function
         rc = FMX_ERR_NOMEM;
         nomem.store(1);
       }
@@ -2007,7 +2007,8 @@ int fmx_regex_compile_batch(const char *const *res, size_t k, int line_only, fmx
         while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
       }
     }
-  });
+  };
+  parallel_for(k, 256, compile_range);      // (starts as many threads as it can get and never throws: fmx_hostpar.cpp)
   if (nomem.load()) {
     for (size_t i = 0; i < k; i++) { delete reinterpret_cast<Regex *>(out[i]); out[i] = nullptr; }
     set_error("out of host memory");
@@ -2022,9 +2023,10 @@ int fmx_regex_compile_batch(const char *const *res, size_t k, int line_only, fmx
 
 int fmx_regex_free_batch(fmx_regex *const *res, size_t k) {
   if (k && !res) { set_error("null argument"); return FMX_ERR_ARG; }
-  parallel_for(k, 4096, [&](size_t a, size_t b) {
+  auto free_range = [&](size_t a, size_t b) {
     for (size_t i = a; i < b; i++) delete reinterpret_cast<Regex *>(res[i]);
-  });
+  };
+  parallel_for(k, 4096, free_range);
   return FMX_OK;
 }
 

@@ -64,7 +64,13 @@ void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_
   };
   std::vector<std::thread> th;
   th.reserve(nt - 1);
-  for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+  for (unsigned t = 1; t < nt; t++) {
+    try {
+      th.emplace_back(work);
+    } catch (...) {       // no more threads to be had (std::system_error): the ones that exist, and this one, take all chunks
+      break;
+    }
+  }
   work();
   for (std::thread &t : th) t.join();
 }

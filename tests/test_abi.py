@@ -132,12 +132,25 @@ def test_config_keys_and_values():
     L = _lib.load()
     ok = {b"layout": [b"onehot", b"bytes", b"auto"], b"checkpoints": [b"superblock", b"auto"], b"ktab": [b"off", b"auto"],
           b"jump": [b"off", b"rows", b"rows3", b"jumps", b"auto"], b"pipeline": [b"on", b"off"], b"validate": [b"1", b"0"],
-          b"threads": [b"3", b"0"]}
+          b"threads": [b"3", b"0"], b"jump_chars": [b"8", b"11", b"9"], b"tables_after": [b"auto", b"100000", b"0"]}
     for key, values in ok.items():
         for v in values:                        # the last value of each list is the default: left in place
             assert L.fmx_config_set(key, v) == 0, (key, v)
         if key != b"validate":                  # ("validate" reads anything but "0" as on)
             assert L.fmx_config_set(key, b"no-such-value") == 3, key
             assert L.fmx_last_error().decode()
+    for key, bad in ((b"jump_chars", b"7"), (b"jump_chars", b"12"), (b"tables_after", b"-1")):
+        assert L.fmx_config_set(key, bad) == 3, (key, bad)
+    # the 8-byte interval form's host-side decode needs no device either
+    import numpy as np
+    pk = np.array([5 | (3 << 40), 7 | (0xFFFFFF << 40), 9, 1, 1, 7 + (1 << 30)], dtype=np.uint64)      # k = 3: a hit, a wide one, a miss; one escape
+    sp, ep = np.zeros(3, dtype=np.uint64), np.zeros(3, dtype=np.uint64)
+    vp = ctypes.c_void_p
+    assert L.fmx_packed_words(3, 1) == 6
+    assert L.fmx_unpack_intervals(pk.ctypes.data_as(vp), 3, 1, sp.ctypes.data_as(vp), ep.ctypes.data_as(vp)) == 0
+    assert sp.tolist() == [5, 7, 9] and ep.tolist() == [8, 7 + (1 << 30), 9]
+    assert L.fmx_unpack_intervals(pk.ctypes.data_as(vp), 3, 0, sp.ctypes.data_as(vp), ep.ctypes.data_as(vp)) == 9       # FMX_ERR_OVERFLOW
+    pk[4] = 3                                                                                                             # an escape entry that names pattern 3 of 3
+    assert L.fmx_unpack_intervals(pk.ctypes.data_as(vp), 3, 1, sp.ctypes.data_as(vp), ep.ctypes.data_as(vp)) == 2       # FMX_ERR_FORMAT
     assert L.fmx_config_set(b"no-such-key", b"1") == 3
     assert L.fmx_config_set(None, b"1") == 3 and L.fmx_config_set(b"jump", None) == 3

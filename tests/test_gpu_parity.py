@@ -2060,3 +2060,34 @@ def test_text_index_parity_literals_and_regexes():
     assert got.size == want.size and got.size > 20
     for f in ("regex", "len", "sp", "ep"):
         assert np.array_equal(got[f], want[f]), f
+
+
+def test_parked_walks_flush_inside_the_kernel():
+    """With a row jump table the patterns a table lookup finds to miss are kept in a per-wave list in LDS (64 entries) and
+    walked inside the search kernel -- when 48 have come together, and before the wave ends.  600 k patterns, most of
+    them with a byte replaced inside their one-row part, so that every wave fills its list several times over: (sp, ep)
+    at the failing step and the executed steps against the oracle, from offsets and as a fixed-length batch."""
+    bwt, eof, counts = synth_bwt(300_000, 1, 6, 23)
+    hip, orc = pair_from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(31)
+    base = lf_walk_patterns(orc, rng, 6000, 24, 0.0, alphabet=[1, 2, 3, 4, 5, 6])
+    pats2d = np.frombuffer(b"".join(base), dtype=np.uint8).reshape(6000, 24).copy()
+    pats2d = np.tile(pats2d, (100, 1))                               # 600 000 patterns
+    k, m = pats2d.shape
+    mut = rng.random(k) < 0.8
+    pos = rng.integers(0, 14, k)                                      # the bytes read at steps 10 .. 23: inside the one-row part
+    pats2d[mut, pos[mut]] = rng.integers(1, 7, int(mut.sum())).astype(np.uint8)
+    buf = pats2d.reshape(-1)
+    off = np.arange(k + 1, dtype=np.uint64) * np.uint64(m)
+    wsp, wep, wsteps = orc.search_batch(buf, off, threads=8)
+    hip.stats_reset()
+    gsp, gep = hip.search_batch(buf, off)
+    st = hip.stats()
+    assert np.array_equal(gsp, wsp) and np.array_equal(gep, wep)
+    assert st["backward_steps"] == int(wsteps.sum()) and st["jump_lookups"] > k // 2
+    assert 0.3 < float((wsp == wep).mean()) < 0.8                      # most replaced bytes made a miss
+    fsp, fep = hip.search_batch_ex(buf, fixed_len=m)
+    assert np.array_equal(fsp, wsp) and np.array_equal(fep, wep)
+    pk = hip.search_batch_ex(buf, fixed_len=m, packed=True, escape_cap=16)
+    usp, uep = hip.unpack_intervals(pk, k, 16)
+    assert np.array_equal(usp, wsp) and np.array_equal(uep, wep)

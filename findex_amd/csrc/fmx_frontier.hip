@@ -64,6 +64,15 @@ constexpr int kFWaves = kFThreads / 64;       // waves of a workgroup (they shar
 struct FlowQueue {
   unsigned long long *g0, *g1, *g2;    // kSub slices x 2 buffers x sub_cap entries each
 };
+// A call's START elements (states = the regexes' firsts, length 0, every row) are not queued: the first launch of a
+// call makes them up where it would have read them from slice `s`, position `p` of the queue -- elem[s * cap + p] =
+// state | its byte << 40, laid out slice by slice when the batch was made resident (round 3 wrote them to the queue
+// in a launch of their own: 12 us of a 0.4 ms call).
+struct StartSrc {                     // (kept in FrontierCtl and read there when a wave takes a batch: no registers held over the rounds)
+  const unsigned long long *elem;
+  unsigned long long cap;             // entries per slice in `elem`
+  unsigned long long ep;              // what a start element carries as its interval's end: n, or 0 = the empty k-mer code
+};
 constexpr uint32_t kMaxLen = 0xFFFFu;
 constexpr uint64_t kMaxRows = 1ull << 40;     // sp / ep fields of a granule
 
@@ -95,8 +104,9 @@ struct FrontierCtl {     // device-resident counters
   unsigned long long truncated;    // some element was not expanded because its follows would have len >= max_len
   uint32_t max_len;
   uint32_t deep_len;               // elements of looping states at least this long jump the wave's queue (express pool)
-  uint32_t fresh;                  // this chain of launches begins a call (k_frontier_reset -> k_frontier_init)
+  uint32_t fresh;                  // this chain of launches begins a call (k_frontier_reset): its first launch makes up the start elements
   unsigned long long left;         // entries queued when the launch began (k_frontier_reset / k_frontier_advance): 0 = nothing to do
+  StartSrc start;                  // this call's start elements (k_frontier_reset)
 };
 struct FrontierSummary { // what the host reads after a chain of launches (k_frontier_advance)
   unsigned long long left;         // entries still queued
@@ -191,6 +201,7 @@ constexpr uint32_t kGrab = FMX_GRAB;            // entries taken from the queue 
 #ifndef FMX_DEEP_PRIO
 #define FMX_DEEP_PRIO 1
 #endif
+
 #ifndef FMX_DEEP_SLACK
 #define FMX_DEEP_SLACK 4u
 #endif
@@ -386,7 +397,18 @@ __device__ __forceinline__ void frontier_pass(const DevIndex &ix, const KTab &kt
     if (room > 64u) room = 64u;
     const uint32_t cnt = left < room ? (uint32_t)left : room;
     unsigned long long e0 = 0, e1 = 0, e2 = 0;
-    if (lane < cnt) { const uint64_t i = in_off + a_next + lane; e0 = fq.g0[i]; e1 = fq.g1[i]; e2 = fq.g2[i]; }
+    if (lane < cnt) {
+      if (j == 0 && ctl->fresh != 0) {                 // uniform over the grid: a call's first launch, its share is start elements
+        const StartSrc ss = ctl->start;
+        const unsigned long long se = ss.elem[(uint64_t)sub * ss.cap + a_next + lane];
+        e0 = se & (0xFFull << 40);                       // the state's byte; sp = 0
+        e1 = ss.ep;
+        e2 = se & 0xFFFFFFFFull;                         // len = 0
+      } else {
+        const uint64_t i = in_off + a_next + lane;
+        e0 = fq.g0[i]; e1 = fq.g1[i]; e2 = fq.g2[i];
+      }
+    }
     a_next += cnt;
     to_pool(cnt, e0, e1, e2);
     return true;
@@ -1045,31 +1067,16 @@ __global__ __launch_bounds__(kFThreads, FMX_FWAVES) void k_frontier(DevIndex ix,
   frontier_pass<WIDE, LAYOUT>(ix, kt, nfa, fq, j, max_rounds, sub_cap, res, seg_cap, ctl, rcnt, counters);
 }
 
-// Between launches (one wave, lane = slice): a buffer that has been emptied is rewound under its next tag; when that
-// is the buffer the slice was emptying and the written one holds entries, the two swap roles.  Also sums up what
-// the host wants to know after a chain.
-__global__ __launch_bounds__(64) void k_frontier_advance(FrontierCtl *__restrict__ ctl, uint64_t sub_cap, FrontierSummary *__restrict__ sum) {
-  SliceCtl &q = ctl->q[threadIdx.x];
-  const uint32_t wr = q.wsel, ot = 1u - wr;
-  // the launch has worked off (or carried over) everything in the buffer it was not writing
-  const unsigned long long lo = 0;
-  const unsigned long long tl = q.tail[wr] < sub_cap ? q.tail[wr] : sub_cap;
-  const unsigned long long lw = tl > q.head[wr] ? tl - q.head[wr] : 0ull;
-  if (q.tail[ot] | q.head[ot]) { q.tail[ot] = 0; q.head[ot] = 0; q.tag[ot] = next_tag(q.tag[ot]); }
-  if (lw) q.wsel = ot;
-  else if (q.tail[wr] | q.head[wr]) { q.tail[wr] = 0; q.head[wr] = 0; q.tag[wr] = next_tag(q.tag[wr]); }
-  const unsigned long long left = wave_sum(lo + lw), results = wave_sum(ctl->res_count[threadIdx.x].v);
-  if (threadIdx.x == 0) { ctl->left = left; sum->left = left; sum->results = results; sum->overflow = ctl->overflow; sum->truncated = ctl->truncated; }
-}
-
 // result groups the device leaves to the host (k_res_sort)
 constexpr uint32_t kSmallGroup = 12;
 constexpr uint32_t kBigMax = 16384;
-constexpr uint32_t kMidGroup = 1024;   // groups up to this size are ordered by one workgroup in LDS (k_res_sort_mid)
+constexpr uint32_t kMidGroup = 1024;   // groups up to this size are ordered by a workgroup in LDS (k_res_sort's second phase)
 struct BigGroups {
-  uint32_t n;                    // groups of more than kSmallGroup results
-  uint32_t n_host;               // of those, the ones left to the host: more than kMidGroup results, or listed past kBigMax
-  uint32_t ent[2 * kBigMax];     // (first result, count) of each such group; count 0 = ordered on the device
+  uint32_t n;                    // groups of more than kMidGroup results: left to the host
+  uint32_t done;                 // workgroups of k_res_sort that have finished (the last one reports the totals)
+  uint32_t total;                // results of the call (k_res_export reads it)
+  uint32_t pad_;
+  uint32_t ent[2 * kBigMax];     // (first result, count) of each such group
 };
 
 namespace {
@@ -1122,31 +1129,6 @@ __device__ __forceinline__ fmx_result *group_out(const ExportDst *dst, fmx_resul
   cap = own_cap;
   return own;
 }
-__global__ __launch_bounds__(256) void k_res_export(const fmx_result *__restrict__ res, const uint32_t *__restrict__ start, uint32_t k,
-                                                     const uint32_t *__restrict__ rcnt, const BigGroups *__restrict__ big,
-                                                     const ExportDst *__restrict__ dst, GroupTotals *__restrict__ tot /* pinned host */) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { tot->n_results = start[k]; tot->n_big = big->n_host ? big->n : 0u; }
-  const ExportDst d = *dst;
-  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
-  if (d.out && !d.direct) {
-    const uint64_t n = start[k] < d.cap ? start[k] : d.cap;
-    // 24-byte results as 16-byte words (both buffers are 16-byte aligned: hipMalloc / page-locked memory), the odd
-    // eight bytes at the end on their own
-    const uint64_t words = 3 * n;                                   // 8-byte words
-    const uint4 *src = reinterpret_cast<const uint4 *>(res);
-    uint4 *out = reinterpret_cast<uint4 *>(d.out);
-    const bool aligned = (reinterpret_cast<uintptr_t>(d.out) & 15u) == 0;
-    if (aligned) {
-      for (uint64_t i = tid; i < words / 2; i += nth) out[i] = src[i];
-      if ((words & 1u) && tid == 0) reinterpret_cast<uint2 *>(d.out)[words - 1] = reinterpret_cast<const uint2 *>(res)[words - 1];
-    } else {
-      for (uint64_t i = tid; i < words; i += nth) reinterpret_cast<uint2 *>(d.out)[i] = reinterpret_cast<const uint2 *>(res)[i];
-    }
-  }
-  if (d.per)
-    for (uint64_t i = tid; i < k; i += nth) d.per[i] = rcnt[i];
-}
-
 // A batch of compiled regexes made resident on one device: concatenated Glushkov tables plus
 // the level-0 frontier (root.firsts x (0, 0, n), retree.scala:576).  Reusable across calls.
 struct RegexBatch {
@@ -1170,24 +1152,30 @@ struct RegexBatch {
   BigGroups *d_big = nullptr;
   FrontierSummary *h_sum = nullptr;    // pinned: what a chain reports (written by k_frontier_advance)
   ExportDst *h_dst = nullptr;          // pinned: where k_res_export writes (set per call)
-  hipGraphExec_t chain_exec = nullptr; // one chain of launches + advance + counter copy, captured once (full grid)
-  hipGraphExec_t chain_small_exec = nullptr;   // the same on the small grid
-  GroupTotals *h_tot = nullptr;        // pinned: the grouping's totals, written by k_res_export
+  // one chain of launches + the grouping, captured once per (grid, delivery): [0] the full grid, [1] the small one;
+  // [.][1] = results delivered in the caller's device memory (no export launch)
+  hipGraphExec_t chain_exec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  GroupTotals *h_tot = nullptr;        // pinned: the grouping's totals, written by k_res_sort's last workgroup
   uint32_t chain_len = 0, chain_rounds = 0;
   uint32_t matches = 0;                // the chain is captured from a batch's second match on (a one-shot batch
                                        // would pay the capture and never replay it)
   ~RegexBatch() {
-    if (chain_exec) (void)hipGraphExecDestroy(chain_exec);
-    if (chain_small_exec) (void)hipGraphExecDestroy(chain_small_exec);
+    drop_graphs();
     if (h_tot) (void)hipHostFree(h_tot);
     if (h_sum) (void)hipHostFree(h_sum);
     if (h_dst) (void)hipHostFree(h_dst);
+  }
+  void drop_graphs() {
+    for (auto &row : chain_exec)
+      for (hipGraphExec_t &g : row)
+        if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
   }
   uint64_t qcap = 0;
   size_t rcap = 0;
   NfaTables nfa{};
   uint32_t *d_first_state = nullptr;   // root.firsts of every regex, regex by regex
-  uint32_t *d_start_state = nullptr;   // the same states in the order the frontier kernel's start elements are queued
+  unsigned long long *d_start_elem = nullptr;   // the frontier kernel's start elements (StartSrc), balanced over the waves, slice by slice
+  uint64_t start_cap = 0;              // entries per slice there
   // reference-order mode (ReTree batches only): heap keys, per-regex firsts, the largest fan-out
   uint32_t *d_st_num = nullptr, *d_first_off = nullptr;
   FolRec *d_fol_rec = nullptr, *d_first_rec = nullptr;
@@ -1236,8 +1224,7 @@ static double frontier_work_estimate(const Regex &re, double n, double sigma, st
   return work;
 }
 
-// The order in which a batch's start elements are written to the work queue.  k_frontier_init deals element i to
-// slice i % kSub, and a launch hands slice s's entries to the waves s, s + kSub, s + 2 kSub .. in contiguous chunks
+// The order of a batch's start elements.  Element i belongs to slice i % kSub (StartSrc), and a launch hands slice s's entries to the waves s, s + kSub, s + 2 kSub .. in contiguous chunks
 // (frontier_pass): which wave gets element i is a function of i, the element count and the number of waves.  The
 // elements are sorted by expected work and dealt to the waves in serpentine passes (heaviest first), so the waves'
 // totals come out even; the element order itself carries no meaning (results are grouped by regex afterwards).
@@ -1394,8 +1381,13 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
     } else {
       q_perm = q_state;
     }
-    HIP_TRY(b->mem.alloc(&b->d_start_state, q_perm.size()), "hipMalloc");
-    if (!q_perm.empty()) HIP_TRY(copy_sync(b->d_start_state, q_perm.data(), q_perm.size() * 4, hipMemcpyHostToDevice, st), "H2D");
+    // element i belongs to slice i % kSub, position i / kSub (what balanced_start_order assumed)
+    b->start_cap = (q_perm.size() + kSub - 1) / kSub;
+    std::vector<unsigned long long> elem((size_t)b->start_cap * kSub, 0ull);
+    for (size_t i = 0; i < q_perm.size(); i++)
+      elem[(i % kSub) * b->start_cap + i / kSub] = (unsigned long long)q_perm[i] | ((unsigned long long)rec_c(recs[q_perm[i]]) << 40);
+    HIP_TRY(b->mem.alloc(&b->d_start_elem, elem.size()), "hipMalloc");
+    if (!elem.empty()) HIP_TRY(copy_sync(b->d_start_elem, elem.data(), elem.size() * 8, hipMemcpyHostToDevice, st), "H2D");
   }
   if (all_retree) {
     HIP_TRY(b->mem.alloc(&b->d_st_num, st_num.size()), "hipMalloc");
@@ -1420,44 +1412,39 @@ int regex_batch_create(const Index *h, const Regex *const *res, size_t k, RegexB
   return FMX_OK;
 }
 
-// A call starts from rewound buffers under fresh tags (one wave, lane = slice): buffer 0 of every slice receives
-// the slice's share of the start elements, buffer 1 is the first one written.
-__global__ __launch_bounds__(64) void k_frontier_reset(FrontierCtl *__restrict__ ctl, uint64_t count, const uint32_t *__restrict__ call /* {max_len, fresh}, pinned host */) {
-  const uint32_t i = threadIdx.x;
-  const uint32_t max_len = call[0], fresh = call[1], deep_len = call[3];
-  if (i == 0) { ctl->fresh = fresh; ctl->deep_len = deep_len; }
-  if (!fresh) return;                      // a chain that continues a call
-  SliceCtl &q = ctl->q[i];
-  q.tail[0] = count > i ? (count - i + kSub - 1) / kSub : 0;
-  q.tail[1] = 0; q.head[0] = 0; q.head[1] = 0;
-  q.tag[0] = next_tag(q.tag[0]); q.tag[1] = next_tag(q.tag[1]);
-  q.wsel = 1;
-  ctl->res_count[i].v = 0;
-  if (i == 0) { ctl->overflow = 0; ctl->truncated = 0; ctl->max_len = max_len; ctl->left = count; }
-}
-// The start elements: states = firsts, len 0, (sp, ep) = (0, n), dealt round-robin over the slices.
-__global__ void k_frontier_init(FlowQueue fq, NfaTables nfa, const uint32_t *__restrict__ first_state, uint64_t count, uint64_t n /* 0: the start elements carry the empty k-mer code */,
-                                uint64_t sub_cap, const FrontierCtl *__restrict__ ctl, uint32_t *__restrict__ rcnt, uint32_t k) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (!ctl->fresh) return;
-  for (uint64_t r = i; r <= k; r += (uint64_t)gridDim.x * blockDim.x) rcnt[r] = 0;      // the frontier kernel counts results per regex
-  if (i < count) {
-    const uint32_t s = (uint32_t)(i % kSub);
-    const uint64_t at = ((uint64_t)s * 2) * sub_cap + i / kSub;
-    const uint32_t st = first_state[i];
-    const unsigned long long tg = (unsigned long long)ctl->q[s].tag[0] << 48;
-    fq.g0[at] = tg | ((unsigned long long)rec_c(nfa.st[st]) << 40);     // sp = 0
-    fq.g1[at] = tg | n;
-    fq.g2[at] = tg | st;                                                  // len = 0
+// A call starts from rewound buffers under fresh tags (workgroup 0's first wave, lane = slice): buffer 0 of every
+// slice stands for the slice's share of the start elements (which the first launch makes up, StartSrc), buffer 1 is
+// the first one written.  The whole grid clears the per-regex result counts.
+__global__ __launch_bounds__(256) void k_frontier_reset(FrontierCtl *__restrict__ ctl, uint64_t count, const uint32_t *__restrict__ call /* {max_len, fresh, direct, deep_len}, pinned host */,
+                                                         uint32_t *__restrict__ rcnt, uint32_t k, StartSrc start) {
+  const uint32_t fresh = call[1];
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const uint32_t i = threadIdx.x;
+    const uint32_t max_len = call[0], deep_len = call[3];
+    if (i == 0) { ctl->fresh = fresh; ctl->deep_len = deep_len; ctl->start = start; }
+    if (fresh) {
+      SliceCtl &q = ctl->q[i];
+      q.tail[0] = count > i ? (count - i + kSub - 1) / kSub : 0;
+      q.tail[1] = 0; q.head[0] = 0; q.head[1] = 0;
+      q.tag[0] = next_tag(q.tag[0]); q.tag[1] = next_tag(q.tag[1]);
+      q.wsel = 1;
+      ctl->res_count[i].v = 0;
+      if (i == 0) { ctl->overflow = 0; ctl->truncated = 0; ctl->max_len = max_len; ctl->left = count; }
+    }
   }
+  if (!fresh) return;                      // a chain that continues a call
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= k; r += (uint64_t)gridDim.x * blockDim.x) rcnt[r] = 0;      // the frontier kernel counts results per regex
 }
 
-// Results leave the device grouped by regex: the frontier kernel counts them per regex where it flushes them; then scan,
-// scatter, sort.
-// Exclusive prefix sums of cnt[0..k] into start[0..k] in three small parallel launches: each workgroup scans
-// its chunk of 1024 counts (start = sums inside the chunk, part[chunk] = the chunk's total), one workgroup
-// scans the chunk totals, and every workgroup adds its chunk's offset.
+// Results leave the device grouped by regex: the frontier kernel counts them per regex where it flushes them; then
+// offsets (a scan), scatter, order -- THREE launches behind the frontier's (round 3 had seven: the start elements' own
+// launch, scan in two, scatter, two sorts, export; at ~5 us each they were a fifth of a C4 call and over half of a
+// call on a real text, where the frontier dies early).
+// Exclusive prefix sums of cnt[0..k] in two parts: start[i] = the sum inside i's chunk of 1024 counts, part[chunk] = the
+// chunk's total.  The consumers add the chunks before theirs themselves (a hundred values for 100 k regexes, summed
+// up in LDS by every workgroup: part_prefix) -- no launch for the scan of the chunk totals, none to add them.
 constexpr uint32_t kScanChunk = 1024;
+constexpr uint32_t kMaxPartsLds = 2048;      // chunk totals a consumer sums up itself (2 M regexes); beyond: k_res_scan_add
 __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s_wave /* [16] */, uint32_t &total) {
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   uint32_t wtot = 0;
@@ -1475,20 +1462,36 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s
   return before + ex;
 }
 
-__global__ __launch_bounds__(kScanChunk) void k_res_scan_chunks(const uint32_t *__restrict__ cnt, uint32_t n,
-                                                                uint32_t *__restrict__ start, uint32_t *__restrict__ part,
-                                                                uint32_t *__restrict__ fill, BigGroups *__restrict__ big) {
+// Between launches (workgroup 0's first wave, lane = slice): a buffer that has been emptied is rewound under its next
+// tag; when that is the buffer the slice was emptying and the written one holds entries, the two swap roles.  Also
+// sums up what the host wants to know after a chain.  Behind a chain's LAST launch the same grid starts the grouping:
+// every workgroup scans its chunk of the per-regex counts (n != 0).
+__global__ __launch_bounds__(kScanChunk) void k_frontier_advance(FrontierCtl *__restrict__ ctl, uint64_t sub_cap, FrontierSummary *__restrict__ sum,
+                                                                 const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ start,
+                                                                 uint32_t *__restrict__ part, uint32_t *__restrict__ fill, BigGroups *__restrict__ big) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    SliceCtl &q = ctl->q[threadIdx.x];
+    const uint32_t wr = q.wsel, ot = 1u - wr;
+    // the launch has worked off (or carried over) everything in the buffer it was not writing
+    const unsigned long long tl = q.tail[wr] < sub_cap ? q.tail[wr] : sub_cap;
+    const unsigned long long lw = tl > q.head[wr] ? tl - q.head[wr] : 0ull;
+    if (q.tail[ot] | q.head[ot]) { q.tail[ot] = 0; q.head[ot] = 0; q.tag[ot] = next_tag(q.tag[ot]); }
+    if (lw) q.wsel = ot;
+    else if (q.tail[wr] | q.head[wr]) { q.tail[wr] = 0; q.head[wr] = 0; q.tag[wr] = next_tag(q.tag[wr]); }
+    const unsigned long long left = wave_sum(lw), results = wave_sum(ctl->res_count[threadIdx.x].v);
+    if (threadIdx.x == 0) { ctl->left = left; sum->left = left; sum->results = results; sum->overflow = ctl->overflow; sum->truncated = ctl->truncated; }
+  }
+  if (!n) return;                                       // uniform over the grid
   __shared__ uint32_t s_wave[16];
   const uint32_t i = blockIdx.x * kScanChunk + threadIdx.x;
   uint32_t total = 0;
   const uint32_t ex = block_excl_scan_1024(i < n ? cnt[i] : 0u, s_wave, total);
   if (i < n) { start[i] = ex; fill[i] = 0; }      // the scatter's cursors start from zero in every grouping
   if (threadIdx.x == 0) part[blockIdx.x] = total;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { big->n = 0; big->n_host = 0; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { big->n = 0; big->done = 0; big->total = 0; }
 }
 
-// Every workgroup adds up the totals of the chunks before its own (a hundred values for 100 k regexes) and adds
-// that to its chunk's sums: no separate launch for the scan of the chunk totals.
+// More chunks than a consumer sums up in LDS: their totals are added here, once, and the consumers get part = null.
 __global__ __launch_bounds__(kScanChunk) void k_res_scan_add(uint32_t *__restrict__ start, uint32_t n,
                                                              const uint32_t *__restrict__ part) {
   __shared__ unsigned long long s_sum[kScanChunk / 64];
@@ -1503,110 +1506,198 @@ __global__ __launch_bounds__(kScanChunk) void k_res_scan_add(uint32_t *__restric
   if (i < n) start[i] += before;
 }
 
+// s_pre[c] = part[0] + .. + part[c - 1] for c = 0 .. nparts, by a workgroup of 256 threads (ends with a barrier).
+// part == null: the offsets are absolute already (k_res_scan_add ran), s_pre is all zeros.
+struct PartPrefix {
+  uint32_t pre[kMaxPartsLds + 8];
+  uint32_t wave[4];
+};
+__device__ __forceinline__ void part_prefix(const uint32_t *__restrict__ part, uint32_t nparts, PartPrefix &pp) {
+  const uint32_t per = (nparts + 256u) / 256u;          // entries per thread, covering 0 .. nparts
+  const uint32_t lo = threadIdx.x * per;
+  uint32_t mine = 0;
+  if (part)
+    for (uint32_t q = lo; q < lo + per && q < nparts; q++) mine += part[q];
+  uint32_t wtot = 0;
+  uint32_t ex = wave_excl_scan(mine, wtot);
+  if ((threadIdx.x & 63u) == 0) pp.wave[threadIdx.x >> 6] = wtot;
+  __syncthreads();
+  for (uint32_t j = 0; j < (threadIdx.x >> 6); j++) ex += pp.wave[j];
+  for (uint32_t q = lo; q < lo + per && q <= nparts; q++) {
+    pp.pre[q] = ex;
+    if (part && q < nparts) ex += part[q];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ uint32_t offset_of(const uint32_t *__restrict__ start, const PartPrefix &pp, uint32_t r) {
+  return start[r] + pp.pre[r / kScanChunk];
+}
+
 __global__ __launch_bounds__(256) void k_res_scatter(const fmx_result *__restrict__ seg, uint64_t seg_cap,
                                                       const FrontierCtl *__restrict__ ctl,
-                                                      const uint32_t *__restrict__ start, uint32_t *__restrict__ fill,
+                                                      const uint32_t *__restrict__ start, const uint32_t *__restrict__ part, uint32_t nparts,
+                                                      uint32_t *__restrict__ fill,
                                                       fmx_result *__restrict__ own, uint64_t own_cap, const ExportDst *__restrict__ dst) {
+  __shared__ PartPrefix s_pp;
   uint64_t out_cap;
   fmx_result *out = group_out(dst, own, own_cap, out_cap);
   const uint32_t sl = blockIdx.y;
   const uint64_t mine = min((uint64_t)ctl->res_count[sl].v, seg_cap);
+  if ((uint64_t)blockIdx.x * blockDim.x >= mine) return;             // uniform over the workgroup: nothing of this slice is ours
+  part_prefix(part, nparts, s_pp);
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < mine; i += (uint64_t)gridDim.x * blockDim.x) {
     const fmx_result r = seg[(uint64_t)sl * seg_cap + i];
-    const uint64_t at = (uint64_t)start[r.regex] + atomicAdd(&fill[r.regex], 1u);
+    const uint64_t at = (uint64_t)offset_of(start, s_pp, r.regex) + atomicAdd(&fill[r.regex], 1u);
     if (at < out_cap) out[at] = r;
   }
 }
 
-// Orders each regex's group by (len, sp, ep): one thread per regex, insertion sort for the usual handful of
-// results; larger groups are listed for k_res_sort_mid / the host.  The results of a workgroup's 256 regexes are one
-// contiguous stretch of `out`: when it fits (it nearly always does) it is sorted in LDS -- an insertion sort is a
-// chain of dependent accesses, 0.1 us each in LDS against 0.5 in L2.
-constexpr uint32_t kSortStage = 768;      // results (18 KB)
-__global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ own, uint64_t own_cap, const uint32_t *__restrict__ start, uint32_t k,
-                                                   BigGroups *__restrict__ big, const ExportDst *__restrict__ dst) {
-  __shared__ fmx_result s_r[kSortStage];
+// Orders each regex's group by (len, sp, ep).  The results of a workgroup's 256 regexes are one contiguous stretch of
+// `out`; it is read into LDS (it nearly always fits), and EVERY RESULT FINDS ITS OWN PLACE: a thread takes a result,
+// counts the results of the same group that sort before it (ties by position) -- independent LDS reads, no chain of
+// dependent accesses -- and writes it to that place of `out` (groups of up to 64; C4's 100 k regexes: 11 000 groups of
+// 2 .. 23 results, 1.2 ms of single-thread insertion sorts in round 3's kernel).  Larger groups, up to 1024 results, are
+// ordered one after the other by a bitonic sort in LDS with all the workgroup's threads; groups beyond that are listed
+// for the host.  The workgroup that finishes last reports the call's totals to the host's page-locked GroupTotals;
+// with the results delivered in device memory (ExportDst::direct) every workgroup also copies its regexes' counts
+// out, and nothing is left for k_res_export to do: it is not launched then.
+constexpr uint32_t kRankGroup = 64;
+__global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ own, uint64_t own_cap, const uint32_t *__restrict__ start,
+                                                   const uint32_t *__restrict__ part, uint32_t nparts, uint32_t k,
+                                                   const uint32_t *__restrict__ rcnt, BigGroups *__restrict__ big,
+                                                   const ExportDst *__restrict__ dst, GroupTotals *__restrict__ tot /* pinned host */) {
+  __shared__ fmx_result s_r[kMidGroup];
+  __shared__ PartPrefix s_pp;
+  __shared__ uint32_t s_off[257];             // offsets of the workgroup's regexes (and of the one behind them)
+  __shared__ uint32_t s_mid[2 * 256], s_nmid;
+  if (threadIdx.x == 0) s_nmid = 0;
+  part_prefix(part, nparts, s_pp);
+  const ExportDst d = *dst;
   uint64_t out_cap;
   fmx_result *out = group_out(dst, own, own_cap, out_cap);
   const uint32_t r0 = blockIdx.x * blockDim.x, r = r0 + threadIdx.x;
-  const uint32_t r_end = r0 + blockDim.x < k ? r0 + blockDim.x : k;
-  const uint32_t base = start[r0], span = start[r_end] - base;      // uniform over the workgroup
-  if ((uint64_t)start[r_end] > out_cap) return;                      // more results than the buffer holds: the call fails with FMX_ERR_OVERFLOW, nothing to order
-  const bool staged = span <= kSortStage;
-  if (staged) {
-    for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) s_r[i] = out[base + i];
-    __syncthreads();
-  }
+  const uint32_t r_end = r0 + blockDim.x < k ? r0 + blockDim.x : k, nr = r_end - r0;
+  for (uint32_t t = threadIdx.x; t <= nr; t += blockDim.x) s_off[t] = offset_of(start, s_pp, r0 + t);
+  const uint32_t total = offset_of(start, s_pp, k);
+  __syncthreads();
+  const uint32_t base = s_off[0], span = s_off[nr] - base;      // uniform over the workgroup
   auto less = [](const fmx_result &a, const fmx_result &b) {
     if (a.len != b.len) return a.len < b.len;
     if (a.sp != b.sp) return a.sp < b.sp;
     return a.ep < b.ep;
   };
-  if (r < k) {
-    const uint32_t lo = start[r], m = start[r + 1] - lo;
-    if (m > kSmallGroup) {
-      const uint32_t at = atomicAdd(&big->n, 1u);
-      if (at < kBigMax) { big->ent[2 * at] = lo; big->ent[2 * at + 1] = m; }
-    } else if (m >= 2) {
-      fmx_result *g = staged ? s_r + (lo - base) : out + lo;
-      for (uint32_t i = 1; i < m; i++) {
-        const fmx_result x = g[i];
-        uint32_t j = i;
-        while (j > 0 && less(x, g[j - 1])) { g[j] = g[j - 1]; j--; }
-        g[j] = x;
+  // more results than the buffer holds: the call fails with FMX_ERR_OVERFLOW, nothing to order
+  if ((uint64_t)base + span <= out_cap) {
+    const bool staged = span <= kMidGroup;
+    if (staged) {
+      for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) s_r[i] = out[base + i];
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) {
+        const fmx_result x = s_r[i];
+        const uint32_t t = x.regex - r0;
+        if (t >= nr) continue;                 // (cannot happen: the stretch holds this workgroup's regexes only)
+        const uint32_t lo = s_off[t] - base, m = s_off[t + 1] - s_off[t];
+        if (m < 2) continue;
+        if (m <= kRankGroup) {
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < m; j++) {
+            const fmx_result y = s_r[lo + j];
+            rank += (less(y, x) || (!less(x, y) && lo + j < i)) ? 1u : 0u;
+          }
+          if (lo + rank != i) out[base + lo + rank] = x;
+        } else if (i == lo) {                  // the group's first result lists it (m <= span <= kMidGroup)
+          const uint32_t at = atomicAdd(&s_nmid, 1u);
+          s_mid[2 * at] = base + lo;
+          s_mid[2 * at + 1] = m;
+        }
+      }
+    } else if (r < r_end) {
+      // a stretch that does not fit (a group of hundreds of results among the 256): one thread per regex, insertion
+      // sort in `out` for the small groups, the others listed
+      const uint32_t lo = s_off[threadIdx.x], m = s_off[threadIdx.x + 1] - lo;
+      if (m > kMidGroup) {
+        const uint32_t at = atomicAdd(&big->n, 1u);
+        if (at < kBigMax) { big->ent[2 * at] = lo; big->ent[2 * at + 1] = m; }
+      } else if (m > kSmallGroup) {
+        const uint32_t at = atomicAdd(&s_nmid, 1u);
+        s_mid[2 * at] = lo;
+        s_mid[2 * at + 1] = m;
+      } else if (m >= 2) {
+        fmx_result *g = out + lo;
+        for (uint32_t i = 1; i < m; i++) {
+          const fmx_result x = g[i];
+          uint32_t j = i;
+          while (j > 0 && less(x, g[j - 1])) { g[j] = g[j - 1]; j--; }
+          g[j] = x;
+        }
       }
     }
-  }
-  if (staged) {
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < span; i += blockDim.x) out[base + i] = s_r[i];
+    const uint32_t nmid = s_nmid;               // the listed groups still lie in `out` as the scatter left them
+    for (uint32_t g = 0; g < nmid; g++) {
+      const uint32_t lo = s_mid[2 * g], m = s_mid[2 * g + 1];
+      uint32_t p2 = 16;
+      while (p2 < m) p2 <<= 1;
+      for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
+        fmx_result x;
+        if (i < m) x = out[lo + i];
+        else { x.regex = 0; x.len = 0xFFFFFFFFu; x.sp = ~0ull; x.ep = ~0ull; }      // padding sorts last
+        s_r[i] = x;
+      }
+      __syncthreads();
+      for (uint32_t size = 2; size <= p2; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+          for (uint32_t i = threadIdx.x; i < p2 / 2; i += blockDim.x) {
+            const uint32_t a = 2 * i - (i & (stride - 1));          // lower index of the pair
+            const uint32_t bidx = a + stride;
+            const bool up = (a & size) == 0;
+            const fmx_result x = s_r[a], y = s_r[bidx];
+            if (less(y, x) == up) { s_r[a] = y; s_r[bidx] = x; }
+          }
+          __syncthreads();
+        }
+      for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) out[lo + i] = s_r[i];
+      __syncthreads();
+    }
+  }
+  if (d.direct && d.per && r < k) d.per[r] = rcnt[r];
+  // No fence here (an agent-scope release writes back the XCD's whole L2: 30 us per launch when every workgroup
+  // asks for one).  What the last workgroup reads of the others is big->n, a device atomic whose returned value each
+  // of their threads has already used, so it has been performed before that thread reaches the barrier below; the
+  // lists and results themselves are read by the host or the next launch, behind the kernel's end.
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&big->done, 1u) == gridDim.x - 1u) {
+    big->total = total;
+    tot->n_results = total;
+    tot->n_big = atomicAdd(&big->n, 0u);
   }
 }
 
-// The groups k_res_sort listed: one workgroup per group, bitonic sort by (len, sp, ep) in LDS (100 k regexes give a
-// few hundred such groups -- a starred class matches at every length; ordering them on the host cost 0.13 ms).
-__global__ __launch_bounds__(256) void k_res_sort_mid(fmx_result *__restrict__ own, uint64_t own_cap, BigGroups *__restrict__ big, const ExportDst *__restrict__ dst) {
-  __shared__ fmx_result s_r[kMidGroup];
-  uint64_t out_cap;
-  fmx_result *out = group_out(dst, own, own_cap, out_cap);
-  const uint32_t nb = big->n < kBigMax ? big->n : kBigMax;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && big->n > kBigMax) atomicAdd(&big->n_host, big->n - kBigMax);
-  auto less = [](const fmx_result &a, const fmx_result &b) {
-    if (a.len != b.len) return a.len < b.len;
-    if (a.sp != b.sp) return a.sp < b.sp;
-    return a.ep < b.ep;
-  };
-  for (uint32_t g = blockIdx.x; g < nb; g += gridDim.x) {
-    const uint32_t lo = big->ent[2 * g], m = big->ent[2 * g + 1];
-    if ((uint64_t)lo + m > out_cap) continue;
-    if (m > kMidGroup) {
-      if (threadIdx.x == 0) atomicAdd(&big->n_host, 1u);
-      continue;
+// Results delivered to the HOST's page-locked buffers (or, in an A/B run, to device memory without the direct form):
+// the ordered results and the per-regex counts are copied there, behind the grouping and before the host's one
+// synchronisation.  Not launched when the grouping worked in the caller's device memory itself.
+__global__ __launch_bounds__(256) void k_res_export(const fmx_result *__restrict__ res, uint32_t k,
+                                                     const uint32_t *__restrict__ rcnt, const BigGroups *__restrict__ big,
+                                                     const ExportDst *__restrict__ dst) {
+  const ExportDst d = *dst;
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+  if (d.out && !d.direct) {
+    const uint64_t n = big->total < d.cap ? big->total : d.cap;
+    // 24-byte results as 16-byte words (both buffers are 16-byte aligned: hipMalloc / page-locked memory), the odd
+    // eight bytes at the end on their own
+    const uint64_t words = 3 * n;                                   // 8-byte words
+    const uint4 *src = reinterpret_cast<const uint4 *>(res);
+    uint4 *out = reinterpret_cast<uint4 *>(d.out);
+    const bool aligned = (reinterpret_cast<uintptr_t>(d.out) & 15u) == 0;
+    if (aligned) {
+      for (uint64_t i = tid; i < words / 2; i += nth) out[i] = src[i];
+      if ((words & 1u) && tid == 0) reinterpret_cast<uint2 *>(d.out)[words - 1] = reinterpret_cast<const uint2 *>(res)[words - 1];
+    } else {
+      for (uint64_t i = tid; i < words; i += nth) reinterpret_cast<uint2 *>(d.out)[i] = reinterpret_cast<const uint2 *>(res)[i];
     }
-    uint32_t p2 = 1;
-    while (p2 < m) p2 <<= 1;
-    for (uint32_t i = threadIdx.x; i < p2; i += blockDim.x) {
-      fmx_result r;
-      if (i < m) r = out[lo + i];
-      else { r.regex = 0; r.len = 0xFFFFFFFFu; r.sp = ~0ull; r.ep = ~0ull; }      // padding sorts last
-      s_r[i] = r;
-    }
-    __syncthreads();
-    for (uint32_t size = 2; size <= p2; size <<= 1)
-      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-        for (uint32_t i = threadIdx.x; i < p2 / 2; i += blockDim.x) {
-          const uint32_t a = 2 * i - (i & (stride - 1));          // lower index of the pair
-          const uint32_t bidx = a + stride;
-          const bool up = (a & size) == 0;
-          const fmx_result x = s_r[a], y = s_r[bidx];
-          if (less(y, x) == up) { s_r[a] = y; s_r[bidx] = x; }
-        }
-        __syncthreads();
-      }
-    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) out[lo + i] = s_r[i];
-    if (threadIdx.x == 0) big->ent[2 * g + 1] = 0;
-    __syncthreads();
   }
+  if (d.per && !d.direct)
+    for (uint64_t i = tid; i < k; i += nth) d.per[i] = rcnt[i];
 }
 
 // `dev`: out / per_regex_count are DEVICE pointers -- the results stay in HBM (the export kernel's copy is then on
@@ -1640,8 +1731,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   if (!b->scratch || b->qcap != qcap || b->rcap < (cap ? cap : 1)) {
     b->scratch.reset(new DevMem());
     b->qcap = 0;
-    for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec})      // they hold the old pointers
-      if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+    b->drop_graphs();                  // they hold the old pointers
     if (!b->h_tot) HIP_TRY(hipHostMalloc((void **)&b->h_tot, sizeof(GroupTotals), hipHostMallocDefault), "hipHostMalloc(totals)");
     if (!b->h_sum) HIP_TRY(hipHostMalloc((void **)&b->h_sum, sizeof(FrontierSummary), hipHostMallocDefault), "hipHostMalloc(summary)");
     if (!b->h_dst) HIP_TRY(hipHostMalloc((void **)&b->h_dst, sizeof(ExportDst), hipHostMallocDefault), "hipHostMalloc(export)");
@@ -1713,6 +1803,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   uint32_t pass = 0;
   uint64_t launches = 1;
   bool alive = true, truncated = false;
+  const StartSrc ss{b->d_start_elem, b->start_cap, kt.k ? 0 : h->n};
+  const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: its offset = the total
+  const bool parts_in_lds = nparts <= kMaxPartsLds;      // the consumers of the offsets add the chunk totals up themselves
   auto launch_pass = [&](hipStream_t s, int grid, uint32_t j, uint32_t rounds) {
     if (h->layout == kLayoutBytes)
       k_frontier<true, kLayoutBytes><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, b->d_rcnt, h->d_counters);
@@ -1743,13 +1836,13 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   static const uint32_t kRoundsSmall = getenv("FMX_FRONTIER_ROUNDS_SMALL") ? (uint32_t)std::max(1, atoi(getenv("FMX_FRONTIER_ROUNDS_SMALL"))) : 32u;
   auto enqueue_chain = [&](hipStream_t s, int grid) -> hipError_t {
     const uint32_t len = grid == grid_small ? kChainSmall : kChain;
-    // a call's first chain begins with the reset and the start elements (h_dst->fresh; both return at once otherwise):
-    // one graph launch per call
-    k_frontier_reset<<<1, 64, 0, s>>>(d_ctl, b->n_first, &b->h_dst->max_len);
-    k_frontier_init<<<(int)((std::max<uint64_t>(b->n_first, kSub) + 255) / 256), 256, 0, s>>>(fq, b->nfa, b->d_start_state, b->n_first, kt.k ? 0 : h->n, sub_cap, d_ctl, b->d_rcnt, (uint32_t)b->k);
+    // a call's first chain begins with the reset (h_dst->fresh; it returns at once otherwise): one graph launch per call
+    k_frontier_reset<<<(int)std::min<size_t>((b->k + 256) / 256, 256), 256, 0, s>>>(d_ctl, b->n_first, &b->h_dst->max_len, b->d_rcnt, (uint32_t)b->k, ss);
     for (uint32_t j = 0; j < len; j++) {
       launch_pass(s, grid, j, grid == grid_small ? kRoundsSmall : (plan.empty() ? kRounds : plan[std::min<size_t>(j, plan.size() - 1)]));
-      k_frontier_advance<<<1, 64, 0, s>>>(d_ctl, sub_cap, b->h_sum);      // the summary goes straight to pinned host memory
+      // the summary goes straight to pinned host memory; behind the chain's last launch the same grid scans the result counts
+      if (j + 1 < len) k_frontier_advance<<<1, kScanChunk, 0, s>>>(d_ctl, sub_cap, b->h_sum, nullptr, 0u, nullptr, nullptr, nullptr, nullptr);
+      else k_frontier_advance<<<nparts, kScanChunk, 0, s>>>(d_ctl, sub_cap, b->h_sum, b->d_rcnt, n_scan, b->d_rstart, b->d_rpart, b->d_rfill, b->d_big);
     }
     return hipGetLastError();
   };
@@ -1779,8 +1872,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   uint64_t total = b->n_first;               // elements queued for the next launch
   const uint64_t kSmallTotal = (uint64_t)grid_small * per_wg;
   if (b->chain_len != kChain || b->chain_rounds != kRounds) {
-    for (hipGraphExec_t *g : {&b->chain_exec, &b->chain_small_exec})
-      if (*g) { (void)hipGraphExecDestroy(*g); *g = nullptr; }
+    b->drop_graphs();
     b->chain_len = kChain;
     b->chain_rounds = kRounds;
   }
@@ -1790,18 +1882,16 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   // not, the grouping is simply done again behind the next chain.  All arguments are fixed for the life of the
   // scratch, so this is a captured graph as well.
   const size_t rcap = b->rcap;
-  auto enqueue_group = [&](hipStream_t s) -> hipError_t {
+  auto enqueue_group = [&](hipStream_t s, bool in_place) -> hipError_t {
     const dim3 rg(8, kSub);
-    const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: start[k] = total
-    k_res_scan_chunks<<<nparts, kScanChunk, 0, s>>>(b->d_rcnt, n_scan, b->d_rstart, b->d_rpart, b->d_rfill, b->d_big);
-    k_res_scan_add<<<nparts, kScanChunk, 0, s>>>(b->d_rstart, n_scan, b->d_rpart);
-    k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, b->d_rfill, d_res, (uint64_t)rcap, b->h_dst);
-    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, (uint64_t)rcap, b->d_rstart, (uint32_t)b->k, b->d_big, b->h_dst);
-    k_res_sort_mid<<<256, 256, 0, s>>>(d_res, (uint64_t)rcap, b->d_big, b->h_dst);
-    k_res_export<<<256, 256, 0, s>>>(d_res, b->d_rstart, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst, b->h_tot);
+    if (!parts_in_lds) k_res_scan_add<<<nparts, kScanChunk, 0, s>>>(b->d_rstart, n_scan, b->d_rpart);
+    const uint32_t *part = parts_in_lds ? b->d_rpart : nullptr;
+    k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, part, nparts, b->d_rfill, d_res, (uint64_t)rcap, b->h_dst);
+    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, (uint64_t)rcap, b->d_rstart, part, nparts, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst, b->h_tot);
+    if (!in_place) k_res_export<<<256, 256, 0, s>>>(d_res, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst);
     return hipGetLastError();
   };
-  auto capture = [&](hipGraphExec_t *exec, int grid) {     // one graph: the chain of launches, then the grouping
+  auto capture = [&](hipGraphExec_t *exec, int grid, bool in_place) {     // one graph: the chain of launches, then the grouping
     // one capture at a time in the process: concurrent captures from several host threads (the multi-device entry
     // point matches its slices in parallel) invalidated each other on ROCm 7.2
     static std::mutex capture_mu;
@@ -1810,7 +1900,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
     if (e == hipSuccess) {
       hipError_t e1 = enqueue_chain(st, grid);
-      if (e1 == hipSuccess) e1 = enqueue_group(st);
+      if (e1 == hipSuccess) e1 = enqueue_group(st, in_place);
       const hipError_t e2 = hipStreamEndCapture(st, &g);
       e = e1 != hipSuccess ? e1 : e2;
     }
@@ -1820,18 +1910,18 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   };
   while (alive) {
     const bool small = total <= kSmallTotal;
-    hipGraphExec_t *exec = small ? &b->chain_small_exec : &b->chain_exec;
+    hipGraphExec_t *exec = &b->chain_exec[small ? 1 : 0][direct ? 1 : 0];
     const int grid = small ? grid_small : grid_full;
     // the graphs are captured from a batch's second match on (a one-shot batch would pay the capture and never replay it)
-    if (use_graph && b->matches >= 2 && !*exec) capture(exec, grid);
+    if (use_graph && b->matches >= 2 && !*exec) capture(exec, grid, direct);
     if (*exec) HIP_TRY(hipGraphLaunch(*exec, st), "hipGraphLaunch(launch chain + grouping)");
     else {
       HIP_TRY(enqueue_chain(st, grid), "k_frontier chain");
-      HIP_TRY(enqueue_group(st), "result grouping kernels");
+      HIP_TRY(enqueue_group(st, direct), "result grouping kernels");
     }
     HIP_TRY(hipEventRecord(e1, st), "hipEventRecord");
     const uint32_t done = small ? kChainSmall : kChain;
-    launches += 2 * done + 10;
+    launches += 2 * done + (direct ? 3 : 4);
     b->tag_bound += done;
     HIP_TRY(hipStreamSynchronize(st), "sync(passes)");
     b->h_dst->fresh = 0;               // further chains of this call continue the search

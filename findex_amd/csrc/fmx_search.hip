@@ -97,6 +97,11 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 #ifndef FMX_SEARCH_WAVES
 #define FMX_SEARCH_WAVES 6      // waves per SIMD the search kernel is compiled for (register budget 512 / waves, in eights)
 #endif
+#ifdef FMX_SEARCHLOG
+// Diagnostic build only (tools/search_wave_timeline.py): begin and end of every wave of the last k_search4 launch on
+// the constant 100 MHz clock, and the batches it searched.
+__device__ unsigned long long g_searchlog[1u << 15][4];
+#endif
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T>
 __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_SEARCH_WAVES, 8))) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
                                                         uint32_t ksigma, const uint4 *__restrict__ jtab, const uint32_t jc,
@@ -107,6 +112,11 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
   constexpr int G = Lay<LAYOUT>::G;              // lanes per pattern
   constexpr uint32_t P = 64 / G;                 // patterns per wave
   constexpr uint32_t R = LAYOUT == kLayoutBytes ? 2u : 1u;    // memory requests per rank query
+#ifdef FMX_SEARCHLOG
+  const unsigned long long sl_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long sl_t1 = 0;
+  uint32_t sl_batches = 0;
+#endif
   // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
   // slot + 2 (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
   __shared__ uint4 s_tab[256];
@@ -300,7 +310,13 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
       if (actw && t == 0) emit(wpid, wsp, wep);
     }
   };
+#ifdef FMX_SEARCHLOG
+  sl_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
+#ifdef FMX_SEARCHLOG
+    sl_batches++;
+#endif
     Stage nxt_stage;
     // One batch, written once and compiled twice: STAGED = its bytes are in LDS; else (a span longer than the LDS area)
     // they are read chunk by chunk from global memory.  Two copies of the code, so that no value of the staged path is
@@ -675,7 +691,16 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     fix_off((uint64_t)batch + 2ull * nwaves, raw2a, raw2b, end1, len1);
   }
   if (kFold) walk_parked();
+#ifdef FMX_SEARCHLOG
+  const unsigned long long sl_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
   counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
+#ifdef FMX_SEARCHLOG
+  if ((threadIdx.x & 63u) == 0 && wave < (1u << 15)) {
+    unsigned long long *e = g_searchlog[wave];
+    e[0] = sl_t0; e[1] = sl_t1; e[2] = sl_t2; e[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)sl_batches << 48);
+  }
+#endif
   if (KT) {
     const unsigned long long lookups = ktl;
     if ((threadIdx.x & 63u) == 0 && lookups)
@@ -1032,3 +1057,9 @@ hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, v
 }
 
 }  // namespace fmx
+
+#ifdef FMX_SEARCHLOG
+extern "C" int fmx_debug_searchlog(void *out, size_t bytes) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fmx::g_searchlog), std::min(bytes, sizeof fmx::g_searchlog)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -31,6 +31,13 @@ for _ in range(calls):
     ts.append(time.perf_counter() - t0)
     ks.append(hip.last_kernel_ms())
     assert n1 == n0 and torch.equal(d_out[: 3 * n0], first) and torch.equal(d_per, per0), "results differ between calls"
+if os.environ.get("C4_GROUPS"):      # sizes of the per-regex result groups (what the grouping kernels order)
+    c = per0.cpu().numpy().astype(np.int64)
+    for lo, hi in ((0, 0), (1, 1), (2, 4), (5, 12), (13, 32), (33, 64), (65, 128), (129, 256), (257, 1024), (1025, 1 << 40)):
+        sel = c[(c >= lo) & (c <= hi)]
+        print("groups of %4d..%-6d: %6d groups, %7d results" % (lo, min(hi, int(c.max())), sel.size, int(sel.sum())))
+    blk = np.add.reduceat(c, np.arange(0, k, 256))
+    print("results per 256 regexes: mean %.0f max %d; blocks over 1024: %d" % (blk.mean(), blk.max(), int((blk > 1024).sum())))
 ks.sort(); ts.sort()
 steps = st["backward_steps"]
 print("lib=%s chain=%s | results %d steps %d | device ms median %.4f min %.4f | call ms median %.4f min %.4f | %.1f G rq/s device (median)"

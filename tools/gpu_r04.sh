@@ -73,6 +73,14 @@ ab:*)
     env $lib timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-path --steps 20 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('ms/step %.4f kernel %.4f value %.0f'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))"
   done; done
   ;;
+wgs:*)
+  # the search kernel on fewer resident workgroups per CU than the occupancy query allows:  wgs:<workload>:<n>,<n>..
+  spec=${PART#wgs:}; wl=${spec%%:*}; vals=${spec#*:}
+  for rep in 1 2; do for v in ${vals//,/ }; do
+    echo -n "$wl FMX_SEARCH_WGS=$v: "
+    FMX_SEARCH_WGS=$v timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-path --steps 20 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('ms/step %.4f kernel %.4f value %.0f'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))"
+  done; done
+  ;;
 overlap)
   # does the exchange run beside the next step's search?  one-rank RCCL (its gather is a device kernel like any rank's),
   # the collective's stream at default / high priority, the search kernel on all / fewer workgroups per CU
@@ -116,6 +124,22 @@ with open("%s/%s_bench_kernel_stats.csv"%(O,wl),"w",newline="") as fo:
     for r in rows: w.writerow([r["Name"].split("(")[0].replace("fmx::",""),r["Calls"],r["TotalDurationNs"],r["AverageNs"],r["MinNs"],r["MaxNs"],r["StdDev"]])
 for r in rows:
     if int(r["Calls"])>=5: print("%-60s calls %4s avg %9.1f us min %9.1f" % (r["Name"].split("(")[0].replace("fmx::","")[:60], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3))
+PY
+  # the last call's launches on the device's clock: begin and end of each, microseconds from the first one's begin
+  python - $O $wl <<'PY' > $O/${wl}_last_call_timeline.txt
+import csv,glob,sys
+O,wl=sys.argv[1],sys.argv[2]
+rows=[]
+for f in glob.glob("%s/trace_%s/*/*_kernel_trace.csv"%(O,wl)):
+    for r in csv.DictReader(open(f)):
+        if "fmx::" in r["Kernel_Name"]: rows.append((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"].split("(")[0].replace("fmx::","").replace("void ","")))
+rows.sort()
+# a call = from a k_frontier_reset (or the step's first kernel) to the next one
+firsts=[i for i,r in enumerate(rows) if r[2].startswith(("k_frontier_reset","k_search4"))]
+if len(firsts)>=3:
+    a,b=firsts[-3],firsts[-1]
+    t0=rows[a][0]
+    for s,e,n in rows[a:b]: print("%9.2f .. %9.2f  (%7.2f us)  %s"%((s-t0)/1e3,(e-t0)/1e3,(e-s)/1e3,n[:50]))
 PY
   rm -rf $O/trace_$wl
   ;;

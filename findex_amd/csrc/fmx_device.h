@@ -373,6 +373,13 @@ constexpr uint32_t kCounterStride = 16;        // uint64 per slot: [0] rank quer
                                                // frontier kernels: [3] rank-line requests, [4] queue appends, [5] results,
                                                // [6] elements stepped, [7] queue entries read, [8] state records loaded; [9] k-mer table lookups; [10] row jump table lookups (16 B); [11] row table lookups (8 B)
 constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterStride * 8;
+// Behind the counters, in the same buffer: the RESIDENCY CENSUS of the search kernel -- begin and end (100 MHz clock) of
+// each workgroup of the last k_search4 launch.  The occupancy query answers one workgroup per CU too many for kernels
+// with 81..96 scalar registers (MI355X_MICROARCH.md, "Residency"): the surplus workgroups start when the first ones
+// end, a second generation that owns an eighth of the batches.  The host counts how many workgroups began before
+// the first one ended and sizes later grids by that (fmx_search.hip, Residency).
+constexpr uint32_t kCensusBlocks = 4096;
+constexpr size_t kCensusBytes = (size_t)kCensusBlocks * 16;
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll

@@ -25,6 +25,8 @@
 //     (66 registers, per-group pattern cursors: 0.278 ms against 0.259 ms in lockstep on C3 -- with a jump table the
 //     kernel is bound by instruction issue, 88 % of the SIMDs' issue slots, not by waiting).
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include "fmx_device.h"
@@ -117,6 +119,9 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
   unsigned long long sl_t1 = 0;
   uint32_t sl_batches = 0;
 #endif
+  // the residency census (fmx_device.h): when this workgroup began
+  if (threadIdx.x == 0 && blockIdx.x < kCensusBlocks)
+    counters[(size_t)kCounterSlots * kCounterStride + 2u * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
   // slot + 2 (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
   __shared__ uint4 s_tab[256];
@@ -701,6 +706,8 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     e[0] = sl_t0; e[1] = sl_t1; e[2] = sl_t2; e[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)sl_batches << 48);
   }
 #endif
+  if (threadIdx.x == 0 && blockIdx.x < kCensusBlocks)       // ... and when its first wave ended
+    counters[(size_t)kCounterSlots * kCounterStride + 2u * blockIdx.x + 1u] = __builtin_amdgcn_s_memrealtime();
   if (KT) {
     const unsigned long long lookups = ktl;
     if ((threadIdx.x & 63u) == 0 && lookups)
@@ -951,15 +958,72 @@ static int blocks_per_cu(K kernel) {
   return nb > 8 ? 8 : nb;
 }
 
+// What the occupancy query says is an upper bound: on this chip a kernel with 81..96 scalar registers gets one
+// workgroup per CU fewer than it answers (MI355X_MICROARCH.md, "Residency"; there is no API for the scalar register
+// count), and the surplus workgroups run as a second generation behind the first -- C5's bytes-layout kernel: 8 asked
+// for, 7 resident, a launch of 0.205 ms instead of 0.170.  So every instantiation of k_search4 is calibrated by a
+// CENSUS of its first full-size launch on a device: the kernel leaves each workgroup's begin and end times behind the
+// counters (fmx_device.h); before the instantiation's next launch the host counts the workgroups that began before the
+// first one ended and divides by the CUs.  One 64 KB copy and one stream synchronisation per instantiation and process.
+struct Residency {
+  std::atomic<int> admitted{0};            // workgroups per CU that were resident at once; 0 = not measured yet
+  std::atomic<uint64_t> pending{0};        // serial of the handle whose last launch of this kernel was a full-size one
+  std::atomic<int> tries{0};
+};
+static int census_read(const Index *h, int grid, int api, hipStream_t st) {
+  std::vector<unsigned long long> t(2 * (size_t)kCensusBlocks);
+  if (hipMemcpyAsync(t.data(), h->d_counters + (size_t)kCounterSlots * kCounterStride, kCensusBytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const int nb = std::min<int>(grid, (int)kCensusBlocks);
+  unsigned long long first_begin = ~0ull, first_end = ~0ull;
+  for (int i = 0; i < nb; i++) {
+    if (!t[2 * i] || t[2 * i + 1] < t[2 * i]) return 0;      // the launch has not finished (another stream), or was not this kernel's
+    first_begin = std::min(first_begin, t[2 * i]);
+    first_end = std::min(first_end, t[2 * i + 1]);
+  }
+  if (first_end < first_begin + 2000) return 0;             // workgroups shorter than 20 us say nothing about who waited for whom
+  int resident = 0;
+  for (int i = 0; i < nb; i++) resident += t[2 * i] < first_end ? 1 : 0;
+  return std::max(1, std::min(api, resident / std::max(1, h->cu_count)));
+}
+
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
                               const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st, uint64_t pk_cap) {
+  static const int api = blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>);
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
-  static const int per_cu = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>))) : blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>);
+  static const int forced = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), api)) : 0;
+  static Residency res[16];
+  Residency &rs = res[(unsigned)h->device & 15u];
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
+  if (!forced && !rs.admitted.load() && rs.pending.load() == h->serial && h->cu_count * api <= (int)kCensusBlocks) {
+    // (another instantiation's launch on this handle in between has overwritten the census: no reading then)
+    const int got = h->census_owner.load() == (const void *)res ? census_read(h, h->cu_count * api, api, st) : 0;
+    rs.pending.store(0);
+    static const bool trace = getenv("FMX_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d> census: %d of the %d workgroups per CU the occupancy query allows were resident\n",
+                       (int)WIDE, LAYOUT, KT, (int)JT, RW, (int)R3T, got, api);
+    if (got) rs.admitted.store(got);
+    else if (rs.tries.fetch_add(1) >= 3) rs.admitted.store(api);      // no usable census (short launches, other streams): the query's answer stands
+  }
+  const int measured = rs.admitted.load();
+  const int per_cu = forced ? forced : (measured ? measured : api);
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
+  static const bool balance = !(getenv("FMX_SEARCH_BALANCE") && atoi(getenv("FMX_SEARCH_BALANCE")) == 0);      // A/B runs
+  if (want > cap && (forced || measured) && balance) {
+    // every wave the same number of batches: with r = ceil(batches / resident waves) rounds, ceil(batches / r) waves
+    // do r batches each (1M patterns on 6144 waves: 10.67 batches per wave -- a third of the waves idle through the
+    // last round; on 5958 waves: 11 each)
+    constexpr uint64_t P = 64 / Lay<LAYOUT>::G, wpb = kSThreads / 64;
+    const uint64_t nbatch = ((uint64_t)k + P - 1) / P, rounds = (nbatch + cap * wpb - 1) / (cap * wpb);
+    const uint64_t waves = (nbatch + rounds - 1) / rounds;
+    grid = (int)std::min<uint64_t>(cap, (waves + wpb - 1) / wpb);
+  } else if (want >= cap && !forced && !measured) {
+    rs.pending.store(h->serial);             // this launch is the census: read before the next one
+  }
+  h->census_owner.store((const void *)res);
   k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
                                                                        R3T ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters,
                                                                        (JT && RW == 0u) ? pk_cap : ~0ull);

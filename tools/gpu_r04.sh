@@ -73,6 +73,16 @@ ab:*)
     env $lib timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-path --steps 20 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('ms/step %.4f kernel %.4f value %.0f'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))"
   done; done
   ;;
+envab:*)
+  # the bench under environment settings:  envab:<workload>:<VAR=val>[+<VAR=val>..],..   ("-" = none)
+  spec=${PART#envab:}; wl=${spec%%:*}; sets=${spec#*:}
+  for rep in 1 2; do for e in ${sets//,/ }; do
+    ev=""; [ "$e" != "-" ] && ev=${e//+/ }
+    echo -n "$wl [$e]: "
+    env $ev timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-path --steps 20 2>$O/envab.err | python -c "import json,sys; d=json.load(sys.stdin); print('ms/step %.4f kernel %.4f value %.0f'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))"
+    grep -h "census" $O/envab.err | sort | uniq -c | sed 's/^/    /'
+  done; done
+  ;;
 wgs:*)
   # the search kernel on fewer resident workgroups per CU than the occupancy query allows:  wgs:<workload>:<n>,<n>..
   spec=${PART#wgs:}; wl=${spec%%:*}; vals=${spec#*:}

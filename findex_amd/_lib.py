@@ -49,7 +49,7 @@ class fmx_stats_t(ctypes.Structure):
                 ("launches", ctypes.c_uint64), ("last_kernel_ms", ctypes.c_double),
                 ("index_bytes", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("n_symbols", ctypes.c_uint32),
                 ("block_bytes", ctypes.c_uint32), ("build_ms", ctypes.c_double), ("layout", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32), ("search_requests", ctypes.c_uint64),
+                ("search_residency", ctypes.c_uint32), ("search_requests", ctypes.c_uint64),
                 ("frontier_requests", ctypes.c_uint64), ("frontier_elements", ctypes.c_uint64),
                 ("frontier_queue_reads", ctypes.c_uint64), ("frontier_queue_writes", ctypes.c_uint64),
                 ("frontier_results", ctypes.c_uint64), ("frontier_records", ctypes.c_uint64),

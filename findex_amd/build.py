@@ -26,38 +26,65 @@ def _hipcc():
     return "hipcc"
 
 
+def _deps():
+    return [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "fmx.h")]
+
+
+def _source_stamp():
+    """Hash of every file a translation unit can see.  The library is up to date when the stamp written beside it is
+    this one -- file times say nothing on a box the tree was copied to, and a source edited WHILE a build runs (hipcc
+    reads a .hip file twice, for the device and for the host) must not leave objects that disagree about a struct."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+STAMP = OUT + ".stamp"
+
+
 def _stale():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "fmx.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _source_stamp()
 
 
 def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    objs = []
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),
              "-I" + CSRC, "-Wall", "-Wno-unused-result"]
-    procs = []
-    for src in SOURCES:
-        obj = os.path.join(OUT_DIR, src + ".o")
-        objs.append(obj)
-        cmd = [_hipcc()] + flags + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed on " + src)
+    for attempt in range(3):
+        stamp = _source_stamp()
+        objs = []
+        procs = []
+        for src in SOURCES:
+            obj = os.path.join(OUT_DIR, src + ".o")
+            objs.append(obj)
+            cmd = [_hipcc()] + flags + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd)))
+        for src, p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("hipcc failed on " + src)
+        if _source_stamp() == stamp:
+            break           # (else: the sources changed under the compilers -- again, from what they are now)
+    else:
+        raise RuntimeError("the sources keep changing while they are compiled")
     tmp = OUT + ".%d.tmp" % os.getpid()
     cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(tmp, OUT)
+    with open(STAMP, "w") as f:
+        f.write(stamp + "\n")
     return OUT
 
 

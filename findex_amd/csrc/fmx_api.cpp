@@ -1251,6 +1251,7 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->frontier_records = cnt[8];
   out->ktab_lookups = cnt[9];
   out->ktab_k = h->kt.k;
+  out->search_residency = h->search_residency.load();
   out->jump_chars = h->jump_bytes ? h->jump_chars : 0;
   out->build_ms = h->build_ms;
   out->tables_build_ms = h->tables_ms;

@@ -105,6 +105,7 @@ struct Index {
   mutable double tables_ms = 0.0;             // host time spent building the k-mer table and the select directory (under their mutexes)
   // when the derived tables are built (fmx_jump.hip, tables_due): patterns searched so far, fmx_prepare seen
   mutable std::atomic<uint64_t> patterns_seen{0};
+  mutable std::atomic<uint32_t> search_residency{0};     // fmx_stats.search_residency
   mutable std::atomic<const void *> census_owner{nullptr};   // the k_search4 instantiation whose launch wrote the residency census last (fmx_search.hip)
   mutable std::atomic<bool> prepared{false};
   mutable std::atomic<uint64_t> peak_table_build_bytes{0};      // most device memory a table build held at once (table + its scratch)

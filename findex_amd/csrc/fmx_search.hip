@@ -964,9 +964,13 @@ static int blocks_per_cu(K kernel) {
 // for, 7 resident, a launch of 0.205 ms instead of 0.170.  So every instantiation of k_search4 is calibrated by a
 // CENSUS of its first full-size launch on a device: the kernel leaves each workgroup's begin and end times behind the
 // counters (fmx_device.h); before the instantiation's next launch the host counts the workgroups that began before the
-// first one ended and divides by the CUs.  One 64 KB copy and one stream synchronisation per instantiation and process.
+// first one ended and divides by the CUs.  A census taken while other work held part of the device (a table build on
+// another stream) counts late workgroups that waited for THAT: only an answer of the query's number or up to two below
+// it is believed, and only when two launches in a row give it.  One 64 KB copy and one stream synchronisation per
+// reading; two or three readings per instantiation and process.
 struct Residency {
   std::atomic<int> admitted{0};            // workgroups per CU that were resident at once; 0 = not measured yet
+  std::atomic<int> candidate{0};           // the last reading (it takes two equal ones)
   std::atomic<uint64_t> pending{0};        // serial of the handle whose last launch of this kernel was a full-size one
   std::atomic<int> tries{0};
 };
@@ -984,7 +988,8 @@ static int census_read(const Index *h, int grid, int api, hipStream_t st) {
   if (first_end < first_begin + 2000) return 0;             // workgroups shorter than 20 us say nothing about who waited for whom
   int resident = 0;
   for (int i = 0; i < nb; i++) resident += t[2 * i] < first_end ? 1 : 0;
-  return std::max(1, std::min(api, resident / std::max(1, h->cu_count)));
+  const int got = resident / std::max(1, h->cu_count);
+  return (got >= api - 2 && got >= 1) ? std::min(api, got) : 0;      // fewer: the device was not this launch's alone
 }
 
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T = false>
@@ -1003,27 +1008,19 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
     static const bool trace = getenv("FMX_TRACE") != nullptr;
     if (trace) fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d> census: %d of the %d workgroups per CU the occupancy query allows were resident\n",
                        (int)WIDE, LAYOUT, KT, (int)JT, RW, (int)R3T, got, api);
-    if (got) rs.admitted.store(got);
-    else if (rs.tries.fetch_add(1) >= 3) rs.admitted.store(api);      // no usable census (short launches, other streams): the query's answer stands
+    if (got && rs.candidate.exchange(got) == got) rs.admitted.store(got);
+    else if (rs.tries.fetch_add(1) >= 5) rs.admitted.store(api);      // no two usable readings (short launches, other streams, a shared device): the query's answer stands
   }
   const int measured = rs.admitted.load();
   const int per_cu = forced ? forced : (measured ? measured : api);
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  static const bool balance = !(getenv("FMX_SEARCH_BALANCE") && atoi(getenv("FMX_SEARCH_BALANCE")) == 0);      // A/B runs
-  if (want > cap && (forced || measured) && balance) {
-    // every wave the same number of batches: with r = ceil(batches / resident waves) rounds, ceil(batches / r) waves
-    // do r batches each (1M patterns on 6144 waves: 10.67 batches per wave -- a third of the waves idle through the
-    // last round; on 5958 waves: 11 each)
-    constexpr uint64_t P = 64 / Lay<LAYOUT>::G, wpb = kSThreads / 64;
-    const uint64_t nbatch = ((uint64_t)k + P - 1) / P, rounds = (nbatch + cap * wpb - 1) / (cap * wpb);
-    const uint64_t waves = (nbatch + rounds - 1) / rounds;
-    grid = (int)std::min<uint64_t>(cap, (waves + wpb - 1) / wpb);
-  } else if (want >= cap && !forced && !measured) {
+  if (want >= cap && !forced && !measured) {
     rs.pending.store(h->serial);             // this launch is the census: read before the next one
   }
   h->census_owner.store((const void *)res);
+  h->search_residency.store((uint32_t)per_cu | ((forced || measured) ? 0x100u : 0u));
   k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
                                                                        R3T ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters,
                                                                        (JT && RW == 0u) ? pk_cap : ~0ull);

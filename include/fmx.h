@@ -467,7 +467,9 @@ typedef struct fmx_stats_t {
   uint32_t block_bytes;      /* bytes fetched per rank query: 64 (one-hot block) or 132 (BWT block + checkpoint) */
   double build_ms;           /* device time of the kernels that built the rank dictionary at open */
   uint32_t layout;           /* 0 = one-hot bit-vectors, 1 = BWT bytes + checkpoints */
-  uint32_t reserved;         /* 0 */
+  uint32_t search_residency; /* workgroups per CU the last fmx_search_batch[_dev] launch was sized for (0: none yet); | 0x100 once
+                                the kernel's residency census has confirmed the number (the occupancy query can answer one
+                                too many: DESIGN.md 3, "residency") */
   uint64_t search_requests;  /* memory requests for rank-dictionary lines issued by fmx_search_batch[_dev]'s kernel */
   /* the regex frontier kernels (fmx_regex_*match*), for their roofline: */
   uint64_t frontier_requests;   /* memory requests for rank-dictionary lines */

@@ -2091,3 +2091,35 @@ def test_parked_walks_flush_inside_the_kernel():
     pk = hip.search_batch_ex(buf, fixed_len=m, packed=True, escape_cap=16)
     usp, uep = hip.unpack_intervals(pk, k, 16)
     assert np.array_equal(usp, wsp) and np.array_equal(uep, wep)
+
+
+@pytest.mark.parametrize("layout", ["onehot", "bytes"])
+def test_search_grid_follows_the_residency_census(layout):
+    """k_search4's grid is sized by what was resident, not by what the occupancy query answers (fmx_search.hip,
+    Residency): after a few full-size launches of one instantiation the census has confirmed a number -- the query's, or
+    up to two below it -- fmx_stats.search_residency carries it with bit 8 set, and the intervals are what they were
+    before the grid changed (and the oracle's)."""
+    findex_amd.set_layout(layout)
+    try:
+        bwt, eof, counts = synth_bwt(3_000_000, 97, 120, 17)
+        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+        rng = np.random.default_rng(5)
+        k, m = 1_000_000, 24
+        walk, _ = hip.lf_walk_batch(rng.integers(0, bwt.size, size=k), m)     # hit patterns: every wave's batches take their full time
+        pats = np.ascontiguousarray(walk[:, ::-1])
+        off = np.arange(0, (k + 1) * m, m, dtype=np.uint64)
+        first = hip.search_batch(pats.reshape(-1), off)
+        seen = set()
+        for _ in range(8):
+            sp, ep = hip.search_batch(pats.reshape(-1), off)
+            assert np.array_equal(sp, first[0]) and np.array_equal(ep, first[1])
+            seen.add(hip.stats()["search_residency"])
+        last = hip.stats()["search_residency"]
+        assert last & 0x100, "no census after nine full-size launches: %s" % sorted(seen)
+        asked = max(v & 0xFF for v in seen)
+        assert 1 <= (last & 0xFF) <= 8 and asked - 2 <= (last & 0xFF) <= asked
+        orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+        wsp, wep, _ = orc.search_batch(pats[:5000].reshape(-1), off[:5001])
+        assert np.array_equal(sp[:5000], wsp) and np.array_equal(ep[:5000], wep)
+    finally:
+        findex_amd.set_layout("auto")

@@ -752,6 +752,9 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
                                   % (int(s1["ktab_k"]), s1["jump_bytes"] / 2**30, s1["row_bytes"] / 2**30,
                                      s1["peak_table_build_bytes"] / 2**30),
             "index_layout": "one-hot bit-vectors, 64-B blocks" if onehot else "BWT bytes + checkpoints",
+            # workgroups per CU the search kernel's grid is sized for (bit 8: confirmed by the kernel's residency census,
+            # DESIGN.md 3 "Residency" -- the occupancy query can answer one too many)
+            "search_residency": "0x%x" % int(hip.stats().get("search_residency", 0)),
         },
         "roofline": roof,
     }

@@ -557,6 +557,37 @@ int fmx_device_count(int *count) {
   return FMX_OK;
 }
 
+// The X.fm sibling of X.bwt (BWTTempStorage.genFMFilename, bwtmerger.scala:33-36: the extension swapped).  The reference
+// cannot open an index without it -- NaiveFMSearcher takes n = fm.size (bwtmerger.scala:339) and FMLoader throws on a bad
+// header (:259-262): element size 4, size * 4 + 9 == file length.  This engine derives its rank dictionary from the .bwt
+// and never reads the lists, so a MISSING .fm is fine; a .fm that is there is held to the reference's checks, and to
+// describing the same n rows as the .bwt -- an index whose files do not belong together fails here as it does there.
+static int check_fm_sibling(const char *bwt_path, bool be, uint64_t n) {
+  std::string p(bwt_path);
+  const size_t slash = p.find_last_of("/\\"), dot = p.find_last_of('.');
+  if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) p.erase(dot);
+  p += ".fm";
+  FILE *f = std::fopen(p.c_str(), "rb");
+  if (!f) return FMX_OK;
+  std::unique_ptr<FILE, int (*)(FILE *)> guard(f, std::fclose);
+  uint8_t hdr[9];
+  if (std::fread(hdr, 1, 9, f) != 9) { g_err = "File " + p + " bad size"; return FMX_ERR_FORMAT; }
+  const unsigned el = hdr[0];
+  const uint64_t size = rd_u64(hdr + 1, be);
+  if (el != 4) { g_err = "File " + p + " bad elSize " + std::to_string(el); return FMX_ERR_FORMAT; }
+  if (fseeko(f, 0, SEEK_END) != 0) { g_err = "seek failed"; return FMX_ERR_IO; }
+  const uint64_t flen = (uint64_t)ftello(f);
+  if (size > (1ull << 40) || size * 4 + 9 != flen) {
+    g_err = "File " + p + " bad size " + std::to_string(size) + " + 0x9 != " + std::to_string(flen) + "(filelen)";
+    return FMX_ERR_FORMAT;
+  }
+  if (size != n) {
+    g_err = "File " + p + " holds " + std::to_string(size) + " rows, " + bwt_path + " " + std::to_string(n) + ": not one index";
+    return FMX_ERR_FORMAT;
+  }
+  return FMX_OK;
+}
+
 int fmx_open(const char *bwt_path, const char *aux_path, int big_endian, int device, fmx_index **out) {
   if (!bwt_path || !aux_path) return arg_fail("path is null");
   uint64_t n = 0, eof = 0;
@@ -566,6 +597,8 @@ int fmx_open(const char *bwt_path, const char *aux_path, int big_endian, int dev
   if (rc != FMX_OK) return rc;
   std::unique_ptr<FILE, int (*)(FILE *)> guard(f, std::fclose);
   rc = load_aux(aux_path, big_endian != 0, counts);
+  if (rc != FMX_OK) return rc;
+  rc = check_fm_sibling(bwt_path, big_endian != 0, n);
   if (rc != FMX_OK) return rc;
   return open_common(nullptr, false, f, n, eof, counts, device, nullptr, out);
 }

@@ -46,7 +46,8 @@ class PinnedArray:
 
 class HipFMSearcher:
     """`new NaiveFMSearcher(filename, bigEndian)`: opens X.bwt and X.aux next to `filename` and
-    builds the rank dictionary in HBM (the reference's X.fm is not needed).
+    builds the rank dictionary in HBM.  The reference's X.fm is not needed; when it is there it must
+    pass FMLoader's checks and hold the .bwt's n rows (fmx_open), or the open fails as the reference's does.
 
     Scalar methods keep the reference's names and Option-like results (tuple or None); each
     `*_batch` method is the batched form the kernels are built for.  Positions are Python ints /

@@ -107,9 +107,12 @@ int fmx_device_count(int *count);
 /* ---- open / close ------------------------------------------------------------
  * fmx_open      : NaiveFMSearcher(filename, bigEndian) constructor, bwtmerger.scala:335-353,
  *                 reading X.bwt (BWTLoader :144-174) and X.aux (AUXLoader :130-142).  The
- *                 reference's third file, X.fm (FMLoader :252-290), is not read: its content
+ *                 reference's third file, X.fm (FMLoader :252-290), is not needed: its content
  *                 is a function of the other two (FMCreator :424-533) and the device rank
- *                 dictionary is built from them directly.
+ *                 dictionary is built from them directly.  An X.fm that IS there (the .bwt's name
+ *                 with the extension swapped, :33-36) is held to FMLoader's checks -- element size
+ *                 4, size * 4 + 9 == file length (:259-262) -- and to n = fm.size (:339) being the
+ *                 .bwt's n: FMX_ERR_FORMAT otherwise, as the reference throws.
  * fmx_open_mem  : the same from host memory (bwt[n] raw bytes incl. the filler at slot eof,
  *                 counts[256] = the .aux array).
  * fmx_open_dev  : the same with the BWT bytes already in device memory; counts may be NULL

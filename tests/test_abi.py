@@ -59,6 +59,39 @@ def test_open_errors_are_statuses_with_messages(tmp_path, testdata):
     assert L.fmx_n(None, None) == 3
 
 
+def test_fm_sibling_is_held_to_the_reference_checks(tmp_path, testdata):
+    """NaiveFMSearcher cannot open an index without X.fm and FMLoader throws on a bad one (bwtmerger.scala:259-262,339:
+    element size 4, size * 4 + 9 == file length, n = fm.size).  The engine never reads the lists, so a missing .fm is
+    fine -- but one that is there must pass those checks and describe the .bwt's n rows; a bad one fails the open with
+    FMX_ERR_FORMAT before any device is touched (so this runs without a GPU), a good one lets the open go on."""
+    import shutil
+    import struct
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    for name, be in (("test1024.cmp", False), ("words", True)):
+        for ext in (".bwt", ".aux"):
+            shutil.copy(os.path.join(testdata, name + ext), tmp_path / (name + ext))
+        bwt, aux, fm = tmp_path / (name + ".bwt"), tmp_path / (name + ".aux"), tmp_path / (name + ".fm")
+        n = struct.unpack(">q" if be else "<q", bwt.read_bytes()[:8])[0]
+        fmt = ">q" if be else "<q"
+
+        def rc_of():
+            return L.fmx_open(str(bwt).encode(), str(aux).encode(), 1 if be else 0, 0, ctypes.byref(h))
+        fm.write_bytes(b"\x08" + struct.pack(fmt, n) + b"\0" * (8 * n))
+        assert rc_of() == 2 and b"bad elSize 8" in L.fmx_last_error()
+        fm.write_bytes(b"\x04" + struct.pack(fmt, n) + b"\0" * (4 * n - 4))
+        assert rc_of() == 2 and b"bad size" in L.fmx_last_error() and b"0x9" in L.fmx_last_error()
+        fm.write_bytes(b"\x04" + struct.pack(fmt, n - 1) + b"\0" * (4 * (n - 1)))
+        assert rc_of() == 2 and b"not one index" in L.fmx_last_error()
+        fm.write_bytes(b"\x04\0\0")
+        assert rc_of() == 2
+        fm.write_bytes(b"\x04" + struct.pack(fmt, n) + b"\0" * (4 * n))       # well-formed: the open goes on to the device
+        rc = rc_of()
+        assert rc in (0, 5), L.fmx_last_error()
+        if rc == 0:
+            L.fmx_close(h)
+
+
 def test_no_cpu_fallback_without_device(testdata):
     """Without a HIP device open() must fail loudly (FMX_ERR_HIP), never compute on the CPU."""
     L = _lib.load()

@@ -1814,12 +1814,15 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     else
       k_frontier<false, kLayoutOneHot><<<grid, kFThreads, 0, s>>>(h->dev, kt, b->nfa, fq, j, rounds, sub_cap, d_res_seg, seg_cap, d_ctl, b->d_rcnt, h->d_counters);
   };
-  // One chain = kChain x (launch + k_frontier_advance) + the summary's copy to pinned host memory.  Its kernel
-  // arguments do not change from chain to chain, so it is captured into a hipGraph once per batch and replayed:
-  // one launch call per chain.  Two chains are kept: the full grid for a batch's wide phase, and a small grid
-  // (64 workgroups: lanes for 16384 elements) for a single regex or the thin end of a batch, whose
-  // launches cost a fraction of the full grid's when most of them find nothing to do.
-  static const bool use_graph = !(getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) == 0);
+  // One chain = reset + kChain x (launch + k_frontier_advance), the grouping behind it.  Two grids: the full one for a
+  // batch's wide phase, and a small one (64 workgroups: lanes for 16384 elements) for a single regex or the thin end of
+  // a batch, whose launches cost a fraction of the full grid's when most of them find nothing to do.
+  // The kernel arguments do not change from chain to chain, so the whole call can be captured into a hipGraph once per
+  // batch and replayed (FMX_FRONTIER_GRAPH=1).  While a call was twelve kernels that paid; at five, the ~18 us between
+  // hipGraphLaunch and the first kernel's start are more than five plain launches cost, which the host enqueues while
+  // the first ones run: C4 0.352 -> 0.342 ms, C4text 0.119 -> 0.110 ms, one 24-character literal 71 -> 70 us per call.
+  // Plain launches are the default.
+  static const bool use_graph = getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) != 0;
   // experiments: rounds per launch of a chain as a comma list (the last entry repeats)
   static const std::vector<uint32_t> plan = [] {
     std::vector<uint32_t> v;

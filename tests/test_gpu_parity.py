@@ -1197,7 +1197,7 @@ def test_regex_queue_tags_wrap_and_launches_hand_over():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FMX_FRONTIER_TAG_LIMIT="5", FMX_FRONTIER_ROUNDS="4", FMX_FRONTIER_ROUNDS_SMALL="4",
-               FMX_FRONTIER_CHAIN="2", FMX_FRONTIER_CHAIN_SMALL="2")
+               FMX_FRONTIER_CHAIN="2", FMX_FRONTIER_CHAIN_SMALL="2", FMX_FRONTIER_GRAPH="1")     # (and the captured-graph form of a call)
     r = subprocess.run([sys.executable, "-c", _QUEUE_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
 

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
   // The parked patterns, P at a time, a lane group each: one-row steps (one rank query + one bit test, as in the step
   // loop) from the row and step they were parked with until the interval is empty -- or, should one not fail after all,
   // to its end -- leaving the reference loop's final values in the output arrays and counting its steps.
-  auto walk_parked = [&]() {
+  auto walk_parked = [&](auto last_tag) {
+    constexpr bool kLast = decltype(last_tag)::value;          // the walk before the wave ends (not the one that makes room inside the batch loop)
     while (npark) {                                            // wave-uniform
       const uint32_t take = npark < P ? npark : P;
       const bool actw = grp < take;
@@ -262,7 +263,27 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
       npark -= take;
       const uint32_t wpid = actw ? s_park_pid[wave_in_wg][slot] : 0u;
       uint32_t wit = actw ? s_park_it[wave_in_wg][slot] : 0u;
-      uint64_t wsp = actw ? s_park_row[wave_in_wg][slot] : 0ull, wep = wsp + (actw ? 1u : 0u);
+      uint64_t wsp = actw ? s_park_row[wave_in_wg][slot] : 0ull;
+      uint32_t wj = (uint32_t)(wsp >> 56);                       // steps that are known to succeed (the lookup that parked it saw them)
+      wsp &= (1ull << 56) - 1;
+      if constexpr (R3T && kLast) {
+        // ... three of them at a time by the three-step row table: one 8-byte load where the step loop below spends three
+        // rank queries (a pattern that misses in the middle of a nine-character entry: 3 dependent requests, not 5).  Only
+        // in the last walk -- where nearly all of them happen: a wave parks ~1.6 patterns per batch of a workload with
+        // 10 % misses and the list holds 64 -- because a second copy of this loop inside the batch loop costs the step
+        // loop a register it does not have (the dictionary's lane address was spilled and re-read at every rank step).
+        while (__builtin_amdgcn_ballot_w64(actw && wj >= 3u)) {
+          const bool go = actw && wj >= 3u;
+          if (go) {
+            wsp = r3tab[wsp] & ((1ull << 40) - 1);
+            wj -= 3u;
+            wit += 3u;
+            steps += 3u;
+          }
+          r3l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(go && t == 0));
+        }
+      }
+      uint64_t wep = wsp + (actw ? 1u : 0u);
       uint64_t wbegin = 0, wend = 0;
       if (actw) po.get(wpid, wbegin, wend);
       const uint32_t wlen = (uint32_t)(wend - wbegin);
@@ -480,6 +501,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
       const uint32_t rem = len - it;
       bool lookedup = false;                                   // this group has taken steps by table lookup in this iteration
       bool park_now = false;                                   // ... or was found to miss by one: it is parked below
+      uint32_t missj = 0;                                      // ... having agreed with its row's text for this many steps first
       if (JT && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) > (uint64_t)G))) {
         // ---- every live group holds at most G rows (one, as a rule: sigma = 128, n = 2^32 -- from the 6th step on) and none
         // is sitting out: a group with jc or more characters left looks its rows up in the row jump table -- J[r] = the
@@ -503,7 +525,10 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
             // one row per group: every lane of the group loads the same entry, the row comes straight out of it
             uint4 je = make_uint4(0, 0, 0, 0);
             if (can) je = jtab[sp];
-            jumped = can && je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
+            const uint32_t d0 = je.x ^ p0, d1 = je.y ^ p1, d2 = (je.z ^ p2) & m2;
+            jumped = can && (d0 | d1 | d2) == 0u;
+            // (an entry's character of step s is its byte s: the first byte that differs is the step that fails)
+            missj = d0 ? (uint32_t)__builtin_ctz(d0) >> 3 : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u + ((uint32_t)__builtin_ctz(d2 | 0x80000000u) >> 3));
             rowj = (uint64_t)(je.z >> 24) | ((uint64_t)je.w << 8);
             jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(can && t == 0));
           } else {
@@ -513,7 +538,9 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
             const bool mine = can && (uint64_t)t < width;
             uint4 je = make_uint4(0, 0, 0, 0);
             if (mine) je = jtab[sp + t];
-            const bool hit = mine && je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
+            const uint32_t d0 = je.x ^ p0, d1 = je.y ^ p1, d2 = (je.z ^ p2) & m2;
+            const bool hit = mine && (d0 | d1 | d2) == 0u;
+            missj = d0 ? (uint32_t)__builtin_ctz(d0) >> 3 : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u + ((uint32_t)__builtin_ctz(d2 | 0x80000000u) >> 3));      // (lane 0's: the entry of row sp)
             const uint32_t lane64g = threadIdx.x & 63u, gbase = lane64g - t;
             const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> gbase) & ((1u << G) - 1u);
             const int first = (int)(gbase + (hm ? (uint32_t)__builtin_ctz(hm) : 0u));
@@ -571,6 +598,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
               park_now = true;
               deferred = true;
               ep = sp;
+              missj = (uint32_t)__builtin_ctz((((uint32_t)(re >> 40) ^ three) & 0xFFFFFFu) | 0x80000000u) >> 3;       // (0 .. 2; lane 0's word is row sp's)
             }                                                                  // (wider and no row agrees: it steps on and ends within three steps)
           }
           r3l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // a lane per row looked up
@@ -582,7 +610,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
           const unsigned long long pm = __builtin_amdgcn_ballot_w64(park_now && t == 0);
           const uint32_t lane64p = threadIdx.x & 63u;
           const uint32_t slot = npark + (uint32_t)__builtin_popcountll(pm & ((1ull << lane64p) - 1ull));
-          if (park_now && t == 0) { s_park_row[wave_in_wg][slot] = sp; s_park_pid[wave_in_wg][slot] = pid; s_park_it[wave_in_wg][slot] = it; }
+          if (park_now && t == 0) { s_park_row[wave_in_wg][slot] = sp | ((uint64_t)missj << 56); s_park_pid[wave_in_wg][slot] = pid; s_park_it[wave_in_wg][slot] = it; }
           npark += (uint32_t)__builtin_popcountll(pm);
         } else {
           if (park_now && t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
@@ -689,13 +717,13 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     } else {
       search_one_batch(std::false_type{});
     }
-    if (kFold && npark > kParkCap - P) walk_parked();      // room for a whole batch's groups
+    if (kFold && npark > kParkCap - P) walk_parked(std::false_type{});      // room for a whole batch's groups
     cur = nxt_stage;
     par ^= 1u;
     end0 = end1; len0 = len1;
     fix_off((uint64_t)batch + 2ull * nwaves, raw2a, raw2b, end1, len1);
   }
-  if (kFold) walk_parked();
+  if (kFold) walk_parked(std::true_type{});
 #ifdef FMX_SEARCHLOG
   const unsigned long long sl_t2 = __builtin_amdgcn_s_memrealtime();
 #endif

@@ -120,8 +120,10 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
   uint32_t sl_batches = 0;
 #endif
   // the residency census (fmx_device.h): when this workgroup began
-  if (threadIdx.x == 0 && blockIdx.x < kCensusBlocks)
+  if (threadIdx.x == 0 && blockIdx.x < kCensusBlocks) {
     counters[(size_t)kCounterSlots * kCounterStride + 2u * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0) counters[(size_t)kCounterSlots * kCounterStride + 2u * kCensusBlocks] = gridDim.x;      // whose entries these are
+  }
   // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
   // slot + 2 (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
   __shared__ uint4 s_tab[256];
@@ -1003,9 +1005,10 @@ struct Residency {
   std::atomic<int> tries{0};
 };
 static int census_read(const Index *h, int grid, int api, hipStream_t st) {
-  std::vector<unsigned long long> t(2 * (size_t)kCensusBlocks);
+  std::vector<unsigned long long> t(2 * (size_t)kCensusBlocks + 2);
   if (hipMemcpyAsync(t.data(), h->d_counters + (size_t)kCounterSlots * kCounterStride, kCensusBytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (t[2 * (size_t)kCensusBlocks] != (unsigned long long)grid) return 0;      // the last launch to write here was not the full-size one (a replayed graph, another stream)
   const int nb = std::min<int>(grid, (int)kCensusBlocks);
   unsigned long long first_begin = ~0ull, first_end = ~0ull;
   for (int i = 0; i < nb; i++) {
@@ -1029,7 +1032,14 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   static Residency res[16];
   Residency &rs = res[(unsigned)h->device & 15u];
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
-  if (!forced && !rs.admitted.load() && rs.pending.load() == h->serial && h->cu_count * api <= (int)kCensusBlocks) {
+  // (a stream that is being captured into a graph can be neither synchronised nor trusted to have run its launches:
+  // no reading and no census launch then -- an uncalibrated instantiation keeps the query's answer meanwhile)
+  const auto capturing = [&]() {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+  };
+  if (!forced && !rs.admitted.load() && rs.pending.load() == h->serial && h->cu_count * api <= (int)kCensusBlocks && !capturing()) {
     // (another instantiation's launch on this handle in between has overwritten the census: no reading then)
     const int got = h->census_owner.load() == (const void *)res ? census_read(h, h->cu_count * api, api, st) : 0;
     rs.pending.store(0);
@@ -1044,7 +1054,7 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  if (want >= cap && !forced && !measured) {
+  if (want >= cap && !forced && !measured && !capturing()) {
     rs.pending.store(h->serial);             // this launch is the census: read before the next one
   }
   h->census_owner.store((const void *)res);

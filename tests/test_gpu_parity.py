@@ -2123,3 +2123,55 @@ def test_search_grid_follows_the_residency_census(layout):
         assert np.array_equal(sp[:5000], wsp) and np.array_equal(ep[:5000], wep)
     finally:
         findex_amd.set_layout("auto")
+
+
+_CAPTURE_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, findex_amd
+from helpers import synth_bwt
+findex_amd.set_layout(sys.argv[2])
+bwt, eof, counts = synth_bwt(3_000_000, 97, 120, 17)
+hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+hip.prepare(ktab=True, jump=True)
+rng = np.random.default_rng(5)
+k, m = 1_000_000, 24
+walk, _ = hip.lf_walk_batch(rng.integers(0, bwt.size, size=k), m)
+dev = torch.device("cuda", 0)
+d_pat = torch.from_numpy(np.ascontiguousarray(walk[:, ::-1]).reshape(-1)).to(dev)
+d_off = torch.arange(0, (k + 1) * m, m, dtype=torch.int64, device=dev)
+sp = [torch.zeros(k, dtype=torch.int64, device=dev) for _ in range(3)]
+ep = [torch.zeros(k, dtype=torch.int64, device=dev) for _ in range(3)]
+def search(i):
+    hip.search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), sp[i].data_ptr(), ep[i].data_ptr(), k, torch.cuda.current_stream().cuda_stream)
+search(0)                                   # the instantiation's first full-size launch: its census is pending now
+torch.cuda.synchronize()
+assert hip.stats()["search_residency"] & 0x100 == 0
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):                   # the stream is being captured: no reading of the census, no synchronisation
+    search(1)
+for _ in range(2):
+    g.replay()
+torch.cuda.synchronize()
+assert torch.equal(sp[1], sp[0]) and torch.equal(ep[1], ep[0]) and int((sp[0] < ep[0]).sum()) == k
+assert hip.stats()["search_residency"] & 0x100 == 0
+for _ in range(6):                          # plain launches again: now it is taken
+    search(2)
+torch.cuda.synchronize()
+assert torch.equal(sp[2], sp[0]) and torch.equal(ep[2], ep[0])
+r = hip.stats()["search_residency"]
+assert r & 0x100, hex(r)
+print("ok", hex(r))
+"""
+
+
+@pytest.mark.parametrize("layout", ["onehot", "bytes"])
+def test_search_inside_a_captured_graph_leaves_the_census_alone(layout):
+    """fmx_search_batch_dev on a stream that is being captured into a graph (a caller's own hipGraph / torch CUDAGraph):
+    the residency census neither reads nor synchronises there -- the capture succeeds, its replays give the intervals of
+    the plain call -- and calibrates from the plain launches that follow.  (A child process: the census is per process.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_SCRIPT, root, layout], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr

@@ -618,31 +618,42 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         step()
     torch.cuda.synchronize()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # The kernel's own duration is measured live, with HIP events on its stream, on every EVENT_EVERY-th step of the timed
+    # region.  Not on every step: an event record is a marker packet the command processor drains the stream for, and
+    # two of them between consecutive launches were 8-11 us of a 150 us step (device clock: launches inside one C5 step
+    # follow each other without a gap, steps were 11 us apart) -- measurement overhead, not the path's.
+    EVENT_EVERY = 4
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if j % EVENT_EVERY == 0 else None
+          for j in range(args.steps)]
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for a, b in ev:
+    for pair in ev:
         i = step_no[0]
         step_no[0] += 1
         if use_dist:
             gather.slot(i)      # (waits for the collective that last used the slot, outside the search's events)
-            a.record()          # torch's current stream == the stream the kernel is launched on
+            if pair:
+                pair[0].record()          # torch's current stream == the stream the kernel is launched on
             gather.search_into(i, hip, pats.data_ptr(), off.data_ptr(), stream)
-            b.record()
+            if pair:
+                pair[1].record()
             gather.launch(i, stream, packed_already=True)
         else:
             sp_i, ep_i = gather.slot(i)
-            a.record()
+            if pair:
+                pair[0].record()
             hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp_i.data_ptr(), ep_i.data_ptr(), k, stream)
-            b.record()
+            if pair:
+                pair[1].record()
     gather.finish()         # every step's gather completes inside the timed region
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    timed = [p for p in ev if p]
+    kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
 
     exchange = measure_exchange(args, torch, dist, hip, gather, k, device, stream, use_dist)
     tot = torch.tensor([dt, float(ranks_per_step), float(hits), kernel_ms], dtype=torch.float64, device=device)
@@ -688,6 +699,8 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
                              "table words x 8 B + %d operand bytes (patterns, offsets, intervals)"
                              % (requests_per_step, line_bytes, lookups_per_step, jumps_per_step, rows_per_step, operand_bytes),
         "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+        "kernel_ms_is": "HIP events around the launch on %d of the %d timed steps (every %dth: the markers themselves cost a "
+                        "step 8-11 us)" % (len(timed), args.steps, EVENT_EVERY),
         "requests_per_launch": all_requests, "rank_line_requests": requests_per_step, "ktab_lookups": lookups_per_step,
         "jump_lookups": jumps_per_step, "jump_table_gib": s1["jump_bytes"] / 2**30,
         "row_lookups": rows_per_step, "row_table_gib": s1["row_bytes"] / 2**30,

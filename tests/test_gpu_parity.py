@@ -2175,3 +2175,52 @@ def test_search_inside_a_captured_graph_leaves_the_census_alone(layout):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _CAPTURE_SCRIPT, root, layout], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+def test_result_groups_of_every_size_are_ordered():
+    """k_res_sort's paths side by side in one batch of 400 regexes (shuffled, so that every workgroup of 256 regexes
+    holds a mix): groups of one result, of 2 .. 12, of 13 .. 64 (every result finds its own place), of 65 .. 1024 (bitonic
+    sort by the workgroup), stretches of more than 1024 results per 256 regexes (not staged in LDS) -- each regex's list
+    against the oracle's, in (len, sp, ep) order, through the host form and the device-resident form."""
+    torch = _torch()
+    from findex_amd.regex import RegexBatch, RESULT_DTYPE
+    bwt, eof, counts = synth_bwt(400_000, 97, 100, 21)           # a..d
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(11)
+    abcd = "abcd"
+    res = []
+    for _ in range(220):                                          # one result each, or none
+        res.append("".join(abcd[i] for i in rng.integers(0, 4, size=int(rng.integers(2, 9)))))
+    for _ in range(100):                                          # 2 .. 12: a class or an option or two
+        lit = "".join(abcd[i] for i in rng.integers(0, 4, size=3))
+        res.append(lit + ["[ab]", "[a-c]", "[a-d]", "[ab][cd]", "[a-c][ab]", "(a|b)c?", "[ab]?[cd]?"][int(rng.integers(0, 7))])
+    for _ in range(50):                                           # 13 .. 64
+        lit = abcd[int(rng.integers(0, 4))]
+        res.append(lit + ["[a-d][a-d]", "[a-d][a-c][ab]", "[ab][ab][ab][ab]", "[a-d][a-d][ab]", "[ab]?[a-d][a-d]"][int(rng.integers(0, 5))])
+    for _ in range(28):                                           # 65 .. 1024
+        res.append(abcd[int(rng.integers(0, 4))] + ["[a-d][a-d][a-d]", "[a-d][a-d][a-d][ab]", "[a-d][a-d][a-d][a-d]", "[ab][a-d][a-d][a-d][ab]?"][int(rng.integers(0, 4))])
+    res += ["[a-d][a-d][a-d][a-d][a-d][ab]", "[a-d][a-d][a-d][a-d][a-c][ab]?"]      # more than 1024
+    order = rng.permutation(len(res))
+    res = [res[i] for i in order]
+    trees = [findex_amd.ReTree(findex_amd.REParser.re2post(r)) for r in res]
+    rb = RegexBatch(hip, trees)
+    out, per = rb.match_raw(max_steps=12, cap=1 << 20)
+    sizes = np.bincount(np.minimum(np.searchsorted([1, 2, 13, 65, 1025], per, side="right"), 5), minlength=6)
+    assert all(sizes[1:] > 0), "the batch misses a size class: %s" % sizes.tolist()
+    at = 0
+    for i, re_ in enumerate(res):
+        want, _ = oracle_results(orc, re_)
+        got = [(int(r["len"]), int(r["sp"]), int(r["ep"])) for r in out[at:at + int(per[i])]]
+        assert all(int(r["regex"]) == i for r in out[at:at + int(per[i])]) and got == want, re_
+        at += int(per[i])
+    assert at == out.size
+    cap = 1 << 20
+    d_out = torch.zeros(cap * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    d_per = torch.zeros(len(trees), dtype=torch.int32, device="cuda")
+    for _ in range(2):                                            # (the second call replays whatever the first one set up)
+        n = rb.match_dev(d_out.data_ptr(), cap, d_per.data_ptr(), max_steps=12)
+        torch.cuda.synchronize()
+        got = np.frombuffer(d_out[: n * RESULT_DTYPE.itemsize].cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
+        assert n == out.size and got.tobytes() == out.tobytes()
+        assert np.array_equal(d_per.cpu().numpy().astype(np.uint32), per)

@@ -58,3 +58,19 @@ wid = np.nonzero(live)[0]
 for x in range(8):
     sel = ((wid // 4) % 8) == x
     print("  XCD %d: waves begin p50 %6.1f, end p50 %6.1f max %6.1f us" % (x, np.percentile((t0[sel] - z) * T, 50), np.percentile((t3[sel] - z) * T, 50), ((t3[sel] - z) * T).max()))
+# What handing the partial last round to the FAST waves would give: every wave keeps its own pace (us per batch);
+# statically the first (batches mod waves) waves take the extra batch, dynamically the ones with the lowest pace do.
+pace = (t2 - t1) * T / np.maximum(nb, 1)
+base_n = int(nb.min())
+n_extra = int((nb > base_n).sum())
+start = (t1 - z) * T
+static_end = start + nb * pace
+fast = np.argsort(pace)[:n_extra]
+dyn_n = np.full(nb.shape, base_n)
+dyn_n[fast] += 1
+dyn_end = start + dyn_n * pace
+print("last round to the fastest waves (same paces): static ends p50 %.1f p99 %.1f max %.1f us; by pace p50 %.1f p99 %.1f max %.1f us"
+      % (np.percentile(static_end, 50), np.percentile(static_end, 99), static_end.max(),
+         np.percentile(dyn_end, 50), np.percentile(dyn_end, 99), dyn_end.max()))
+# and with perfect balance (work stealing at batch granularity): total work / waves
+print("perfect balance: %.1f us" % (start.mean() + (nb * pace).sum() / nb.size))

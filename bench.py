@@ -694,6 +694,12 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "traffic_source": (traffic[1] if traffic and traffic[0] is None else
                            ("committed profile profiles/%s (separate rocprofv3 --pmc passes of this very source; not "
                             "measured in this run)" % traffic[1]) if traffic else "no PMC profile of this workload committed"),
+        "algorithmic_over_traffic": round(alg_bytes / traffic[0], 3) if traffic and traffic[0] else None,
+        "traffic_note": "HBM is read in 64-byte sectors: the %d 16-byte table entries of a launch cost %d MB there against %d MB "
+                        "algorithmic -- the difference between traffic and algorithmic bytes, not re-reads (the lookups are "
+                        "random rows: no second entry of a sector is ever wanted); the bound is requests per second, not bytes"
+                        % (lookups_per_step + jumps_per_step, (lookups_per_step + jumps_per_step) * 64 // 10**6,
+                           (lookups_per_step + jumps_per_step) * 16 // 10**6),
         "algorithmic_bytes_per_launch": alg_bytes,
         "algorithmic_bytes": "%d rank-line requests x %g B + (%d k-mer table + %d row jump table) entries x 16 B + %d row "
                              "table words x 8 B + %d operand bytes (patterns, offsets, intervals)"
@@ -993,6 +999,11 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
                      "(truncated_at_max_len); on a real text a frontier dies by itself (workload c4text)" % max_len),
         }
     roof["traffic"] = traffic[0] if traffic else None
+    if traffic and traffic[0]:
+        # algorithmic bytes over the PMC traffic of the committed profile: below 1 where the kernel re-reads lines that left
+        # the L2 (the frontier's state records), a few per cent above 1 where requests that are priced as HBM reads hit the L2
+        # (the reference-order kernel: 3 % of its rank lines, and element slots overwritten before they are written back)
+        roof["algorithmic_over_traffic"] = round(roof["algorithmic_bytes_per_launch"] / traffic[0], 3)
     roof["traffic_source"] = (traffic[1] if traffic and traffic[0] is None else
                               ("committed profile profiles/%s (separate rocprofv3 --pmc passes of this very source; not "
                                "measured in this run)" % traffic[1]) if traffic else "no PMC profile of this workload committed")

@@ -507,6 +507,13 @@ int fmx_config_set(const char *key, const char *value) {
     else return arg_fail("jump must be auto, rows, rows3, jumps or off");
     return FMX_OK;
   }
+  if (std::strcmp(key, "jump_pairs") == 0) {
+    if (std::strcmp(value, "auto") == 0) jump_set_pairs(-1);
+    else if (std::strcmp(value, "on") == 0) jump_set_pairs(1);
+    else if (std::strcmp(value, "off") == 0) jump_set_pairs(0);
+    else return arg_fail("jump_pairs must be auto, on or off");
+    return FMX_OK;
+  }
   if (std::strcmp(key, "jump_chars") == 0) {
     char *end = nullptr;
     const long v = std::strtol(value, &end, 10);

@@ -90,6 +90,7 @@ struct Index {
   mutable bool jt_ready = false;
   mutable void *d_jump = nullptr;
   mutable uint64_t jump_bytes = 0;
+  mutable bool jump_pairs = false;              // the table holds pairs J[r] | J[LF^jc r] (32 bytes per row): up to 2 jc steps per request
   mutable uint32_t jump_chars = 0;              // characters (backward steps) one entry of the row jump table stands for: 8 .. 11
   // row table of the regex frontier (fmx_jump.hip): (BWT'[r], LF r) per row, 8 bytes; built at the first regex match
   mutable std::mutex r1_mu;
@@ -151,6 +152,7 @@ hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out, bool buil
 hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build = true);   // fmx_jump.hip (nullptr: none)
 hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build = true);   // fmx_jump.hip (nullptr: none)
 int drop_tables(Index *h, unsigned what);       // fmx_jump.hip: fmx_drop_tables
+void jump_set_pairs(int v);         // fmx_config_set("jump_pairs", "auto" | "on" | "off")
 void jump_set_chars(int chars);     // fmx_config_set("jump_chars", "8" .. "11")
 void jump_set_mode(int mode);      // fmx_config_set("jump", ..): bit 0 = the row table, bit 1 = the row jump table, bit 2 = the three-step row table
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form

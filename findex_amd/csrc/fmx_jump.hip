@@ -39,7 +39,7 @@ constexpr int kJThreads = 256;
 // J[r]: one lane group per row walks the jc steps.  r3 != nullptr: floor(jc / 3) lookups of the three-step table R3 (one
 // 8-byte word each, every lane of the group the same address) and jc mod 3 rank queries; else jc rank queries.
 template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kJThreads) void k_jump_build(DevIndex ix, const unsigned long long *__restrict__ r3, uint4 *__restrict__ out, uint32_t jc) {
+__global__ __launch_bounds__(kJThreads) void k_jump_build(DevIndex ix, const unsigned long long *__restrict__ r3, uint4 *__restrict__ out, uint32_t jc, uint32_t pairs) {
   __shared__ uint64_t s_cf[256];
   __shared__ uint16_t s_slot[256];
   for (int c = threadIdx.x; c < 256; c += blockDim.x) { s_cf[c] = ix.cf[c]; s_slot[c] = ix.slot[c]; }
@@ -47,8 +47,11 @@ __global__ __launch_bounds__(kJThreads) void k_jump_build(DevIndex ix, const uns
   constexpr int G = Lay<LAYOUT>::G;
   const LaneConst lc = lane_const<G>();
   const uint64_t ngroups = (uint64_t)gridDim.x * (kJThreads / G);
+  // pairs: out[2 r] = J[r] and out[2 r + 1] = J[LF^jc r], the entry of the row the first one lands on -- 32 bytes, one
+  // sector, one request for up to 2 jc steps of a search (k_search4<.., JT = 2>)
   for (uint64_t r0 = ((uint64_t)blockIdx.x * kJThreads + threadIdx.x) / G; r0 < ix.n; r0 += ngroups) {
     uint64_t r = r0;
+    for (uint32_t part = 0; part <= pairs; part++) {
     unsigned long long lo = 0;      // characters 0 .. 7
     uint32_t hi = 0;                // characters 8 .. 10
     uint32_t s = 0;                 // characters walked so far
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(kJThreads) void k_jump_build(DevIndex ix, const uns
       else hi |= c << (8u * (s - 8u));
       r = s_cf[c] + rank_excl<WIDE, LAYOUT>(ix, c, s_slot[c], r, lc);
     }
-    if (lc.t == 0) out[r0] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), hi | ((uint32_t)(r & 0xFFu) << 24), (uint32_t)(r >> 8));
+    if (lc.t == 0) out[pairs ? 2 * r0 + part : r0] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), hi | ((uint32_t)(r & 0xFFu) << 24), (uint32_t)(r >> 8));
+    }
   }
 }
 
@@ -123,6 +127,8 @@ __global__ __launch_bounds__(kJThreads) void k_row3_init(DevIndex ix, unsigned l
 
 static std::atomic<int> g_jump_mode{7};      // bit 0: row table (R1), bit 1: row jump table (J8), bit 2: three-step row table (R3)
 void jump_set_mode(int mode) { g_jump_mode.store(mode & 7, std::memory_order_relaxed); }
+static std::atomic<int> g_jump_pairs{-1};     // -1 auto (indexes of 2^30 rows and more, when 32 n bytes fit), 0 never, 1 whenever they fit
+void jump_set_pairs(int v) { g_jump_pairs.store(v, std::memory_order_relaxed); }
 static std::atomic<int> g_jump_chars{9};
 void jump_set_chars(int chars) { g_jump_chars.store(chars, std::memory_order_relaxed); }
 
@@ -211,7 +217,7 @@ static hipError_t build_jump(const Index *h, hipStream_t st) {
   static const int forced = getenv("FMX_JUMP") ? atoi(getenv("FMX_JUMP")) : -1;      // 0 = off, 1 = whenever it fits
   if (forced == 0 || (forced < 0 && !(g_jump_mode.load(std::memory_order_relaxed) & 2))) return hipSuccess;
   if (!rows_eligible(h)) return hipSuccess;
-  const uint64_t bytes = h->n * 16;
+  uint64_t bytes = h->n * 16;
   // the three-step table first: the search kernel uses it beside J, and J is built from it (two lookups instead of six
   // of the eight rank queries per row)
   const unsigned long long *r3 = nullptr;
@@ -220,6 +226,14 @@ static hipError_t build_jump(const Index *h, hipStream_t st) {
   hipError_t e = hipMemGetInfo(&free_b, &total_b);
   if (e != hipSuccess) return e;
   // the table and a margin for the callers' batches (the dictionary, the k-mer table and R3 are resident already)
+  // Pairs of entries (32 bytes per row: up to 2 jc steps per request, k_search4<.., JT = 2>) where the quad layout's index
+  // is large enough for requests to be what binds (n >= 2^30) and twice the table fits beside everything else;
+  // fmx_config_set("jump_pairs", "auto" | "on" | "off"); FMX_JUMP_PAIRS=0|1 overrides it (tests)
+  const char *pe = getenv("FMX_JUMP_PAIRS");
+  const int pcfg = pe ? (atoi(pe) != 0 ? 1 : 0) : g_jump_pairs.load(std::memory_order_relaxed);
+  const bool want_pairs = r3 && h->layout != kLayoutBytes && (pcfg < 0 ? h->n >= (1ull << 30) : pcfg != 0);
+  const bool pairs = want_pairs && 2 * bytes + (8ull << 30) <= free_b;
+  if (pairs) bytes *= 2;
   if (bytes + (8ull << 30) > free_b && !(forced == 1 && bytes + (1ull << 28) <= free_b)) return hipSuccess;
   static const bool trace = getenv("FMX_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
@@ -234,7 +248,7 @@ static hipError_t build_jump(const Index *h, hipStream_t st) {
   {
     const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
     const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
-#define CALL(W, L) k_jump_build<W, L><<<grid, kJThreads, 0, st>>>(h->dev, r3, (uint4 *)a, jc)
+#define CALL(W, L) k_jump_build<W, L><<<grid, kJThreads, 0, st>>>(h->dev, r3, (uint4 *)a, jc, pairs ? 1u : 0u)
     FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
     e = hipGetLastError();
@@ -244,6 +258,7 @@ static hipError_t build_jump(const Index *h, hipStream_t st) {
   if (e != hipSuccess) { (void)hipFree(a); return e; }
   h->d_jump = a;
   h->jump_bytes = bytes;
+  h->jump_pairs = pairs;
   h->jump_chars = jc;
   note_table_build(h, bytes);
   return hipSuccess;
@@ -269,7 +284,7 @@ hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out, bool buil
 // again by fmx_prepare or when the threshold is met anew.
 int drop_tables(Index *h, unsigned what) {
   if (what & 4u) {
-    { std::lock_guard<std::mutex> lk(h->jt_mu); if (h->d_jump) (void)hipFree(h->d_jump); h->d_jump = nullptr; h->jump_bytes = 0; h->jt_ready = false; }
+    { std::lock_guard<std::mutex> lk(h->jt_mu); if (h->d_jump) (void)hipFree(h->d_jump); h->d_jump = nullptr; h->jump_bytes = 0; h->jump_pairs = false; h->jt_ready = false; }
     { std::lock_guard<std::mutex> lk(h->r3_mu); if (h->d_row3) (void)hipFree(h->d_row3); h->d_row3 = nullptr; h->row3_bytes = 0; h->r3_ready = false; }
     h->prepared.store(false, std::memory_order_relaxed);
     h->patterns_seen.store(0, std::memory_order_relaxed);

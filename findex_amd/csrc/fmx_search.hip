@@ -104,7 +104,7 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // the constant 100 MHz clock, and the batches it searched.
 __device__ unsigned long long g_searchlog[1u << 15][4];
 #endif
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T>
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T>
 __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_SEARCH_WAVES, 8))) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
                                                         uint32_t ksigma, const uint4 *__restrict__ jtab, const uint32_t jc,
                                                         const unsigned long long *__restrict__ r3tab, const uint8_t *__restrict__ pat,
@@ -504,6 +504,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
       bool lookedup = false;                                   // this group has taken steps by table lookup in this iteration
       bool park_now = false;                                   // ... or was found to miss by one: it is parked below
       uint32_t missj = 0;                                      // ... having agreed with its row's text for this many steps first
+      uint32_t park_ahead = 0;                                 // ... from the step this many behind the wave's clock (a pair's first entry agreed)
       if (JT && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) > (uint64_t)G))) {
         // ---- every live group holds at most G rows (one, as a rule: sigma = 128, n = 2^32 -- from the 6th step on) and none
         // is sitting out: a group with jc or more characters left looks its rows up in the row jump table -- J[r] = the
@@ -513,25 +514,46 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
         // three-step word); between an entry's arrival and the next entry's request stand a comparison and a select.
         const bool can = alive && rem >= jc;
         if (__builtin_amdgcn_ballot_w64(can)) {
-          uint32_t p0, p1, p2;
-          chars12(it, can, p0, p1, p2);      // (LDS: they arrive long before the entries requested below)
-          const uint32_t m2 = jc > 8u ? ((1u << (8u * (jc - 8u))) - 1u) : 0u;
+          // JT == 2: the table holds PAIRS of entries, J[r] and J[LF^jc r] side by side in 32 bytes -- one request (a sector)
+          // for up to 2 jc steps: the group's even lanes take the first entry and the pattern's next jc characters, its odd
+          // lanes the second entry and the jc characters behind those (staged batches of the quad layout only)
+          constexpr bool kPair = JT == 2u && STAGED && G == 4;
           const uint64_t width = ep - sp;
-          bool jumped = false;
+          const bool single = !__builtin_amdgcn_ballot_w64(can && width != 1u);      // every group that looks up holds one row
+          const uint32_t half = (kPair && single) ? (t & 1u) : 0u;
+          const bool can2 = kPair && single && can && rem >= 2u * jc;
+          uint32_t p0, p1, p2;
+          chars12(it + (half && can2 ? jc : 0u), can, p0, p1, p2);      // (LDS: they arrive long before the entries requested below)
+          const uint32_t m2 = jc > 8u ? ((1u << (8u * (jc - 8u))) - 1u) : 0u;
+          bool jumped = false, pair_both = false, pair_then_miss = false;
           uint64_t rowj = 0;
           uint32_t nrows = 1;
           // ONE 16-byte load per row, everything taken out of it unconditionally: with the row used only under `if (hit)`,
           // the compiler sank that half of the load behind the comparison -- two dependent loads per lookup (round 4,
           // profiles/r04_c3_bound.md)
-          if (!__builtin_amdgcn_ballot_w64(can && width != 1u)) {
+          if (single) {
             // one row per group: every lane of the group loads the same entry, the row comes straight out of it
             uint4 je = make_uint4(0, 0, 0, 0);
-            if (can) je = jtab[sp];
+            if (can) je = jtab[(JT == 2u ? 2ull * sp : sp) + (half && can2 ? 1u : 0u)];
             const uint32_t d0 = je.x ^ p0, d1 = je.y ^ p1, d2 = (je.z ^ p2) & m2;
             jumped = can && (d0 | d1 | d2) == 0u;
             // (an entry's character of step s is its byte s: the first byte that differs is the step that fails)
             missj = d0 ? (uint32_t)__builtin_ctz(d0) >> 3 : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u + ((uint32_t)__builtin_ctz(d2 | 0x80000000u) >> 3));
             rowj = (uint64_t)(je.z >> 24) | ((uint64_t)je.w << 8);
+            if constexpr (kPair) {
+              // what the two halves found, to every lane of the group: the first entry's verdict decides whether the group
+              // moves at all, the second one's whether it moves jc steps or 2 jc
+              const uint32_t ok = jumped ? 1u : 0u;
+              const bool ok1 = group_bcast<G, 0>(ok) != 0u, ok2 = can2 && group_bcast<G, 1>(ok) != 0u;
+              const uint32_t rlo1 = group_bcast<G, 0>((uint32_t)rowj), rhi1 = group_bcast<G, 0>((uint32_t)(rowj >> 32));
+              const uint32_t rlo2 = group_bcast<G, 1>((uint32_t)rowj), rhi2 = group_bcast<G, 1>((uint32_t)(rowj >> 32));
+              const uint32_t mj1 = group_bcast<G, 0>(missj), mj2 = group_bcast<G, 1>(missj);
+              jumped = can && ok1;
+              pair_both = ok1 && ok2;
+              pair_then_miss = can2 && ok1 && !ok2;            // jc steps, and parked behind them with what the second entry saw
+              rowj = pair_both ? (((uint64_t)rhi2 << 32) | rlo2) : (((uint64_t)rhi1 << 32) | rlo1);
+              missj = pair_then_miss ? mj2 : mj1;
+            }
             jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(can && t == 0));
           } else {
             // two to G rows somewhere: lane t looks up row sp + t; the rows whose characters are the pattern's go on to
@@ -539,7 +561,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
             // the new interval begins at the first survivor's image and has as many rows as there are survivors
             const bool mine = can && (uint64_t)t < width;
             uint4 je = make_uint4(0, 0, 0, 0);
-            if (mine) je = jtab[sp + t];
+            if (mine) je = jtab[JT == 2u ? 2ull * (sp + t) : sp + t];      // (the first entry of a pair)
             const uint32_t d0 = je.x ^ p0, d1 = je.y ^ p1, d2 = (je.z ^ p2) & m2;
             const bool hit = mine && (d0 | d1 | d2) == 0u;
             missj = d0 ? (uint32_t)__builtin_ctz(d0) >> 3 : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u + ((uint32_t)__builtin_ctz(d2 | 0x80000000u) >> 3));      // (lane 0's: the entry of row sp)
@@ -561,10 +583,12 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
               park_now = true;
               deferred = true;
             }                                                        // (wider and no row agrees: it steps on and ends within jc steps)
-            ep = jumped ? rowj + nrows : (deferred ? sp : ep);       // parked: not alive any more
+            const uint32_t took = jumped ? (pair_both ? 2u * jc : jc) : 0u;
+            if (pair_then_miss) { park_now = true; deferred = true; park_ahead = jc; }
+            ep = (jumped && !pair_then_miss) ? rowj + nrows : ((deferred && !pair_then_miss) ? sp : (pair_then_miss ? rowj : ep));       // parked: not alive any more
             sp = jumped ? rowj : sp;
-            steps += jumped ? jc : 0u;
-            skip = jumped ? jc : 0u;
+            steps += took;
+            skip = pair_then_miss ? 0u : took;
             lookedup = jumped;
           }
         }
@@ -612,7 +636,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
           const unsigned long long pm = __builtin_amdgcn_ballot_w64(park_now && t == 0);
           const uint32_t lane64p = threadIdx.x & 63u;
           const uint32_t slot = npark + (uint32_t)__builtin_popcountll(pm & ((1ull << lane64p) - 1ull));
-          if (park_now && t == 0) { s_park_row[wave_in_wg][slot] = sp | ((uint64_t)missj << 56); s_park_pid[wave_in_wg][slot] = pid; s_park_it[wave_in_wg][slot] = it; }
+          if (park_now && t == 0) { s_park_row[wave_in_wg][slot] = sp | ((uint64_t)missj << 56); s_park_pid[wave_in_wg][slot] = pid; s_park_it[wave_in_wg][slot] = it + park_ahead; }
           npark += (uint32_t)__builtin_popcountll(pm);
         } else {
           if (park_now && t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
         bool cand = alive && !deferred && skip != 0u;      // the smallest `skip` among them, a bit at a time
         uint32_t adv = 0;
 #pragma unroll
-        for (int bit = 3; bit >= 0; bit--) {
+        for (int bit = (JT == 2u ? 4 : 3); bit >= 0; bit--) {
           const bool z = cand && ((skip >> bit) & 1u) == 0u;
           if (__builtin_amdgcn_ballot_w64(z)) cand = z;
           else adv |= 1u << bit;
@@ -1023,7 +1047,7 @@ static int census_read(const Index *h, int grid, int api, hipStream_t st) {
   return (got >= api - 2 && got >= 1) ? std::min(api, got) : 0;      // fewer: the device was not this launch's alone
 }
 
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, bool JT, uint32_t RW, bool R3T = false>
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
                               const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st, uint64_t pk_cap) {
   static const int api = blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>);
@@ -1097,24 +1121,27 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
   if (rows == 1) {
     const unsigned long long *r1 = nullptr;
     if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
-    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, jt, r1, pat, off, sp, ep, k, st, pk_cap);
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, h->jump_pairs ? nullptr : jt, r1, pat, off, sp, ep, k, st, pk_cap);
   }
   if (jt) {      // and the three-step table beside it, for the steps no aligned jump covers
     const unsigned long long *r3 = nullptr;
     if (rows != 0 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
-    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, true, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap)
-              : launch_v4kj<WIDE, LAYOUT, KT, true, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap);
+    if (h->jump_pairs)      // (pairs are built from the three-step table: it is there)
+      return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap)
+                : launch_v4kj<WIDE, LAYOUT, KT, 2u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap);
+    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap)
+              : launch_v4kj<WIDE, LAYOUT, KT, 1u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap);
   }
   if (rows != 0) {
     const unsigned long long *r3 = nullptr, *r1 = nullptr;
     bool have1;
     { std::lock_guard<std::mutex> lk(h->r1_mu); have1 = h->d_row1 != nullptr; }
     if (!have1 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
-    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, false, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st, pk_cap);
+    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st, pk_cap);
     if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
-    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, false, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st, pk_cap);
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st, pk_cap);
   }
-  return launch_v4kj<WIDE, LAYOUT, KT, false, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st, pk_cap);
+  return launch_v4kj<WIDE, LAYOUT, KT, 0u, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st, pk_cap);
 }
 
 template <bool WIDE, uint32_t LAYOUT>

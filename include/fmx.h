@@ -74,7 +74,11 @@ int fmx_abi_version(void);
  *   - the row jump table: per row the nine BWT characters an LF walk from it reads and the row it ends on, 16 n
  *     bytes -- nine steps of a literal search with one 16-byte lookup when the pattern's next nine characters match
  *     (key "jump_chars": "8" .. "11" characters per entry for tables built afterwards; 9 is the default)
- *     (built when 16 n bytes + 8 GiB of HBM are free -- one allocation: key "tables_after" says when);
+ *     (built when 16 n bytes + 8 GiB of HBM are free -- one allocation: key "tables_after" says when).
+ *     Key "jump_pairs": "auto" (default) / "on" / "off": the table holds PAIRS of entries, a row's own and that of the
+ *     row it lands on, side by side in 32 bytes -- one memory request (a 64-byte sector either way) then serves up to
+ *     2 x jump_chars steps.  32 n bytes; "auto" builds pairs for the one-hot layout when the index has 2^30 rows or more
+ *     and 32 n bytes + 8 GiB are free ("on": whenever they are free);
  *   - the three-step row table: the same with three characters, 8 n bytes -- built instead where the jump table does
  *     not fit; the one-row part of every pattern is then walked by one lane per pattern;
  *   - the row table: BWT'[r] and LF r in 8 bytes per row -- the regex frontier steps its one-row elements with it
@@ -487,9 +491,11 @@ typedef struct fmx_stats_t {
   double tables_build_ms;       /* host time spent building the k-mer table, the row jump table and the select directory
                                  * (at first use or in fmx_prepare): what a handle's first search / first Psi pays on top
                                  * of build_ms */
-  uint64_t jump_lookups;        /* 16-byte row-jump-table entries fetched by fmx_search_batch[_dev]'s kernel (each stands
-                                 * for jump_chars backward steps when the pattern's next jump_chars characters match it) */
-  uint64_t jump_bytes;          /* device bytes of the row jump table (0: the handle has none); part of index_bytes */
+  uint64_t jump_lookups;        /* row-jump-table lookups (one memory request each) by fmx_search_batch[_dev]'s kernel: an entry
+                                 * stands for jump_chars backward steps when the pattern's next jump_chars characters match
+                                 * it, a pair of entries ("jump_pairs") for up to twice as many */
+  uint64_t jump_bytes;          /* device bytes of the row jump table (0: the handle has none; 16 n, or 32 n with pairs);
+                                 * part of index_bytes */
   uint64_t row_lookups;         /* 8-byte row-table words fetched (one or three backward steps of a one-row interval each):
                                  * by the one-row part of fmx_search_batch[_dev] and by the regex frontier */
   uint64_t row_bytes;           /* device bytes of the row table and the three-step row table (0: none); part of index_bytes */

@@ -165,7 +165,8 @@ def test_config_keys_and_values():
     L = _lib.load()
     ok = {b"layout": [b"onehot", b"bytes", b"auto"], b"checkpoints": [b"superblock", b"auto"], b"ktab": [b"off", b"auto"],
           b"jump": [b"off", b"rows", b"rows3", b"jumps", b"auto"], b"pipeline": [b"on", b"off"], b"validate": [b"1", b"0"],
-          b"threads": [b"3", b"0"], b"jump_chars": [b"8", b"11", b"9"], b"tables_after": [b"auto", b"100000", b"0"]}
+          b"threads": [b"3", b"0"], b"jump_chars": [b"8", b"11", b"9"], b"tables_after": [b"auto", b"100000", b"0"],
+          b"jump_pairs": [b"on", b"off", b"auto"]}
     for key, values in ok.items():
         for v in values:                        # the last value of each list is the default: left in place
             assert L.fmx_config_set(key, v) == 0, (key, v)

@@ -26,6 +26,12 @@ def pair_from_mem(bwt, eof, counts):
     return findex_amd.HipFMSearcher.from_mem(bwt, eof, counts), oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
 
 
+def jump_row_bytes(layout="onehot"):
+    """Bytes per row of the row jump table these small indexes get: 16, or 32 when pairs of entries are forced on
+    (FMX_JUMP_PAIRS=1; by default only indexes of 2^30 rows and more get pairs; never the bytes layout)."""
+    return 32 if (os.environ.get("FMX_JUMP_PAIRS") == "1" and layout != "bytes") else 16
+
+
 def check_occ(hip, orc, rng, k, symbols):
     c = rng.choice(np.asarray(symbols, dtype=np.uint8), size=k)
     i = rng.integers(-1, orc.n + 2, size=k, dtype=np.int64)
@@ -491,7 +497,8 @@ def test_row_jump_table_on_and_off_agree(layout):
                         assert st["row_bytes"] == (8 * orc.n if jump in ("auto", "rows", "rows3") else 0)
                         assert (st["row_lookups"] > 0) == (jump in ("auto", "rows", "rows3"))
                         if jump in ("auto", "jumps"):
-                            assert st["jump_bytes"] == 16 * orc.n and st["jump_lookups"] > 2 * len(uniform) and st["jump_chars"] == 9
+                            row_b = jump_row_bytes(layout) if jump == "auto" else 16      # (pairs are built from the three-step table: not with "jumps" alone)
+                            assert st["jump_bytes"] == row_b * orc.n and st["jump_lookups"] > (1 if row_b == 32 else 2) * len(uniform) and st["jump_chars"] == 9
                             # the table itself: (BWT' along an 8-step LF walk, the row it ends on) -- spot-check through a
                             # search of the walked characters from a one-row start is what check_search just did; the
                             # executed steps equal the oracle's although fewer lines were requested
@@ -584,7 +591,7 @@ def test_prepare_builds_every_table_up_front():
     assert st0["jump_bytes"] == 0 and st0["row_bytes"] == 0 and st0["ktab_k"] == 0
     hip.prepare(ktab=True, select=True, jump=True, frontier=True)
     st1 = hip.stats()
-    assert st1["ktab_k"] > 0 and st1["jump_bytes"] == 16 * orc.n and st1["row_bytes"] == 16 * orc.n      # R3 + R1: 8 n each
+    assert st1["ktab_k"] > 0 and st1["jump_bytes"] == jump_row_bytes() * orc.n and st1["row_bytes"] == 16 * orc.n      # R3 + R1: 8 n each
     assert st1["tables_build_ms"] > 0
     rng = np.random.default_rng(6)
     pats = lf_walk_patterns(orc, rng, 3000, 30, 0.2, alphabet=list(range(1, 21)))
@@ -627,8 +634,8 @@ def test_tables_are_built_lazily():
         assert hip.stats()["jump_bytes"] == 0
         check_search(hip, orc, big)                          # 66001 >= 65536: this search builds and uses them
         st = hip.stats()
-        assert st["jump_bytes"] == 16 * orc.n and st["row_bytes"] == 8 * orc.n and st["jump_lookups"] > 0
-        assert st["peak_table_build_bytes"] == 16 * orc.n, "the row jump table is built in one allocation"
+        assert st["jump_bytes"] == jump_row_bytes() * orc.n and st["row_bytes"] == 8 * orc.n and st["jump_lookups"] > 0
+        assert st["peak_table_build_bytes"] == jump_row_bytes() * orc.n, "the row jump table is built in one allocation"
         assert st["patterns_seen"] == 1 + 2 * 600 + 2 * 32400
         hip.drop_tables()
         st = hip.stats()
@@ -636,7 +643,7 @@ def test_tables_are_built_lazily():
         check_search(hip, orc, pats)
         assert hip.stats()["jump_bytes"] == 0
         hip.prepare(ktab=False, jump=True)
-        assert hip.stats()["jump_bytes"] == 16 * orc.n
+        assert hip.stats()["jump_bytes"] == jump_row_bytes() * orc.n
         hip.stats_reset()
         check_search(hip, orc, pats)
         assert hip.stats()["jump_lookups"] > 0
@@ -646,7 +653,7 @@ def test_tables_are_built_lazily():
         hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
         hip.prepare(ktab=True, jump=True)
         st = hip.stats()
-        assert st["jump_bytes"] == 16 * orc.n and st["row_bytes"] == 0
+        assert st["jump_bytes"] == 16 * orc.n and st["row_bytes"] == 0          # (pairs are built from the three-step table: none here)
         check_search(hip, orc, pats)
         hip.close()
     finally:
@@ -2224,3 +2231,23 @@ def test_result_groups_of_every_size_are_ordered():
         got = np.frombuffer(d_out[: n * RESULT_DTYPE.itemsize].cpu().numpy().tobytes(), dtype=RESULT_DTYPE)
         assert n == out.size and got.tobytes() == out.tobytes()
         assert np.array_equal(d_per.cpu().numpy().astype(np.uint32), per)
+
+
+@pytest.mark.parametrize("which", ["modes", "repeats", "spans", "walks", "census"])
+def test_row_jump_table_as_pairs_of_entries(which, monkeypatch):
+    """The row jump table as pairs J[r] | J[LF^jc r] (32 bytes per row, k_search4<.., JT = 2>: up to 2 x jump_chars steps
+    per request; by default only for indexes of 2^30 rows and more -- the C3 tests at full size run it -- forced here on the
+    small ones): the row-table tests in every mode and entry width, the repetitive texts (intervals of a few rows: the
+    first entries only), the staged spans' edges, the parked walks (a pattern that agrees with a pair's first entry and
+    not with its second jumps nine steps and parks behind them) and the residency census, all against the oracle."""
+    monkeypatch.setenv("FMX_JUMP_PAIRS", "1")
+    if which == "modes":
+        test_row_jump_table_on_and_off_agree("onehot")
+    elif which == "repeats":
+        test_row_tables_on_repetitive_texts("onehot")
+    elif which == "spans":
+        test_staged_pattern_spans_edges("onehot")
+    elif which == "walks":
+        test_parked_walks_flush_inside_the_kernel()
+    else:
+        test_search_grid_follows_the_residency_census("onehot")

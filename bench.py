@@ -681,7 +681,8 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     onehot = st["layout"] == 0
     line_bytes = 64.0 if onehot else 66.0        # bytes layout: a 128-B block and its 4-B checkpoint, one request each
     operand_bytes = k * m + 8 * (k + 1) + 16 * k
-    alg_bytes = requests_per_step * line_bytes + 16.0 * (lookups_per_step + jumps_per_step) + 8.0 * rows_per_step + operand_bytes
+    jump_entry = 32.0 if s1["jump_bytes"] >= 32 * n else 16.0      # a pair of entries per lookup, or one
+    alg_bytes = requests_per_step * line_bytes + 16.0 * lookups_per_step + jump_entry * jumps_per_step + 8.0 * rows_per_step + operand_bytes
     all_requests = requests_per_step + lookups_per_step + jumps_per_step + rows_per_step      # every one a dependent random request
     ksec = kernel_ms * 1e-3
     achieved = alg_bytes / ksec / 1e9
@@ -695,15 +696,15 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
                            ("committed profile profiles/%s (separate rocprofv3 --pmc passes of this very source; not "
                             "measured in this run)" % traffic[1]) if traffic else "no PMC profile of this workload committed"),
         "algorithmic_over_traffic": round(alg_bytes / traffic[0], 3) if traffic and traffic[0] else None,
-        "traffic_note": "HBM is read in 64-byte sectors: the %d 16-byte table entries of a launch cost %d MB there against %d MB "
+        "traffic_note": "HBM is read in 64-byte sectors: the %d 16- and 32-byte table lookups of a launch cost %d MB there against %d MB "
                         "algorithmic -- the difference between traffic and algorithmic bytes, not re-reads (the lookups are "
                         "random rows: no second entry of a sector is ever wanted); the bound is requests per second, not bytes"
                         % (lookups_per_step + jumps_per_step, (lookups_per_step + jumps_per_step) * 64 // 10**6,
-                           (lookups_per_step + jumps_per_step) * 16 // 10**6),
+                           int(lookups_per_step * 16 + jumps_per_step * jump_entry) // 10**6),
         "algorithmic_bytes_per_launch": alg_bytes,
-        "algorithmic_bytes": "%d rank-line requests x %g B + (%d k-mer table + %d row jump table) entries x 16 B + %d row "
+        "algorithmic_bytes": "%d rank-line requests x %g B + %d k-mer table entries x 16 B + %d row jump table lookups x %g B + %d row "
                              "table words x 8 B + %d operand bytes (patterns, offsets, intervals)"
-                             % (requests_per_step, line_bytes, lookups_per_step, jumps_per_step, rows_per_step, operand_bytes),
+                             % (requests_per_step, line_bytes, lookups_per_step, jumps_per_step, jump_entry, rows_per_step, operand_bytes),
         "kernel_ms": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
         "kernel_ms_is": "HIP events around the launch on %d of the %d timed steps (every %dth: the markers themselves cost a "
                         "step 8-11 us)" % (len(timed), args.steps, EVENT_EVERY),
@@ -757,7 +758,9 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
             "rank_queries_are": "occ evaluations of the reference's loop on these inputs (2 per backward step, early "
                                 "exits counted) -- a reference-equivalent count, not executed popcounts: the kernel serves them "
                                 "with rank_queries_per_request per memory request (k-mer table for the first K steps, one "
-                                "row-jump-table entry per %d steps once the interval is a row, shared blocks)" % max(int(s1["jump_chars"]), 1),
+                                "row-jump-table %s per %d steps once the interval is a row, shared blocks)"
+                                % ("request -- a pair of entries, 32 bytes --" if s1["jump_bytes"] >= 32 * n else "entry",
+                                   max(int(s1["jump_chars"]), 1) * (2 if s1["jump_bytes"] >= 32 * n else 1)),
             "parallelism": "patterns sharded over %d GPU(s), index replicated%s"
                            % (world, (", one gather of the hit intervals per step (%s form, delivered to %s), overlapped with the "
                                       "next step's search" % (args.exchange, "rank 0" if args.delivery == "root" else "every rank"))

@@ -56,7 +56,9 @@ class fmx_stats_t(ctypes.Structure):
                 ("ktab_lookups", ctypes.c_uint64), ("ktab_k", ctypes.c_uint32), ("jump_chars", ctypes.c_uint32),
                 ("tables_build_ms", ctypes.c_double), ("jump_lookups", ctypes.c_uint64), ("jump_bytes", ctypes.c_uint64),
                 ("row_lookups", ctypes.c_uint64), ("row_bytes", ctypes.c_uint64),
-                ("peak_table_build_bytes", ctypes.c_uint64), ("patterns_seen", ctypes.c_uint64)]
+                ("peak_table_build_bytes", ctypes.c_uint64), ("patterns_seen", ctypes.c_uint64),
+                ("tables_held_bytes", ctypes.c_uint64), ("table_budget_bytes", ctypes.c_uint64),
+                ("hbm_free_after_tables", ctypes.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/fmx.h declares
@@ -75,7 +77,9 @@ SYMBOLS = {
     "fmx_open_dev": (_i32, [_vp, _u64, _u64, _vp, _i32, _vp, _P(_vp)]),
     "fmx_open_block": (_i32, [_vp, _u64, _vp, _u64, _i32, _P(_vp)]),
     "fmx_close": (_i32, [_vp]),
+    "fmx_index_config_set": (_i32, [_vp, _cp, _cp]),
     "fmx_prepare": (_i32, [_vp, _u32]),
+    "fmx_prepare_ex": (_i32, [_vp, _u32, _u64]),
     "fmx_drop_tables": (_i32, [_vp, _u32]),
     "fmx_n": (_i32, [_vp, _P(_u64)]),
     "fmx_eof": (_i32, [_vp, _P(_u64)]),

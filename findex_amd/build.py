@@ -53,12 +53,24 @@ def _stale():
         return f.read().strip() != _source_stamp()
 
 
+def _unit_stamp(src, flags):
+    """Hash of what ONE translation unit can see: its source, every header, the flags."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join(flags).encode())
+    for d in [os.path.join(CSRC, src)] + [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(ROOT, "include", "fmx.h")]:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     if not force and not _stale():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"),
-             "-I" + CSRC, "-Wall", "-Wno-unused-result"]
+             "-I" + CSRC, "-Wall", "-Wno-unused-result"] + os.environ.get("FMX_CXXFLAGS", "").split()
     for attempt in range(3):
         stamp = _source_stamp()
         objs = []
@@ -66,13 +78,24 @@ def build(force=False, verbose=False):
         for src in SOURCES:
             obj = os.path.join(OUT_DIR, src + ".o")
             objs.append(obj)
+            # an object is kept when the stamp beside it names exactly what this unit would be compiled from
+            ustamp = _unit_stamp(src, flags)
+            try:
+                with open(obj + ".stamp") as f:
+                    fresh = os.path.exists(obj) and f.read().strip() == ustamp
+            except OSError:
+                fresh = False
+            if fresh and not force:
+                continue
             cmd = [_hipcc()] + flags + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            procs.append((src, subprocess.Popen(cmd)))
-        for src, p in procs:
+            procs.append((src, obj, ustamp, subprocess.Popen(cmd)))
+        for src, obj, ustamp, p in procs:
             if p.wait() != 0:
                 raise RuntimeError("hipcc failed on " + src)
+            with open(obj + ".stamp", "w") as f:
+                f.write(ustamp + "\n")
         if _source_stamp() == stamp:
             break           # (else: the sources changed under the compilers -- again, from what they are now)
     else:

@@ -33,8 +33,6 @@ int layout_preference() { return g_layout_pref.load(std::memory_order_relaxed); 
 static std::atomic<uint64_t> g_serial{0};
 static std::atomic<int> g_force_superblocks{0};
 static std::atomic<int> g_validate{0};
-static std::atomic<int> g_ktab{1};
-bool ktab_enabled() { return g_ktab.load(std::memory_order_relaxed) != 0; }
 bool validate_device_operands() { return g_validate.load(std::memory_order_relaxed) != 0; }
 bool force_superblocks() { return g_force_superblocks.load(std::memory_order_relaxed) != 0; }
 
@@ -308,6 +306,7 @@ static int open_common(const void *src, bool src_on_device, FILE *src_file, uint
   Index *h = new (std::nothrow) Index();
   if (!h) { g_err = "out of host memory"; return FMX_ERR_NOMEM; }
   h->serial = ++g_serial;
+  h->policy = default_policy();        // this handle's own copy from here on
   if (block) {
     h->block_mode = true;
     std::memcpy(h->block_bs, block->bs, sizeof h->block_bs);
@@ -482,12 +481,6 @@ int fmx_config_set(const char *key, const char *value) {
     else return arg_fail("layout must be auto, onehot or bytes");
     return FMX_OK;
   }
-  if (std::strcmp(key, "ktab") == 0) {
-    if (std::strcmp(value, "auto") == 0) g_ktab.store(1);
-    else if (std::strcmp(value, "off") == 0) g_ktab.store(0);
-    else return arg_fail("ktab must be auto or off");
-    return FMX_OK;
-  }
   if (std::strcmp(key, "validate") == 0) {
     g_validate.store(std::strcmp(value, "0") != 0);
     return FMX_OK;
@@ -496,37 +489,6 @@ int fmx_config_set(const char *key, const char *value) {
     if (std::strcmp(value, "auto") == 0) g_force_superblocks.store(0);
     else if (std::strcmp(value, "superblock") == 0) g_force_superblocks.store(1);
     else return arg_fail("checkpoints must be auto or superblock");
-    return FMX_OK;
-  }
-  if (std::strcmp(key, "jump") == 0) {
-    if (std::strcmp(value, "auto") == 0) jump_set_mode(7);
-    else if (std::strcmp(value, "off") == 0) jump_set_mode(0);
-    else if (std::strcmp(value, "rows") == 0) jump_set_mode(1);
-    else if (std::strcmp(value, "jumps") == 0) jump_set_mode(2);
-    else if (std::strcmp(value, "rows3") == 0) jump_set_mode(4);
-    else return arg_fail("jump must be auto, rows, rows3, jumps or off");
-    return FMX_OK;
-  }
-  if (std::strcmp(key, "jump_pairs") == 0) {
-    if (std::strcmp(value, "auto") == 0) jump_set_pairs(-1);
-    else if (std::strcmp(value, "on") == 0) jump_set_pairs(1);
-    else if (std::strcmp(value, "off") == 0) jump_set_pairs(0);
-    else return arg_fail("jump_pairs must be auto, on or off");
-    return FMX_OK;
-  }
-  if (std::strcmp(key, "jump_chars") == 0) {
-    char *end = nullptr;
-    const long v = std::strtol(value, &end, 10);
-    if (end == value || *end || v < 8 || v > 11) return arg_fail("jump_chars must be 8, 9, 10 or 11");
-    jump_set_chars((int)v);
-    return FMX_OK;
-  }
-  if (std::strcmp(key, "tables_after") == 0) {
-    if (std::strcmp(value, "auto") == 0) { tables_set_after(-1); return FMX_OK; }
-    char *end = nullptr;
-    const long long v = std::strtoll(value, &end, 10);
-    if (end == value || *end || v < 0) return arg_fail("tables_after must be auto or a non-negative number of patterns");
-    tables_set_after(v);
     return FMX_OK;
   }
   if (std::strcmp(key, "pipeline") == 0) {
@@ -542,7 +504,21 @@ int fmx_config_set(const char *key, const char *value) {
     set_host_threads((unsigned)v);
     return FMX_OK;
   }
+  // the table policy's keys: the defaults a handle copies when it is opened (fmx_index_config_set: one handle's own)
+  const char *why = nullptr;
+  const int pr = policy_set(default_policy(), key, value, &why);
+  if (pr == 0) return FMX_OK;
+  if (pr == 2) return arg_fail(why);
   return arg_fail("unknown configuration key");
+}
+
+int fmx_index_config_set(fmx_index *idx, const char *key, const char *value) {
+  if (!idx || !key || !value) return arg_fail("null argument");
+  const char *why = nullptr;
+  const int pr = policy_set(H(idx)->policy, key, value, &why);
+  if (pr == 0) return FMX_OK;
+  if (pr == 2) return arg_fail(why);
+  return arg_fail("not a per-handle key (ktab, jump, jump_pairs, jump_chars, tables_after, table_budget)");
 }
 
 int fmx_host_alloc(size_t bytes, void **out) {
@@ -636,20 +612,20 @@ int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[2
 
 int fmx_prepare(const fmx_index *idx, unsigned what) {
   if (!idx) return arg_fail("null argument");
-  if (what & ~(unsigned)(FMX_PREPARE_KTAB | FMX_PREPARE_SELECT | FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER)) return arg_fail("unknown fmx_prepare flag");
+  if (what & ~(unsigned)(FMX_PREPARE_KTAB | FMX_PREPARE_SELECT | FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER | FMX_PREPARE_SEARCH)) return arg_fail("unknown fmx_prepare flag");
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
   CtxLease lease(h);
   if (!lease.c) return FMX_ERR_HIP;
   if (what & FMX_PREPARE_KTAB) {
-    h->prepared.store(true, std::memory_order_relaxed);
+    h->prepared_ktab.store(true, std::memory_order_relaxed);      // (its own flag: the row tables stay under their threshold)
     KTab kt;
     HIP_TRY(ktab_get(h, lease.c->stream, &kt), "k-mer table");
   }
   if (what & FMX_PREPARE_SELECT) HIP_TRY(select_prepare(h, lease.c->stream), "select directory");
   if (what & FMX_PREPARE_JUMP) {
-    h->prepared.store(true, std::memory_order_relaxed);      // from now on searches use (and may build) the row tables
+    h->prepared_rows.store(true, std::memory_order_relaxed);      // from now on searches use (and may build) the row tables
     const uint4 *jt = nullptr;
     HIP_TRY(jump_get(h, lease.c->stream, &jt), "jump table");
     const unsigned long long *r3 = nullptr;
@@ -659,12 +635,24 @@ int fmx_prepare(const fmx_index *idx, unsigned what) {
     const unsigned long long *r1 = nullptr;
     HIP_TRY(row1_get(h, lease.c->stream, &r1), "row table");
   }
+  // the literal search kernel this handle's tables select, calibrated here (its residency census: fmx_search.hip) so that no
+  // _dev call ever has to read anything back
+  if (what & (FMX_PREPARE_KTAB | FMX_PREPARE_JUMP | FMX_PREPARE_SEARCH)) HIP_TRY(search_calibrate(h, lease.c->stream), "search calibration");
   return FMX_OK;
+}
+
+int fmx_prepare_ex(fmx_index *idx, unsigned what, uint64_t budget_bytes) {
+  if (!idx) return arg_fail("null argument");
+  if (budget_bytes) {
+    H(idx)->policy.budget_bytes.store(budget_bytes, std::memory_order_relaxed);
+    H(idx)->policy.budget_ppm.store(0, std::memory_order_relaxed);
+  }
+  return fmx_prepare(idx, what);
 }
 
 int fmx_drop_tables(fmx_index *idx, unsigned what) {
   if (!idx) return arg_fail("null argument");
-  if (!what || (what & ~(unsigned)(FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER))) return arg_fail("fmx_drop_tables frees the row tables only (FMX_PREPARE_JUMP, FMX_PREPARE_FRONTIER)");
+  if (!what || (what & ~(unsigned)(FMX_PREPARE_KTAB | FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER))) return arg_fail("fmx_drop_tables frees the k-mer table and the row tables (FMX_PREPARE_KTAB, FMX_PREPARE_JUMP, FMX_PREPARE_FRONTIER)");
   Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
@@ -673,6 +661,7 @@ int fmx_drop_tables(fmx_index *idx, unsigned what) {
 }
 
 int fmx_close(fmx_index *idx) {
+  if (!idx) return FMX_OK;            // closing nothing is not an error (a wrapper whose handle was already taken: hipfm.scala)
   destroy(H(idx));
   return FMX_OK;
 }
@@ -1297,6 +1286,15 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->tables_build_ms = h->tables_ms;
   out->peak_table_build_bytes = h->peak_table_build_bytes.load(std::memory_order_relaxed);
   out->patterns_seen = h->patterns_seen.load(std::memory_order_relaxed);
+  out->tables_held_bytes = h->tables_held.load(std::memory_order_relaxed);
+  out->hbm_free_after_tables = h->hbm_free_after_tables.load(std::memory_order_relaxed);
+  {
+    const uint32_t ppm = h->policy.budget_ppm.load(std::memory_order_relaxed);
+    uint64_t budget = h->policy.budget_bytes.load(std::memory_order_relaxed);
+    size_t free_b = 0, total_b = 0;
+    if (ppm && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = (uint64_t)((double)(free_b + out->tables_held_bytes) * ((double)ppm * 1e-6));
+    out->table_budget_bytes = budget;
+  }
   return FMX_OK;
 }
 

@@ -380,6 +380,7 @@ constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterStride * 8;
 // the first one ended and sizes later grids by that (fmx_search.hip, Residency).
 constexpr uint32_t kCensusBlocks = 4096;
 constexpr size_t kCensusBytes = (size_t)kCensusBlocks * 16 + 16;      // + one word behind the entries: the grid of the launch that wrote them
+constexpr size_t kCalibScratchBytes = 64;                             // behind the census: the calibration launch's empty pattern (two zero offsets) and its output words
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll

@@ -49,6 +49,31 @@ struct HostRank {
   size_t stride = 0;                // nslots * 4 + 256
 };
 
+// What a handle may build beside its rank dictionary, and when (round 5: per handle -- until round 4 these were process-global
+// atomics in fmx_jump.hip, so two handles in one JVM could not differ).  fmx_config_set sets the DEFAULTS a handle takes at
+// open; fmx_index_config_set changes one handle's own copy afterwards (a table that exists stays until fmx_drop_tables).
+struct TablePolicy {
+  std::atomic<int> ktab{1};                    // the k-mer jump table: 1 auto, 0 off
+  std::atomic<int> jump_mode{7};               // bit 0: row table (R1), bit 1: row jump table (J), bit 2: three-step row table (R3)
+  std::atomic<int> jump_pairs{-1};             // -1 auto (indexes of 2^30 rows and more, when 32 n bytes fit), 0 never, 1 whenever they fit
+  std::atomic<int> jump_chars{9};
+  std::atomic<long long> tables_after{-1};     // patterns before a search builds tables; -1 auto
+  // the BUDGET: device bytes all derived tables of this handle (k-mer, row, row jump, select) may hold together
+  std::atomic<uint64_t> budget_bytes{~0ull};   // ~0: none (what fits beside the margins)
+  std::atomic<uint32_t> budget_ppm{0};         // != 0: a fraction (millionths) of the HBM that is free when a table is decided, the handle's own tables counted as free
+  TablePolicy() = default;
+  TablePolicy(const TablePolicy &o) { *this = o; }
+  TablePolicy &operator=(const TablePolicy &o) {
+    ktab.store(o.ktab.load()); jump_mode.store(o.jump_mode.load()); jump_pairs.store(o.jump_pairs.load());
+    jump_chars.store(o.jump_chars.load()); tables_after.store(o.tables_after.load());
+    budget_bytes.store(o.budget_bytes.load()); budget_ppm.store(o.budget_ppm.load());
+    return *this;
+  }
+};
+TablePolicy &default_policy();          // fmx_jump.hip: what fmx_config_set writes and fmx_open* copies
+// One policy key = value into `p`: 0 ok, 1 unknown key (not a table key), 2 bad value (*why says which values there are)
+int policy_set(TablePolicy &p, const char *key, const char *value, const char **why);
+
 struct Index {
   uint64_t serial = 0;          // unique per open in this process: what a resident regex batch remembers of its index
   int device = 0;
@@ -107,8 +132,13 @@ struct Index {
   // when the derived tables are built (fmx_jump.hip, tables_due): patterns searched so far, fmx_prepare seen
   mutable std::atomic<uint64_t> patterns_seen{0};
   mutable std::atomic<uint32_t> search_residency{0};     // fmx_stats.search_residency
-  mutable std::atomic<const void *> census_owner{nullptr};   // the k_search4 instantiation whose launch wrote the residency census last (fmx_search.hip)
-  mutable std::atomic<bool> prepared{false};
+  // fmx_prepare has been asked for the k-mer table / the row tables: searches use them (and build what a drop took away)
+  // whatever the pattern count says.  One flag per table (one shared flag made prepare(KTAB) build 40 n bytes
+  // of row tables inside the next search).
+  mutable std::atomic<bool> prepared_ktab{false}, prepared_rows{false};
+  mutable TablePolicy policy;                                   // this handle's own (copied from the defaults at open)
+  mutable std::atomic<uint64_t> tables_held{0};                 // device bytes of all derived tables right now (what the budget counts)
+  mutable std::atomic<uint64_t> hbm_free_after_tables{0};       // hipMemGetInfo's free bytes right after the last table build (0: none built)
   mutable std::atomic<uint64_t> peak_table_build_bytes{0};      // most device memory a table build held at once (table + its scratch)
   // select directory for Psi (fmx_select.hip), built on first use
   mutable std::mutex sel_mu;
@@ -140,21 +170,22 @@ struct CtxLease {            // scope guard around ctx_acquire / ctx_release
   CtxLease(const CtxLease &) = delete;
   CtxLease &operator=(const CtxLease &) = delete;
 };
-bool ktab_enabled();                            // fmx_config_set("ktab", "auto" | "off")
 // The derived tables are built when they have a chance to pay: by fmx_prepare, or at the search that brings the patterns a
 // handle has been asked for to `threshold` (fmx_config_set("tables_after", ..)); `build` = false only looks.
 bool tables_due(const Index *h, uint64_t k, bool small_table);      // fmx_jump.hip: counts k, then decides
-void tables_set_after(long long patterns);                          // fmx_config_set("tables_after", "auto" | N)
 void note_table_build(const Index *h, uint64_t bytes_held);
+// Room for one more derived table of this handle: min(free HBM - margin, what the handle's budget leaves); 0 when hipMemGetInfo fails.
+uint64_t table_room(const Index *h, uint64_t margin);
+void tables_account(const Index *h, int64_t delta);                 // a table of |delta| bytes was built (+) or freed (-)
 hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out, bool build = true);     // fmx_ktab.hip
 hipError_t select_prepare(const Index *h, hipStream_t st);          // fmx_select.hip: builds the select directory now
 hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out, bool build = true);   // fmx_jump.hip (nullptr: the handle has none)
 hipError_t row1_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build = true);   // fmx_jump.hip (nullptr: none)
 hipError_t row3_get(const Index *h, hipStream_t st, const unsigned long long **out, bool build = true);   // fmx_jump.hip (nullptr: none)
 int drop_tables(Index *h, unsigned what);       // fmx_jump.hip: fmx_drop_tables
-void jump_set_pairs(int v);         // fmx_config_set("jump_pairs", "auto" | "on" | "off")
-void jump_set_chars(int chars);     // fmx_config_set("jump_chars", "8" .. "11")
-void jump_set_mode(int mode);      // fmx_config_set("jump", ..): bit 0 = the row table, bit 1 = the row jump table, bit 2 = the three-step row table
+// fmx_search.hip: the residency census of the k_search4 instantiation this handle's full-size searches use now, taken with
+// calibration launches on `st` (synchronises it): fmx_prepare's last step, never a _dev call's.
+hipError_t search_calibrate(const Index *h, hipStream_t st);
 bool force_superblocks();                       // fmx_config_set("checkpoints", "superblock"): the bytes layout's >= 2^32-count form
 int layout_preference();                        // -1 auto, else kLayoutOneHot / kLayoutBytes (fmx_config_set)
 int hip_fail(hipError_t e, const char *what);   // records the message, returns FMX_ERR_HIP

@@ -65,11 +65,14 @@ static hipError_t build_ktab(const Index *h, hipStream_t st) {
   h->kt.k = 0;
   h->kt.sigma = sigma;
   static const int forced = getenv("FMX_KTAB") ? atoi(getenv("FMX_KTAB")) : -1;      // 0 = off, k > 0 = exactly k levels
-  if (sigma < 2 || forced == 0 || !ktab_enabled()) return hipSuccess;
+  if (sigma < 2 || forced == 0 || !h->policy.ktab.load(std::memory_order_relaxed)) return hipSuccess;
   size_t free_b = 0, total_b = 0;
   hipError_t e = hipMemGetInfo(&free_b, &total_b);
   if (e != hipSuccess) return e;
-  const uint64_t max_bytes = std::min<uint64_t>(16ull << 30, free_b / 4);
+  // at most 16 GiB, a quarter of the free HBM, and a quarter of what the handle's budget leaves (the row tables want the rest)
+  const uint64_t room = table_room(h, 0);
+  const uint64_t share = std::max<uint64_t>(room / 4, std::min<uint64_t>(room, 64ull << 20));
+  const uint64_t max_bytes = std::min<uint64_t>(std::min<uint64_t>(16ull << 30, free_b / 4), share);
   uint32_t k = 0;
   uint64_t entries = 1, all = 0;
   for (;;) {
@@ -131,6 +134,7 @@ static hipError_t build_ktab(const Index *h, hipStream_t st) {
   h->kt.dense = static_cast<const uint8_t *>(d_dense);
   h->kt_bytes = all * 16 + 256;
   note_table_build(h, h->kt_bytes);
+  tables_account(h, (int64_t)h->kt_bytes);
   return hipSuccess;
 }
 

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
                                                         const unsigned long long *__restrict__ r3tab, const uint8_t *__restrict__ pat,
                                                         const PatOff po,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
-                                                        uint32_t k, unsigned long long *__restrict__ counters, const uint64_t pk_cap) {
+                                                        uint32_t k, unsigned long long *__restrict__ counters, const uint64_t pk_cap,
+                                                        const uint32_t spin) {
   constexpr int G = Lay<LAYOUT>::G;              // lanes per pattern
   constexpr uint32_t P = 64 / G;                 // patterns per wave
   constexpr uint32_t R = LAYOUT == kLayoutBytes ? 2u : 1u;    // memory requests per rank query
@@ -123,6 +124,12 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
   if (threadIdx.x == 0 && blockIdx.x < kCensusBlocks) {
     counters[(size_t)kCounterSlots * kCounterStride + 2u * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x == 0) counters[(size_t)kCounterSlots * kCounterStride + 2u * kCensusBlocks] = gridDim.x;      // whose entries these are
+  }
+  if (spin) {
+    // a CALIBRATION launch (search_calibrate, from fmx_prepare): every workgroup stays resident for `spin` ticks of the
+    // 100 MHz clock whatever its batch holds, so that "began before the first one ended" means "was resident beside it"
+    const unsigned long long c0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - c0 < spin) __builtin_amdgcn_s_sleep(32);
   }
   // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
   // slot + 2 (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
@@ -1016,76 +1023,85 @@ static int blocks_per_cu(K kernel) {
 // workgroup per CU fewer than it answers (MI355X_MICROARCH.md, "Residency"; there is no API for the scalar register
 // count), and the surplus workgroups run as a second generation behind the first -- C5's bytes-layout kernel: 8 asked
 // for, 7 resident, a launch of 0.205 ms instead of 0.170.  So every instantiation of k_search4 is calibrated by a
-// CENSUS of its first full-size launch on a device: the kernel leaves each workgroup's begin and end times behind the
-// counters (fmx_device.h); before the instantiation's next launch the host counts the workgroups that began before the
-// first one ended and divides by the CUs.  A census taken while other work held part of the device (a table build on
-// another stream) counts late workgroups that waited for THAT: only an answer of the query's number or up to two below
-// it is believed, and only when two launches in a row give it.  One 64 KB copy and one stream synchronisation per
-// reading; two or three readings per instantiation and process.
+// CENSUS on the device it runs on: a calibration launch of the full grid (one empty pattern; every workgroup spins
+// 60 us) leaves each workgroup's begin and end times behind the counters (fmx_device.h); the host counts the workgroups
+// that began before the first one ended and divides by the CUs.  A census taken while other work held part of the
+// device counts late workgroups that waited for THAT: only an answer of the query's number or up to two below it is
+// believed, and only when two launches in a row give it (at most four are made).
+// Round 4 took the readings inside fmx_search_batch_dev -- a 64 KB copy and a stream synchronisation on the CALLER's
+// stream in the 2nd to 6th full-size call, against the header's promise that _dev entry points only enqueue work
+// (ADVICE r4).  Now search_calibrate does it: called by fmx_prepare, and by the search that builds
+// a handle's tables at its threshold (that call allocates and synchronises anyway, and says so); no other call reads
+// anything back.  An instantiation that was never calibrated keeps the query's answer.
 struct Residency {
   std::atomic<int> admitted{0};            // workgroups per CU that were resident at once; 0 = not measured yet
-  std::atomic<int> candidate{0};           // the last reading (it takes two equal ones)
-  std::atomic<uint64_t> pending{0};        // serial of the handle whose last launch of this kernel was a full-size one
-  std::atomic<int> tries{0};
+  std::mutex mu;                           // one calibration at a time per instantiation and device
 };
+constexpr uint32_t kCalibSpin = 6000;      // 60 us
 static int census_read(const Index *h, int grid, int api, hipStream_t st) {
   std::vector<unsigned long long> t(2 * (size_t)kCensusBlocks + 2);
   if (hipMemcpyAsync(t.data(), h->d_counters + (size_t)kCounterSlots * kCounterStride, kCensusBytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  if (t[2 * (size_t)kCensusBlocks] != (unsigned long long)grid) return 0;      // the last launch to write here was not the full-size one (a replayed graph, another stream)
+  if (t[2 * (size_t)kCensusBlocks] != (unsigned long long)grid) return 0;      // the last launch to write here was not the calibration (another stream's search)
   const int nb = std::min<int>(grid, (int)kCensusBlocks);
   unsigned long long first_begin = ~0ull, first_end = ~0ull;
   for (int i = 0; i < nb; i++) {
-    if (!t[2 * i] || t[2 * i + 1] < t[2 * i]) return 0;      // the launch has not finished (another stream), or was not this kernel's
+    if (!t[2 * i] || t[2 * i + 1] < t[2 * i]) return 0;      // overwritten half-way by another launch
     first_begin = std::min(first_begin, t[2 * i]);
     first_end = std::min(first_end, t[2 * i + 1]);
   }
-  if (first_end < first_begin + 2000) return 0;             // workgroups shorter than 20 us say nothing about who waited for whom
+  if (first_end < first_begin + kCalibSpin / 2) return 0;
   int resident = 0;
   for (int i = 0; i < nb; i++) resident += t[2 * i] < first_end ? 1 : 0;
   const int got = resident / std::max(1, h->cu_count);
   return (got >= api - 2 && got >= 1) ? std::min(api, got) : 0;      // fewer: the device was not this launch's alone
 }
 
+// cal: this is search_calibrate's call -- nothing is searched, the instantiation is calibrated
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
-                              const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st, uint64_t pk_cap) {
+                              const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st, uint64_t pk_cap, bool cal) {
   static const int api = blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>);
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
   static const int forced = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), api)) : 0;
   static Residency res[16];
   Residency &rs = res[(unsigned)h->device & 15u];
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
-  // (a stream that is being captured into a graph can be neither synchronised nor trusted to have run its launches:
-  // no reading and no census launch then -- an uncalibrated instantiation keeps the query's answer meanwhile)
-  const auto capturing = [&]() {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return cs != hipStreamCaptureStatusNone;
-  };
-  if (!forced && !rs.admitted.load() && rs.pending.load() == h->serial && h->cu_count * api <= (int)kCensusBlocks && !capturing()) {
-    // (another instantiation's launch on this handle in between has overwritten the census: no reading then)
-    const int got = h->census_owner.load() == (const void *)res ? census_read(h, h->cu_count * api, api, st) : 0;
-    rs.pending.store(0);
+  if (cal) {
+    std::lock_guard<std::mutex> lk(rs.mu);
+    if (forced || rs.admitted.load() || h->cu_count * api > (int)kCensusBlocks) return hipSuccess;
     static const bool trace = getenv("FMX_TRACE") != nullptr;
-    if (trace) fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d> census: %d of the %d workgroups per CU the occupancy query allows were resident\n",
-                       (int)WIDE, LAYOUT, KT, (int)JT, RW, (int)R3T, got, api);
-    if (got && rs.candidate.exchange(got) == got) rs.admitted.store(got);
-    else if (rs.tries.fetch_add(1) >= 5) rs.admitted.store(api);      // no two usable readings (short launches, other streams, a shared device): the query's answer stands
+    // scratch behind the census entries: two zero words (the offsets of one empty pattern) and the two output words
+    unsigned long long *scr = h->d_counters + (kCounterBytes + kCensusBytes) / 8;
+    const PatOff po{(const uint64_t *)scr, 0ull};
+    const int grid = h->cu_count * api;
+    int last = 0, got = 0;
+    for (int attempt = 0; attempt < 4 && !rs.admitted.load(); attempt++) {
+      k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
+                                                                           R3T ? r1 : nullptr, (const uint8_t *)h->d_bwt, po, (uint64_t *)(scr + 2), (uint64_t *)(scr + 3),
+                                                                           1u, h->d_counters, ~0ull, kCalibSpin);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      got = census_read(h, grid, api, st);
+      if (trace) fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d> census: %d of the %d workgroups per CU the occupancy query allows were resident\n",
+                         (int)WIDE, LAYOUT, KT, (int)JT, RW, (int)R3T, got, api);
+      if (got && got == last) rs.admitted.store(got);
+      last = got;
+    }
+    if (!rs.admitted.load()) rs.admitted.store(-1);      // no two agreeing readings (a shared device): the query's answer stands, and is not asked again
+    const int m = rs.admitted.load();
+    h->search_residency.store((uint32_t)(m > 0 ? m : api) | (m > 0 ? 0x100u : 0u));
+    return hipSuccess;
   }
-  const int measured = rs.admitted.load();
+  const int measured = std::max(0, rs.admitted.load());
   const int per_cu = forced ? forced : (measured ? measured : api);
   uint64_t want = ((uint64_t)k + per_wg - 1) / per_wg;
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
-  if (want >= cap && !forced && !measured && !capturing()) {
-    rs.pending.store(h->serial);             // this launch is the census: read before the next one
-  }
-  h->census_owner.store((const void *)res);
   h->search_residency.store((uint32_t)per_cu | ((forced || measured) ? 0x100u : 0u));
   k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
                                                                        R3T ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters,
-                                                                       (JT && RW == 0u) ? pk_cap : ~0ull);
+                                                                       (JT && RW == 0u) ? pk_cap : ~0ull, 0u);
   if (RW) {     // the one-row part of every search, a lane per pattern
     const uint64_t wg = ((uint64_t)k + kSThreads - 1) / kSThreads;
     const int g1 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 32);
@@ -1105,13 +1121,22 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
 }
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
 static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
-                             uint32_t k, hipStream_t st, uint64_t pk_cap) {
+                             uint32_t k, hipStream_t st, uint64_t pk_cap, bool cal) {
   // the row tables are built by fmx_prepare or by the search that brings the handle's patterns to the threshold
   // (fmx_jump.hip, tables_due); until then -- a per-call adapter's single queries -- every step is walked on the dictionary
-  const bool due = tables_due(h, k, false);
+  // (the search that finds them due builds them -- it allocates and synchronises, fmx.h says so -- and calibrates the
+  // kernel they select right away: later calls only enqueue)
+  bool built_now = false;
+  const bool due = !cal && tables_due(h, k, false);
+  if (due) { std::lock_guard<std::mutex> lk(h->jt_mu); built_now = !h->jt_ready; }
   const uint4 *jt = nullptr;
   hipError_t e = jump_get(h, st, &jt, due);
   if (e != hipSuccess) return e;
+  if (built_now) {
+    const unsigned long long *r3b = nullptr;
+    (void)row3_get(h, st, &r3b, true);
+    if ((e = search_calibrate(h, st)) != hipSuccess) return e;
+  }
   // With a row jump table the lane groups finish the one-row part themselves, eight steps per lookup, in lockstep
   // (C3: 0.240 ms; handing it to k_search_rows: 0.248 ms -- both run at ~37 G requests/s, and the hand-over costs two
   // more launches: C2 0.129 -> 0.155 ms).  Without one (it does not fit: C5, n = 2^34) a table of a third of the size
@@ -1121,40 +1146,40 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
   if (rows == 1) {
     const unsigned long long *r1 = nullptr;
     if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
-    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, h->jump_pairs ? nullptr : jt, r1, pat, off, sp, ep, k, st, pk_cap);
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, h->jump_pairs ? nullptr : jt, r1, pat, off, sp, ep, k, st, pk_cap, cal);
   }
   if (jt) {      // and the three-step table beside it, for the steps no aligned jump covers
     const unsigned long long *r3 = nullptr;
     if (rows != 0 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
     if (h->jump_pairs)      // (pairs are built from the three-step table: it is there)
-      return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap)
-                : launch_v4kj<WIDE, LAYOUT, KT, 2u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap);
-    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap)
-              : launch_v4kj<WIDE, LAYOUT, KT, 1u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap);
+      return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, cal)
+                : launch_v4kj<WIDE, LAYOUT, KT, 2u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, cal);
+    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, cal)
+              : launch_v4kj<WIDE, LAYOUT, KT, 1u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, cal);
   }
   if (rows != 0) {
     const unsigned long long *r3 = nullptr, *r1 = nullptr;
     bool have1;
     { std::lock_guard<std::mutex> lk(h->r1_mu); have1 = h->d_row1 != nullptr; }
     if (!have1 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
-    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st, pk_cap);
+    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st, pk_cap, cal);
     if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
-    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st, pk_cap);
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st, pk_cap, cal);
   }
-  return launch_v4kj<WIDE, LAYOUT, KT, 0u, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st, pk_cap);
+  return launch_v4kj<WIDE, LAYOUT, KT, 0u, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st, pk_cap, cal);
 }
 
 template <bool WIDE, uint32_t LAYOUT>
 static hipError_t launch_v4(const Index *h, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
-                            uint32_t k, hipStream_t st, uint64_t pk_cap) {
+                            uint32_t k, hipStream_t st, uint64_t pk_cap, bool cal = false) {
   KTab kt;
-  const hipError_t e = ktab_get(h, st, &kt, tables_due(h, k, true));
+  const hipError_t e = ktab_get(h, st, &kt, !cal && tables_due(h, k, true));
   if (e != hipSuccess) return e;
   // the search uses the table's levels in steps of four characters (all levels are kept: fmx_ktab.hip)
-  if (kt.k >= 12) return launch_v4k<WIDE, LAYOUT, 12>(h, kt, pat, off, sp, ep, k, st, pk_cap);
-  if (kt.k >= 8) return launch_v4k<WIDE, LAYOUT, 8>(h, kt, pat, off, sp, ep, k, st, pk_cap);
-  if (kt.k >= 4) return launch_v4k<WIDE, LAYOUT, 4>(h, kt, pat, off, sp, ep, k, st, pk_cap);
-  return launch_v4k<WIDE, LAYOUT, 0>(h, kt, pat, off, sp, ep, k, st, pk_cap);
+  if (kt.k >= 12) return launch_v4k<WIDE, LAYOUT, 12>(h, kt, pat, off, sp, ep, k, st, pk_cap, cal);
+  if (kt.k >= 8) return launch_v4k<WIDE, LAYOUT, 8>(h, kt, pat, off, sp, ep, k, st, pk_cap, cal);
+  if (kt.k >= 4) return launch_v4k<WIDE, LAYOUT, 4>(h, kt, pat, off, sp, ep, k, st, pk_cap, cal);
+  return launch_v4k<WIDE, LAYOUT, 0>(h, kt, pat, off, sp, ep, k, st, pk_cap, cal);
 }
 
 // One launch per call: no scratch, nothing to own per stream, so concurrent calls on one handle need no lock.
@@ -1177,6 +1202,17 @@ hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, v
   }
   hipError_t e = hipSuccess;
 #define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, po, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st, pack_cap)
+  FMX_LAYOUT_DISPATCH(h, CALL);
+#undef CALL
+  return e;
+}
+
+// The residency census of the k_search4 instantiation this handle's tables select now (see Residency above).
+hipError_t search_calibrate(const Index *h, hipStream_t st) {
+  if (search_variant() == 1) return hipSuccess;
+  hipError_t e = hipSuccess;
+  const PatOff po{(const uint64_t *)h->d_cf, 0ull};
+#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)h->d_bwt, po, nullptr, nullptr, 1u, st, ~0ull, true)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
   return e;

@@ -263,6 +263,7 @@ static hipError_t ensure_select(const Index *h, hipStream_t st, SelDir *out) {
     if (d_tot) (void)hipFree(d_tot);
     if (e != hipSuccess) return e;
     h->sel_bytes = entries * 4;
+    tables_account(h, (int64_t)h->sel_bytes);      // (Psi cannot do without it: counted against the budget, never refused by it)
     h->sel_ready = true;
     h->tables_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
   }

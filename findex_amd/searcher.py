@@ -359,14 +359,24 @@ class HipFMSearcher:
                                                _ptr(ranks), ctypes.byref(done)))
         return ranks[: text.size], int(done.value)
 
-    def prepare(self, ktab=True, select=False, jump=False, frontier=False):
-        """fmx_prepare: build the k-mer jump table / the select directory / the literal search's row tables (J, R3) / the
-        regex frontier's row table now instead of at the threshold or at first use."""
-        _lib.check(self._L.fmx_prepare(self._h, (1 if ktab else 0) | (2 if select else 0) | (4 if jump else 0) | (8 if frontier else 0)))
+    def prepare(self, ktab=True, select=False, jump=False, frontier=False, search=False, budget_bytes=0):
+        """fmx_prepare[_ex]: build the k-mer jump table / the select directory / the literal search's row tables (J, R3) / the
+        regex frontier's row table now instead of at the threshold or at first use, and calibrate the search kernel they
+        select (`search` alone: only that).  budget_bytes != 0: the handle's "table_budget" first (fmx_prepare_ex)."""
+        what = (1 if ktab else 0) | (2 if select else 0) | (4 if jump else 0) | (8 if frontier else 0) | (16 if search else 0)
+        if budget_bytes:
+            _lib.check(self._L.fmx_prepare_ex(self._h, what, int(budget_bytes)))
+        else:
+            _lib.check(self._L.fmx_prepare(self._h, what))
 
-    def drop_tables(self, jump=True, frontier=True):
-        """fmx_drop_tables: free the row jump table and the three-step row table / the frontier's row table."""
-        _lib.check(self._L.fmx_drop_tables(self._h, (4 if jump else 0) | (8 if frontier else 0)))
+    def drop_tables(self, jump=True, frontier=True, ktab=False):
+        """fmx_drop_tables: free the row jump table and the three-step row table / the frontier's row table / the k-mer table."""
+        _lib.check(self._L.fmx_drop_tables(self._h, (4 if jump else 0) | (8 if frontier else 0) | (1 if ktab else 0)))
+
+    def config_set(self, key, value):
+        """fmx_index_config_set: this handle's own table policy ("ktab", "jump", "jump_pairs", "jump_chars", "tables_after",
+        "table_budget"); tables that exist stay until drop_tables."""
+        _lib.check(self._L.fmx_index_config_set(self._h, key.encode(), str(value).encode()))
 
     # ---- statistics
     def stats(self):

@@ -24,7 +24,9 @@
  *    handle are allowed from different host threads.
  *  - Plain entry points take HOST pointers and move data themselves.  The `_dev`
  *    twins take DEVICE pointers plus a hipStream_t (as void*) and only enqueue
- *    work: inputs already resident in HBM, outputs left in HBM.
+ *    work: inputs already resident in HBM, outputs left in HBM.  (One exception, stated at
+ *    fmx_prepare: the single search that builds a handle's derived tables at its threshold when the
+ *    caller never called fmx_prepare; fmx_regex_batch_match_dev is synchronous by design.)
  *  - There is no CPU fallback anywhere: without a usable HIP device every compute
  *    entry point fails with FMX_ERR_HIP.
  */
@@ -38,7 +40,7 @@
 extern "C" {
 #endif
 
-#define FMX_ABI_VERSION 4
+#define FMX_ABI_VERSION 5
 
 enum {
   FMX_OK = 0,
@@ -60,7 +62,9 @@ typedef struct fmx_regex_batch fmx_regex_batch;   /* a set of compiled regexes m
 
 const char *fmx_last_error(void);
 int fmx_abi_version(void);
-/* Process-wide options.  key "layout": "auto" (default: one-hot bit-vectors, one 64-byte block per
+/* Process-wide options.  The table keys ("ktab", "jump", "jump_pairs", "jump_chars", "tables_after", "table_budget") are the
+ * DEFAULTS a handle copies when it is opened; fmx_index_config_set changes one handle's own copy afterwards, so two handles
+ * in one process (one JVM) can differ.  key "layout": "auto" (default: one-hot bit-vectors, one 64-byte block per
  * rank query, when sigma*n/7 bytes fit in free HBM and n < 2^37; else BWT bytes + checkpoints, two
  * lines per rank query), "onehot", "bytes".  key "ktab": "auto" (default) / "off": the k-mer jump table that
  * answers a search's first K backward steps with one lookup (built on a handle's first search; K is chosen from n
@@ -93,6 +97,14 @@ int fmx_abi_version(void);
  * first search).  A per-call adapter's single queries never build one.  (The regex frontier builds the k-mer table and its
  * row table at a handle's first match: a frontier is thousands of steps.)  fmx_stats_t.patterns_seen,
  * .peak_table_build_bytes; fmx_drop_tables frees them again.
+ * key "table_budget": "auto" (default) / N / F: the most device memory ALL derived tables of a handle (k-mer table, row
+ * tables, row jump table, select directory) may hold together -- N bytes, or a fraction F written with a point ("0.5": that
+ * share of the HBM that is free when a table is decided, the handle's own tables counted as free); "auto": whatever fits
+ * beside the built-in margins (8 GiB for the row jump table, 4-8 GiB for the others).  Under a budget the k-mer table takes
+ * at most a quarter of it, then the three-step row table (8 n), then the row jump table as pairs (32 n) if that still fits,
+ * else as single entries (16 n), else not at all -- searches give the same answers with any subset.  At C3 (n = 2^32) "auto"
+ * ends up holding 4 + 32 + 128 GiB beside the 81 GiB index; "100000000000" keeps it to 4 + 32 + 64 GiB.
+ * fmx_stats_t.tables_held_bytes, .table_budget_bytes, .hbm_free_after_tables; fmx_prepare_ex sets it with the build.
  * key "pipeline": "off" (default) / "on": fmx_search_batch with 128 k patterns or more in page-locked buffers cut into
  * chunks whose uploads, searches and downloads overlap on three streams, instead of whole arrays up, one search, whole
  * arrays down.  Same results; which is faster depends on how the platform's asynchronous copies compare with its
@@ -138,21 +150,35 @@ int fmx_open_dev(const void *d_bwt, uint64_t n, uint64_t eof, const int64_t *cou
  *                  serves every entry point (search, getPrevRange ... are inherited from SuffixAlgo there too). */
 int fmx_open_block(const uint8_t *bwt, uint64_t n, const int64_t bucket_starts[256], uint64_t rk0, int device,
                    fmx_index **out);
-int fmx_close(fmx_index *idx);
+int fmx_close(fmx_index *idx);          /* NULL: nothing to close, FMX_OK */
+/* One handle's own table policy (the keys fmx_config_set lists as table keys; FMX_ERR_ARG for any other key or a bad value).
+ * Tables that exist are not touched: fmx_drop_tables + fmx_prepare rebuild under the new policy. */
+int fmx_index_config_set(fmx_index *idx, const char *key, const char *value);
 /* Builds now what a handle otherwise builds when its searches reach the "tables_after" threshold (literal search) or
  * at first use (Psi, regex match) -- FMX_PREPARE_KTAB: the k-mer jump table (up to min(16 GiB, a quarter of the free
- * HBM)); FMX_PREPARE_SELECT: the select directory (first Psi / nextSubstr; at most ~n bytes); FMX_PREPARE_JUMP: the
- * tables of the literal search's one-row part -- the three-step row table and the row jump table (8 n + 16 n bytes, one
- * allocation each; each skipped when that much HBM is not free); FMX_PREPARE_FRONTIER: the regex frontier's row table
- * (8 n bytes, otherwise built at the first regex match) -- so that no later call allocates device memory or synchronises
- * a stream: for a caller that captures its stream, or that times its first search.  A table that cannot be built (no
- * memory) is left out: searches then walk every step on the rank dictionary, with the same results.  The time spent is
- * reported as fmx_stats_t.tables_build_ms. */
-enum { FMX_PREPARE_KTAB = 1, FMX_PREPARE_SELECT = 2, FMX_PREPARE_JUMP = 4, FMX_PREPARE_FRONTIER = 8 };
+ * HBM, a quarter of the budget)); FMX_PREPARE_SELECT: the select directory (first Psi / nextSubstr; at most ~n bytes);
+ * FMX_PREPARE_JUMP: the tables of the literal search's one-row part -- the three-step row table and the row jump table
+ * (8 n + 16 n or 32 n bytes, one allocation each; each skipped when that much HBM is not free or not in the handle's
+ * budget); FMX_PREPARE_FRONTIER: the regex frontier's row table (8 n bytes, otherwise built at the first regex match);
+ * FMX_PREPARE_SEARCH (implied by KTAB and JUMP): calibrates the literal search kernel the handle's tables select -- a few
+ * 60-us launches on the library's own stream that count how many of its workgroups a CU really holds
+ * (fmx_stats_t.search_residency).  Each flag stands for its own table only: FMX_PREPARE_KTAB alone leaves the row tables to
+ * their threshold.
+ * THE CONTRACT: after fmx_prepare has built a table, no later call builds, allocates for, or synchronises a stream for
+ * THAT table; with KTAB | JUMP (| FRONTIER | SELECT for regex / Psi callers) prepared, every _dev entry point only
+ * enqueues work -- safe inside a stream capture, and a caller that times its first search times a search.  Without
+ * fmx_prepare, the ONE search that brings a handle to its "tables_after" threshold builds the tables inside the call
+ * (it allocates and synchronises `stream`; FMX_ERR_HIP under a stream capture), and calibrates; every other _dev
+ * call only enqueues.  A table that cannot be built (no memory, no budget) is left out: searches then walk every step on
+ * the rank dictionary, with the same results.  The time spent is reported as fmx_stats_t.tables_build_ms.
+ * fmx_prepare_ex: the same under a budget -- budget_bytes != 0 becomes the handle's "table_budget" first. */
+enum { FMX_PREPARE_KTAB = 1, FMX_PREPARE_SELECT = 2, FMX_PREPARE_JUMP = 4, FMX_PREPARE_FRONTIER = 8, FMX_PREPARE_SEARCH = 16 };
 int fmx_prepare(const fmx_index *idx, unsigned what);
-/* Frees the row tables again (what = FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER in any combination: the row jump table and
- * the three-step row table, 16 n + 8 n bytes / the frontier's row table, 8 n bytes) and forgets the handle's pattern count, so that they come back only by fmx_prepare or when
- * the threshold is met anew.  No other call may be using the handle. */
+int fmx_prepare_ex(fmx_index *idx, unsigned what, uint64_t budget_bytes);
+/* Frees derived tables again (what = FMX_PREPARE_KTAB | FMX_PREPARE_JUMP | FMX_PREPARE_FRONTIER in any combination: the
+ * k-mer table / the row jump table and the three-step row table, 16-32 n + 8 n bytes / the frontier's row table, 8 n
+ * bytes) and forgets the handle's pattern count, so that they come back only by fmx_prepare or when the threshold is met
+ * anew (under the handle's policy as it is then).  No other call may be using the handle. */
 int fmx_drop_tables(fmx_index *idx, unsigned what);
 
 /* ---- scalars: SuffixAlgo.n / cf, findex.scala:10-12; NaiveFMSearcher.cf bwtmerger.scala:346-352 */
@@ -475,8 +501,8 @@ typedef struct fmx_stats_t {
   double build_ms;           /* device time of the kernels that built the rank dictionary at open */
   uint32_t layout;           /* 0 = one-hot bit-vectors, 1 = BWT bytes + checkpoints */
   uint32_t search_residency; /* workgroups per CU the last fmx_search_batch[_dev] launch was sized for (0: none yet); | 0x100 once
-                                the kernel's residency census has confirmed the number (the occupancy query can answer one
-                                too many: DESIGN.md 3, "residency") */
+                                the kernel's residency census (fmx_prepare) has confirmed the number (the occupancy query can
+                                answer one too many: DESIGN.md 3, "residency") */
   uint64_t search_requests;  /* memory requests for rank-dictionary lines issued by fmx_search_batch[_dev]'s kernel */
   /* the regex frontier kernels (fmx_regex_*match*), for their roofline: */
   uint64_t frontier_requests;   /* memory requests for rank-dictionary lines */
@@ -502,6 +528,9 @@ typedef struct fmx_stats_t {
   uint64_t peak_table_build_bytes;   /* most device memory one derived table's build held at once: since round 4 the table
                                       * itself (the row jump table was built through a second buffer of its size before) */
   uint64_t patterns_seen;       /* patterns this handle's literal searches have been asked for (what "tables_after" counts) */
+  uint64_t tables_held_bytes;   /* device bytes of all derived tables of this handle now (what "table_budget" counts) */
+  uint64_t table_budget_bytes;  /* the handle's budget in bytes (a fraction resolved against the HBM free now); ~0: none */
+  uint64_t hbm_free_after_tables;   /* free device memory right after the handle's last table build (hipMemGetInfo; 0: none built) */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 /* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */

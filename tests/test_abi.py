@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_device_count():
     L = _lib.load()
-    assert L.fmx_abi_version() == 4
+    assert L.fmx_abi_version() == 5
     n = ctypes.c_int(-1)
     assert L.fmx_device_count(ctypes.byref(n)) == 0 and n.value >= 0
 
@@ -36,7 +36,7 @@ def test_abi_version_and_device_count():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.fmx_result) == 24
     assert ctypes.sizeof(_lib.fmx_limits) == 24
-    assert ctypes.sizeof(_lib.fmx_stats_t) == 200
+    assert ctypes.sizeof(_lib.fmx_stats_t) == 224
 
 
 def test_open_errors_are_statuses_with_messages(tmp_path, testdata):
@@ -166,14 +166,15 @@ def test_config_keys_and_values():
     ok = {b"layout": [b"onehot", b"bytes", b"auto"], b"checkpoints": [b"superblock", b"auto"], b"ktab": [b"off", b"auto"],
           b"jump": [b"off", b"rows", b"rows3", b"jumps", b"auto"], b"pipeline": [b"on", b"off"], b"validate": [b"1", b"0"],
           b"threads": [b"3", b"0"], b"jump_chars": [b"8", b"11", b"9"], b"tables_after": [b"auto", b"100000", b"0"],
-          b"jump_pairs": [b"on", b"off", b"auto"]}
+          b"jump_pairs": [b"on", b"off", b"auto"], b"table_budget": [b"100000000000", b"0.5", b"1.0", b"0", b"auto"]}
     for key, values in ok.items():
         for v in values:                        # the last value of each list is the default: left in place
             assert L.fmx_config_set(key, v) == 0, (key, v)
         if key != b"validate":                  # ("validate" reads anything but "0" as on)
             assert L.fmx_config_set(key, b"no-such-value") == 3, key
             assert L.fmx_last_error().decode()
-    for key, bad in ((b"jump_chars", b"7"), (b"jump_chars", b"12"), (b"tables_after", b"-1")):
+    for key, bad in ((b"jump_chars", b"7"), (b"jump_chars", b"12"), (b"tables_after", b"-1"), (b"table_budget", b"1.5"),
+                     (b"table_budget", b"0.0"), (b"table_budget", b"-5")):
         assert L.fmx_config_set(key, bad) == 3, (key, bad)
     # the 8-byte interval form's host-side decode needs no device either
     import numpy as np
@@ -188,3 +189,7 @@ def test_config_keys_and_values():
     assert L.fmx_unpack_intervals(pk.ctypes.data_as(vp), 3, 1, sp.ctypes.data_as(vp), ep.ctypes.data_as(vp)) == 2       # FMX_ERR_FORMAT
     assert L.fmx_config_set(b"no-such-key", b"1") == 3
     assert L.fmx_config_set(None, b"1") == 3 and L.fmx_config_set(b"jump", None) == 3
+    # the per-handle form refuses a null handle before it looks at the key; closing nothing is not an error (fmx.h)
+    assert L.fmx_index_config_set(None, b"jump", b"off") == 3
+    assert L.fmx_close(None) == 0
+    assert L.fmx_prepare_ex(None, 1, 0) == 3

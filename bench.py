@@ -549,6 +549,56 @@ def measure_host_path(torch, hip, pats, off, sp_dev, ep_dev, k, m, reps=5):
     return out
 
 
+def measure_rank_only(args, torch, hip, batches, k, stream, device, onehot, rank):
+    """The RANK kernel's own roofline (north_star: "each rank(c,i) is one coalesced load plus an in-lane popcount ... achieved
+    HBM GB/s against the ~8 TB/s peak"; bwtmerger.scala:354-375 is what it replaces): the same ring of batches with every
+    derived table OFF -- k-mer table, row jump table, row tables dropped and disabled on this handle -- so that every backward
+    step of every pattern is executed as rank-dictionary line requests (one per step once the interval is a row, two while sp
+    and ep lie in different blocks).  What is reported is EXECUTED work: line requests per second (device counter), their
+    bytes at the line's size against the HBM peak.  Changes the handle's tables: call it last."""
+    sp = torch.empty(k, dtype=torch.int64, device=device)
+    ep = torch.empty(k, dtype=torch.int64, device=device)
+    hip.drop_tables(jump=True, frontier=True, ktab=True)
+    hip.config_set("ktab", "off")
+    hip.config_set("jump", "off")
+    hip.prepare(ktab=False, search=True)          # nothing to build: calibrates the table-less kernel's grid
+    ring = len(batches)
+    per = []
+    for bp, bo in batches:
+        hip.stats_reset()
+        hip.search_batch_dev(bp.data_ptr(), bo.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
+        torch.cuda.synchronize()
+        sj = hip.stats()
+        assert sj["ktab_lookups"] == 0 and sj["jump_lookups"] == 0 and sj["row_lookups"] == 0 and sj["tables_held_bytes"] == 0
+        per.append((int(sj["search_requests"]), int(sj["rank_queries"])))
+    steps = max(args.steps, 5)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(steps):
+        bp, bo = batches[i % ring]
+        hip.search_batch_dev(bp.data_ptr(), bo.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    reqs = sum(per[i % ring][0] for i in range(steps)) / float(steps)
+    occs = sum(per[i % ring][1] for i in range(steps)) / float(steps)
+    line = 64.0 if onehot else 66.0
+    achieved = reqs * line / (ms * 1e-3) / 1e9
+    log(rank, "rank_only (all derived tables off): %.4f ms per step, %.2f G executed rank-line requests/s = %.0f GB/s (%.3f of peak)"
+        % (ms, reqs / ms / 1e6, achieved, achieved / HBM_PEAK_GBS))
+    return {"ms": ms, "steps": steps, "executed_rank_queries_per_s": reqs / (ms * 1e-3),
+            "executed_rank_queries_is": "rank-dictionary line requests the kernel issued per second (device counter): each is one "
+                                        "%d-byte block fetched and popcounted in the lane group -- one per backward step on a one-row "
+                                        "interval, one or two on a wider one" % int(line),
+            "rank_line_requests_per_launch": reqs, "reference_occ_evaluations_per_s": occs / (ms * 1e-3),
+            "bytes_per_request": line, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "requests_G_per_s": reqs / ms / 1e6, "request_frac": reqs / ms / 1e6 / REQUEST_CEILING_G_PER_S,
+            "kernel": "k_search4 with KT = 0, no row tables: every step on the rank dictionary",
+            "what": "the same ring of %d batches, fmx_drop_tables + this handle's ktab = off / jump = off; HIP events around %d "
+                    "back-to-back steps" % (ring, steps)}
+
+
 # ---------------------------------------------------------------- the two kinds of workload
 def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_dist, stream):
     is_text = args.workload in TEXT
@@ -575,9 +625,16 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     if not want_cpu:
         del bwt
         torch.cuda.empty_cache()
-    pats, off = make_patterns(torch, hip, n, sigma, k, m, seed * 1000 + rank, device, stream)
-    # the intervals land in the slots of a pipelined gather: with N > 1 the all-gather of step i (RCCL over
-    # xGMI, 16 B per pattern) runs on the collective's stream while step i+1 is being searched
+    # A RING of distinct pattern batches, rotated through the steps (round 5).  The reference's search(in) never sees the
+    # same query twice (findex.scala:15-31), but until round 4 every timed figure replayed ONE batch: a C3 step touches
+    # ~335 MB of distinct 64-byte sectors, which straddles the 256 MiB Infinity Cache, so part of a replayed step was served
+    # on die (profiles/r05_c3_cold.md).  With R >= 8 batches, R x that lies between two uses of any line: every step runs
+    # against HBM.  The replayed-batch figure is kept beside the headline as `replayed_batch_ms`.
+    ring = max(1, args.ring)
+    batches = [make_patterns(torch, hip, n, sigma, k, m, seed * 1000 + rank + 7919 * j, device, stream) for j in range(ring)]
+    pats, off = batches[0]
+    # the intervals land in the slots of a pipelined gather: with N > 1 the gather of step i (RCCL over
+    # xGMI, 8 B per pattern) runs on the collective's stream while step i+1 is being searched
     from findex_amd.distributed import IntervalGather
     gather = IntervalGather(k, device, form=args.exchange, delivery=args.delivery, searcher=hip)
     step_no = [0]
@@ -585,58 +642,59 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     def step():
         i = step_no[0]
         step_no[0] += 1
+        bp, bo = batches[i % ring]
         if use_dist:        # the intervals are written in the exchange's form by the search itself, then gathered: the path's one exchange
-            gather.search_into(i, hip, pats.data_ptr(), off.data_ptr(), stream)
+            gather.search_into(i, hip, bp.data_ptr(), bo.data_ptr(), stream)
             gather.launch(i, stream, packed_already=True)
             return None, None
         sp, ep = gather.slot(i)
-        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
+        hip.search_batch_dev(bp.data_ptr(), bo.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
         return sp, ep
 
-    # rank queries one step executes (device counter; identical every step)
-    hip.stats_reset()
-    sp, ep = step()
-    gather.finish()
-    torch.cuda.synchronize()
-    if sp is None:          # the packed form went to the exchange: the intervals themselves, for the hit count
-        sp, ep = gather.mine[0][0], gather.mine[0][1]
-        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
-        torch.cuda.synchronize()
+    # what one step of each batch executes (device counters; the batches differ by a fraction of a per cent), and batch 0's
+    # intervals for the hit count, the host path and the CPU baseline
+    sp0 = torch.empty(k, dtype=torch.int64, device=device)
+    ep0 = torch.empty(k, dtype=torch.int64, device=device)
+    per_batch = []
+    hits_b = []
+    for j in range(ring):
+        bp, bo = batches[j]
         hip.stats_reset()
-        step()
-        gather.finish()
+        hip.search_batch_dev(bp.data_ptr(), bo.data_ptr(), sp0.data_ptr(), ep0.data_ptr(), k, stream)
         torch.cuda.synchronize()
+        sj = hip.stats()
+        per_batch.append({f: int(sj[f]) for f in ("rank_queries", "search_requests", "ktab_lookups", "jump_lookups", "row_lookups")})
+        hits_b.append(int((sp0 < ep0).sum().item()))
+    hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp0.data_ptr(), ep0.data_ptr(), k, stream)
+    torch.cuda.synchronize()
     s1 = hip.stats()
-    ranks_per_step = int(s1["rank_queries"])
-    requests_per_step = int(s1["search_requests"])
-    lookups_per_step = int(s1["ktab_lookups"])
-    jumps_per_step = int(s1["jump_lookups"])
-    rows_per_step = int(s1["row_lookups"])
-    hits = int((sp < ep).sum().item())
-    sp0, ep0 = sp.clone(), ep.clone()
-    for _ in range(max(0, args.warmup - 1)):
+    for _ in range(max(0, args.warmup)):
         step()
+    gather.finish()
     torch.cuda.synchronize()
 
     # The kernel's own duration is measured live, with HIP events on its stream, on every EVENT_EVERY-th step of the timed
     # region.  Not on every step: an event record is a marker packet the command processor drains the stream for, and
     # two of them between consecutive launches were 8-11 us of a 150 us step (device clock: launches inside one C5 step
-    # follow each other without a gap, steps were 11 us apart) -- measurement overhead, not the path's.
-    EVENT_EVERY = 4
+    # follow each other without a gap, steps were 11 us apart) -- measurement overhead, not the path's.  (3: coprime with the
+    # ring's 8, so the timed launches rotate through the batches too.)
+    EVENT_EVERY = 3
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if j % EVENT_EVERY == 0 else None
           for j in range(args.steps)]
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    first_timed = step_no[0]
     t0 = time.perf_counter()
     for pair in ev:
         i = step_no[0]
         step_no[0] += 1
+        bp, bo = batches[i % ring]
         if use_dist:
             gather.slot(i)      # (waits for the collective that last used the slot, outside the search's events)
             if pair:
                 pair[0].record()          # torch's current stream == the stream the kernel is launched on
-            gather.search_into(i, hip, pats.data_ptr(), off.data_ptr(), stream)
+            gather.search_into(i, hip, bp.data_ptr(), bo.data_ptr(), stream)
             if pair:
                 pair[1].record()
             gather.launch(i, stream, packed_already=True)
@@ -644,7 +702,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
             sp_i, ep_i = gather.slot(i)
             if pair:
                 pair[0].record()
-            hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp_i.data_ptr(), ep_i.data_ptr(), k, stream)
+            hip.search_batch_dev(bp.data_ptr(), bo.data_ptr(), sp_i.data_ptr(), ep_i.data_ptr(), k, stream)
             if pair:
                 pair[1].record()
     gather.finish()         # every step's gather completes inside the timed region
@@ -654,6 +712,31 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     dt = time.perf_counter() - t0
     timed = [p for p in ev if p]
     kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
+    # the work of exactly the timed steps
+    timed_batches = [(first_timed + j) % ring for j in range(args.steps)]
+
+    def mean_of(f):
+        return sum(per_batch[b][f] for b in timed_batches) / float(args.steps)
+    ranks_per_step = mean_of("rank_queries")
+    requests_per_step = mean_of("search_requests")
+    lookups_per_step = mean_of("ktab_lookups")
+    jumps_per_step = mean_of("jump_lookups")
+    rows_per_step = mean_of("row_lookups")
+    hits = sum(hits_b[b] for b in timed_batches) / float(args.steps)
+
+    # ---- the same step on ONE batch replayed (what rounds 1-4 reported): part of it is served by the Infinity Cache
+    def replay(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp0.data_ptr(), ep0.data_ptr(), k, stream)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp0.data_ptr(), ep0.data_ptr(), k, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    replayed_ms = replay(max(args.steps, 5))
 
     exchange = measure_exchange(args, torch, dist, hip, gather, k, device, stream, use_dist)
     tot = torch.tensor([dt, float(ranks_per_step), float(hits), kernel_ms], dtype=torch.float64, device=device)
@@ -717,6 +800,10 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         # for comparison only, it is not a fraction of anything
         "survey_equiv_GBps": ranks_per_step * survey_bytes_per_rank(n_sigma) / ksec / 1e9,
         "index_resident_in": resident,
+        "index_resident_in_is": ("the steps rotate through %d distinct batches: ~%.1f GB of distinct 64-byte sectors are touched between two "
+                                 "uses of any line, %.0fx the 256 MiB Infinity Cache -- nothing of a step is served on die "
+                                 "(profiles/r05_c3_cold.md); replayed_batch_ms is the same step on ONE batch replayed"
+                                 % (ring, ring * all_requests * 64 / 1e9, ring * all_requests * 64 / INFINITY_CACHE_BYTES)) if resident == "hbm" else None,
     }
     if resident == "hbm":
         # the limit that binds this access pattern: distinct dependent memory requests per second
@@ -743,6 +830,10 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "dtype": "u64",
         "data": "synthetic" if not is_text else "synthetic text with natural repeats (words.txt's words drawn with replacement), its true BWT",
         "patterns_per_sec": world * k * args.steps / dt,
+        "ring_batches": ring,
+        "ms_per_step_is": "steps rotate through %d distinct pattern batches (seeds differ): no step sees a batch the device has just "
+                          "searched; the same step on ONE replayed batch: replayed_batch_ms" % ring,
+        "replayed_batch_ms": replayed_ms,
         # co-headline: what the memory system is asked per second; `value` counts the reference's occ evaluations,
         # which the tables of rounds 2-4 serve with fewer and fewer requests -- compare rounds by patterns_per_sec / this
         "requests_G_per_s": world * all_requests * args.steps / dt / 1e9,
@@ -781,10 +872,14 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "roofline": roof,
     }
     if world == 1 and not args.no_host_path:
+        # (batch 0's intervals again: sp0 / ep0 held the replayed batch's, which they are)
         out["host_path"] = measure_host_path(torch, hip, pats, off, sp0, ep0, k, m)
         log(rank, "host path: pageable %.3f ms, page-locked %.3f ms, lean (no offsets, 8-byte intervals) %.3f ms per call"
             % (out["host_path"]["pageable"]["ms_per_call"], out["host_path"]["page_locked"]["ms_per_call"],
                out["host_path"]["lean_pageable"]["ms_per_call"]))
+    if rank == 0 and not args.no_rank_only:
+        # (after everything else that uses this handle's tables, before the CPU leg, which does not use the handle)
+        out["rank_only"] = measure_rank_only(args, torch, hip, batches, k, stream, device, onehot, rank)
     if want_cpu:
         cores = effective_cores()
         sample = min(k, 200_000)
@@ -1067,6 +1162,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(LITERAL) + sorted(REGEX) + sorted(TEXT))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive sub-record of the literal workloads")
+    ap.add_argument("--no-rank-only", action="store_true", help="skip the tables-off sub-record of the literal workloads (executed rank work)")
+    ap.add_argument("--ring", type=int, default=8,
+                    help="literal workloads: distinct pattern batches the steps rotate through (1 = one batch replayed, rounds 1-4)")
     ap.add_argument("--exchange", default="packed", choices=["packed", "pairs"],
                     help="N > 1, literal workloads: the intervals travel as 8 bytes (default) or 16 bytes per pattern")
     ap.add_argument("--delivery", default="root", choices=["root", "all"],

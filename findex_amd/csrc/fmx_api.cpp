@@ -645,7 +645,7 @@ int fmx_prepare_ex(fmx_index *idx, unsigned what, uint64_t budget_bytes) {
   if (!idx) return arg_fail("null argument");
   if (budget_bytes) {
     H(idx)->policy.budget_bytes.store(budget_bytes, std::memory_order_relaxed);
-    H(idx)->policy.budget_ppm.store(0, std::memory_order_relaxed);
+    H(idx)->policy.budget_ppb.store(0, std::memory_order_relaxed);
   }
   return fmx_prepare(idx, what);
 }
@@ -1289,10 +1289,10 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->tables_held_bytes = h->tables_held.load(std::memory_order_relaxed);
   out->hbm_free_after_tables = h->hbm_free_after_tables.load(std::memory_order_relaxed);
   {
-    const uint32_t ppm = h->policy.budget_ppm.load(std::memory_order_relaxed);
+    const uint32_t ppm = h->policy.budget_ppb.load(std::memory_order_relaxed);
     uint64_t budget = h->policy.budget_bytes.load(std::memory_order_relaxed);
     size_t free_b = 0, total_b = 0;
-    if (ppm && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = (uint64_t)((double)(free_b + out->tables_held_bytes) * ((double)ppm * 1e-6));
+    if (ppm && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = (uint64_t)((double)(free_b + out->tables_held_bytes) * ((double)ppm * 1e-9));
     out->table_budget_bytes = budget;
   }
   return FMX_OK;

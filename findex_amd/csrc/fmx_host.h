@@ -60,13 +60,13 @@ struct TablePolicy {
   std::atomic<long long> tables_after{-1};     // patterns before a search builds tables; -1 auto
   // the BUDGET: device bytes all derived tables of this handle (k-mer, row, row jump, select) may hold together
   std::atomic<uint64_t> budget_bytes{~0ull};   // ~0: none (what fits beside the margins)
-  std::atomic<uint32_t> budget_ppm{0};         // != 0: a fraction (millionths) of the HBM that is free when a table is decided, the handle's own tables counted as free
+  std::atomic<uint32_t> budget_ppb{0};         // != 0: a fraction (billionths) of the HBM that is free when a table is decided, the handle's own tables counted as free
   TablePolicy() = default;
   TablePolicy(const TablePolicy &o) { *this = o; }
   TablePolicy &operator=(const TablePolicy &o) {
     ktab.store(o.ktab.load()); jump_mode.store(o.jump_mode.load()); jump_pairs.store(o.jump_pairs.load());
     jump_chars.store(o.jump_chars.load()); tables_after.store(o.tables_after.load());
-    budget_bytes.store(o.budget_bytes.load()); budget_ppm.store(o.budget_ppm.load());
+    budget_bytes.store(o.budget_bytes.load()); budget_ppb.store(o.budget_ppb.load());
     return *this;
   }
 };

@@ -184,19 +184,19 @@ int policy_set(TablePolicy &p, const char *key, const char *value, const char **
   }
   if (is("table_budget")) {
     // "auto": none beyond the margins; "0.25" (a number with a point, 0 < f <= 1): that share of the free HBM; "N": N bytes
-    if (val("auto")) { p.budget_bytes.store(~0ull); p.budget_ppm.store(0); return 0; }
+    if (val("auto")) { p.budget_bytes.store(~0ull); p.budget_ppb.store(0); return 0; }
     if (std::strchr(value, '.')) {
       char *end = nullptr;
       const double f = std::strtod(value, &end);
       if (end == value || *end || !(f > 0.0) || f > 1.0) { *why = "table_budget as a fraction must be in (0, 1]"; return 2; }
-      p.budget_ppm.store((uint32_t)(f * 1e6 + 0.5));
+      p.budget_ppb.store((uint32_t)std::max(1.0, f * 1e9 + 0.5));
       p.budget_bytes.store(~0ull);
       return 0;
     }
     uint64_t v = 0;
     if (!parse_u64(value, &v)) { *why = "table_budget must be auto, a number of bytes, or a fraction of the free HBM like 0.5"; return 2; }
     p.budget_bytes.store(v);
-    p.budget_ppm.store(0);
+    p.budget_ppb.store(0);
     return 0;
   }
   return 1;
@@ -238,8 +238,8 @@ uint64_t table_room(const Index *h, uint64_t margin) {
   uint64_t room = free_b > margin ? free_b - margin : 0;
   const uint64_t held = h->tables_held.load(std::memory_order_relaxed);
   uint64_t budget = h->policy.budget_bytes.load(std::memory_order_relaxed);
-  const uint32_t ppm = h->policy.budget_ppm.load(std::memory_order_relaxed);
-  if (ppm) budget = (uint64_t)((double)(free_b + held) * ((double)ppm * 1e-6));
+  const uint32_t ppm = h->policy.budget_ppb.load(std::memory_order_relaxed);
+  if (ppm) budget = (uint64_t)((double)(free_b + held) * ((double)ppm * 1e-9));
   if (budget != ~0ull) room = std::min(room, budget > held ? budget - held : 0);
   return room;
 }

@@ -1069,28 +1069,30 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
   if (cal) {
     std::lock_guard<std::mutex> lk(rs.mu);
-    if (forced || rs.admitted.load() || h->cu_count * api > (int)kCensusBlocks) return hipSuccess;
-    static const bool trace = getenv("FMX_TRACE") != nullptr;
-    // scratch behind the census entries: two zero words (the offsets of one empty pattern) and the two output words
-    unsigned long long *scr = h->d_counters + (kCounterBytes + kCensusBytes) / 8;
-    const PatOff po{(const uint64_t *)scr, 0ull};
-    const int grid = h->cu_count * api;
-    int last = 0, got = 0;
-    for (int attempt = 0; attempt < 4 && !rs.admitted.load(); attempt++) {
-      k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
-                                                                           R3T ? r1 : nullptr, (const uint8_t *)h->d_bwt, po, (uint64_t *)(scr + 2), (uint64_t *)(scr + 3),
-                                                                           1u, h->d_counters, ~0ull, kCalibSpin);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) return e;
-      got = census_read(h, grid, api, st);
-      if (trace) fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d> census: %d of the %d workgroups per CU the occupancy query allows were resident\n",
-                         (int)WIDE, LAYOUT, KT, (int)JT, RW, (int)R3T, got, api);
-      if (got && got == last) rs.admitted.store(got);
-      last = got;
+    if (!forced && !rs.admitted.load() && h->cu_count * api <= (int)kCensusBlocks) {
+      static const bool trace = getenv("FMX_TRACE") != nullptr;
+      // scratch behind the census entries: two zero words (the offsets of one empty pattern) and the two output words
+      unsigned long long *scr = h->d_counters + (kCounterBytes + kCensusBytes) / 8;
+      const PatOff po{(const uint64_t *)scr, 0ull};
+      const int grid = h->cu_count * api;
+      { const hipError_t e0 = hipMemsetAsync(scr, 0, kCalibScratchBytes, st); if (e0 != hipSuccess) return e0; }      // (the offsets MUST be zeros: the kernel reads pat[off])
+      int last = 0, got = 0;
+      for (int attempt = 0; attempt < 4 && !rs.admitted.load(); attempt++) {
+        k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
+                                                                             R3T ? r1 : nullptr, (const uint8_t *)h->d_bwt, po, (uint64_t *)(scr + 2), (uint64_t *)(scr + 3),
+                                                                             1u, h->d_counters, ~0ull, kCalibSpin);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        got = census_read(h, grid, api, st);
+        if (trace) fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d> census: %d of the %d workgroups per CU the occupancy query allows were resident\n",
+                           (int)WIDE, LAYOUT, KT, (int)JT, RW, (int)R3T, got, api);
+        if (got && got == last) rs.admitted.store(got);
+        last = got;
+      }
+      if (!rs.admitted.load()) rs.admitted.store(-1);      // no two agreeing readings (a shared device): the query's answer stands, and is not asked again
     }
-    if (!rs.admitted.load()) rs.admitted.store(-1);      // no two agreeing readings (a shared device): the query's answer stands, and is not asked again
     const int m = rs.admitted.load();
-    h->search_residency.store((uint32_t)(m > 0 ? m : api) | (m > 0 ? 0x100u : 0u));
+    h->search_residency.store(forced ? ((uint32_t)forced | 0x100u) : ((uint32_t)(m > 0 ? m : api) | (m > 0 ? 0x100u : 0u)));
     return hipSuccess;
   }
   const int measured = std::max(0, rs.admitted.load());

@@ -648,6 +648,20 @@ def test_tables_are_built_lazily():
         check_search(hip, orc, pats)
         assert hip.stats()["jump_lookups"] > 0
         hip.close()
+        # one flag per table: prepare(KTAB) alone builds the k-mer table and leaves the row tables to their threshold
+        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+        hip.prepare(ktab=True)
+        check_search(hip, orc, pats)
+        st = hip.stats()
+        assert st["ktab_k"] > 0 and st["jump_bytes"] == 0 and st["row_bytes"] == 0, "prepare(KTAB) made a search build the row tables"
+        hip.close()
+        # ... and the reverse: prepare(JUMP) alone leaves the k-mer table to its threshold of 1024 patterns
+        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+        hip.prepare(ktab=False, jump=True)
+        check_search(hip, orc, pats[:300])
+        st = hip.stats()
+        assert st["ktab_k"] == 0 and st["jump_bytes"] == jump_row_bytes() * orc.n
+        hip.close()
         # "jumps" alone: no three-step table to build from -- eight rank queries per row, same table
         findex_amd.config_set("jump", "jumps")
         hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
@@ -659,6 +673,94 @@ def test_tables_are_built_lazily():
     finally:
         findex_amd.config_set("tables_after", "0")
         findex_amd.config_set("jump", "auto")
+
+
+def test_two_handles_with_their_own_table_policies():
+    """The table policy lives on the handle (round 5; until round 4: process-global atomics, so two handles in one JVM could
+    not differ): fmx_config_set writes the defaults a handle copies at open, fmx_index_config_set changes one handle's own.
+    Two handles on one index, one process: the first with every table off, the second with 11-character entries in pairs;
+    a third, opened afterwards, has the untouched defaults.  Answers are the oracle's on all three."""
+    bwt, eof, counts = synth_bwt(600_000, 1, 20, 15)
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(3)
+    pats = lf_walk_patterns(orc, rng, 2000, 40, 0.2, alphabet=list(range(1, 21)))
+    a = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    b = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    a.config_set("jump", "off")
+    a.config_set("ktab", "off")
+    b.config_set("jump_chars", 11)
+    b.config_set("jump_pairs", "on")
+    for h in (a, b):
+        h.prepare(ktab=True, jump=True)
+    sa, sb = a.stats(), b.stats()
+    assert sa["jump_bytes"] == 0 and sa["row_bytes"] == 0 and sa["ktab_k"] == 0 and sa["tables_held_bytes"] == 0
+    assert sb["jump_bytes"] == 32 * orc.n and sb["jump_chars"] == 11 and sb["row_bytes"] == 8 * orc.n and sb["ktab_k"] > 0
+    assert sb["tables_held_bytes"] >= 40 * orc.n and sb["table_budget_bytes"] == 2**64 - 1
+    c = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)          # the defaults were not touched
+    c.prepare(ktab=True, jump=True)
+    sc = c.stats()
+    assert sc["jump_bytes"] == jump_row_bytes() * orc.n and sc["jump_chars"] == 9 and sc["ktab_k"] > 0
+    for h in (a, b, c):
+        h.stats_reset()
+        check_search(h, orc, pats)
+    assert a.stats()["jump_lookups"] == 0 and a.stats()["ktab_lookups"] == 0
+    assert b.stats()["jump_lookups"] > 0 and c.stats()["jump_lookups"] > 0
+    # a handle's policy can change under it: drop + prepare rebuild by the new one
+    b.drop_tables(jump=True, frontier=False, ktab=True)
+    assert b.stats()["tables_held_bytes"] == 0
+    b.config_set("jump_pairs", "off")
+    b.config_set("jump_chars", 8)
+    b.prepare(ktab=True, jump=True)
+    sb = b.stats()
+    assert sb["jump_bytes"] == 16 * orc.n and sb["jump_chars"] == 8
+    check_search(b, orc, pats)
+    with pytest.raises(findex_amd.FmxError):
+        a.config_set("layout", "bytes")                                # not a per-handle key
+    with pytest.raises(findex_amd.FmxError):
+        a.config_set("jump_chars", 12)
+    for h in (a, b, c):
+        h.close()
+
+
+def test_table_budget_decides_what_is_built():
+    """"table_budget" (round 5): the device bytes ALL derived tables of a handle may hold.  n = 2 000 000, sigma = 20: the
+    k-mer table is 2.7 MB (K = 4), the three-step table 16 MB, the row jump table 32 MB as single entries and 64 MB as
+    pairs.  Budgets that admit everything / single entries only / the three-step table only / the k-mer table only / next to
+    nothing; fmx_prepare_ex and the per-handle key; a fraction.  The handle never holds more than its budget, what is
+    left out is what the header says, and every configuration answers like the oracle."""
+    bwt, eof, counts = synth_bwt(2_000_000, 1, 20, 6)
+    orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+    rng = np.random.default_rng(12)
+    pats = lf_walk_patterns(orc, rng, 1500, 36, 0.2, alphabet=list(range(1, 21)))
+    n = orc.n
+    MB = 1_000_000
+    for budget, want_jump, want_rows, want_k in ((200 * MB, 32 * n, 8 * n, True), (60 * MB, 16 * n, 8 * n, True),
+                                                 (30 * MB, 0, 8 * n, True), (10 * MB, 0, 0, True), (256, 0, 0, False)):      # (256 bytes: not even the 20 one-character entries)
+        hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+        base = hip.stats()["index_bytes"]                                     # the rank dictionary, the BWT bytes, C[], counters
+        hip.config_set("jump_pairs", "on")
+        hip.prepare(ktab=True, jump=True, budget_bytes=budget)              # fmx_prepare_ex
+        st = hip.stats()
+        assert st["table_budget_bytes"] == budget and st["tables_held_bytes"] <= budget, (budget, st["tables_held_bytes"])
+        assert st["jump_bytes"] == want_jump and st["row_bytes"] == want_rows and (st["ktab_k"] > 0) == want_k, (budget, st)
+        assert st["tables_held_bytes"] == st["index_bytes"] - base
+        if st["tables_held_bytes"]:
+            assert st["hbm_free_after_tables"] > 0
+        check_search(hip, orc, pats)
+        hip.nextSubstr_batch(np.arange(5, dtype=np.uint64), 6)                # the select directory is never refused, but it is counted
+        assert hip.stats()["tables_held_bytes"] > st["tables_held_bytes"]
+        hip.close()
+    hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+    hip.config_set("table_budget", "0.0000001")                               # a fraction of the free HBM: ~25 KB here
+    hip.prepare(ktab=True, jump=True)
+    st = hip.stats()
+    assert st["jump_bytes"] == 0 and st["row_bytes"] == 0 and 0 < st["table_budget_bytes"] < MB
+    check_search(hip, orc, pats)
+    hip.config_set("table_budget", "auto")
+    hip.drop_tables(jump=True, frontier=False, ktab=True)
+    hip.prepare(ktab=True, jump=True)
+    assert hip.stats()["jump_bytes"] == jump_row_bytes() * n
+    hip.close()
 
 
 def test_pipelined_host_batch_pageable_and_pinned():
@@ -1764,6 +1866,26 @@ def test_full_size_properties(log2n, extra, sigma):
         assert sum(e - s for s, e in parts) == bnd - a
         srt = sorted(parts)
         assert all(srt[j][1] <= srt[j + 1][0] for j in range(len(srt) - 1))
+    if sigma == 128:
+        # ---- the budget at C3's own size: by default the derived tables take 4 + 32 + 128 GiB beside the
+        # 81 GiB index and leave ~27 GiB of the device; under a budget of 110 GiB the row jump table is built as single
+        # entries (4 + 32 + 64 GiB), a caller allocates 40 GiB afterwards, and the answers are what they were
+        st = hip.stats()
+        assert st["jump_bytes"] == 32 * n and st["row_bytes"] == 8 * n and st["tables_held_bytes"] > 160 << 30
+        hip.drop_tables(jump=True, frontier=True, ktab=True)
+        assert hip.stats()["tables_held_bytes"] == 0
+        hip.prepare(ktab=True, jump=True, budget_bytes=110 << 30)
+        st = hip.stats()
+        assert st["jump_bytes"] == 16 * n and st["row_bytes"] == 8 * n and st["ktab_k"] == 4
+        assert st["tables_held_bytes"] <= 110 << 30 and st["hbm_free_after_tables"] >= 40 << 30, st
+        room = torch.empty(40 << 30, dtype=torch.uint8, device="cuda")
+        room[:: 1 << 20] = 1
+        torch.cuda.synchronize()
+        sp2, ep2 = hip.search_batch(pats.reshape(-1), off)
+        assert np.array_equal(sp2, sp) and np.array_equal(ep2, ep)
+        print("[full_size C3] tables under a 110 GiB budget: %.1f GiB held, built in %.0f ms, %.1f GiB free afterwards"
+              % (st["tables_held_bytes"] / 2**30, st["tables_build_ms"], st["hbm_free_after_tables"] / 2**30))
+        del room
 
 
 @pytest.mark.timeout(900)
@@ -2103,9 +2225,10 @@ def test_parked_walks_flush_inside_the_kernel():
 @pytest.mark.parametrize("layout", ["onehot", "bytes"])
 def test_search_grid_follows_the_residency_census(layout):
     """k_search4's grid is sized by what was resident, not by what the occupancy query answers (fmx_search.hip,
-    Residency): after a few full-size launches of one instantiation the census has confirmed a number -- the query's, or
-    up to two below it -- fmx_stats.search_residency carries it with bit 8 set, and the intervals are what they were
-    before the grid changed (and the oracle's)."""
+    Residency).  Round 5: the census is taken by calibration launches where the tables are built -- fmx_prepare, or (this
+    session: "tables_after" = 0) the handle's first search -- never by a later call: once the first search has returned,
+    fmx_stats.search_residency carries a confirmed number (bit 8) -- the query's, or up to two below it -- every later
+    launch is sized by it, and the intervals are the oracle's."""
     findex_amd.set_layout(layout)
     try:
         bwt, eof, counts = synth_bwt(3_000_000, 97, 120, 17)
@@ -2116,15 +2239,18 @@ def test_search_grid_follows_the_residency_census(layout):
         pats = np.ascontiguousarray(walk[:, ::-1])
         off = np.arange(0, (k + 1) * m, m, dtype=np.uint64)
         first = hip.search_batch(pats.reshape(-1), off)
-        seen = set()
-        for _ in range(8):
+        r0 = hip.stats()["search_residency"]
+        assert r0 & 0x100, "the search that built the tables did not calibrate its kernel: %#x" % r0
+        assert 1 <= (r0 & 0xFF) <= 8
+        for _ in range(4):
             sp, ep = hip.search_batch(pats.reshape(-1), off)
             assert np.array_equal(sp, first[0]) and np.array_equal(ep, first[1])
-            seen.add(hip.stats()["search_residency"])
-        last = hip.stats()["search_residency"]
-        assert last & 0x100, "no census after nine full-size launches: %s" % sorted(seen)
-        asked = max(v & 0xFF for v in seen)
-        assert 1 <= (last & 0xFF) <= 8 and asked - 2 <= (last & 0xFF) <= asked
+            assert hip.stats()["search_residency"] == r0
+        # a second handle of the same shape finds the instantiation calibrated: prepare has nothing to launch
+        hip2 = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+        hip2.prepare(ktab=True, jump=True)
+        assert hip2.stats()["search_residency"] == r0
+        hip2.close()
         orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
         wsp, wep, _ = orc.search_batch(pats[:5000].reshape(-1), off[:5001])
         assert np.array_equal(sp[:5000], wsp) and np.array_equal(ep[:5000], wep)
@@ -2151,37 +2277,50 @@ sp = [torch.zeros(k, dtype=torch.int64, device=dev) for _ in range(3)]
 ep = [torch.zeros(k, dtype=torch.int64, device=dev) for _ in range(3)]
 def search(i):
     hip.search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), sp[i].data_ptr(), ep[i].data_ptr(), k, torch.cuda.current_stream().cuda_stream)
-search(0)                                   # the instantiation's first full-size launch: its census is pending now
-torch.cuda.synchronize()
-assert hip.stats()["search_residency"] & 0x100 == 0
+sys.stderr.flush()
+r0 = hip.stats()["search_residency"]
+assert r0 & 0x100, hex(r0)                  # fmx_prepare calibrated the kernel its tables select: nothing is left for a search to read
+built = hip.stats()["tables_build_ms"]
+print("FIRST-SEARCH follows", file=sys.stderr, flush=True)
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):                   # the stream is being captured: no reading of the census, no synchronisation
-    search(1)
+with torch.cuda.graph(g):                   # the handle's FIRST search, on a stream that is being captured (torch: global mode --
+    search(1)                               # a hipMalloc, a hipMemcpy or a hipStreamSynchronize in here fails the capture)
 for _ in range(2):
     g.replay()
 torch.cuda.synchronize()
+search(0)                                   # the plain call
+torch.cuda.synchronize()
 assert torch.equal(sp[1], sp[0]) and torch.equal(ep[1], ep[0]) and int((sp[0] < ep[0]).sum()) == k
-assert hip.stats()["search_residency"] & 0x100 == 0
-for _ in range(6):                          # plain launches again: now it is taken
+for _ in range(6):
     search(2)
 torch.cuda.synchronize()
 assert torch.equal(sp[2], sp[0]) and torch.equal(ep[2], ep[0])
-r = hip.stats()["search_residency"]
-assert r & 0x100, hex(r)
+st = hip.stats()
+r = st["search_residency"]
+assert r == r0, (hex(r), hex(r0))
+assert st["tables_build_ms"] == built, "a table was built after fmx_prepare"
 print("ok", hex(r))
 """
 
 
 @pytest.mark.parametrize("layout", ["onehot", "bytes"])
 def test_search_inside_a_captured_graph_leaves_the_census_alone(layout):
-    """fmx_search_batch_dev on a stream that is being captured into a graph (a caller's own hipGraph / torch CUDAGraph):
-    the residency census neither reads nor synchronises there -- the capture succeeds, its replays give the intervals of
-    the plain call -- and calibrates from the plain launches that follow.  (A child process: the census is per process.)"""
+    """The header's contract (fmx.h, fmx_prepare): after fmx_prepare the _dev entry points only enqueue work.  A handle's very
+    FIRST fmx_search_batch_dev is made on a stream that is being captured into a torch CUDAGraph (global capture mode: any
+    allocation, synchronous copy or stream synchronisation by this thread fails the capture) -- the capture succeeds, its
+    replays give the intervals of the plain call, the grid is the one fmx_prepare's census confirmed, and no table is
+    built afterwards.  Under FMX_TRACE the library reports every census launch: all of them must precede the first
+    search.  (A child process: the census is per process and instantiation.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _CAPTURE_SCRIPT, root, layout], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+    env = dict(os.environ, FMX_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_SCRIPT, root, layout], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    lines = [ln for ln in r.stderr.splitlines() if "census" in ln or "FIRST-SEARCH" in ln]      # (both on stderr: in order)
+    assert any("census" in ln for ln in lines), "FMX_TRACE shows no census launch at all:\n" + r.stderr
+    first_search = [i for i, ln in enumerate(lines) if "FIRST-SEARCH" in ln][0]
+    assert not any("census" in ln for ln in lines[first_search:]), "a census was read after the first search:\n" + "\n".join(lines)
 
 
 def test_result_groups_of_every_size_are_ordered():

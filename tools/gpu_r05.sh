@@ -1,0 +1,61 @@
+#!/bin/bash
+# round 5's GPU-box sessions, by part:  tools/gpu_r05.sh <tag> <part> [...]     (other parts: tools/gpu_r04.sh)
+#   cold[:wl]     tools/c3_cold.py: per-launch durations of first / replayed / ring / flushed launches (tables on and off)
+#   coldpmc[:wl]  the same under rocprofv3 --pmc, one counter group per pass (never with other traces), labelled per phase
+#   coldtrace     the bench under rocprofv3 --kernel-trace: every k_search4 launch of the session, in order
+#   alloc         tools/ubench/alloc: what device allocation costs by API, chunk size and host threads
+O=gpurun_out/${1:-r05}; mkdir -p $O
+TAG=$1
+shift
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1 || { echo build failed; tail -5 $O/build.log; exit 1; }
+for PART in "$@"; do
+case $PART in
+cold|cold:*)
+  wl=c3; [ "$PART" != cold ] && wl=${PART#cold:}
+  timeout -k 10 400 python tools/c3_cold.py --workload $wl 2>&1 | grep -v amdgpu.ids > $O/${wl}_cold.txt; echo "cold $wl rc=$?"; grep "^SUMMARY" $O/${wl}_cold.txt
+  timeout -k 10 400 python tools/c3_cold.py --workload $wl --tables off 2>&1 | grep -v amdgpu.ids > $O/${wl}_cold_tables_off.txt; echo "cold (tables off) rc=$?"; grep "^SUMMARY" $O/${wl}_cold_tables_off.txt
+  ;;
+coldpmc|coldpmc:*)
+  wl=c3; [ "$PART" != coldpmc ] && wl=${PART#coldpmc:}
+  mkdir -p $O/coldpmc_$wl
+  i=0
+  for grp in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum" \
+             "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
+             "GRBM_GUI_ACTIVE GRBM_UTCL2_BUSY TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum" \
+             "TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_STALL_MISSFIFO_FULL_sum" \
+             "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD"; do
+    i=$((i+1))
+    (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $REPO/$O/coldpmc_$wl/pass$i -- python3 $REPO/tools/c3_cold.py --workload $wl > $REPO/$O/coldpmc_$wl/pass$i.log 2>&1) || echo "pass $i failed: $grp"
+    echo "coldpmc pass $i done: $grp"
+  done
+  python tools/c3_cold_pmc.py $O/coldpmc_$wl $O/${wl}_cold_counters.csv > $O/${wl}_cold_counters.txt 2>&1; cat $O/${wl}_cold_counters.txt
+  rm -rf $O/coldpmc_$wl/pass*/
+  ;;
+coldtrace)
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/trace_bench -- python3 $REPO/bench.py --steps 20 --warmup 5 > $REPO/$O/c3_bench_under_rocprof.json 2> $REPO/$O/c3_bench_under_rocprof.err); echo "rocprof bench exit $?"
+  python - $O <<'PY'
+import csv,glob,sys
+O=sys.argv[1]
+rows=[]
+for f in glob.glob("%s/trace_bench/*/*_kernel_trace.csv"%O):
+    for r in csv.DictReader(open(f)):
+        if "fmx::" in r["Kernel_Name"]: rows.append((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"].split("(")[0].replace("fmx::","").replace("void ","")))
+rows.sort()
+with open(O+"/c3_bench_launches_in_order.txt","w") as fo:
+    fo.write("# every fmx kernel of one `python bench.py --steps 20 --warmup 5` session under rocprofv3 --kernel-trace, in order: start (ms since the first), duration (us), kernel\n")
+    t0=rows[0][0] if rows else 0
+    for s,e,n in rows:
+        if n.startswith(("k_search4","k_lf_walk","k_jump","k_row3","k_ktab","k_occ")): fo.write("%10.3f %9.2f  %s\n"%((s-t0)/1e6,(e-s)/1e3,n[:70]))
+srch=[(e-s)/1e3 for s,e,n in rows if n.startswith("k_search4")]
+print("k_search4 launches:",len(srch)); print(" ".join("%.1f"%x for x in srch))
+PY
+  rm -rf $O/trace_bench
+  ;;
+alloc)
+  hipcc -O2 --offload-arch=gfx950 -o tools/ubench/alloc tools/ubench/alloc.hip -lpthread > $O/alloc_build.log 2>&1 || { echo "alloc build failed"; tail -3 $O/alloc_build.log; }
+  timeout -k 10 500 tools/ubench/alloc > $O/alloc.txt 2>&1; echo "alloc rc=$?"; cat $O/alloc.txt
+  ;;
+*) bash tools/gpu_r04.sh $TAG $PART ;;
+esac
+done

@@ -859,6 +859,10 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
             "ranks_in_group": dist.get_world_size() if use_dist else 1,
             "index_gib": s1["index_bytes"] / 2**30, "index_build_ms": st["build_ms"],
             "tables_build_ms": s1["tables_build_ms"],
+            "tables_alloc_ms": s1["tables_alloc_ms"],
+            "tables_alloc_ms_is": "of tables_build_ms: the time inside hipMalloc -- ~0 when the device's memory has not been held since the box "
+                                  "came up, seconds when a process released it just before (the driver wipes released memory before it "
+                                  "hands it out again: profiles/r05_alloc.md); the rest is the build kernels",
             "tables_build_ms_is": "the k-mer jump table (K = %d), the row jump table (%.1f GiB) and the row table (%.1f GiB), built "
                                   "here by fmx_prepare (by default: when a handle has searched n / 64 patterns): paid once per open on "
                                   "top of index_build_ms; the most a build held at once: %.1f GiB"

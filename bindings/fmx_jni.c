@@ -148,8 +148,9 @@ JNIEXPORT void JNICALL FN(searchBatchFixed0)(JNIEnv *e, jobject self, jlong h, j
   jsize nb = (*e)->GetArrayLength(e, pat);
   if (len <= 0 || nb % len != 0 || (*e)->GetArrayLength(e, out) < 2 * (nb / len)) { rethrow(e, FMX_ERR_ARG); return; }
   jsize k = nb / len;
-  jbyte *p = in_bytes(e, pat, nb);
   jlong *r = malloc(sizeof(jlong) * (size_t)(k > 0 ? 2 * k : 1));
+  if (!r) { rethrow(e, FMX_ERR_NOMEM); return; }      /* before the pattern bytes are copied out of the JVM */
+  jbyte *p = in_bytes(e, pat, nb);
   fmx_search_opts opts = {(uint32_t)len, 0, 0};
   int rc = (p && r) ? fmx_search_batch_ex(H(h), (const uint8_t *)p, 0, (uint64_t *)r, (uint64_t *)r + k, (size_t)k, &opts) : FMX_ERR_NOMEM;
   if (rc == FMX_OK && k > 0) (*e)->SetLongArrayRegion(e, out, 0, 2 * k, r);
@@ -164,8 +165,12 @@ JNIEXPORT void JNICALL FN(searchBatchPackedDirect0)(JNIEnv *e, jobject self, jlo
                                                     jlong escapeCap) {
   uint8_t *p = (*e)->GetDirectBufferAddress(e, pat);
   uint64_t *r = (*e)->GetDirectBufferAddress(e, out);
-  if (!p || !r || k < 0 || len <= 0 || escapeCap < 0 || (*e)->GetDirectBufferCapacity(e, pat) < k * (jlong)len ||
-      (*e)->GetDirectBufferCapacity(e, out) < 8 * (jlong)fmx_packed_words((size_t)k, (size_t)escapeCap)) {
+  /* escapeCap <= k: more escape entries than patterns are never needed -- and it keeps 8 * (k + 1 + 2 * escapeCap) from
+   * wrapping (k * len fits the pattern buffer's jlong capacity, so k < 2^63 / len; 3 k + 1 words then fit 64 bits for any
+   * len >= 1 only below 2^59: checked) */
+  if (!p || !r || k < 0 || len <= 0 || escapeCap < 0 || escapeCap > k || k > ((jlong)1 << 58) ||
+      (*e)->GetDirectBufferCapacity(e, pat) / (jlong)len < k ||
+      (*e)->GetDirectBufferCapacity(e, out) / 8 < (jlong)fmx_packed_words((size_t)k, (size_t)escapeCap)) {
     rethrow(e, FMX_ERR_ARG);
     return;
   }
@@ -406,7 +411,22 @@ JNIEXPORT jint JNICALL FN(calcGapsChain0)(JNIEnv *e, jobject self, jlong h, jbyt
  * the regex frontier's row table (what & 8) now, not at the threshold or at first use */
 JNIEXPORT void JNICALL FN(prepare0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_prepare(H(h), (unsigned)what)); }
 
-/* fmx_drop_tables: free the row tables again (what & 4: J and R3, what & 8: the frontier's) */
+/* fmx_prepare_ex: the same under a budget of device bytes for all derived tables of the handle (0: the handle's own policy) */
+JNIEXPORT void JNICALL FN(prepareEx0)(JNIEnv *e, jobject self, jlong h, jint what, jlong budgetBytes) {
+  rethrow(e, budgetBytes < 0 ? FMX_ERR_ARG : fmx_prepare_ex((fmx_index *)H(h), (unsigned)what, (uint64_t)budgetBytes));
+}
+
+/* fmx_index_config_set: one handle's own table policy ("ktab", "jump", "jump_pairs", "jump_chars", "tables_after", "table_budget") */
+JNIEXPORT void JNICALL FN(indexConfigSet0)(JNIEnv *e, jobject self, jlong h, jstring key, jstring value) {
+  const char *k = (*e)->GetStringUTFChars(e, key, 0);
+  const char *v = (*e)->GetStringUTFChars(e, value, 0);
+  int rc = (k && v) ? fmx_index_config_set((fmx_index *)H(h), k, v) : FMX_ERR_NOMEM;
+  if (v) (*e)->ReleaseStringUTFChars(e, value, v);
+  if (k) (*e)->ReleaseStringUTFChars(e, key, k);
+  rethrow(e, rc);
+}
+
+/* fmx_drop_tables: free derived tables again (what & 1: the k-mer table, what & 4: J and R3, what & 8: the frontier's) */
 JNIEXPORT void JNICALL FN(dropTables0)(JNIEnv *e, jobject self, jlong h, jint what) { rethrow(e, fmx_drop_tables(H(h), (unsigned)what)); }
 
 /* fmx_config_set: process-wide settings ("layout", "checkpoints", "ktab", "jump", "tables_after", "pipeline", "validate", "threads") */

@@ -19,6 +19,7 @@
 package org.fmindex
 
 import java.nio.{ByteBuffer, ByteOrder}
+import java.util.concurrent.atomic.{AtomicBoolean, AtomicLong}
 import org.fmindex.re2.SAResult
 
 object HipFM {
@@ -48,6 +49,8 @@ object HipFM {
   @native def searchBatchPackedDirect0(h: Long, pat: ByteBuffer, len: Int, out: ByteBuffer, k: Long, escapeCap: Long): Unit
   @native def dropTables0(h: Long, what: Int): Unit
   @native def prepare0(h: Long, what: Int): Unit
+  @native def prepareEx0(h: Long, what: Int, budgetBytes: Long): Unit
+  @native def indexConfigSet0(h: Long, key: String, value: String): Unit
   @native def configSet0(key: String, value: String): Unit
   @native def occHost0(h: Long, c: Int, i: Long): Long
   @native def calcGapsChain0(h: Long, text: Array[Byte], from: Int, rank0: Long, lastChar: Int, rklst: Long, ranks: Array[Long]): Int
@@ -69,7 +72,16 @@ object HipFM {
 /** The SuffixAlgo part shared by both searchers: everything is answered by the device through the handle `h`. */
 trait HipSuffixAlgo extends SuffixAlgo {
   import HipFM._
-  protected def h: Long
+  /** The native handle, 0 once closed.  close() and the finalizer both go through `release`, which takes the handle out of
+    * the box exactly once: a caller that closes and is later finalized (or closes twice) reaches fmx_close once, not twice
+    * -- round 4 passed an immutable `h` to close0 from both and freed the index twice inside the JVM. */
+  protected def hbox: AtomicLong
+  protected def h: Long = {
+    val v = hbox.get
+    if (v == 0L) throw new IllegalStateException("HipFM: the index handle is closed")
+    v
+  }
+  private def release(): Unit = { val v = hbox.getAndSet(0L); if (v != 0L) close0(v) }
   lazy val n: Int = n0(h).toInt
   def nLong: Long = n0(h)
   def cf(c: Int): Int = cf0(h, c).toInt
@@ -121,8 +133,8 @@ trait HipSuffixAlgo extends SuffixAlgo {
     List.tabulate(k)(j => (o(2 * j).toInt, o(2 * j + 1).toInt))
   }
 
-  def close(): Unit = close0(h)
-  override def finalize(): Unit = close0(h)
+  def close(): Unit = release()
+  override def finalize(): Unit = release()
 }
 
 /** Same constructor arguments and sibling-file rule as NaiveFMSearcher (bwtmerger.scala:335-338, 17-36); X.fm is not
@@ -130,8 +142,8 @@ trait HipSuffixAlgo extends SuffixAlgo {
 class HipFMSearcher(filename: String, bigEndian: Boolean = true, device: Int = 0)
     extends SuffixWalkingAlgo with HipSuffixAlgo {
   import HipFM._
-  protected val h: Long =
-    open0(BWTTempStorage.genBWTFilename(filename), BWTTempStorage.genAuxFilename(filename), bigEndian, device)
+  protected val hbox =
+    new AtomicLong(open0(BWTTempStorage.genBWTFilename(filename), BWTTempStorage.genAuxFilename(filename), bigEndian, device))
   val K = 256
   lazy val eof: Long = eof0(h)
   def handle: Long = h
@@ -172,6 +184,10 @@ class HipFMSearcher(filename: String, bigEndian: Boolean = true, device: Int = 0
 
   /** Build the derived tables now (fmx_prepare: 1 = k-mer table, 2 = select directory, 4 = the literal search's row tables, 8 = the regex frontier's) / free the row tables. */
   def prepare(what: Int): Unit = prepare0(h, what)
+  /** The same under a budget: at most budgetBytes of device memory for all derived tables of this handle (fmx_prepare_ex). */
+  def prepare(what: Int, budgetBytes: Long): Unit = prepareEx0(h, what, budgetBytes)
+  /** This handle's own table policy (fmx_index_config_set): "ktab", "jump", "jump_pairs", "jump_chars", "tables_after", "table_budget". */
+  def configSet(key: String, value: String): Unit = indexConfigSet0(h, key, value)
   def dropTables(): Unit = dropTables0(h, 4 | 8)
 }
 
@@ -186,14 +202,20 @@ object HipFMSearcher {
     val cnt = words.get(k)
     if (cnt > escapeCap) throw new Exception(cnt + " intervals of 2^24 - 1 rows or more, the escape list holds " + escapeCap)
     var j = 0
-    while (j < cnt) { val q = words.get(k + 1 + 2 * j).toInt; out(q) = (out(q)._1, words.get(k + 2 + 2 * j)); j += 1 }
+    while (j < cnt) {
+      val ql = words.get(k + 1 + 2 * j)            // (checked as a Long: narrowing first would let 2^32 + 3 pass for pattern 3)
+      if (ql < 0L || ql >= k.toLong) throw new Exception("escape entry " + j + " names pattern " + ql + " of " + k)      // fmx_unpack_intervals: FMX_ERR_FORMAT
+      val q = ql.toInt
+      out(q) = (out(q)._1, words.get(k + 2 + 2 * j))
+      j += 1
+    }
     out
   }
 }
 
 /** NaiveBWTSearcher(bwt, bucketStarts, rk0) (findex.scala:459-506): the searcher BWTMerger2.calcGaps uses. */
 class HipBWTSearcher(bwt: Array[Byte], bucketStarts: Array[Long], rk0: Int, device: Int = 0) extends HipSuffixAlgo {
-  protected val h: Long = HipFM.openBlock0(bwt, bucketStarts, rk0, device)
+  protected val hbox = new AtomicLong(HipFM.openBlock0(bwt, bucketStarts, rk0, device))
   val K = bucketStarts.length
   // calcGaps (bwtmerger.scala:981-1023) asks ONE occ at a time, each depending on the last: answered on the host from
   // the library's copy of the dictionary (fmx_occ_host: a count + a scan of < 256 bytes), not by a kernel launch
@@ -273,6 +295,7 @@ class HipRegexBatch(sa: HipFMSearcher, res: Array[String], lineOnly: Boolean = f
   val results: ByteBuffer = HipFMSearcher.pinned(24L * cap)
   val perRegex: ByteBuffer = HipFMSearcher.pinned(4L * math.max(res.length, 1))
   private val status = new Array[Int](1)
+  private val closed = new AtomicBoolean(false)
   var truncated = false
 
   /** Every match of every regex up to maxSteps characters (0 = 4096); returns the number of records in `results`. */
@@ -296,7 +319,7 @@ class HipRegexBatch(sa: HipFMSearcher, res: Array[String], lineOnly: Boolean = f
     lists
   }
 
-  def close(): Unit = {
+  def close(): Unit = if (closed.compareAndSet(false, true)) {      // once
     regexBatchFree0(batch)
     handles.foreach(regexFree0)
     hostFree0(results)

@@ -58,7 +58,7 @@ class fmx_stats_t(ctypes.Structure):
                 ("row_lookups", ctypes.c_uint64), ("row_bytes", ctypes.c_uint64),
                 ("peak_table_build_bytes", ctypes.c_uint64), ("patterns_seen", ctypes.c_uint64),
                 ("tables_held_bytes", ctypes.c_uint64), ("table_budget_bytes", ctypes.c_uint64),
-                ("hbm_free_after_tables", ctypes.c_uint64)]
+                ("hbm_free_after_tables", ctypes.c_uint64), ("tables_alloc_ms", ctypes.c_double)]
 
 
 # name -> (restype, argtypes); every symbol include/fmx.h declares

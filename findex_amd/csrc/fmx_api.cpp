@@ -1284,6 +1284,7 @@ int fmx_stats(const fmx_index *idx, fmx_stats_t *out) {
   out->jump_chars = h->jump_bytes ? h->jump_chars : 0;
   out->build_ms = h->build_ms;
   out->tables_build_ms = h->tables_ms;
+  out->tables_alloc_ms = (double)h->tables_alloc_us.load(std::memory_order_relaxed) * 1e-3;
   out->peak_table_build_bytes = h->peak_table_build_bytes.load(std::memory_order_relaxed);
   out->patterns_seen = h->patterns_seen.load(std::memory_order_relaxed);
   out->tables_held_bytes = h->tables_held.load(std::memory_order_relaxed);

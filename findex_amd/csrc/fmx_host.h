@@ -138,6 +138,7 @@ struct Index {
   mutable std::atomic<bool> prepared_ktab{false}, prepared_rows{false};
   mutable TablePolicy policy;                                   // this handle's own (copied from the defaults at open)
   mutable std::atomic<uint64_t> tables_held{0};                 // device bytes of all derived tables right now (what the budget counts)
+  mutable std::atomic<uint64_t> tables_alloc_us{0};             // of tables_ms: microseconds spent inside hipMalloc for the tables (the driver wiping memory somebody released: profiles/r05_alloc.md)
   mutable std::atomic<uint64_t> hbm_free_after_tables{0};       // hipMemGetInfo's free bytes right after the last table build (0: none built)
   mutable std::atomic<uint64_t> peak_table_build_bytes{0};      // most device memory a table build held at once (table + its scratch)
   // select directory for Psi (fmx_select.hip), built on first use
@@ -176,7 +177,8 @@ bool tables_due(const Index *h, uint64_t k, bool small_table);      // fmx_jump.
 void note_table_build(const Index *h, uint64_t bytes_held);
 // Room for one more derived table of this handle: min(free HBM - margin, what the handle's budget leaves); 0 when hipMemGetInfo fails.
 uint64_t table_room(const Index *h, uint64_t margin);
-void tables_account(const Index *h, int64_t delta);                 // a table of |delta| bytes was built (+) or freed (-)
+void tables_account(const Index *h, int64_t delta);
+hipError_t table_malloc(const Index *h, void **p, size_t bytes);    // hipMalloc for a derived table, its time added to tables_alloc_us                 // a table of |delta| bytes was built (+) or freed (-)
 hipError_t ktab_get(const Index *h, hipStream_t st, KTab *out, bool build = true);     // fmx_ktab.hip
 hipError_t select_prepare(const Index *h, hipStream_t st);          // fmx_select.hip: builds the select directory now
 hipError_t jump_get(const Index *h, hipStream_t st, const uint4 **out, bool build = true);   // fmx_jump.hip (nullptr: the handle has none)

@@ -232,6 +232,12 @@ void tables_account(const Index *h, int64_t delta) {
   if (delta > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) h->hbm_free_after_tables.store(free_b, std::memory_order_relaxed);
   else if (delta > 0) (void)hipGetLastError();
 }
+hipError_t table_malloc(const Index *h, void **p, size_t bytes) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const hipError_t e = hipMalloc(p, bytes);
+  h->tables_alloc_us.fetch_add((uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+  return e;
+}
 uint64_t table_room(const Index *h, uint64_t margin) {
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
@@ -250,7 +256,7 @@ static void build_row_words(const Index *h, hipStream_t st, uint64_t margin, voi
   const uint64_t bytes = h->n * 8;
   if (bytes > table_room(h, margin)) return;
   void *p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
+  hipError_t e = table_malloc(h, &p, bytes);
   if (e == hipSuccess) {
     const uint64_t per_wg = kJThreads / (h->layout == kLayoutBytes ? 8 : 4);
     const int grid = (int)std::min<uint64_t>((h->n + per_wg - 1) / per_wg, (uint64_t)h->cu_count * 8);
@@ -332,7 +338,7 @@ static hipError_t build_jump(const Index *h, hipStream_t st) {
   };
   const uint32_t jc = (uint32_t)std::min(11, std::max(8, h->policy.jump_chars.load(std::memory_order_relaxed)));
   void *a = nullptr;
-  e = hipMalloc(&a, bytes);
+  e = table_malloc(h, &a, bytes);
   if (e != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }      // no table, no error
   mark("allocated");
   {

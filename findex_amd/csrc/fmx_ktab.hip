@@ -92,7 +92,7 @@ static hipError_t build_ktab(const Index *h, hipStream_t st) {
     if (h->slot[c] < kSlotEof) { dense[c] = (uint8_t)h->slot[c]; sym_of[h->slot[c]] = (uint8_t)c; }    // slots number the present symbols densely
   }
   void *d_all = nullptr, *d_dense = nullptr, *d_sym = nullptr;
-  e = hipMalloc(&d_all, all * 16);
+  e = table_malloc(h, &d_all, all * 16);
   if (e == hipSuccess) e = hipMalloc(&d_dense, 256);
   if (e == hipSuccess) e = hipMalloc(&d_sym, 256);
   if (e == hipSuccess) e = hipMemcpyAsync(d_dense, dense, 256, hipMemcpyHostToDevice, st);

@@ -244,7 +244,7 @@ static hipError_t ensure_select(const Index *h, hipStream_t st, SelDir *out) {
     }
     for (uint32_t s = 0; s < h->nslots; s++) off[s + 1] = off[s] + ((totals[s] + ((1ull << shift[s]) - 1)) >> shift[s]) + 1;
     const uint64_t entries = off[h->nslots];
-    hipError_t e = hipMalloc(&h->d_sel_dir, (entries ? entries : 1) * 4 + 16);
+    hipError_t e = table_malloc(h, &h->d_sel_dir, (entries ? entries : 1) * 4 + 16);
     if (e == hipSuccess) e = hipMalloc(&h->d_sel_off, off.size() * 8);
     if (e == hipSuccess) e = hipMalloc(&h->d_sel_shift, shift.size());
     uint64_t *d_tot = nullptr;

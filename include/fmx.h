@@ -531,6 +531,9 @@ typedef struct fmx_stats_t {
   uint64_t tables_held_bytes;   /* device bytes of all derived tables of this handle now (what "table_budget" counts) */
   uint64_t table_budget_bytes;  /* the handle's budget in bytes (a fraction resolved against the HBM free now); ~0: none */
   uint64_t hbm_free_after_tables;   /* free device memory right after the handle's last table build (hipMemGetInfo; 0: none built) */
+  double tables_alloc_ms;       /* of tables_build_ms: the time spent inside hipMalloc for the tables -- ~0 on memory nobody has held
+                                 * since the box came up, 45-60 ms per GiB on memory a process released shortly before (the driver
+                                 * wipes it first: profiles/r05_alloc.md); the rest of tables_build_ms is the build kernels */
 } fmx_stats_t;
 int fmx_stats(const fmx_index *idx, fmx_stats_t *out);
 /* fmx_stats_t.last_kernel_ms alone, without the device synchronisation and counter read-back of fmx_stats. */

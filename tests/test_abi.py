@@ -36,7 +36,7 @@ def test_abi_version_and_device_count():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.fmx_result) == 24
     assert ctypes.sizeof(_lib.fmx_limits) == 24
-    assert ctypes.sizeof(_lib.fmx_stats_t) == 224
+    assert ctypes.sizeof(_lib.fmx_stats_t) == 232
 
 
 def test_open_errors_are_statuses_with_messages(tmp_path, testdata):

@@ -68,3 +68,34 @@ def test_jni_symbol_prefix_matches_the_scala_object():
     assert re.search(r"^package org\.fmindex", src, re.M)
     assert re.search(r"object HipFM\b", src)
     assert "#define FN(name) Java_org_fmindex_HipFM_00024_##name" in open(JNI_C).read()
+
+
+def test_close0_is_reachable_from_exactly_one_guarded_site():
+    """`def close() = close0(h)` and `override def finalize() = close0(h)` on an immutable handle freed an
+    index twice whenever a caller closed and the GC later finalized.  Text-level (no scalac here): besides its @native
+    declaration, close0 is called at ONE place; that place takes the handle out of an AtomicLong with getAndSet(0) and skips
+    0; close() and finalize() both go through it; every other native sees the handle through the accessor that refuses 0."""
+    src = open(SCALA).read()
+    calls = [m.start() for m in re.finditer(r"\bclose0\s*\(", src)]
+    decl = [m.start() for m in re.finditer(r"@native\s+def\s+close0\s*\(", src)]
+    assert len(decl) == 1 and len(calls) == 2, "close0 must be declared once and called once: %d uses" % len(calls)
+    site = src[src.rfind("\n", 0, max(calls)) + 1: src.find("\n", max(calls))]
+    assert "getAndSet(0L)" in site and "!= 0L" in site and "private def release" in site, site
+    assert re.search(r"def close\(\): Unit = release\(\)", src) and re.search(r"override def finalize\(\): Unit = release\(\)", src)
+    assert re.search(r"protected def h: Long = \{\s*val v = hbox\.get\s*if \(v == 0L\) throw", src), "natives must refuse a closed handle"
+    assert "protected val h: Long" not in src, "a searcher keeps its handle in the AtomicLong box, not in an immutable val"
+    # the resident regex batch frees its natives once, too
+    assert re.search(r"def close\(\): Unit = if \(closed\.compareAndSet\(false, true\)\)", src)
+    # and fmx_close(NULL) is a no-op on the C side (tests/test_abi.py::test_config_keys_and_values calls it)
+    api = open(os.path.join(ROOT, "findex_amd", "csrc", "fmx_api.cpp")).read()
+    assert re.search(r"int fmx_close\(fmx_index \*idx\) \{\s*if \(!idx\) return FMX_OK;", api)
+
+
+def test_packed_decode_checks_the_escape_entrys_pattern():
+    """HipFMSearcher.unpack narrowed an escape entry's pattern id with .toInt and indexed with it unchecked; the C
+    decoder answers FMX_ERR_FORMAT there.  The Scala decode now compares the Long with k before narrowing, and the JNI entry
+    point refuses escapeCap > k (which also keeps its capacity arithmetic from wrapping)."""
+    src = open(SCALA).read()
+    assert re.search(r"if \(ql < 0L \|\| ql >= k\.toLong\) throw", src)
+    c = open(JNI_C).read()
+    assert "escapeCap > k" in c and "GetDirectBufferCapacity(e, out) / 8 <" in c

@@ -56,6 +56,16 @@ alloc)
   hipcc -O2 --offload-arch=gfx950 -o tools/ubench/alloc tools/ubench/alloc.hip -lpthread > $O/alloc_build.log 2>&1 || { echo "alloc build failed"; tail -3 $O/alloc_build.log; }
   timeout -k 10 500 tools/ubench/alloc > $O/alloc.txt 2>&1; echo "alloc rc=$?"; cat $O/alloc.txt
   ;;
+abenv:*)
+  # A/B of library variants and environment settings on one box:  abenv:<workload>:<tag>[+VAR=val..],..   ("-" = the product build)
+  spec=${PART#abenv:}; wl=${spec%%:*}; items=${spec#*:}
+  for rep in 1 2; do for it in ${items//,/ }; do
+    tag=${it%%+*}; envs=""; [ "$it" != "$tag" ] && envs=${it#*+} && envs=${envs//+/ }
+    lib=""; [ "$tag" != "-" ] && lib="FMX_LIB=$PWD/findex_amd/lib/variants/libfmx_$tag.so"
+    echo -n "$wl [$it]: "
+    env $lib $envs timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-path --no-rank-only --steps 40 --warmup 5 2>$O/abenv.err | python -c "import json,sys; d=json.load(sys.stdin); print('ms/step %.4f kernel %.4f replayed %.4f req/s %.2f'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['replayed_batch_ms'], d['requests_G_per_s']))" || tail -3 $O/abenv.err
+  done; done
+  ;;
 *) bash tools/gpu_r04.sh $TAG $PART ;;
 esac
 done

@@ -380,25 +380,42 @@ def pmc_traffic(workload, kernel):
 
 # ---------------------------------------------------------------- CPU baselines (the only users of oracle/)
 def oracle_index(torch, bwt_dev, eof, cores, rank):
-    """The oracle's index over the SAME BWT the GPU run uses: bytes copied to the host, symbol counts, inverted
-    position lists (4 bytes per row) sorted on all cores.  None when the host cannot hold it."""
+    """The oracle's index over the SAME BWT the GPU run uses: bytes copied to the host, then
+      - the reference's own structure, inverted position lists (4 bytes per row) sorted on all cores, where it can exist:
+        n <= 2^32 (32-bit entries) and 6 n bytes of host memory;
+      - else BASELINE.md's fallback for large n, symbol checkpoints every 256 positions + a scan of the BWT bytes
+        (oracle.SampledFMSearcher: n + 4 sigma n / 256 bytes -- 48 GiB at C5), which computes the same occ / search
+        (tests/test_oracle_kat.py holds it to the inverted lists) -- `orc.kind` says which.
+    None when the host can hold neither."""
     import oracle
     n = bwt_dev.numel()
-    need = 6 * n + (2 << 30)
     avail = host_mem_available()
-    if n > (1 << 32) or (avail and avail < need):
-        log(rank, "cpu_baseline: n=%d needs %.0f GiB of host memory (%.0f GiB available, lists hold 32-bit entries)"
-            % (n, need / 2**30, avail / 2**30))
-        return None, 0.0
+
+    def to_host():
+        h = np.empty(n, dtype=np.uint8)
+        chunk = 1 << 28
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            h[a:b] = bwt_dev[a:b].cpu().numpy()
+        return h
     t0 = time.time()
-    h_bwt = np.empty(n, dtype=np.uint8)
-    chunk = 1 << 28
-    for a in range(0, n, chunk):
-        b = min(n, a + chunk)
-        h_bwt[a:b] = bwt_dev[a:b].cpu().numpy()
-    counts = oracle.histogram(h_bwt, eof, threads=cores)
-    orc = oracle.NaiveFMSearcher.from_mem(h_bwt, eof, counts, threads=cores)
-    del h_bwt
+    if n <= (1 << 32) and not (avail and avail < 6 * n + (2 << 30)):
+        h_bwt = to_host()
+        counts = oracle.histogram(h_bwt, eof, threads=cores)
+        orc = oracle.NaiveFMSearcher.from_mem(h_bwt, eof, counts, threads=cores)
+        del h_bwt
+        orc.kind = "inverted lists + binary-search occ (the reference's structure, bwtmerger.scala:354-375)"
+        return orc, time.time() - t0
+    need = 3 * n + (2 << 30)          # the bytes + checkpoints of up to 128 symbols (4 * 128 / 256 = 2 bytes per row)
+    if avail and avail < need:
+        log(rank, "cpu_baseline: n=%d needs %.0f GiB of host memory even as checkpoints (%.0f GiB available)" % (n, need / 2**30, avail / 2**30))
+        return None, 0.0
+    h_bwt = to_host()
+    orc = oracle.SampledFMSearcher(h_bwt, eof, threads=cores)
+    orc.kind = ("symbol checkpoints every 256 positions + a scan of the BWT bytes (BASELINE.md's structure for n >= 2^31: the "
+                "reference's 32-bit inverted lists cannot describe 2^%d rows); same occ / search as the lists, %.0f GiB"
+                % (n.bit_length() - 1, (orc.bytes() + n) / 2**30))
+    log(rank, "cpu_baseline: n=%d: checkpoints + BWT bytes on the host (%.0f GiB) in %.1fs" % (n, (orc.bytes() + n) / 2**30, time.time() - t0))
     return orc, time.time() - t0
 
 
@@ -426,8 +443,9 @@ def cpu_baseline_literal(torch, orc, t_build, n, pats, off, sp, ep, sample, m, c
     return {"value": ranks / dt / 1e6, "unit": "M rank-queries/s", "cores": cores, "kind": "port",
             "one_core_value": 2 * int(steps1.sum()) / dt1 / 1e6,
             "patterns_per_s": sample / dt, "index_build_s": t_build, "n": n,
-            "sample": "%s; first %d of the timed batch's %d-char patterns; inverted lists + binary-search occ in C "
-                      "with OpenMP; the GPU's (sp, ep) for them are bit-equal" % (note, sample, m)}
+            "structure": getattr(orc, "kind", "inverted lists + binary-search occ"),
+            "sample": "%s; first %d of the timed batch's %d-char patterns; %s, in C with OpenMP; the GPU's (sp, ep) for them "
+                      "are bit-equal" % (note, sample, m, getattr(orc, "kind", "inverted lists + binary-search occ"))}
 
 
 def cpu_baseline_regex(orc, t_build, n, res, trees, gpu_out, sample, max_len, ref_mode, cores, rank, note):

@@ -35,7 +35,6 @@
 namespace fmx {
 
 constexpr int kSThreads = 256;
-constexpr uint64_t kDeferMark = 1ull << 63;      // ep_out of a pattern parked for k_search_defer (rows are < 2^38)
 
 // Bytes pat[pos-1], pat[pos-2], pat[pos-3], pat[pos-4] in byte lanes 0..3 (fewer when pos < 4).
 __device__ __forceinline__ uint32_t fetch4(const uint8_t *__restrict__ pat, uint64_t pos) {
@@ -88,11 +87,11 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // JT: the handle has a row jump table (fmx_jump.hip): once every stepping group of the wave holds one row, eight steps
 // at a time are ONE 16-byte lookup for every group whose next eight pattern characters are the ones its row's entry
 // names; the others walk those eight steps as before while the ones that jumped wait.
-// RW > 0: the handle has a row table (fmx_jump.hip, row1_get / row3_get): a group whose interval has become ONE ROW parks
-// its pattern -- sp_out = the row, ep_out = kDeferMark | step number -- and k_search_rows (below) finishes it with one
-// LANE per pattern, since from there on a search needs no rank query: this kernel then runs only the k-mer lookup and
-// the few steps on wide intervals.  RW = 1: parked at once; RW = 3 (the table takes three steps per word): parked when
-// the steps left are a multiple of three, after up to two more one-row steps here.
+// RW > 0: the handle has a row table and no row jump table (fmx_jump.hip, row1_get / row3_get): a group whose interval has
+// become ONE ROW hands its pattern to the wave's rows list, and in the wave's next rows phase a LANE finishes it -- from
+// there on a search needs no rank query (rows_phase below; until round 4 a second and a third launch).  RW = 1: handed
+// over at once; RW = 3 (the table takes three steps per word): when the steps left are a multiple of three, after up to
+// two more one-row steps by the group.
 // R3T (with JT): the handle also has the three-step row table (fmx_jump.hip): a one-row group that is not at a chunk
 // boundary, or has fewer than eight characters left, takes three steps with one 8-byte lookup instead of three rank
 // queries -- at C3 the three steps between the wide part of a search and its first aligned jump.
@@ -179,17 +178,33 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
   // row jump table (and no hand-over to k_search_rows) therefore parks them in a list in LDS and walks them densely, a
   // lane group each, when 48 have come together and before the wave ends (walk_parked below) -- round 3 parked them in
   // the output arrays for a second launch, k_search_defer: 26-30 us behind the 150 of this one at C3.
-  constexpr bool kFold = JT && RW == 0u;
-  constexpr uint32_t kParkCap = 64;
+  // Round 5: a kernel WITHOUT a row jump table but with a row table (RW: the three-step table where J does not fit -- C5,
+  // n = 2^34 -- or the frontier's one-step table) finishes every pattern itself too.  Until round 4 it parked a pattern whose
+  // interval had become one row in the OUTPUT arrays and two more launches picked them up (k_search_rows: one lane per
+  // pattern, 64 chains per wave; k_search_defer: the failing step).  Now the wave keeps those patterns in a second list in
+  // LDS and, whenever 64 have come together (eight batches of the bytes layout), turns into what k_search_rows was for
+  // one phase: every LANE walks one pattern through the row table, three (one) steps per 8-byte word; the patterns whose
+  // row disagrees go on to the walk list above and are finished by lane groups.  One launch instead of three (C5: two
+  // launch ramps and tails, and a round trip of the parked state through the output arrays, gone).
+  constexpr bool kFold = (JT && RW == 0u) || RW != 0u;          // the wave has a walk list
+  constexpr uint32_t kParkCap = RW ? 128u : 64u;                // (a rows phase may hand over 64 at once)
   __shared__ uint64_t s_park_row[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
   __shared__ uint32_t s_park_pid[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
   __shared__ uint32_t s_park_it[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
   uint32_t npark = 0;               // entries in this wave's list (wave-uniform)
-  // A pattern's final interval (a group's first lane calls).  pk_cap != ~0 (only a kernel that finishes every pattern
-  // itself is launched that way): straight into the 8-byte form (fmx.h) -- word q of sp_out, wide intervals appended to
-  // the escape list behind word k -- instead of a pass of k_pack_intervals over both arrays behind the search.
+  constexpr uint32_t kRowsCap = 64u + P;                        // the one-row patterns waiting for their lane: a phase starts at 64
+  __shared__ uint64_t s_rows_row[RW ? kSThreads / 64 : 1][RW ? kRowsCap : 1];
+  __shared__ uint64_t s_rows_end[RW ? kSThreads / 64 : 1][RW ? kRowsCap : 1];      // end of the pattern in the pattern buffer
+  __shared__ uint32_t s_rows_pid[RW ? kSThreads / 64 : 1][RW ? kRowsCap : 1];
+  __shared__ uint32_t s_rows_it[RW ? kSThreads / 64 : 1][RW ? kRowsCap : 1];
+  __shared__ uint32_t s_rows_len[RW ? kSThreads / 64 : 1][RW ? kRowsCap : 1];
+  uint32_t nrows = 0;               // entries in it (wave-uniform)
+  uint32_t rsteps = 0, rlooks = 0;  // steps taken and row-table words fetched by this LANE in rows phases
+  // A pattern's final interval (the lane that holds it calls).  pk_cap != ~0: straight into the 8-byte form (fmx.h) -- word
+  // q of sp_out, wide intervals appended to the escape list behind word k -- instead of a pass of k_pack_intervals over
+  // both arrays behind the search (every variant of this kernel finishes all of its patterns itself since round 5).
   auto emit = [&](uint32_t q, uint64_t a, uint64_t b) {
-    if (kFold && pk_cap != ~0ull) {
+    if (pk_cap != ~0ull) {
       unsigned long long *pk = reinterpret_cast<unsigned long long *>(sp_out);
       const uint64_t w = b - a;
       if (w >= kPackWide) {
@@ -345,6 +360,79 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
       if (actw && t == 0) emit(wpid, wsp, wep);
     }
   };
+  // A rows phase (RW kernels): 64 of the waiting one-row patterns (all of them when the wave is about to end), one per LANE.
+  // A one-row search needs no rank query -- it compares the pattern with the text in front of its row's suffix, which the
+  // row table holds: R3[r] = (BWT'[r], BWT'[LF r], BWT'[LF^2 r]; LF^3 r), three steps per 8-byte word (RW = 3; the hand-over
+  // left a multiple of three steps), or R1[r] = (BWT'[r]; LF r), one step per word (RW = 1) -- so it needs no lane group
+  // either: 64 dependent chains per wave where the lane groups keep 8 (16).  A pattern that gets through is finished here;
+  // one whose row disagrees FAILS within the word's steps, and the reference loop's values at the failing step are a rank
+  // query: it goes to the walk list, at the step the word began with, for the lane groups.
+  auto rows_phase = [&](const bool all) {
+    if constexpr (RW != 0u) {
+      while (nrows >= (all ? 1u : 64u)) {                        // wave-uniform
+        const uint32_t take = nrows < 64u ? nrows : 64u;
+        const bool on = lane64 < take;
+        const uint32_t slot = nrows - take + (on ? lane64 : 0u);
+        nrows -= take;
+        uint64_t row = on ? s_rows_row[wave_in_wg][slot] : 0ull;
+        const uint64_t rend = on ? s_rows_end[wave_in_wg][slot] : 0ull;
+        const uint32_t rpid = on ? s_rows_pid[wave_in_wg][slot] : 0u;
+        const uint32_t rlen = on ? s_rows_len[wave_in_wg][slot] : 0u;
+        uint32_t rit = on ? s_rows_it[wave_in_wg][slot] : 0u;
+        bool live = on;
+        while (__builtin_amdgcn_ballot_w64(live)) {
+          const uint32_t rem = rlen - rit;
+          bool fail = false;                                       // this lane's pattern goes to the walk list now
+          if constexpr (RW == 3u) {
+            const bool tm = live && rem >= 3u;
+            unsigned long long re = 0;
+            uint32_t d = 0;
+            if (tm) {                                              // pat[rend - rit - 3 .. rend - rit + 1): inside the pattern (rit >= 1)
+              re = r3tab[row];
+              __builtin_memcpy(&d, pat + (rend - rit - 3), 4);
+            }
+            if (tm && (uint32_t)(re >> 40) == __builtin_bswap32(d << 8)) {
+              rlooks++;
+              row = re & ((1ull << 40) - 1);
+              rit += 3;
+              rsteps += 3;
+            } else if (live) {
+              rlooks += tm ? 1u : 0u;
+              if (rem == 0u) emit(rpid, row, row + 1);             // through
+              else fail = true;                                    // the failing step is within these three (or a tail of one or two)
+              live = false;
+            }
+          } else {
+            const bool rm = live && rem != 0u;
+            unsigned long long re = 0;
+            uint32_t c = 0;
+            if (rm) {
+              re = r3tab[row];                                     // (the one-step table is passed in the same argument)
+              c = pat[rend - rit - 1];
+            }
+            const uint32_t c2 = (uint32_t)(re >> 40) & 0xFFu;
+            if (rm && c == c2 && c2 != 0u) {
+              rlooks++;
+              row = re & ((1ull << 40) - 1);
+              rit++;
+              rsteps++;
+            } else if (live) {
+              rlooks += rm ? 1u : 0u;
+              if (rem == 0u) emit(rpid, row, row + 1);
+              else fail = true;                                    // the failing step (or the end-of-text row): a rank query
+              live = false;
+            }
+          }
+          const unsigned long long fm = __builtin_amdgcn_ballot_w64(fail);
+          if (fm) {
+            const uint32_t ps = npark + (uint32_t)__builtin_popcountll(fm & ((1ull << lane64) - 1ull));
+            if (fail) { s_park_row[wave_in_wg][ps] = row; s_park_pid[wave_in_wg][ps] = rpid; s_park_it[wave_in_wg][ps] = rit; }
+            npark += (uint32_t)__builtin_popcountll(fm);
+          }
+        }
+      }
+    }
+  };
 #ifdef FMX_SEARCHLOG
   sl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -476,14 +564,25 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     }
     uint32_t skip = 0;                                         // steps this group has jumped over and still sits out
     uint32_t cursor_it = KT ? KT : 1u;                         // the step (ch, nx) stand for
-    bool deferred = false;                                     // this group's pattern was parked for k_search_defer
+    bool deferred = false;                                     // this group's pattern was handed on (walk list / rows list)
     for (uint32_t it = KT ? KT : 1u;; it++) {                  // `it` is wave-uniform
       bool alive = it < len && sp < ep;
-      if (RW && alive && (ep - sp) == 1 && (RW == 1u || (len - it) % (RW ? RW : 1u) == 0u)) {      // one row: the rest is k_search_rows'
-        if (t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
-        deferred = true;
-        ep = sp;
-        alive = false;
+      if constexpr (RW != 0u) {      // one row: the rest is a lane's, in the wave's next rows phase
+        const bool hand = alive && (ep - sp) == 1 && (RW == 1u || (len - it) % RW == 0u);
+        const unsigned long long hm = __builtin_amdgcn_ballot_w64(hand && t == 0);
+        if (hm) {
+          const uint32_t slot = nrows + (uint32_t)__builtin_popcountll(hm & ((1ull << lane64) - 1ull));
+          if (hand && t == 0) {
+            s_rows_row[wave_in_wg][slot] = sp; s_rows_end[wave_in_wg][slot] = end; s_rows_pid[wave_in_wg][slot] = pid;
+            s_rows_it[wave_in_wg][slot] = it; s_rows_len[wave_in_wg][slot] = len;
+          }
+          nrows += (uint32_t)__builtin_popcountll(hm);
+        }
+        if (hand) {
+          deferred = true;
+          ep = sp;
+          alive = false;
+        }
       }
       if (!__builtin_amdgcn_ballot_w64(alive)) break;
       // the cursor (`ch`: what is left of the current chunk, `nx`: the next chunk) set for step ni; it is maintained step by
@@ -585,8 +684,8 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
             if (!jumped && width == 1u) {
               // The pattern differs from its one row's text within these characters: it misses, and what is left to find is
               // where -- the reference loop's values at the failing step.  Walking there here would hold up the whole wave
-              // (every lane executes the steps, the groups that jumped wait): the group parks its state in its output
-              // slots and retires; k_search_defer walks the parked patterns of 64 at a time, densely.
+              // (every lane executes the steps, the groups that jumped wait): the group parks its state in the wave's
+              // walk list and retires; walk_parked walks the parked patterns P at a time, densely.
               park_now = true;
               deferred = true;
             }                                                        // (wider and no row agrees: it steps on and ends within jc steps)
@@ -639,14 +738,12 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
       }
       if (JT && __builtin_amdgcn_ballot_w64(park_now)) {
         // (sp is still the row the lookup was made with: a parked group's sp is not touched again)
-        if constexpr (kFold) {
+        if constexpr (kFold) {      // (park_now is only ever set by a table lookup: JT)
           const unsigned long long pm = __builtin_amdgcn_ballot_w64(park_now && t == 0);
           const uint32_t lane64p = threadIdx.x & 63u;
           const uint32_t slot = npark + (uint32_t)__builtin_popcountll(pm & ((1ull << lane64p) - 1ull));
           if (park_now && t == 0) { s_park_row[wave_in_wg][slot] = sp | ((uint64_t)missj << 56); s_park_pid[wave_in_wg][slot] = pid; s_park_it[wave_in_wg][slot] = it + park_ahead; }
           npark += (uint32_t)__builtin_popcountll(pm);
-        } else {
-          if (park_now && t == 0) { sp_out[pid] = sp; ep_out[pid] = kDeferMark | it; }
         }
       }
       if ((JT || R3T) && !__builtin_amdgcn_ballot_w64(alive && skip == 0u && !deferred)) {
@@ -750,17 +847,32 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     } else {
       search_one_batch(std::false_type{});
     }
-    if (kFold && npark > kParkCap - P) walk_parked(std::false_type{});      // room for a whole batch's groups
+    if constexpr (RW != 0u) {
+      if (nrows >= 64u) {
+        if (npark > kParkCap - 64u) walk_parked(std::false_type{});         // room for all a rows phase may hand over
+        rows_phase(false);
+      }
+    } else {
+      if (kFold && npark > kParkCap - P) walk_parked(std::false_type{});    // room for a whole batch's groups
+    }
     cur = nxt_stage;
     par ^= 1u;
     end0 = end1; len0 = len1;
     fix_off((uint64_t)batch + 2ull * nwaves, raw2a, raw2b, end1, len1);
   }
+  if constexpr (RW != 0u) {
+    if (npark > kParkCap - 64u) walk_parked(std::false_type{});
+    rows_phase(true);
+  }
   if (kFold) walk_parked(std::true_type{});
 #ifdef FMX_SEARCHLOG
   const unsigned long long sl_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
-  counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
+  counters_add(counters, (t == 0 ? 2ull * steps : 0ull) + 2ull * rsteps, (t == 0 ? steps : 0u) + rsteps, t == 0 ? reqs : 0u);
+  if (RW) {      // the rows phases' row-table words (counters[11])
+    const unsigned long long rl = wave_sum((unsigned long long)rlooks);
+    if ((threadIdx.x & 63u) == 0 && rl) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 11, rl);
+  }
 #ifdef FMX_SEARCHLOG
   if ((threadIdx.x & 63u) == 0 && wave < (1u << 15)) {
     unsigned long long *e = g_searchlog[wave];
@@ -784,218 +896,6 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     if ((threadIdx.x & 63u) == 0 && lookups)
       atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 11, lookups);
   }
-}
-
-// One-row searches, one LANE per pattern (k_search4<.., RW> parks a pattern as soon as its interval is a single row:
-// sp_out[pid] = the row, ep_out[pid] = kDeferMark | the step number).  From there a search is a comparison of the
-// pattern with the text in front of that row's suffix, and the two derived tables hold that text:
-//     J[r]  = (BWT'[r], BWT'[LF r], .., BWT'[LF^7 r] ; LF^8 r)     16 bytes (fmx_jump.hip), eight steps per lookup
-//     R1[r] = (BWT'[r] ; LF r)                                        8 bytes, one step per lookup
-// Neither needs a lane group (no rank query: nothing to popcount), so each lane walks its own pattern: 64 dependent
-// chains per wave where the lane groups of k_search4 keep 16 (8 in the bytes layout), and a dozen instructions per
-// lookup.  A pattern with eight or more characters left looks its row up in J; if they are not the entry's it fails
-// within these eight and finds where with R1, as does a pattern's tail of fewer than eight.  The step that FAILS is
-// not taken here: the reference loop's values at that step are a rank query (C[c] + rank(c, r) for a c that is not
-// BWT'[r]), so the pattern is parked again, at that step, for k_search_defer's lane groups -- one pattern in ten at C3.
-// MODE 0: R1 only; 1: J and R1; 2: R3, the three-step row table (fmx_jump.hip) -- R3[r] = (BWT'[r], BWT'[LF r], BWT'[LF^2 r] ;
-// LF^3 r) in 8 bytes, three steps per lookup, for an index whose J does not fit; k_search4<.., RW = 3> parks a pattern
-// with a multiple of three steps left, so only patterns that fail are parked again.
-template <int MODE>
-__global__ __launch_bounds__(kSThreads) void k_search_rows(const uint4 *__restrict__ jtab, const uint32_t jc, const unsigned long long *__restrict__ row1,
-                                                            const uint8_t *__restrict__ pat, const PatOff po,
-                                                            uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
-                                                            unsigned long long *__restrict__ counters) {
-  const uint64_t nth = (uint64_t)gridDim.x * kSThreads;
-  uint32_t steps = 0, looks = 0, rlooks = 0;      // lookups in J (counters[10]) and in R1 / R3 (counters[11])
-  for (uint64_t base = (uint64_t)blockIdx.x * kSThreads + (threadIdx.x & ~63u); base < k; base += nth) {      // wave-uniform
-    const uint64_t pid = base + (threadIdx.x & 63u);
-    const bool in = pid < k;
-    const uint64_t e0 = in ? ep_out[pid] : 0ull;
-    bool live = (e0 & kDeferMark) != 0ull;
-    uint64_t row = live ? sp_out[pid] : 0ull;
-    uint32_t it = (uint32_t)e0;
-    uint64_t begin = 0, end = 0;
-    if (live) po.get(pid, begin, end);
-    const uint32_t len = (uint32_t)(end - begin);
-    uint32_t walk = 0;                           // steps still to be walked one by one after a lookup in J that did not agree
-    while (__builtin_amdgcn_ballot_w64(live)) {
-      const uint32_t rem = len - it;
-      if (MODE == 2) {
-        const bool tm = live && rem >= 3u;
-        unsigned long long re = 0;
-        uint32_t d = 0;
-        if (tm) {                                // pat[end - it - 3 .. end - it + 1): inside the pattern (it >= 1)
-          re = row1[row];
-          __builtin_memcpy(&d, pat + (end - it - 3), 4);
-        }
-        if (tm && (uint32_t)(re >> 40) == __builtin_bswap32(d << 8)) {
-          rlooks++;
-          row = re & ((1ull << 40) - 1);
-          it += 3;
-          steps += 3;
-        } else if (live) {
-          rlooks += tm ? 1u : 0u;
-          sp_out[pid] = row;                     // through (rem == 0), or k_search_defer's: the failing step, a tail of one or two
-          ep_out[pid] = rem == 0u ? row + 1 : (kDeferMark | it);
-          live = false;
-        }
-        continue;
-      }
-      const bool jm = MODE == 1 && live && rem >= jc && walk == 0u;
-      const bool rm = live && rem != 0u && !jm;
-      uint4 je = make_uint4(0, 0, 0, 0);
-      uint32_t p0 = 0, p1 = 0, p2 = 0, c = 0;
-      unsigned long long re = 0;
-      if (jm) {                                  // the pattern's next jc (8 .. 11) characters, the first in byte lane 0 of p0
-        je = jtab[row];
-        uint32_t d0, d1;
-        __builtin_memcpy(&d0, pat + (end - it - 4), 4);
-        __builtin_memcpy(&d1, pat + (end - it - 8), 4);
-        p0 = __builtin_bswap32(d0);
-        p1 = __builtin_bswap32(d1);
-        for (uint32_t j = 8; j < jc; j++) p2 |= (uint32_t)pat[end - it - 1 - j] << (8u * (j - 8u));
-      }
-      if (rm) {
-        re = row1[row];
-        c = pat[end - it - 1];
-      }
-      if (jm) {
-        looks++;
-        const uint32_t m2 = jc > 8u ? ((1u << (8u * (jc - 8u))) - 1u) : 0u;
-        const bool agree = je.x == p0 && je.y == p1 && ((je.z ^ p2) & m2) == 0u;
-        const uint64_t rowj = (uint64_t)(je.z >> 24) | ((uint64_t)je.w << 8);      // unconditional: keeps the entry ONE 16-byte load (k_search4)
-        row = agree ? rowj : row;
-        it += agree ? jc : 0u;
-        steps += agree ? jc : 0u;
-        walk = agree ? walk : jc;
-      } else if (rm) {
-        rlooks++;
-        const uint32_t c2 = (uint32_t)(re >> 40) & 0xFFu;
-        if (c == c2 && c2 != 0u) {
-          row = re & ((1ull << 40) - 1);
-          it++;
-          steps++;
-          walk -= walk ? 1u : 0u;
-        } else {                                 // the failing step (or the end-of-text row): a rank query, k_search_defer's
-          sp_out[pid] = row;
-          ep_out[pid] = kDeferMark | it;
-          live = false;
-        }
-      } else if (live) {                         // the pattern is through
-        sp_out[pid] = row;
-        ep_out[pid] = row + 1;
-        live = false;
-      }
-    }
-  }
-  counters_add(counters, 2ull * steps, steps, 0);
-  const unsigned long long lookups = wave_sum((unsigned long long)looks);
-  if ((threadIdx.x & 63u) == 0 && lookups) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 10, lookups);
-  const unsigned long long rlookups = wave_sum((unsigned long long)rlooks);
-  if ((threadIdx.x & 63u) == 0 && rlookups) atomicAdd(counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + 11, rlookups);
-}
-
-// The patterns still parked after that (sp_out[pid] = a row, ep_out[pid] = kDeferMark | the step number): with a row
-// table, the ones k_search_rows left at their failing step; without one, the ones whose lookup in J did not agree in
-// k_search4<.., JT> -- they fail within the next eight steps.  A wave looks at 128 consecutive patterns, hands the
-// parked ones to its lane groups and walks each with ordinary one-row steps until its interval is empty (or, should
-// it not fail after all, to its end), leaving the reference loop's final values and counting its steps.  One pattern
-// in ten is parked at C3, so a wave walks ~6 of them at once where the search kernel would have made 64 lanes execute
-// the steps of one or two.
-template <bool WIDE, uint32_t LAYOUT>
-__global__ __launch_bounds__(kSThreads) void k_search_defer(DevIndex ix, const uint8_t *__restrict__ pat, const PatOff po,
-                                                             uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out, uint32_t k,
-                                                             unsigned long long *__restrict__ counters) {
-  constexpr int G = Lay<LAYOUT>::G;
-  constexpr uint32_t P = 64 / G;
-  constexpr uint32_t R = LAYOUT == kLayoutBytes ? 2u : 1u;
-  __shared__ uint4 s_tab[256];
-  for (int c = threadIdx.x; c < 256; c += blockDim.x) {
-    const uint64_t cf = ix.cf[c];
-    const uint16_t s = ix.slot[c];
-    uint64_t vb = 0;
-    if (s < kSlotEof) vb = LAYOUT == kLayoutBytes ? (uint64_t)s + 2 : (uint64_t)(uintptr_t)ix.bv + (uint64_t)s * ix.nblocks * kBlockBytes;
-    else if (s == kSlotEof) vb = 1;
-    s_tab[c] = make_uint4((uint32_t)cf, (uint32_t)(cf >> 32), (uint32_t)vb, (uint32_t)(vb >> 32));
-  }
-  __syncthreads();
-  const LaneConst lc = lane_const<G>();
-  const uint32_t t = lc.t, lane = threadIdx.x & 63u, grp = lane / G;
-  const uint32_t lane_off = t * 16;
-  const uint32_t wave = (blockIdx.x * kSThreads + threadIdx.x) >> 6, nwaves = gridDim.x * (kSThreads / 64);
-  uint32_t steps = 0, reqs = 0;
-  // 128 patterns per look: with one pattern in ten parked that fills most of a wave's lane groups, and the walks are
-  // chains of dependent requests -- the fewer rounds of them, the sooner the launch ends
-  for (uint64_t base = (uint64_t)wave * 128; base < k; base += (uint64_t)nwaves * 128) {
-    const uint64_t mine = base + lane;
-    const uint64_t e0 = mine < k ? ep_out[mine] : 0ull, e1 = mine + 64 < k ? ep_out[mine + 64] : 0ull;
-    unsigned long long m0 = __builtin_amdgcn_ballot_w64((e0 & kDeferMark) != 0ull);
-    unsigned long long m1 = __builtin_amdgcn_ballot_w64((e1 & kDeferMark) != 0ull);
-    while (m0 | m1) {
-      uint32_t pick = 128;                       // the grp-th parked pattern of this round
-      for (uint32_t j = 0; j < P && (m0 | m1); j++) {
-        uint32_t b;
-        if (m0) { b = (uint32_t)__builtin_ctzll(m0); m0 &= m0 - 1; }
-        else { b = 64u + (uint32_t)__builtin_ctzll(m1); m1 &= m1 - 1; }
-        if (grp == j) pick = b;
-      }
-      const bool act = pick < 128u;
-      const uint64_t pid = base + (act ? pick : 0u);
-      uint64_t sp = act ? sp_out[pid] : 0ull, ep = sp + (act ? 1u : 0u);
-      uint32_t it = act ? (uint32_t)ep_out[pid] : 0u;
-      uint64_t begin = 0, end = 0;
-      if (act) po.get(pid, begin, end);
-      const uint32_t len = (uint32_t)(end - begin);
-      for (;;) {                                 // eight steps at a time
-        const uint32_t rem = len - it;
-        if (!__builtin_amdgcn_ballot_w64(act && sp < ep && rem != 0u)) break;
-        const uint32_t nst = rem < 8u ? rem : 8u;
-        uint64_t chars = 0;                      // the next nst characters, the one of step `it` in the low byte
-        if (act && sp < ep) {
-          if (nst == 8u) {
-            uint32_t lo, hi;
-            __builtin_memcpy(&lo, pat + (end - it - 8), 4);
-            __builtin_memcpy(&hi, pat + (end - it - 4), 4);
-            chars = ((uint64_t)__builtin_bswap32(lo) << 32) | __builtin_bswap32(hi);
-          } else {
-            for (uint32_t s = 0; s < nst; s++) chars |= (uint64_t)pat[end - it - 1 - s] << (8u * s);
-          }
-        }
-        for (uint32_t s = 0; s < 8; s++) {
-          const bool stepping = act && sp < ep && s < nst;
-          if (!__builtin_amdgcn_ballot_w64(stepping)) break;
-          if (stepping) {
-            const uint32_t c = (uint32_t)(chars >> (8u * s)) & 0xFFu;
-            const uint4 en = s_tab[c];
-            const uint64_t cfc = ((uint64_t)en.y << 32) | en.x;
-            const uint64_t vb = ((uint64_t)en.w << 32) | en.z;
-            if (vb > 1) {
-              if (LAYOUT == kLayoutBytes) {
-                const ByteRankReq q1 = byte_rank_issue(ix, (uint16_t)(vb - 2), sp, lc);
-                sp = cfc + byte_rank_finish(q1, c, lc);
-                ep = sp + byte_match_bit(q1, c, lc);
-              } else {
-                uint32_t b1, m1;
-                split448(sp, b1, m1);
-                const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
-                sp = cfc + rank_finish<WIDE>(w1, m1, lc);
-                ep = sp + payload_bit(w1, m1, lc);
-              }
-              reqs += R;
-            } else {
-              const uint64_t r1 = cfc + ((vb == 1 && sp > ix.eof) ? 1u : 0u);
-              ep = cfc + ((vb == 1 && ep > ix.eof) ? 1u : 0u);
-              sp = r1;
-            }
-            steps++;
-          }
-        }
-        it += nst;                               // (meaningless once the interval is empty: the loop ends then)
-      }
-      if (act && t == 0) { sp_out[pid] = sp; ep_out[pid] = ep; }
-    }
-  }
-  counters_add(counters, t == 0 ? 2ull * steps : 0ull, t == 0 ? steps : 0u, t == 0 ? reqs : 0u);
 }
 
 hipError_t launch_search_v1(const Index *h, const void *d_pat, PatOff po, void *d_sp, void *d_ep, uint64_t k,
@@ -1079,7 +979,7 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
       int last = 0, got = 0;
       for (int attempt = 0; attempt < 4 && !rs.admitted.load(); attempt++) {
         k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
-                                                                             R3T ? r1 : nullptr, (const uint8_t *)h->d_bwt, po, (uint64_t *)(scr + 2), (uint64_t *)(scr + 3),
+                                                                             (R3T || RW) ? r1 : nullptr, (const uint8_t *)h->d_bwt, po, (uint64_t *)(scr + 2), (uint64_t *)(scr + 3),
                                                                              1u, h->d_counters, ~0ull, kCalibSpin);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -1101,25 +1001,11 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   uint64_t cap = (uint64_t)h->cu_count * per_cu;
   int grid = (int)(want < cap ? (want ? want : 1) : cap);
   h->search_residency.store((uint32_t)per_cu | ((forced || measured) ? 0x100u : 0u));
+  // ONE launch in every configuration (round 5: the kernels without a row jump table used to be followed by k_search_rows and
+  // k_search_defer); the 8-byte form, where asked for, is written by the kernel itself
   k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
-                                                                       R3T ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters,
-                                                                       (JT && RW == 0u) ? pk_cap : ~0ull, 0u);
-  if (RW) {     // the one-row part of every search, a lane per pattern
-    const uint64_t wg = ((uint64_t)k + kSThreads - 1) / kSThreads;
-    const int g1 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 32);
-    if (RW == 3) k_search_rows<2><<<g1, kSThreads, 0, st>>>(nullptr, 0u, r1, pat, off, sp, ep, k, h->d_counters);
-    else if (jt) k_search_rows<1><<<g1, kSThreads, 0, st>>>(jt, h->jump_chars, r1, pat, off, sp, ep, k, h->d_counters);
-    else k_search_rows<0><<<g1, kSThreads, 0, st>>>(nullptr, 0u, r1, pat, off, sp, ep, k, h->d_counters);
-  }
-  if (RW) {     // the patterns k_search_rows left at their failing step (it reads the batch's ep_out once: 8 bytes per pattern; no state shared between calls)
-    const uint64_t wg = ((uint64_t)k + 2 * kSThreads - 1) / (2 * kSThreads);       // a wave looks at 128 patterns
-    const int g2 = (int)std::min<uint64_t>(wg ? wg : 1, (uint64_t)h->cu_count * 8);
-    k_search_defer<WIDE, LAYOUT><<<g2, kSThreads, 0, st>>>(h->dev, pat, off, sp, ep, k, h->d_counters);
-  }
-  hipError_t e = hipGetLastError();
-  // the 8-byte form was asked for and this set of kernels leaves (sp, ep): packed in place behind them
-  if (e == hipSuccess && pk_cap != ~0ull && !(JT && RW == 0u)) e = launch_pack_intervals(h, sp, ep, k, pk_cap, sp, st);
-  return e;
+                                                                       (R3T || RW) ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters, pk_cap, 0u);
+  return hipGetLastError();
 }
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
 static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,

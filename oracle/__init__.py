@@ -97,6 +97,16 @@ def lib():
     L.orc_occ_chain.argtypes = [vp, vp, u64, i64, vp]
     L.orc_match_sa_batch_ordered.restype = i64
     L.orc_match_sa_batch_ordered.argtypes = L.orc_match_sa_batch.argtypes
+    L.orc_sampled_open.restype = vp
+    L.orc_sampled_open.argtypes = [vp, u64, u64, i32, P(i32)]
+    L.orc_sampled_close.argtypes = [vp]
+    L.orc_sampled_bytes.restype = u64
+    L.orc_sampled_bytes.argtypes = [vp]
+    L.orc_sampled_occ.restype = i64
+    L.orc_sampled_occ.argtypes = [vp, i32, i64]
+    L.orc_sampled_cf.restype = i64
+    L.orc_sampled_cf.argtypes = [vp, i32]
+    L.orc_sampled_search_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp, i32]
     _lib = L
     return L
 
@@ -400,6 +410,53 @@ class NaiveFMSearcher:
         out["sp"] = out_sp[:got]
         out["ep"] = out_ep[:got]
         return out, int(pops.value), int(trunc.value)
+
+
+class SampledFMSearcher:
+    """occ / cf / search over per-256-position symbol checkpoints + a scan of the BWT bytes (fmx_oracle.c, "Sampled-checkpoint
+    variant"): the CPU baseline for indexes the inverted lists cannot describe (n > 2^32, or no 6 n bytes of host memory) --
+    BASELINE.md's "sampled popcount structure".  Same function as NaiveFMSearcher.occ / .search, another data structure;
+    held to it by tests/test_oracle_kat.py.  The BWT array is NOT copied: keep it alive."""
+
+    def __init__(self, bwt, eof, threads=1):
+        self._L = lib()
+        self._bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+        err = ctypes.c_int(0)
+        self._h = self._L.orc_sampled_open(_ptr(self._bwt), self._bwt.size, int(eof), int(threads), ctypes.byref(err))
+        if not self._h:
+            raise OracleError("orc_sampled_open failed (%d)" % err.value)
+        self.n = int(self._bwt.size)
+        self.eof = int(eof)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orc_sampled_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bytes(self):
+        return int(self._L.orc_sampled_bytes(self._h))
+
+    def cf(self, c):
+        return int(self._L.orc_sampled_cf(self._h, int(c)))
+
+    def occ(self, c, i):
+        return int(self._L.orc_sampled_occ(self._h, int(c), int(i)))
+
+    def search_batch(self, pat, off, threads=1):
+        pat = np.ascontiguousarray(pat, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        k = off.size - 1
+        sp = np.zeros(k, dtype=np.uint64)
+        ep = np.zeros(k, dtype=np.uint64)
+        steps = np.zeros(k, dtype=np.uint32)
+        self._L.orc_sampled_search_batch(self._h, _ptr(pat), _ptr(off), k, _ptr(sp), _ptr(ep), _ptr(steps), int(threads))
+        return sp, ep, steps
 
 
 class SAISNaiveSearcher(NaiveFMSearcher):

@@ -673,3 +673,134 @@ int64_t orc_match_sa_batch_ordered(const orc_index *ix, int64_t k, const int64_t
                              max_iterations, max_len, threads, res_start, out_len, out_sp, out_ep, cap, pops_total,
                              n_truncated, 0);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Sampled-checkpoint variant of occ, for indexes the inverted lists cannot describe (n > 2^32: uint32 entries; or 6 n bytes
+ * of host memory that are not there).  BASELINE.md ("CPU-baseline plan", n >= 2^31): "if host RAM cannot hold it, the CPU
+ * baseline switches to a sampled popcount structure and the report says so".  NOT the reference's data structure -- the
+ * reference binary-searches the .fm lists (F/bwtmerger.scala:354-375) -- but the same function: occ(c, i) = #{p <= i :
+ * BWT'[p] == c} with BWT' = the BWT with slot eof read as symbol 0, cf(c) = NaiveFMSearcher.bucketStarts (:346-350), and the
+ * reference's own search loop on top (F/findex.scala:15-31).  tests/test_oracle_kat.py holds it to the inverted-list oracle
+ * on every fixture file and on random indexes.
+ *   chk[b * nslots + s] = occurrences of the s-th present symbol in BWT'[0 .. 256 b)          (uint32: every count < 2^32)
+ *   occ(c, i) = chk[(i + 1) / 256][slot(c)] + #{p in [256 * ((i + 1) / 256), i] : BWT'[p] == c}
+ * 4 * nslots / 256 bytes per row beside the BWT itself: n = 2^34, sigma = 128 -> 32 GiB + 16 GiB. */
+typedef struct orc_sampled {
+  uint64_t n, eof, nblocks;
+  const uint8_t *bwt;        /* the caller's bytes (kept alive by the caller); slot eof is read as 0 */
+  uint32_t nslots;
+  int16_t slot[ALPHA_SIZE];  /* symbol -> dense slot, -1: does not occur */
+  uint64_t bs[ALPHA_SIZE];   /* bucketStarts, F/bwtmerger.scala:346-350 */
+  uint32_t *chk;
+} orc_sampled;
+
+void orc_sampled_close(orc_sampled *s) {
+  if (!s) return;
+  free(s->chk);
+  free(s);
+}
+
+orc_sampled *orc_sampled_open(const uint8_t *bwt, uint64_t n, uint64_t eof, int threads, int *err) {
+  *err = ORC_OK;
+  if (n < 1 || eof >= n) { *err = ORC_ERR_RANGE; return NULL; }
+  orc_sampled *s = calloc(1, sizeof *s);
+  if (!s) { *err = ORC_ERR_NOMEM; return NULL; }
+  s->n = n; s->eof = eof; s->bwt = bwt;
+  s->nblocks = n / 256 + 1;
+  /* pass 1: per-chunk histograms of BWT' (the chunks are whole blocks) */
+  const uint64_t chunk_blocks = 1u << 12;                       /* 1 Mi positions per chunk */
+  const uint64_t nchunks = (s->nblocks + chunk_blocks - 1) / chunk_blocks;
+  uint64_t *hist = calloc(nchunks * ALPHA_SIZE, sizeof(uint64_t));
+  if (!hist) { orc_sampled_close(s); *err = ORC_ERR_NOMEM; return NULL; }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 0 ? threads : 1)
+#endif
+  for (int64_t ch = 0; ch < (int64_t)nchunks; ch++) {
+    uint64_t a = (uint64_t)ch * chunk_blocks * 256, b = a + chunk_blocks * 256;
+    if (b > n) b = n;
+    uint64_t *h = hist + (uint64_t)ch * ALPHA_SIZE;
+    for (uint64_t p = a; p < b; p++) h[p == eof ? 0 : bwt[p]]++;
+  }
+  int64_t total[ALPHA_SIZE];
+  memset(total, 0, sizeof total);
+  for (uint64_t ch = 0; ch < nchunks; ch++)
+    for (int c = 0; c < ALPHA_SIZE; c++) total[c] += (int64_t)hist[ch * ALPHA_SIZE + c];
+  for (int c = 0; c < ALPHA_SIZE; c++) {
+    s->slot[c] = -1;
+    if (total[c] > 0) {
+      if ((uint64_t)total[c] >= (1ull << 32)) { free(hist); orc_sampled_close(s); *err = ORC_ERR_RANGE; return NULL; }
+      s->slot[c] = (int16_t)s->nslots++;
+    }
+  }
+  {   /* bucketStarts = c2bs(aux with c(0) := 1): cf(0) = 0, cf(c) = 1 + sum_{1 <= j < c} aux[j]; aux = the counts without the EOF symbol */
+    int64_t aux[ALPHA_SIZE];
+    for (int c = 0; c < ALPHA_SIZE; c++) aux[c] = total[c];
+    aux[0] = 1;
+    c2bs(aux, s->bs);
+  }
+  s->chk = malloc(s->nblocks * (uint64_t)s->nslots * sizeof(uint32_t));
+  if (!s->chk) { free(hist); orc_sampled_close(s); *err = ORC_ERR_NOMEM; return NULL; }
+  /* chunk prefix sums, then pass 2: every chunk fills its blocks' checkpoints from its own start */
+  uint64_t run[ALPHA_SIZE];
+  memset(run, 0, sizeof run);
+  for (uint64_t ch = 0; ch < nchunks; ch++)
+    for (int c = 0; c < ALPHA_SIZE; c++) { const uint64_t v = hist[ch * ALPHA_SIZE + c]; hist[ch * ALPHA_SIZE + c] = run[c]; run[c] += v; }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 0 ? threads : 1)
+#endif
+  for (int64_t ch = 0; ch < (int64_t)nchunks; ch++) {
+    uint32_t cnt[ALPHA_SIZE];
+    for (int c = 0; c < ALPHA_SIZE; c++) cnt[c] = (uint32_t)hist[(uint64_t)ch * ALPHA_SIZE + c];
+    uint64_t b0 = (uint64_t)ch * chunk_blocks, b1 = b0 + chunk_blocks;
+    if (b1 > s->nblocks) b1 = s->nblocks;
+    for (uint64_t b = b0; b < b1; b++) {
+      uint32_t *row = s->chk + b * s->nslots;
+      for (int c = 0; c < ALPHA_SIZE; c++) if (s->slot[c] >= 0) row[s->slot[c]] = cnt[c];
+      uint64_t a = b * 256, e = a + 256;
+      if (e > n) e = n;
+      for (uint64_t p = a; p < e; p++) cnt[p == eof ? 0 : bwt[p]]++;
+    }
+  }
+  free(hist);
+  return s;
+}
+
+uint64_t orc_sampled_bytes(const orc_sampled *s) { return s->nblocks * (uint64_t)s->nslots * sizeof(uint32_t); }
+
+/* NaiveFMSearcher.occ's VALUE (F/bwtmerger.scala:354-375): #{p <= key : BWT'[p] == c}; key < 0 -> 0, key >= n clamps */
+static int64_t sampled_occ(const orc_sampled *s, int c, int64_t key) {
+  if (key < 0 || s->slot[c] < 0) return 0;
+  uint64_t x = (uint64_t)key + 1;                 /* positions [0, x) */
+  if (x > s->n) x = s->n;
+  const uint64_t b = x >> 8;
+  int64_t r = s->chk[b * s->nslots + (uint32_t)s->slot[c]];
+  for (uint64_t p = b << 8; p < x; p++) r += (p == s->eof ? 0 : s->bwt[p]) == c;
+  return r;
+}
+int64_t orc_sampled_occ(const orc_sampled *s, int c, int64_t key) { return (c < 0 || c > 255) ? ORC_ERR_INDEX : sampled_occ(s, c, key); }
+int64_t orc_sampled_cf(const orc_sampled *s, int c) { return (c < 0 || c > 255) ? ORC_ERR_INDEX : (int64_t)s->bs[c]; }
+
+/* SuffixAlgo.search, F/findex.scala:15-31, over the sampled occ (bytes read unsigned, like orc_search with strict_signed = 0) */
+int orc_sampled_search_batch(const orc_sampled *s, const uint8_t *pat, const uint64_t *off, uint64_t k,
+                             uint64_t *sp_out, uint64_t *ep_out, uint32_t *steps, int threads) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(threads > 0 ? threads : 1)
+#endif
+  for (int64_t q = 0; q < (int64_t)k; q++) {
+    const uint8_t *in = pat + off[q];
+    int64_t sp = 0, ep = (int64_t)s->n, i = (int64_t)(off[q + 1] - off[q]) - 1;
+    uint32_t st = 0;
+    while (sp < ep && i >= 0) {
+      const int c = in[i];
+      i -= 1;
+      const int64_t nsp = (int64_t)s->bs[c] + sampled_occ(s, c, sp - 1);
+      const int64_t nep = (int64_t)s->bs[c] + sampled_occ(s, c, ep - 1);
+      sp = nsp; ep = nep;
+      st++;
+    }
+    sp_out[q] = (uint64_t)sp; ep_out[q] = (uint64_t)ep;
+    if (steps) steps[q] = st;
+  }
+  (void)threads;
+  return ORC_OK;
+}

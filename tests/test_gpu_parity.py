@@ -1707,6 +1707,13 @@ def test_bytes_layout_c5_shape(checkpoints):
     assert int(col.sum()) == n
     for i in (0, eof, (1 << 33) + 7):
         assert int(hip.occ_batch(np.arange(0, 129, dtype=np.uint8), np.full(129, i, dtype=np.int64)).sum()) == i + 1
+    # the CPU oracle at this size: the sampled-checkpoint structure over this very BWT (the inverted lists stop at 2^32
+    # rows; oracle.SampledFMSearcher computes the same occ / search: tests/test_oracle_kat.py) -- 48 GiB of host memory, once
+    orc = None
+    if checkpoints == "auto":
+        import bench
+        orc, t_orc = bench.oracle_index(torch, bwt, eof, bench.effective_cores(), 0)
+        print("[c5_shape] oracle on the run's own index: %s, %.0fs" % (getattr(orc, "kind", None), t_orc))
     del bwt
     k, m = 1_000_000, 24
     rows = rng.integers(0, n, k).astype(np.uint64)
@@ -1733,6 +1740,17 @@ def test_bytes_layout_c5_shape(checkpoints):
     wsp, wep, wsteps = reference_loop_by_prev_range(hip, inalpha)
     assert np.array_equal(isp, wsp) and np.array_equal(iep, wep) and isteps == int(wsteps.sum())
     assert int((wsp == wep).sum()) > 90_000 and int((wsp[wsp == wep] > np.uint64(1 << 32)).sum()) > 50_000
+    if orc is not None:      # ... and bit for bit against the oracle: 100k hits, the 100k in-alphabet misses, random occ operands
+        import bench
+        cores = bench.effective_cores()
+        osp, oep, ost = orc.search_batch(inalpha.reshape(-1), off[:100_001], threads=cores)
+        assert np.array_equal(isp, osp) and np.array_equal(iep, oep) and isteps == int(ost.sum())
+        osp, oep, ost = orc.search_batch(pats[:100_000].reshape(-1), off[:100_001], threads=cores)
+        assert np.array_equal(sp[:100_000], osp) and np.array_equal(ep[:100_000], oep) and int(ost.sum()) == 100_000 * m
+        qc = rng.integers(0, 130, 2000).astype(np.uint8)
+        qi = np.concatenate([rng.integers(-1, n, 1990), [-1, 0, eof, (1 << 32) - 1, 1 << 32, (1 << 33) + 5, n - 2, n - 1, n, n + 9]]).astype(np.int64)
+        assert hip.occ_batch(qc, qi).astype(np.int64).tolist() == [orc.occ(int(c), int(i)) for c, i in zip(qc, qi)]
+        orc.close()
     # the same patterns cut into ragged pieces: a prefix of a hit pattern hits an interval that contains the full hit
     cut = rng.integers(1, m + 1, 100_000)
     pieces = [pats[j, :cut[j]].tobytes() for j in range(100_000)]

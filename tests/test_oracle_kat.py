@@ -218,3 +218,50 @@ def test_occ_matches_bruteforce_random():
         c = int(rng.integers(0, 7))
         i = int(rng.integers(-1, 5000))
         assert sa.occ(c, i) == int((b2[: i + 1] == c).sum())
+
+
+def test_sampled_checkpoint_oracle_equals_the_inverted_lists(testdata):
+    """The CPU baseline's second structure (oracle.SampledFMSearcher: symbol checkpoints every 256 positions + a scan of the
+    BWT bytes -- BASELINE.md's "sampled popcount structure" for n >= 2^31, where the 32-bit inverted lists stop) computes
+    the same cf / occ / search as the restatement of NaiveFMSearcher that the reference's vectors pin: on every fixture
+    file, on block edges, with bytes >= 0x80, at the EOF row, and on random indexes."""
+    import glob
+    rng = np.random.default_rng(20)
+    cases = []
+    for f in sorted(glob.glob(os.path.join(testdata, "*.bwt"))):
+        be = os.path.basename(f) == "words.bwt"
+        bwt, _, eof = oracle.load_bwt_file(f, bigEndian=be)
+        cases.append((os.path.basename(f), np.array(bwt, dtype=np.uint8), eof))
+    assert len(cases) >= 7
+    for n, lo, hi in ((1, 1, 1), (255, 1, 2), (256, 1, 2), (257, 1, 2), (5000, 1, 255), (70001, 97, 122), (3000, 200, 255)):
+        cases.append(("random n=%d" % n, rng.integers(lo, hi + 1, n).astype(np.uint8), int(rng.integers(0, n))))
+    for name, bwt, eof in cases:
+        n = bwt.size
+        counts = oracle.histogram(bwt, eof)
+        a = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+        b = oracle.SampledFMSearcher(bwt, eof, threads=2)
+        syms = sorted(set(int(c) for c in np.unique(bwt)) | {0, 1, 255})
+        for c in syms:
+            assert a.cf(c) == b.cf(c), (name, c)
+        keys = np.unique(np.clip(np.concatenate([[-1, 0, 1, eof - 1, eof, eof + 1, n - 2, n - 1, n, n + 7, 254, 255, 256, 257, 511, 512],
+                                                 rng.integers(-1, n + 2, 300)]), -1, n + 7))
+        for c in syms[:12] + syms[-3:]:
+            for i in keys:
+                assert a.occ(c, int(i)) == b.occ(c, int(i)), (name, c, int(i))
+        # patterns: stretches the LF walk reads (hits) and random ones
+        pats = []
+        for _ in range(200):
+            r, m, s = int(rng.integers(0, n)), int(rng.integers(0, 9)), []
+            for _ in range(m):
+                c = a.bwt_read(r)
+                s.append(c)
+                r = a.getPrevI(r)
+            pats.append(bytes(reversed(s)))
+        pats += [bytes(rng.choice(syms, size=int(rng.integers(1, 5))).astype(np.uint8)) for _ in range(200)]
+        buf = np.frombuffer(b"".join(pats), dtype=np.uint8)
+        off = np.concatenate([[0], np.cumsum([len(p) for p in pats])]).astype(np.uint64)
+        wsp, wep, wst = a.search_batch(buf, off)
+        gsp, gep, gst = b.search_batch(buf, off, threads=3)
+        assert np.array_equal(wsp, gsp) and np.array_equal(wep, gep) and np.array_equal(wst, gst), name
+        assert int((wsp < wep).sum()) > 50, name
+        b.close()

@@ -728,6 +728,8 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if use_dist and gather.overflow(step_no[0] - 1):       # (a collective; outside the timed region) more wide intervals than the packed form's escape list holds
+        raise SystemExit("bench: the last step's escape list overflowed -- the exchange must run in the 16-byte form (--exchange pairs)")
     timed = [p for p in ev if p]
     kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
     # the work of exactly the timed steps
@@ -976,6 +978,13 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     log(rank, "fresh batch of %d regexes: compile %.3fs + resident %.3fs + first match %.3fs (workload generation %.1fs)"
         % (k, t1 - t0, t2 - t1, t3 - t2, t_gen))
     batch = findex_amd.ReTree.prepare_batch(hip, trees)
+    # a ring of resident batches the steps rotate through (round 5, like the literal workloads' pattern batches): no call
+    # matches the batch the device has just matched.  Batch 0 is the one the CPU baseline checks.
+    ring = max(1, args.regex_ring)
+    batches = [batch]
+    for j in range(1, ring):
+        _, trees_j = make_regexes(k, seed * 1000 + rank + 7919 * j, text_sample)
+        batches.append(findex_amd.ReTree.prepare_batch(hip, trees_j))
 
     from findex_amd.distributed import all_gather_varlen
     from findex_amd.regex import RESULT_DTYPE
@@ -988,29 +997,41 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
     d_out = torch.empty(3 * cap, dtype=torch.int64, device=device)          # 24-byte records as three words
     d_per = torch.empty(max(k, 1), dtype=torch.int32, device=device)
 
-    def step():
+    step_no = [0]
+
+    def step(b=None):
+        if b is None:
+            b = batches[step_no[0] % ring]
+            step_no[0] += 1
         if ref_mode:
-            out, _ = batch.match_raw(cap=cap, copy=False, **lim)
+            out, _ = b.match_raw(cap=cap, copy=False, **lim)
             n_res = out.size
             if use_dist:
                 d_out[: 3 * n_res].copy_(torch.from_numpy(out.view(np.int64).reshape(-1)))
         else:
-            n_res = batch.match_dev(d_out.data_ptr(), cap, d_per.data_ptr(), max_steps=max_len)
+            n_res = b.match_dev(d_out.data_ptr(), cap, d_per.data_ptr(), max_steps=max_len)
         if use_dist:        # the path's one exchange: every rank receives every rank's result list (sizes, then payload)
             all_gather_varlen(d_out[: 3 * n_res])
         return n_res
 
+    # what a call executes, averaged over the ring's batches (device counters; they differ by a per cent or two)
     hip.stats_reset()
-    n_results = int(step())
-    s1 = hip.stats()
+    n_results_b = [int(step(b)) for b in reversed(batches)]          # (batch 0 last: its results are the ones compared below)
     torch.cuda.synchronize()
+    s_all = hip.stats()
+    s1 = dict(s_all)
+    for f in ("rank_queries", "backward_steps", "frontier_requests", "frontier_elements", "frontier_queue_reads", "frontier_queue_writes",
+              "frontier_results", "frontier_records", "ktab_lookups", "row_lookups"):
+        s1[f] = s_all[f] / float(ring)
+    n_results = n_results_b[-1]
     if ref_mode:
         out_res = batch.match_raw(cap=cap, **lim)[0]
     else:
         out_res = d_out[: 3 * n_results].cpu().numpy().view(RESULT_DTYPE)
-    steps_per_call = int(s1["backward_steps"])
+    steps_per_call = s1["backward_steps"]
     ranks_per_step = 2 * steps_per_call
-    for _ in range(max(0, args.warmup - 1)):
+    n_results = sum(n_results_b) / float(ring)
+    for _ in range(max(0, args.warmup)):
         step()
     if use_dist:
         dist.barrier()
@@ -1025,6 +1046,15 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         dist.barrier()
     dt = time.perf_counter() - t0
     kernel_ms = sum(kms) / len(kms)
+    # ... and the same call on ONE batch replayed (what rounds 1-4 reported)
+    for _ in range(2):
+        step(batch)
+    torch.cuda.synchronize()
+    tr = time.perf_counter()
+    for _ in range(max(args.steps, 5)):
+        step(batch)
+    torch.cuda.synchronize()
+    replayed_ms = (time.perf_counter() - tr) / max(args.steps, 5) * 1e3
     host_delivered = None
     if not ref_mode:        # the same call with the results written into page-locked host memory (PCIe-inclusive)
         for _ in range(3):
@@ -1141,6 +1171,10 @@ def run_regex(args, torch, dist, findex_amd, rank, world, local, device, use_dis
         "dtype": "u64",
         "data": "synthetic" if not is_text else "synthetic text with natural repeats (words.txt's words drawn with replacement), its true BWT; regex literals are stretches of the text",
         "regexes_per_sec": world * k * args.steps / dt,
+        "ring_batches": ring,
+        "ms_per_step_is": "calls rotate through %d distinct resident regex batches (seeds differ): no call matches the batch the device "
+                          "has just matched; the same call on ONE batch replayed: replayed_batch_ms" % ring,
+        "replayed_batch_ms": replayed_ms,
         "regexes_per_sec_is": "a RESIDENT batch (compiled and on the device) matched again and again; a batch given as "
                               "strings and matched once runs at fresh_batch.regexes_per_s",
         "fresh_batch": fresh_batch,
@@ -1187,6 +1221,8 @@ def main():
     ap.add_argument("--no-rank-only", action="store_true", help="skip the tables-off sub-record of the literal workloads (executed rank work)")
     ap.add_argument("--ring", type=int, default=8,
                     help="literal workloads: distinct pattern batches the steps rotate through (1 = one batch replayed, rounds 1-4)")
+    ap.add_argument("--regex-ring", type=int, default=4,
+                    help="regex workloads: distinct resident batches the calls rotate through (1 = one batch replayed, rounds 1-4)")
     ap.add_argument("--exchange", default="packed", choices=["packed", "pairs"],
                     help="N > 1, literal workloads: the intervals travel as 8 bytes (default) or 16 bytes per pattern")
     ap.add_argument("--delivery", default="root", choices=["root", "all"],

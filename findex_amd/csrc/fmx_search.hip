@@ -296,6 +296,9 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
         // in the last walk -- where nearly all of them happen: a wave parks ~1.6 patterns per batch of a workload with
         // 10 % misses and the list holds 64 -- because a second copy of this loop inside the batch loop costs the step
         // loop a register it does not have (the dictionary's lane address was spilled and re-read at every rank step).
+        // Round 5 also tried the last walk with TWO patterns per lane group, every request of both in flight before either is
+        // waited for (17 parked patterns per wave = one round instead of two): no change at C3 (0.1389-0.1395 against
+        // 0.1373-0.1391 ms on one box) -- the waves' last walks overlap other waves' batches until the very end.
         while (__builtin_amdgcn_ballot_w64(actw && wj >= 3u)) {
           const bool go = actw && wj >= 3u;
           if (go) {

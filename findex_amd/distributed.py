@@ -367,6 +367,23 @@ class IntervalGather:
                 self.work[j].wait()
                 self.work[j] = None
 
+    def overflow(self, i):
+        """A collective every rank calls for slot i (after its launch): True ON EVERY RANK when any rank's batch held more
+        wide intervals (2^24 - 1 rows or more: patterns of a character or two) than the escape list of the packed form has
+        room for -- word k of a rank's send buffer counts them all, the list keeps the first escape_cap.  The intervals
+        beyond it are NOT in the payload: every rank then repeats the slot in the 16-byte form (IntervalGather(form="pairs")).
+        Until round 4 only the root found out, by an OverflowError while decoding, after the exchange.
+        One all-reduce of one word; synchronises this rank's slot.  Always False for form "pairs"."""
+        j = i % self.depth
+        if self.form != "packed":
+            return False
+        if self.work[j] is not None:
+            self.work[j].wait()
+        over = (self.send[j][self.k: self.k + 1] > self.cap).to(torch.int64)
+        if self.live and self.world > 1:
+            dist.all_reduce(over, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(over.item()))
+
     def intervals(self, out, r):
         """(sp, ep) of rank r's batch as uint64 host arrays from a received buffer (None where nothing was delivered)."""
         if out is None:

@@ -133,6 +133,39 @@ def _rank_main(rank, world, port, q):
                 g.finish()
                 got.append(None if outs[4] is None else [[x.tolist() for x in g.intervals(outs[4], r)] for r in range(world)])
                 seen[form + "/" + delivery] = (got, g.payload_bytes)
+        # an overfull escape list: rank 1's batch alone holds three wide intervals where the list takes two --
+        # EVERY rank learns of it from overflow(i) (until round 4 only the root did, by an exception while decoding), and
+        # the slot is repeated in the 16-byte form, which has no such limit
+        g = D.IntervalGather(4, torch.device("cpu"), form="packed", delivery="root", escape_cap=2)
+        a, b = g.slot(0)
+        a.copy_(torch.arange(4) + 1000 * rank)
+        b.copy_(a + 5)
+        if rank == 1:
+            b[:3] = a[:3] + (1 << 30)
+        out0 = g.launch(0)
+        over0 = g.overflow(0)
+        a1, b1 = g.slot(1)
+        a1.copy_(a)
+        b1.copy_(a + 7)                              # nothing wide: no overflow on any rank
+        g.launch(1)
+        over1 = g.overflow(1)
+        g.finish()
+        root_raises = None
+        if out0 is not None:
+            try:
+                g.intervals(out0, 1)
+                root_raises = False
+            except OverflowError:
+                root_raises = True
+        g2 = D.IntervalGather(4, torch.device("cpu"), form="pairs", delivery="root")
+        a2, b2 = g2.slot(0)
+        a2.copy_(a)
+        b2.copy_(b)
+        out2 = g2.launch(0)
+        g2.finish()
+        redo = None if out2 is None else [[x.tolist() for x in g2.intervals(out2, r)] for r in range(world)]
+        assert g2.overflow(0) is False
+        seen["overflow"] = (over0, over1, root_raises, redo)
         # the one-call form: every (form, delivery), a searcher whose answers include wide intervals and misses, and a
         # byte distribution that leaves the middle rank of three without a pattern
         fake = FakeSearcher()
@@ -179,6 +212,18 @@ def test_gloo_ranks_match_single_process(world):
     for rank, sp, ep, res, cuts, parts, seen, ex1, ex2, kw_refused, sharded, fcuts in got:
         assert [tuple(x) for x in ex1] == want1 and [tuple(x) for x in ex2] == want2
         assert kw_refused
+        over0, over1, root_raises, redo = seen.pop("overflow")
+        assert over0 is True and over1 is False, "every rank must learn of rank 1's overfull escape list (rank %d: %s %s)" % (rank, over0, over1)
+        assert root_raises == (True if rank == 0 else None)
+        if rank == 0:                                # the repeat in the 16-byte form carries all three wide intervals
+            for r in range(world):
+                a = [j + 1000 * r for j in range(4)]
+                b = [x + 5 for x in a]
+                if r == 1:
+                    b[:3] = [x + (1 << 30) for x in a[:3]]
+                assert redo[r] == [a, b], r
+        else:
+            assert redo is None
         for key, (batches, payload) in seen.items():
             form, delivery = key.split("/")
             assert payload == (8 * (4 + 1 + 2 * 2) if form == "packed" else 16 * 4)

@@ -56,6 +56,10 @@ alloc)
   hipcc -O2 --offload-arch=gfx950 -o tools/ubench/alloc tools/ubench/alloc.hip -lpthread > $O/alloc_build.log 2>&1 || { echo "alloc build failed"; tail -3 $O/alloc_build.log; }
   timeout -k 10 500 tools/ubench/alloc > $O/alloc.txt 2>&1; echo "alloc rc=$?"; cat $O/alloc.txt
   ;;
+writevalue)
+  hipcc -O2 --offload-arch=gfx950 -o tools/ubench/writevalue tools/ubench/writevalue.hip > $O/wv_build.log 2>&1
+  timeout -k 10 120 tools/ubench/writevalue > $O/writevalue.txt 2>&1; echo "writevalue rc=$?"; cat $O/writevalue.txt
+  ;;
 abenv:*)
   # A/B of library variants and environment settings on one box:  abenv:<workload>:<tag>[+VAR=val..],..   ("-" = the product build)
   spec=${PART#abenv:}; wl=${spec%%:*}; items=${spec#*:}

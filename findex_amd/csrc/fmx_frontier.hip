@@ -1148,6 +1148,16 @@ struct RegexBatch {
   fmx_result *d_res_seg = nullptr;    // kSub result slices the levels append to
   FrontierCtl *d_ctl = nullptr;
   uint32_t *d_rcnt = nullptr, *d_rstart = nullptr, *d_rfill = nullptr;   // per-regex result counts / offsets
+  // Round 5: a call that ends normally leaves the batch READY for the next one -- k_res_sort's last workgroup rewinds the
+  // queue's slices (what k_frontier_reset's first wave did), and the scan of the per-regex counts zeroes the OTHER of two
+  // count arrays, which the next call counts into -- so that a call with the same limits starts with the frontier launch
+  // (one launch and ~6 us less per call; C4text: a twentieth of the call).  pre_* = what the batch was left ready for.
+  uint32_t *d_rcnt2[2] = {nullptr, nullptr};
+  uint32_t rc_sel = 0;
+  bool pre_ok = false;
+  uint32_t pre_max_len = 0, pre_deep = 0;
+  size_t pre_count = 0;
+  StartSrc pre_ss{nullptr, 0, 0};
   uint32_t *d_rpart = nullptr;         // chunk totals of the offsets' scan
   BigGroups *d_big = nullptr;
   FrontierSummary *h_sum = nullptr;    // pinned: what a chain reports (written by k_frontier_advance)
@@ -1468,7 +1478,8 @@ __device__ __forceinline__ uint32_t block_excl_scan_1024(uint32_t v, uint32_t *s
 // every workgroup scans its chunk of the per-regex counts (n != 0).
 __global__ __launch_bounds__(kScanChunk) void k_frontier_advance(FrontierCtl *__restrict__ ctl, uint64_t sub_cap, FrontierSummary *__restrict__ sum,
                                                                  const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ start,
-                                                                 uint32_t *__restrict__ part, uint32_t *__restrict__ fill, BigGroups *__restrict__ big) {
+                                                                 uint32_t *__restrict__ part, uint32_t *__restrict__ fill, BigGroups *__restrict__ big,
+                                                                 uint32_t *__restrict__ zero_next /* the count array the NEXT call counts into, or null */) {
   if (blockIdx.x == 0 && threadIdx.x < 64) {
     SliceCtl &q = ctl->q[threadIdx.x];
     const uint32_t wr = q.wsel, ot = 1u - wr;
@@ -1486,7 +1497,7 @@ __global__ __launch_bounds__(kScanChunk) void k_frontier_advance(FrontierCtl *__
   const uint32_t i = blockIdx.x * kScanChunk + threadIdx.x;
   uint32_t total = 0;
   const uint32_t ex = block_excl_scan_1024(i < n ? cnt[i] : 0u, s_wave, total);
-  if (i < n) { start[i] = ex; fill[i] = 0; }      // the scatter's cursors start from zero in every grouping
+  if (i < n) { start[i] = ex; fill[i] = 0; if (zero_next) zero_next[i] = 0; }      // the scatter's cursors start from zero in every grouping
   if (threadIdx.x == 0) part[blockIdx.x] = total;
   if (blockIdx.x == 0 && threadIdx.x == 0) { big->n = 0; big->done = 0; big->total = 0; }
 }
@@ -1565,8 +1576,10 @@ constexpr uint32_t kRankGroup = 64;
 __global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ own, uint64_t own_cap, const uint32_t *__restrict__ start,
                                                    const uint32_t *__restrict__ part, uint32_t nparts, uint32_t k,
                                                    const uint32_t *__restrict__ rcnt, BigGroups *__restrict__ big,
-                                                   const ExportDst *__restrict__ dst, GroupTotals *__restrict__ tot /* pinned host */) {
+                                                   const ExportDst *__restrict__ dst, GroupTotals *__restrict__ tot /* pinned host */,
+                                                   FrontierCtl *__restrict__ ctl, uint64_t count, StartSrc start_src, uint32_t pre_next) {
   __shared__ fmx_result s_r[kMidGroup];
+  __shared__ uint32_t s_last;
   __shared__ PartPrefix s_pp;
   __shared__ uint32_t s_off[257];             // offsets of the workgroup's regexes (and of the one behind them)
   __shared__ uint32_t s_mid[2 * 256], s_nmid;
@@ -1666,10 +1679,32 @@ __global__ __launch_bounds__(256) void k_res_sort(fmx_result *__restrict__ own, 
   // of their threads has already used, so it has been performed before that thread reaches the barrier below; the
   // lists and results themselves are read by the host or the next launch, behind the kernel's end.
   __syncthreads();
-  if (threadIdx.x == 0 && atomicAdd(&big->done, 1u) == gridDim.x - 1u) {
-    big->total = total;
-    tot->n_results = total;
-    tot->n_big = atomicAdd(&big->n, 0u);
+  if (threadIdx.x == 0) {
+    const bool last = atomicAdd(&big->done, 1u) == gridDim.x - 1u;
+    s_last = last ? 1u : 0u;
+    if (last) {
+      big->total = total;
+      tot->n_results = total;
+      tot->n_big = atomicAdd(&big->n, 0u);
+    }
+  }
+  if (pre_next) {                          // uniform over the grid
+    // The call is over when its last launch left nothing queued: the workgroup that finishes last then leaves the batch
+    // READY for a next call with the same limits -- the slices rewound under fresh tags, buffer 0 standing for the start
+    // elements, exactly what k_frontier_reset's first wave does -- so that such a call begins with the frontier launch
+    // itself (the host skips the reset launch: regex_batch_match, pre_ok).  Nothing of this grouping reads the slices
+    // any more (the scatter is done); a call that is NOT over (left != 0) keeps its state and resets as before.
+    __syncthreads();
+    if (s_last && threadIdx.x < kSub && ctl->left == 0 && ctl->overflow == 0) {
+      const uint32_t i = threadIdx.x;
+      SliceCtl &q = ctl->q[i];
+      q.tail[0] = count > i ? (count - i + kSub - 1) / kSub : 0;
+      q.tail[1] = 0; q.head[0] = 0; q.head[1] = 0;
+      q.tag[0] = next_tag(q.tag[0]); q.tag[1] = next_tag(q.tag[1]);
+      q.wsel = 1;
+      ctl->res_count[i].v = 0;
+      if (i == 0) { ctl->fresh = 1; ctl->deep_len = d.deep_len; ctl->start = start_src; ctl->truncated = 0; ctl->max_len = d.max_len; ctl->left = count; }
+    }
   }
 }
 
@@ -1745,10 +1780,14 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     b->tag_bound = ~0u;                // new memory: zeroed below (tag 0 = never written)
     {   // counts, fill cursors and the big-group list in one block: one memset clears what a grouping starts from
       uint32_t *blk = nullptr;
-      HIP_TRY(b->scratch->alloc(&blk, 2 * (b->k + 1) + (sizeof(BigGroups) + 3) / 4), "hipMalloc(result counts)");
+      HIP_TRY(b->scratch->alloc(&blk, 3 * (b->k + 1) + (sizeof(BigGroups) + 3) / 4), "hipMalloc(result counts)");
+      b->d_rcnt2[0] = blk;
+      b->d_rcnt2[1] = blk + 2 * (b->k + 1);
       b->d_rcnt = blk;
+      b->rc_sel = 0;
+      b->pre_ok = false;
       b->d_rfill = blk + (b->k + 1);
-      b->d_big = reinterpret_cast<BigGroups *>(blk + 2 * (b->k + 1));
+      b->d_big = reinterpret_cast<BigGroups *>(blk + 3 * (b->k + 1));
     }
     HIP_TRY(b->scratch->alloc(&b->d_rstart, b->k + 1), "hipMalloc(result offsets)");
     HIP_TRY(b->scratch->alloc(&b->d_rpart, (b->k + 1) / kScanChunk + 2), "hipMalloc(scan parts)");
@@ -1779,6 +1818,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     for (unsigned long long *g : {fq.g0, fq.g1, fq.g2}) HIP_TRY(hipMemsetAsync(g, 0, 2 * kSub * sub_cap * 8, st), "hipMemset(queue)");
     HIP_TRY(hipMemsetAsync(d_ctl, 0, sizeof(FrontierCtl), st), "hipMemset(ctl)");
     b->tag_bound = 0;
+    b->pre_ok = false;                 // (whatever the last call left ready is gone: this call resets by launch)
   }
   b->tag_bound++;
   mark("setup");
@@ -1804,6 +1844,26 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   uint64_t launches = 1;
   bool alive = true, truncated = false;
   const StartSrc ss{b->d_start_elem, b->start_cap, kt.k ? 0 : h->n};
+  // `pre_next`: this call leaves the batch ready for the next one (not with captured graphs: their arguments are fixed, and
+  // the two count arrays alternate).  `pre_now`: the LAST call left it ready for exactly this one -- no reset launch.
+  static const bool pre_off = (getenv("FMX_FRONTIER_GRAPH") && atoi(getenv("FMX_FRONTIER_GRAPH")) != 0) ||
+                              (getenv("FMX_FRONTIER_PRERESET") && atoi(getenv("FMX_FRONTIER_PRERESET")) == 0);
+  const bool pre_next = !pre_off;
+  const uint32_t deep_len_now = [&] {
+    const double sig = (double)std::max<uint32_t>(h->nslots, 2u);
+    static const int deep_extra = getenv("FMX_FRONTIER_DEEP") ? atoi(getenv("FMX_FRONTIER_DEEP")) : 2;      // A/B runs
+    return (uint32_t)std::max(1.0, std::ceil(std::log((double)h->n + 1.0) / std::log(sig)) + deep_extra);
+  }();
+  if (pre_next) {
+    if (b->pre_ok) b->rc_sel ^= 1u;          // the array the last call's scan zeroed
+    b->d_rcnt = b->d_rcnt2[b->rc_sel];
+  } else {
+    b->rc_sel = 0;
+    b->d_rcnt = b->d_rcnt2[0];
+  }
+  const bool pre_now = pre_next && b->pre_ok && b->pre_max_len == max_steps && b->pre_deep == deep_len_now && b->pre_count == b->n_first &&
+                       b->pre_ss.elem == ss.elem && b->pre_ss.cap == ss.cap && b->pre_ss.ep == ss.ep;
+  b->pre_ok = false;                         // until this call has ended normally
   const uint32_t n_scan = (uint32_t)b->k + 1, nparts = (n_scan + kScanChunk - 1) / kScanChunk;     // cnt[k] is 0: its offset = the total
   const bool parts_in_lds = nparts <= kMaxPartsLds;      // the consumers of the offsets add the chunk totals up themselves
   auto launch_pass = [&](hipStream_t s, int grid, uint32_t j, uint32_t rounds) {
@@ -1840,12 +1900,13 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   auto enqueue_chain = [&](hipStream_t s, int grid) -> hipError_t {
     const uint32_t len = grid == grid_small ? kChainSmall : kChain;
     // a call's first chain begins with the reset (h_dst->fresh; it returns at once otherwise): one graph launch per call
-    k_frontier_reset<<<(int)std::min<size_t>((b->k + 256) / 256, 256), 256, 0, s>>>(d_ctl, b->n_first, &b->h_dst->max_len, b->d_rcnt, (uint32_t)b->k, ss);
+    if (!(pre_now && b->h_dst->fresh))
+      k_frontier_reset<<<(int)std::min<size_t>((b->k + 256) / 256, 256), 256, 0, s>>>(d_ctl, b->n_first, &b->h_dst->max_len, b->d_rcnt, (uint32_t)b->k, ss);
     for (uint32_t j = 0; j < len; j++) {
       launch_pass(s, grid, j, grid == grid_small ? kRoundsSmall : (plan.empty() ? kRounds : plan[std::min<size_t>(j, plan.size() - 1)]));
       // the summary goes straight to pinned host memory; behind the chain's last launch the same grid scans the result counts
-      if (j + 1 < len) k_frontier_advance<<<1, kScanChunk, 0, s>>>(d_ctl, sub_cap, b->h_sum, nullptr, 0u, nullptr, nullptr, nullptr, nullptr);
-      else k_frontier_advance<<<nparts, kScanChunk, 0, s>>>(d_ctl, sub_cap, b->h_sum, b->d_rcnt, n_scan, b->d_rstart, b->d_rpart, b->d_rfill, b->d_big);
+      if (j + 1 < len) k_frontier_advance<<<1, kScanChunk, 0, s>>>(d_ctl, sub_cap, b->h_sum, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, nullptr);
+      else k_frontier_advance<<<nparts, kScanChunk, 0, s>>>(d_ctl, sub_cap, b->h_sum, b->d_rcnt, n_scan, b->d_rstart, b->d_rpart, b->d_rfill, b->d_big, pre_next ? b->d_rcnt2[b->rc_sel ^ 1u] : nullptr);
     }
     return hipGetLastError();
   };
@@ -1862,12 +1923,9 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
   b->h_dst->per = export_per ? per_regex_count : nullptr;
   b->h_dst->max_len = max_steps;
   b->h_dst->fresh = 1;
-  {   // ceil(log_sigma n) steps narrow an interval to a single row; what still branches two steps later is rare on any
-      // index (a row has one preceding character) and is what the longest chains of dependent steps are made of
-    const double sig = (double)std::max<uint32_t>(h->nslots, 2u);
-    static const int deep_extra = getenv("FMX_FRONTIER_DEEP") ? atoi(getenv("FMX_FRONTIER_DEEP")) : 2;      // A/B runs
-    b->h_dst->deep_len = (uint32_t)std::max(1.0, std::ceil(std::log((double)h->n + 1.0) / std::log(sig)) + deep_extra);
-  }
+  // ceil(log_sigma n) steps narrow an interval to a single row; what still branches two steps later is rare on any
+  // index (a row has one preceding character) and is what the longest chains of dependent steps are made of
+  b->h_dst->deep_len = deep_len_now;
   static const bool no_direct = getenv("FMX_EXPORT_DIRECT") && atoi(getenv("FMX_EXPORT_DIRECT")) == 0;      // A/B runs
   b->h_dst->direct = (dev && export_out && !no_direct) ? 1u : 0u;
   const bool direct = b->h_dst->direct != 0;
@@ -1890,7 +1948,7 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (!parts_in_lds) k_res_scan_add<<<nparts, kScanChunk, 0, s>>>(b->d_rstart, n_scan, b->d_rpart);
     const uint32_t *part = parts_in_lds ? b->d_rpart : nullptr;
     k_res_scatter<<<rg, 256, 0, s>>>(d_res_seg, seg_cap, d_ctl, b->d_rstart, part, nparts, b->d_rfill, d_res, (uint64_t)rcap, b->h_dst);
-    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, (uint64_t)rcap, b->d_rstart, part, nparts, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst, b->h_tot);
+    k_res_sort<<<(int)((b->k + 255) / 256), 256, 0, s>>>(d_res, (uint64_t)rcap, b->d_rstart, part, nparts, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst, b->h_tot, d_ctl, (uint64_t)b->n_first, ss, pre_next ? 1u : 0u);
     if (!in_place) k_res_export<<<256, 256, 0, s>>>(d_res, (uint32_t)b->k, b->d_rcnt, b->d_big, b->h_dst);
     return hipGetLastError();
   };
@@ -1939,6 +1997,13 @@ int regex_batch_match(const Index *h, RegexBatch *b, const fmx_limits *lim, fmx_
     if (trace)
       fprintf(stderr, "[fmx] frontier after launch %u: queue %llu, results %llu, overflow %llu\n", pass,
               (unsigned long long)total, (unsigned long long)n_res, sum.overflow);
+  }
+  if (pre_next && sum.overflow == 0) {       // the device saw the same (left == 0, no overflow) and left the batch ready: k_res_sort
+    b->pre_ok = true;
+    b->pre_max_len = max_steps;
+    b->pre_deep = deep_len_now;
+    b->pre_count = b->n_first;
+    b->pre_ss = ss;
   }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);

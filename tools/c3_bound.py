@@ -59,22 +59,28 @@ def patterns(k, m, miss, sd):
     return pats.reshape(-1), off
 
 
+RING = 4      # distinct batches per point, rotated through the timed launches (round 5: no launch sees the batch the device has just searched)
+
+
 def point(k, m, miss, sd=1):
-    pats, off = patterns(k, m, miss, sd)
+    ring = [patterns(k, m, miss, sd + 7919 * j) for j in range(RING)]
     sp = torch.empty(k, dtype=torch.int64, device=dev)
     ep = torch.empty(k, dtype=torch.int64, device=dev)
-    for _ in range(2):
+    for pats, off in ring:
         hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
     torch.cuda.synchronize()
+    pats, off = ring[0]
     hip.stats_reset()
     hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
     torch.cuda.synchronize()
     s = hip.stats()
+    hits = float((sp < ep).sum().item()) / k
     ts = []
-    for _ in range(a.reps):
+    for r in range(max(a.reps, RING)):
+        bp, bo = ring[(r + 1) % RING]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
+        hip.search_batch_dev(bp.data_ptr(), bo.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, stream)
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
@@ -82,7 +88,7 @@ def point(k, m, miss, sd=1):
     req = int(s["search_requests"]) + int(s["ktab_lookups"]) + int(s["jump_lookups"]) + int(s["row_lookups"])
     print("k %8d  m %3d  miss %.2f : %7.4f ms (min %7.4f)  requests %9d = %8d rank + %8d ktab + %8d jump + %8d row  -> %6.2f G req/s, "
           "%7.1f G rank-q/s, hits %.3f" % (k, m, miss, ms, min(ts), req, s["search_requests"], s["ktab_lookups"], s["jump_lookups"],
-                                          s["row_lookups"], req / ms / 1e6, s["rank_queries"] / ms / 1e6, float((sp < ep).sum().item()) / k), flush=True)
+                                          s["row_lookups"], req / ms / 1e6, s["rank_queries"] / ms / 1e6, hits), flush=True)
     return ms, req
 
 

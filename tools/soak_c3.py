@@ -17,18 +17,30 @@ bwt, eof = bench.make_bwt(torch, n, sigma, seed, dev); torch.cuda.synchronize()
 hip = findex_amd.HipFMSearcher.from_device(bwt.data_ptr(), n, eof, None, device=0, stream=stream)
 hip.prepare(ktab=True, jump=True)
 del bwt
-pats, off = bench.make_patterns(torch, hip, n, sigma, k, m, seed * 1000, dev, stream)
-sp = [torch.zeros(k, dtype=torch.int64, device=dev) for _ in range(2)]
-ep = [torch.zeros(k, dtype=torch.int64, device=dev) for _ in range(2)]
+RING = 3          # distinct batches, rotated (round 5): every call's output is compared with its batch's first
+ring = [bench.make_patterns(torch, hip, n, sigma, k, m, seed * 1000 + 7919 * j, dev, stream) for j in range(RING)]
 esc = 4096
-pk = [torch.zeros(hip.packed_words(k, esc), dtype=torch.int64, device=dev) for _ in range(2)]
-hip.search_batch_dev(pats.data_ptr(), off.data_ptr(), sp[0].data_ptr(), ep[0].data_ptr(), k, stream)
-hip.search_batch_ex_dev(pats.data_ptr(), off.data_ptr(), pk[0].data_ptr(), ep[1].data_ptr(), k, stream, packed=True, escape_cap=esc)
-torch.cuda.synchronize()
-nesc = int(pk[0][k])
+ref = []
+for bp, bo in ring:
+    rsp, rep_ = torch.zeros(k, dtype=torch.int64, device=dev), torch.zeros(k, dtype=torch.int64, device=dev)
+    rpk = torch.zeros(hip.packed_words(k, esc), dtype=torch.int64, device=dev)
+    scratch = torch.zeros(k, dtype=torch.int64, device=dev)
+    hip.search_batch_dev(bp.data_ptr(), bo.data_ptr(), rsp.data_ptr(), rep_.data_ptr(), k, stream)
+    hip.search_batch_ex_dev(bp.data_ptr(), bo.data_ptr(), rpk.data_ptr(), scratch.data_ptr(), k, stream, packed=True, escape_cap=esc)
+    torch.cuda.synchronize()
+    ref.append((rsp, rep_, rpk))
+sp = [None, torch.zeros(k, dtype=torch.int64, device=dev)]
+ep = [None, torch.zeros(k, dtype=torch.int64, device=dev)]
+pk = [None, torch.zeros(hip.packed_words(k, esc), dtype=torch.int64, device=dev)]
 bad = 0
 t0 = time.time()
 for i in range(calls):
+    pats, off = ring[(i // 2) % RING]
+    sp[0], ep[0], pk[0] = ref[(i // 2) % RING]
+    nesc = int(pk[0][k]) if i < 2 * RING else nesc_by[(i // 2) % RING]
+    if i < 2 * RING:
+        nesc_by = globals().setdefault("nesc_by", {})
+        nesc_by[(i // 2) % RING] = nesc
     if i & 1:
         pk[1].zero_()
         hip.search_batch_ex_dev(pats.data_ptr(), off.data_ptr(), pk[1].data_ptr(), ep[1].data_ptr(), k, stream, packed=True, escape_cap=esc)
@@ -45,6 +57,6 @@ for i in range(calls):
     if (i + 1) % 1000 == 0:
         print("%d calls, %d differ, %.1fs" % (i + 1, bad, time.time() - t0), flush=True)
 st = hip.stats()
-print("soak %s: %d calls of %d patterns (%d hits, %d wide intervals in the packed form), %d differ; search_residency 0x%x"
-      % (wl, calls, k, int((sp[0] < ep[0]).sum()), nesc, bad, st["search_residency"]))
+print("soak %s: %d calls rotating through %d batches of %d patterns (%d hits in the last, %d wide intervals in the packed form), %d differ; search_residency 0x%x"
+      % (wl, calls, RING, k, int((sp[0] < ep[0]).sum()), nesc, bad, st["search_residency"]))
 sys.exit(1 if bad else 0)

@@ -29,6 +29,7 @@ for bp, bo in ring:
     hip.search_batch_ex_dev(bp.data_ptr(), bo.data_ptr(), rpk.data_ptr(), scratch.data_ptr(), k, stream, packed=True, escape_cap=esc)
     torch.cuda.synchronize()
     ref.append((rsp, rep_, rpk))
+nesc_ref = [int(r[2][k]) for r in ref]
 sp = [None, torch.zeros(k, dtype=torch.int64, device=dev)]
 ep = [None, torch.zeros(k, dtype=torch.int64, device=dev)]
 pk = [None, torch.zeros(hip.packed_words(k, esc), dtype=torch.int64, device=dev)]
@@ -37,10 +38,7 @@ t0 = time.time()
 for i in range(calls):
     pats, off = ring[(i // 2) % RING]
     sp[0], ep[0], pk[0] = ref[(i // 2) % RING]
-    nesc = int(pk[0][k]) if i < 2 * RING else nesc_by[(i // 2) % RING]
-    if i < 2 * RING:
-        nesc_by = globals().setdefault("nesc_by", {})
-        nesc_by[(i // 2) % RING] = nesc
+    nesc = nesc_ref[(i // 2) % RING]
     if i & 1:
         pk[1].zero_()
         hip.search_batch_ex_dev(pats.data_ptr(), off.data_ptr(), pk[1].data_ptr(), ep[1].data_ptr(), k, stream, packed=True, escape_cap=esc)

@@ -35,7 +35,7 @@ coldpmc|coldpmc:*)
 coldtrace)
   (cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/$O/trace_bench -- python3 $REPO/bench.py --steps 20 --warmup 5 > $REPO/$O/c3_bench_under_rocprof.json 2> $REPO/$O/c3_bench_under_rocprof.err); echo "rocprof bench exit $?"
   python - $O <<'PY'
-import csv,glob,sys
+import csv,glob,sys,collections
 O=sys.argv[1]
 rows=[]
 for f in glob.glob("%s/trace_bench/*/*_kernel_trace.csv"%O):
@@ -49,6 +49,25 @@ with open(O+"/c3_bench_launches_in_order.txt","w") as fo:
         if n.startswith(("k_search4","k_lf_walk","k_jump","k_row3","k_ktab","k_occ")): fo.write("%10.3f %9.2f  %s\n"%((s-t0)/1e6,(e-s)/1e3,n[:70]))
 srch=[(e-s)/1e3 for s,e,n in rows if n.startswith("k_search4")]
 print("k_search4 launches:",len(srch)); print(" ".join("%.1f"%x for x in srch))
+# rocprofv3's own per-kernel statistics, and beside them the search kernel's WITHOUT fmx_prepare's calibration launches (the leading
+# launches of an instantiation that last about as long as the 60-us spin they consist of: < 0.6 of the instantiation's median)
+import statistics
+stats=[]
+for f in glob.glob("%s/trace_bench/*/*_kernel_stats.csv"%O):
+    for r in csv.DictReader(open(f)):
+        if "fmx::" in r["Name"]: stats.append(r)
+by=collections.OrderedDict() if False else {}
+for s_,e,n in rows:
+    if n.startswith("k_search4"): by.setdefault(n,[]).append((e-s_))
+with open(O+"/c3_bench_kernel_stats.csv","w",newline="") as fo:
+    w=csv.writer(fo); w.writerow(["Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs","StdDev"])
+    for r in stats: w.writerow([r["Name"].split("(")[0].replace("fmx::",""),r["Calls"],r["TotalDurationNs"],r["AverageNs"],r["MinNs"],r["MaxNs"],r["StdDev"]])
+    for n,v in by.items():
+        med=statistics.median(v); lead=0
+        while lead < len(v) and v[lead] < 0.6*med: lead+=1
+        u=v[lead:]
+        w.writerow([n+" [searches only: without the %d calibration launches of fmx_prepare]"%lead,len(u),sum(u),"%.1f"%(sum(u)/len(u)),min(u),max(u),"%.1f"%(statistics.pstdev(u) if len(u)>1 else 0.0)])
+        print("%s: %d searches, avg %.1f us (min %.1f, max %.1f); %d calibration launches left out"%(n[:50],len(u),sum(u)/len(u)/1e3,min(u)/1e3,max(u)/1e3,lead))
 PY
   rm -rf $O/trace_bench
   ;;

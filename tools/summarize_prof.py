@@ -31,15 +31,39 @@ with open(dst + "_kernel_stats.csv", "w", newline="") as fo:
         w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"],
                     r["StdDev"]])
 
+# fmx_prepare calibrates the search kernel with a few 60-us launches of k_search4 itself (its residency census, round 5): they
+# are the dispatches of that kernel BEFORE the workload generates its patterns (k_lf_walk) and are left out of every figure
+# of k_search4 below -- counted, and said so in the summary.
+def is_calibration(rows_of_file, r):
+    if "k_search4" not in r["Kernel_Name"]:
+        return False
+    walks = [int(x["Dispatch_Id"]) for x in rows_of_file if "k_lf_walk" in x["Kernel_Name"]]
+    return bool(walks) and int(r["Dispatch_Id"]) < min(walks)
+
+
 agg = collections.defaultdict(list)
 meta = {}
+n_calib = 0
 for f in glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
+    rows_f = list(csv.DictReader(open(f)))
+    for r in rows_f:
         if "fmx::" not in r["Kernel_Name"]:
+            continue
+        if is_calibration(rows_f, r):
             continue
         k = short(r["Kernel_Name"])
         agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"], r["Grid_Size"])
+# the search kernel's durations without the calibration launches, from the kernel trace of pass 0
+search_ns = collections.defaultdict(list)
+for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+    rows_f = list(csv.DictReader(open(f)))
+    for r in rows_f:
+        if "k_search4" in r["Kernel_Name"]:
+            if is_calibration(rows_f, r):
+                n_calib += 1
+            else:
+                search_ns[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open(dst + "_counters.csv", "w", newline="") as fo:
     w = csv.writer(fo)
     w.writerow(["Kernel", "Counter", "Dispatches", "Mean"])
@@ -91,6 +115,12 @@ with open(dst + "_summary.md", "w") as fo:
         m = meta.get(k, ("", "", "", "", ""))
         fo.write("| %s | %s | %.4f | %.4f | %.4f | %s | %s | %s |\n" % (
             k, r["Calls"], float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, float(r["MaxNs"]) / 1e6, m[0], m[1], m[2]))
+    for k, v in sorted(search_ns.items()):
+        fo.write("| %s WITHOUT fmx_prepare's %d calibration launches (60-us launches of this kernel that count its resident "
+                 "workgroups: not searches) | %d | %.4f | %.4f | %.4f | | | |\n" % (k, n_calib, len(v), sum(v) / len(v) / 1e6, min(v) / 1e6, max(v) / 1e6))
+    if search_ns:
+        fo.write("\nEvery counter of `k_search4` below is a mean over its SEARCH launches only (the calibration launches, which precede the "
+                 "workload's pattern generation, are left out); the workload rotates a ring of distinct batches through them.\n")
     fo.write("\nHBM traffic per dispatch.  FETCH_SIZE / WRITE_SIZE are in KiB.  FETCH_SIZE is calibrated on the "
              "workload's k_occ launch, whose read bytes are known (%s B: one rank-dictionary block per random query plus "
              "the streamed (c, i) inputs): one KiB of FETCH_SIZE stands for %.0f bytes in this access pattern "

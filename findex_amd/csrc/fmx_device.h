@@ -186,6 +186,57 @@ __device__ __forceinline__ uint32_t payload_bit(uint4 w, uint32_t rem, const Lan
   return group_or<4>(bit);
 }
 
+// ---- the same block served by a PAIR of lanes (round 5, k_search4<.., G2>): lane u of a pair (u = lane & 1) loads bytes
+// 16u .. 16u+15 with one instruction and bytes 32+16u .. 32+16u+15 with a second, so a wave carries 32 patterns instead of 16
+// -- twice the dependent chains per wave for the same registers per lane, at the price of a second request for the block's
+// upper half.  Why: tools/c3_halfbatch.py -- a launch's time is its waves' round trips, not its requests.
+constexpr int kDppPairLane0 = 0xA0;    // quad_perm [0,0,2,2]: lane 0 of each pair to both
+constexpr int kDppPairLane1 = 0xF5;    // quad_perm [1,1,3,3]
+__device__ __forceinline__ uint32_t pair_sum(uint32_t v) { return v + dpp<kDppXor1>(v); }
+__device__ __forceinline__ uint32_t pair_or(uint32_t v) { return v | dpp<kDppXor1>(v); }
+template <int U>
+__device__ __forceinline__ uint32_t pair_bcast(uint32_t v) { return dpp<U ? kDppPairLane1 : kDppPairLane0>(v); }
+struct Blk2 { uint4 a, b; };           // a: dwords 4u .. 4u+3 of the block, b: dwords 8+4u .. 8+4u+3
+// header + #{set payload bits below rem}, to both lanes of the pair (rank_finish's counterpart).  u = lane & 1.
+template <bool WIDE>
+__device__ __forceinline__ uint64_t rank_finish_g2(const Blk2 &w, uint32_t rem, uint32_t u) {
+  const uint32_t wa[4] = {w.a.x, w.a.y, w.a.z, w.a.w}, wb[4] = {w.b.x, w.b.y, w.b.z, w.b.w};
+  const uint32_t hlo = u == 0 ? w.a.x : 0u;
+  uint32_t cnt = WIDE ? 0u : hlo;
+  // payload position of dword d of the block = 32 (d - 2); a.j is dword 4u + j (the header where u = 0, j < 2), b.j dword 8 + 4u + j
+  const uint32_t base_a = 128u * u - 64u, base_b = 128u * u + 192u;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    uint32_t nb = __builtin_elementwise_sub_sat(rem, base_a + 32u * j);
+    if (j < 2) nb = u == 0 ? 0u : nb;                     // lane 0's first two dwords are the count, not payload
+    uint32_t x = __builtin_amdgcn_ubfe(wa[j], 0u, nb);
+    x = nb > 31u ? wa[j] : x;
+    cnt = bcnt_acc(x, cnt);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t nb = __builtin_elementwise_sub_sat(rem, base_b + 32u * j);
+    uint32_t x = __builtin_amdgcn_ubfe(wb[j], 0u, nb);
+    x = nb > 31u ? wb[j] : x;
+    cnt = bcnt_acc(x, cnt);
+  }
+  if (!WIDE) return pair_sum(cnt);
+  const uint32_t hhi = pair_or(u == 0 ? w.a.y : 0u);
+  return (((uint64_t)hhi << 32) | pair_or(hlo)) + pair_sum(cnt);
+}
+// bit `rem` of the block's payload, to both lanes of the pair
+__device__ __forceinline__ uint32_t payload_bit_g2(const Blk2 &w, uint32_t rem, uint32_t u) {
+  const uint32_t d = (rem >> 5) + 2;                     // dword of the block that holds the bit: 2 .. 15
+  const bool in_b = d >= 8;
+  const uint32_t owner = (d >> 2) & 1u;                  // dwords 0-3, 8-11: lane 0; 4-7, 12-15: lane 1
+  const uint4 h = in_b ? w.b : w.a;
+  const uint32_t comp = d & 3u;
+  const uint32_t word = comp < 2u ? (comp == 0u ? h.x : h.y) : (comp == 2u ? h.z : h.w);
+  uint32_t bit = __builtin_amdgcn_ubfe(word, rem, 1u);   // offset taken mod 32
+  bit = owner == u ? bit : 0u;
+  return pair_or(bit);
+}
+
 // Loads in the global (not flat) address space from an integer address.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 load_line16(uint64_t addr) {

@@ -103,16 +103,26 @@ __device__ __forceinline__ uint32_t pat_chunk(const uint8_t *__restrict__ pat, c
 // the constant 100 MHz clock, and the batches it searched.
 __device__ unsigned long long g_searchlog[1u << 15][4];
 #endif
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T>
-__global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_SEARCH_WAVES, 8))) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
+// G2 (round 5, one-hot layout only): a pattern is served by a PAIR of lanes instead of a quad -- 32 patterns per wave, the
+// dictionary's 64-byte block fetched as two 32-byte halves (fmx_device.h, Blk2).  tools/c3_halfbatch.py: with the same 1M
+// pattern slots holding 16 / 8 / 4 / 2 real patterns per batch a C3 launch takes 0.132 / 0.102 / 0.093 / 0.088 ms -- its
+// time is the round trips of its waves' lockstep batches (a wave works through ~10 of them, ~8.5 us each whatever they
+// hold), not its requests.  Twice the patterns per batch is half the batches per wave.
+#ifndef FMX_SEARCH_WAVES_G2
+#define FMX_SEARCH_WAVES_G2 5
+#endif
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T, bool G2 = false>
+__global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? FMX_SEARCH_WAVES_G2 : FMX_SEARCH_WAVES, 8))) void k_search4(DevIndex ix, const uint4 *__restrict__ ktab, const uint8_t *__restrict__ kdense,
                                                         uint32_t ksigma, const uint4 *__restrict__ jtab, const uint32_t jc,
                                                         const unsigned long long *__restrict__ r3tab, const uint8_t *__restrict__ pat,
                                                         const PatOff po,
                                                         uint64_t *__restrict__ sp_out, uint64_t *__restrict__ ep_out,
                                                         uint32_t k, unsigned long long *__restrict__ counters, const uint64_t pk_cap,
                                                         const uint32_t spin) {
-  constexpr int G = Lay<LAYOUT>::G;              // lanes per pattern
+  static_assert(!G2 || LAYOUT == kLayoutOneHot, "pairs of lanes serve the one-hot layout only");
+  constexpr int G = G2 ? 2 : Lay<LAYOUT>::G;     // lanes per pattern
   constexpr uint32_t P = 64 / G;                 // patterns per wave
+  constexpr uint32_t RG = G2 ? 4u : (uint32_t)G; // rows of an interval a group can look up in the row tables at once (a pair's lanes take two rows each)
   constexpr uint32_t R = LAYOUT == kLayoutBytes ? 2u : 1u;    // memory requests per rank query
 #ifdef FMX_SEARCHLOG
   const unsigned long long sl_t0 = __builtin_amdgcn_s_memrealtime();
@@ -145,14 +155,41 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     s_tab[c] = make_uint4((uint32_t)cf, (uint32_t)(cf >> 32), (uint32_t)vb, (uint32_t)(vb >> 32));
   }
   __syncthreads();
-  const LaneConst lc = lane_const<G>();
-  const uint32_t t = lc.t;
+  const LaneConst lc = lane_const<G2 ? 4 : G>();      // (a pair's lane takes its positions from t itself: rank_finish_g2)
+  const uint32_t t = G2 ? (threadIdx.x & 1u) : lc.t;
   const uint32_t lane_off = t * 16;
+  uint32_t steps = 0, reqs = 0;     // reqs: memory requests for rank-dictionary lines (counters[2])
+  // A rank query of the one-hot layout for this lane group, whatever its width: rank_excl(x) of the symbol whose vector begins at
+  // vb, and (bit) BWT'[x] == that symbol.  Issue and finish are separate so that a step can have two blocks in flight.
+  struct Blk { uint4 a, b; };
+  // (a pair fetches the block's upper 32 bytes only when the query looks there: positions 192 and up -- payload dwords 6 .. 13;
+  // `upto` = the largest in-block position asked of this block.  43 % of the queries are answered by the lower half alone.)
+  auto blk_load = [&](uint64_t vb, uint32_t b1, uint32_t upto) -> Blk {
+    const uint64_t at = vb + lane_off + (uint64_t)b1 * kBlockBytes;
+    Blk w;
+    w.a = load_line16(at);
+    w.b = make_uint4(0, 0, 0, 0);
+    if constexpr (G2) {
+      if (upto >= 192u) w.b = load_line16(at + 32);      // (the same 64-byte line: served by the L2 miss the lower half started -- not counted as a request)
+    }
+    return w;
+  };
+  auto blk_rank = [&](const Blk &w, uint32_t m1) -> uint64_t {
+    if constexpr (G2) return rank_finish_g2<WIDE>(Blk2{w.a, w.b}, m1, t);
+    else return rank_finish<WIDE>(w.a, m1, lc);
+  };
+  auto blk_bit = [&](const Blk &w, uint32_t m1) -> uint32_t {
+    if constexpr (G2) return payload_bit_g2(Blk2{w.a, w.b}, m1, t);
+    else return payload_bit(w.a, m1, lc);
+  };
+  constexpr uint32_t RB = 1u;                     // memory requests (distinct lines) per one-hot block
+  // lane 0 / lane 1 of the group to all its lanes
+  auto gbc0 = [&](uint32_t v) -> uint32_t { if constexpr (G2) return pair_bcast<0>(v); else return group_bcast<G, 0>(v); };
+  auto gbc1 = [&](uint32_t v) -> uint32_t { if constexpr (G2) return pair_bcast<1>(v); else return group_bcast<G, 1>(v); };
   const uint32_t wave = (blockIdx.x * kSThreads + threadIdx.x) >> 6;
   const uint32_t nwaves = gridDim.x * (kSThreads / 64);
   const uint32_t grp = (threadIdx.x & 63) / G;
   const uint32_t nbatch = (k + P - 1) / P;
-  uint32_t steps = 0, reqs = 0;     // reqs: memory requests for rank-dictionary lines (counters[2])
   // Pattern pipeline.  A wave's 16 (8) patterns lie one behind the other in the pattern buffer, so their bytes are ONE
   // contiguous span: it is fetched with one coalesced wave-level load (16 bytes per lane, up to 1 KiB) while the batch
   // before it is searched, parked in the wave's own LDS area, and every chunk of pattern bytes the search consumes is an
@@ -167,7 +204,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
   // ahead): its waves hold 8 patterns, not 16, so the staging costs the same instructions and registers for half the
   // lines saved -- C5's share of this kernel went from 0.181 to 0.217 ms with it (62 -> 70 registers, 8 -> 7 waves).
   constexpr bool kStage = LAYOUT != kLayoutBytes;
-  constexpr uint32_t kStageBytes = 1024, kStagePad = 16;
+  constexpr uint32_t kStageBytes = G2 ? 2048 : 1024, kStagePad = 16;      // (a pair-of-lanes wave's 32 patterns: two 16-byte loads per lane)
   // two areas per wave: the batch being searched reads one while the next batch's span is parked in the other as soon as
   // it has arrived (it arrives with the batch's first table lookup: no registers hold it across the search)
   __shared__ __attribute__((aligned(16))) uint32_t s_pat[kSThreads / 64][2][kStage ? (kStagePad + kStageBytes + 16) / 4 : 4];
@@ -187,7 +224,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
   // row disagrees go on to the walk list above and are finished by lane groups.  One launch instead of three (C5: two
   // launch ramps and tails, and a round trip of the parked state through the output arrays, gone).
   constexpr bool kFold = (JT && RW == 0u) || RW != 0u;          // the wave has a walk list
-  constexpr uint32_t kParkCap = RW ? 128u : 64u;                // (a rows phase may hand over 64 at once)
+  constexpr uint32_t kParkCap = RW ? 128u : (G2 ? 96u : 64u);   // (a rows phase may hand over 64 at once; a pair-of-lanes batch parks up to 32)
   __shared__ uint64_t s_park_row[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
   __shared__ uint32_t s_park_pid[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
   __shared__ uint32_t s_park_it[kFold ? kSThreads / 64 : 1][kFold ? kParkCap : 1];
@@ -235,7 +272,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     e = po.fixed ? (q + 1) * po.fixed : v1;
     len = pid < k ? (uint32_t)(e - b) : 0u;
   };
-  struct Stage { uint4 w; uint64_t base; bool ok; };      // base: offset in the pattern buffer of LDS byte kStagePad (16-byte aligned address)
+  struct Stage { uint4 w; uint4 w2; uint64_t base; bool ok; };      // base: offset in the pattern buffer of LDS byte kStagePad (16-byte aligned address); w2: the second KiB (G2)
   auto stage_issue = [&](uint64_t e, uint32_t len) {
     const uint64_t b = e - len;
     const uint64_t b0 = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
@@ -247,10 +284,17 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
     st.base = al - pat_addr;                                  // (wraps below zero when the buffer itself is unaligned: only differences are used)
     st.w = make_uint4(0, 0, 0, 0);
     if (st.ok && 16ull * lane64 < span) st.w = load_line16(al + 16u * lane64);      // the 16-byte block that holds the span's last byte is the last one read
+    st.w2 = make_uint4(0, 0, 0, 0);
+    if constexpr (G2) {
+      if (st.ok && 1024ull + 16ull * lane64 < span) st.w2 = load_line16(al + 1024u + 16u * lane64);
+    }
     return st;
   };
   auto stage_park = [&](const Stage &st, uint32_t area) {
     if (st.ok) *reinterpret_cast<uint4 *>(s_pat[wave_in_wg][area] + (kStagePad + 16u * lane64) / 4) = st.w;
+    if constexpr (G2) {
+      if (st.ok) *reinterpret_cast<uint4 *>(s_pat[wave_in_wg][area] + (kStagePad + 1024u + 16u * lane64) / 4) = st.w2;
+    }
   };
   // the tail of a pattern: its first NT chunks (chunk i = the four bytes the search consumes at steps 4i .. 4i+3,
   // first one in byte lane 0); NT = 1 without the table, KT / 4 with it
@@ -345,11 +389,11 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
               } else {
                 uint32_t b1, m1;
                 split448(wsp, b1, m1);
-                const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
-                wsp = cfc + rank_finish<WIDE>(w1, m1, lc);
-                wep = wsp + payload_bit(w1, m1, lc);
+                const Blk w1 = blk_load(vb, b1, m1);
+                wsp = cfc + blk_rank(w1, m1);
+                wep = wsp + blk_bit(w1, m1);
               }
-              reqs += R;
+              reqs += R * RB;
             } else {
               const uint64_t r1 = cfc + ((vb == 1 && wsp > ix.eof) ? 1u : 0u);
               wep = cfc + ((vb == 1 && wep > ix.eof) ? 1u : 0u);
@@ -558,7 +602,26 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
           if (stepping) {
             const uint32_t c = (tailq.c[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
             const uint4 e = s_tab[c];
-            reqs += backward_step<WIDE, LAYOUT>(ix, c, s_slot[c], ((uint64_t)e.y << 32) | e.x, lc, sp, ep);
+            if constexpr (G2) {      // (backward_step of fmx_device.h is written for the layout's own lane group)
+              const uint64_t cfc = ((uint64_t)e.y << 32) | e.x, vb = ((uint64_t)e.w << 32) | e.z;
+              if (vb > 1) {
+                uint32_t b1, b2, m1, m2;
+                split448(sp, b1, m1);
+                split448(ep, b2, m2);
+                const Blk w1 = blk_load(vb, b1, b2 != b1 ? m1 : (m1 > m2 ? m1 : m2));
+                Blk w2 = w1;
+                if (b2 != b1) { w2 = blk_load(vb, b2, m2); reqs += RB; }
+                sp = cfc + blk_rank(w1, m1);
+                ep = cfc + blk_rank(w2, m2);
+                reqs += RB;
+              } else {
+                const uint64_t r1 = cfc + ((vb == 1 && sp > ix.eof) ? 1u : 0u);
+                ep = cfc + ((vb == 1 && ep > ix.eof) ? 1u : 0u);
+                sp = r1;
+              }
+            } else {
+              reqs += backward_step<WIDE, LAYOUT>(ix, c, s_slot[c], ((uint64_t)e.y << 32) | e.x, lc, sp, ep);
+            }
             steps++;
           }
         }
@@ -614,7 +677,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
       bool park_now = false;                                   // ... or was found to miss by one: it is parked below
       uint32_t missj = 0;                                      // ... having agreed with its row's text for this many steps first
       uint32_t park_ahead = 0;                                 // ... from the step this many behind the wave's clock (a pair's first entry agreed)
-      if (JT && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) > (uint64_t)G))) {
+      if (JT && !__builtin_amdgcn_ballot_w64(alive && (skip != 0u || (ep - sp) > (uint64_t)RG))) {
         // ---- every live group holds at most G rows (one, as a rule: sigma = 128, n = 2^32 -- from the 6th step on) and none
         // is sitting out: a group with jc or more characters left looks its rows up in the row jump table -- J[r] = the
         // jc characters an LF walk from r reads and the row it ends on (fmx_jump.hip).  The pattern's characters come from
@@ -626,7 +689,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
           // JT == 2: the table holds PAIRS of entries, J[r] and J[LF^jc r] side by side in 32 bytes -- one request (a sector)
           // for up to 2 jc steps: the group's even lanes take the first entry and the pattern's next jc characters, its odd
           // lanes the second entry and the jc characters behind those (staged batches of the quad layout only)
-          constexpr bool kPair = JT == 2u && STAGED && G == 4;
+          constexpr bool kPair = JT == 2u && STAGED && (G == 4 || G == 2);
           const uint64_t width = ep - sp;
           const bool single = !__builtin_amdgcn_ballot_w64(can && width != 1u);      // every group that looks up holds one row
           const uint32_t half = (kPair && single) ? (t & 1u) : 0u;
@@ -653,10 +716,10 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
               // what the two halves found, to every lane of the group: the first entry's verdict decides whether the group
               // moves at all, the second one's whether it moves jc steps or 2 jc
               const uint32_t ok = jumped ? 1u : 0u;
-              const bool ok1 = group_bcast<G, 0>(ok) != 0u, ok2 = can2 && group_bcast<G, 1>(ok) != 0u;
-              const uint32_t rlo1 = group_bcast<G, 0>((uint32_t)rowj), rhi1 = group_bcast<G, 0>((uint32_t)(rowj >> 32));
-              const uint32_t rlo2 = group_bcast<G, 1>((uint32_t)rowj), rhi2 = group_bcast<G, 1>((uint32_t)(rowj >> 32));
-              const uint32_t mj1 = group_bcast<G, 0>(missj), mj2 = group_bcast<G, 1>(missj);
+              const bool ok1 = gbc0(ok) != 0u, ok2 = can2 && gbc1(ok) != 0u;
+              const uint32_t rlo1 = gbc0((uint32_t)rowj), rhi1 = gbc0((uint32_t)(rowj >> 32));
+              const uint32_t rlo2 = gbc1((uint32_t)rowj), rhi2 = gbc1((uint32_t)(rowj >> 32));
+              const uint32_t mj1 = gbc0(missj), mj2 = gbc1(missj);
               jumped = can && ok1;
               pair_both = ok1 && ok2;
               pair_then_miss = can2 && ok1 && !ok2;            // jc steps, and parked behind them with what the second entry saw
@@ -668,13 +731,33 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
             // two to G rows somewhere: lane t looks up row sp + t; the rows whose characters are the pattern's go on to
             // LF^jc of themselves -- LF keeps the order of rows that carry the same character, so they land side by side:
             // the new interval begins at the first survivor's image and has as many rows as there are survivors
+            const uint32_t lane64g = threadIdx.x & 63u, gbase = lane64g - t;
+            if constexpr (G2) {
+              // (a pair: lane t takes rows sp + t and sp + 2 + t -- up to four rows, like a quad)
+              const bool mn0 = can && (uint64_t)t < width, mn1 = can && (uint64_t)(2u + t) < width;
+              uint4 j0 = make_uint4(0, 0, 0, 0), j1 = make_uint4(0, 0, 0, 0);
+              if (mn0) j0 = jtab[JT == 2u ? 2ull * (sp + t) : sp + t];
+              if (mn1) j1 = jtab[JT == 2u ? 2ull * (sp + 2u + t) : sp + 2u + t];
+              const uint32_t d0 = j0.x ^ p0, d1 = j0.y ^ p1, d2 = (j0.z ^ p2) & m2;
+              const bool hit0 = mn0 && (d0 | d1 | d2) == 0u;
+              const bool hit1 = mn1 && ((j1.x ^ p0) | (j1.y ^ p1) | ((j1.z ^ p2) & m2)) == 0u;
+              missj = d0 ? (uint32_t)__builtin_ctz(d0) >> 3 : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u + ((uint32_t)__builtin_ctz(d2 | 0x80000000u) >> 3));      // (lane 0's first entry: row sp's)
+              const uint32_t hm = ((uint32_t)(__builtin_amdgcn_ballot_w64(hit0) >> gbase) & 3u) | (((uint32_t)(__builtin_amdgcn_ballot_w64(hit1) >> gbase) & 3u) << 2);
+              const uint32_t fr = hm ? (uint32_t)__builtin_ctz(hm) : 0u;           // the first surviving row: sp + fr, held by lane fr & 1 as its entry fr >> 1
+              const uint4 js = (fr >> 1) ? j1 : j0;
+              const int first = (int)(gbase + (fr & 1u));
+              const uint32_t rlo = (uint32_t)__shfl((int)((js.z >> 24) | (js.w << 8)), first, 64), rhi = (uint32_t)__shfl((int)(js.w >> 24), first, 64);
+              jumped = can && hm != 0u;
+              rowj = ((uint64_t)rhi << 32) | rlo;
+              nrows = (uint32_t)__builtin_popcount(hm);
+              jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mn0)) + (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mn1));
+            } else {
             const bool mine = can && (uint64_t)t < width;
             uint4 je = make_uint4(0, 0, 0, 0);
             if (mine) je = jtab[JT == 2u ? 2ull * (sp + t) : sp + t];      // (the first entry of a pair)
             const uint32_t d0 = je.x ^ p0, d1 = je.y ^ p1, d2 = (je.z ^ p2) & m2;
             const bool hit = mine && (d0 | d1 | d2) == 0u;
             missj = d0 ? (uint32_t)__builtin_ctz(d0) >> 3 : (d1 ? 4u + ((uint32_t)__builtin_ctz(d1) >> 3) : 8u + ((uint32_t)__builtin_ctz(d2 | 0x80000000u) >> 3));      // (lane 0's: the entry of row sp)
-            const uint32_t lane64g = threadIdx.x & 63u, gbase = lane64g - t;
             const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> gbase) & ((1u << G) - 1u);
             const int first = (int)(gbase + (hm ? (uint32_t)__builtin_ctz(hm) : 0u));
             const uint32_t rlo = (uint32_t)__shfl((int)((je.z >> 24) | (je.w << 8)), first, 64), rhi = (uint32_t)__shfl((int)(je.w >> 24), first, 64);
@@ -682,6 +765,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
             rowj = ((uint64_t)rhi << 32) | rlo;
             nrows = (uint32_t)__builtin_popcount(hm);
             jtl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine));      // an entry per row looked up
+            }
           }
           if (can) {
             if (!jumped && width == 1u) {
@@ -709,18 +793,37 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
         // the groups that wait this way come free together (taken at any step, their three-step rests would interleave
         // and the row jump table, which wants every group free at once, would never be reached).
         const uint64_t width = ep - sp;
-        const bool want3 = alive && skip == 0u && !deferred && !lookedup && width >= 1u && width <= (uint64_t)G && rem >= 3u &&
+        const bool want3 = alive && skip == 0u && !deferred && !lookedup && width >= 1u && width <= (uint64_t)RG && rem >= 3u &&
                            (rem < jc || it % 3u == 0u);
         if (__builtin_amdgcn_ballot_w64(want3)) {
           const uint32_t three = chars4(it) & 0xFFFFFFu;
-          const bool mine = want3 && (uint64_t)t < width;
-          unsigned long long re = 0;
+          const uint32_t lane64 = threadIdx.x & 63u, base = lane64 - t;
+          unsigned long long re = 0;                      // lane 0's: row sp's word (what a miss is located with)
+          uint32_t hm, lo3, hi3;
+          bool mine;
+          if constexpr (G2) {                             // a pair: rows sp + t and sp + 2 + t
+            mine = want3 && (uint64_t)t < width;
+            const bool mine1 = want3 && (uint64_t)(2u + t) < width;
+            unsigned long long re1 = 0;
+            if (mine) re = r3tab[sp + t];
+            if (mine1) re1 = r3tab[sp + 2u + t];
+            const bool h0 = mine && (uint32_t)(re >> 40) == three, h1 = mine1 && (uint32_t)(re1 >> 40) == three;
+            hm = ((uint32_t)(__builtin_amdgcn_ballot_w64(h0) >> base) & 3u) | (((uint32_t)(__builtin_amdgcn_ballot_w64(h1) >> base) & 3u) << 2);
+            const uint32_t fr = hm ? (uint32_t)__builtin_ctz(hm) : 0u;
+            const unsigned long long rs = (fr >> 1) ? re1 : re;
+            const int first = (int)(base + (fr & 1u));
+            lo3 = (uint32_t)__shfl((int)(uint32_t)rs, first, 64);
+            hi3 = (uint32_t)__shfl((int)(uint32_t)(rs >> 32), first, 64);
+            r3l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(mine1));      // (the first rows' words are counted below)
+          } else {
+          mine = want3 && (uint64_t)t < width;
           if (mine) re = r3tab[sp + t];
           const bool hit = mine && (uint32_t)(re >> 40) == three;
-          const uint32_t lane64 = threadIdx.x & 63u, base = lane64 - t;
-          const uint32_t hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> base) & ((1u << G) - 1u);
+          hm = (uint32_t)(__builtin_amdgcn_ballot_w64(hit) >> base) & ((1u << G) - 1u);
           const int first = (int)(base + (hm ? (uint32_t)__builtin_ctz(hm) : 0u));
-          const uint32_t lo3 = (uint32_t)__shfl((int)(uint32_t)re, first, 64), hi3 = (uint32_t)__shfl((int)(uint32_t)(re >> 32), first, 64);
+          lo3 = (uint32_t)__shfl((int)(uint32_t)re, first, 64);
+          hi3 = (uint32_t)__shfl((int)(uint32_t)(re >> 32), first, 64);
+          }
           if (want3) {
             const bool took = hm != 0u;
             if (took) {
@@ -786,11 +889,11 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
             } else {
               uint32_t b1, m1;
               split448(sp, b1, m1);
-              const uint4 w1 = load_line16(vb + lane_off + (uint64_t)b1 * kBlockBytes);
-              sp = cfc + rank_finish<WIDE>(w1, m1, lc);
-              ep = sp + payload_bit(w1, m1, lc);
+              const Blk w1 = blk_load(vb, b1, m1);
+              sp = cfc + blk_rank(w1, m1);
+              ep = sp + blk_bit(w1, m1);
             }
-            reqs += R;
+            reqs += R * RB;
           } else {
             const uint64_t r1 = special(cfc, vb, sp);
             ep = special(cfc, vb, ep);
@@ -819,13 +922,12 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(FMX_S
             uint32_t b1, b2, m1, m2;
             split448(sp, b1, m1);
             split448(ep, b2, m2);
-            const uint64_t base = vb + lane_off;
-            const uint4 w1 = load_line16(base + (uint64_t)b1 * kBlockBytes);
-            uint4 w2 = w1;                                     // narrow intervals: sp and ep share a block
-            if (b2 != b1) { w2 = load_line16(base + (uint64_t)b2 * kBlockBytes); reqs += 1; }
-            sp = cfc + rank_finish<WIDE>(w1, m1, lc);
-            ep = cfc + rank_finish<WIDE>(w2, m2, lc);
-            reqs += 1;
+            const Blk w1 = blk_load(vb, b1, b2 != b1 ? m1 : (m1 > m2 ? m1 : m2));
+            Blk w2 = w1;                                       // narrow intervals: sp and ep share a block
+            if (b2 != b1) { w2 = blk_load(vb, b2, m2); reqs += RB; }
+            sp = cfc + blk_rank(w1, m1);
+            ep = cfc + blk_rank(w2, m2);
+            reqs += RB;
           }
         } else {
           const uint64_t r1 = special(cfc, vb, sp);
@@ -961,15 +1063,15 @@ static int census_read(const Index *h, int grid, int api, hipStream_t st) {
 }
 
 // cal: this is search_calibrate's call -- nothing is searched, the instantiation is calibrated
-template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T = false>
+template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T = false, bool G2 = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
                               const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st, uint64_t pk_cap, bool cal) {
-  static const int api = blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T>);
+  static const int api = blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T, G2>);
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
   static const int forced = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), api)) : 0;
   static Residency res[16];
   Residency &rs = res[(unsigned)h->device & 15u];
-  constexpr uint64_t per_wg = kSThreads / Lay<LAYOUT>::G;
+  constexpr uint64_t per_wg = kSThreads / (G2 ? 2 : Lay<LAYOUT>::G);
   if (cal) {
     std::lock_guard<std::mutex> lk(rs.mu);
     if (!forced && !rs.admitted.load() && h->cu_count * api <= (int)kCensusBlocks) {
@@ -981,14 +1083,14 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
       { const hipError_t e0 = hipMemsetAsync(scr, 0, kCalibScratchBytes, st); if (e0 != hipSuccess) return e0; }      // (the offsets MUST be zeros: the kernel reads pat[off])
       int last = 0, got = 0;
       for (int attempt = 0; attempt < 4 && !rs.admitted.load(); attempt++) {
-        k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
+        k_search4<WIDE, LAYOUT, KT, JT, RW, R3T, G2><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
                                                                              (R3T || RW) ? r1 : nullptr, (const uint8_t *)h->d_bwt, po, (uint64_t *)(scr + 2), (uint64_t *)(scr + 3),
                                                                              1u, h->d_counters, ~0ull, kCalibSpin);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         got = census_read(h, grid, api, st);
-        if (trace) fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d> census: %d of the %d workgroups per CU the occupancy query allows were resident\n",
-                           (int)WIDE, LAYOUT, KT, (int)JT, RW, (int)R3T, got, api);
+        if (trace) fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d,%d> census: %d of the %d workgroups per CU the occupancy query allows were resident\n",
+                           (int)WIDE, LAYOUT, KT, (int)JT, RW, (int)R3T, (int)G2, got, api);
         if (got && got == last) rs.admitted.store(got);
         last = got;
       }
@@ -1006,7 +1108,7 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   h->search_residency.store((uint32_t)per_cu | ((forced || measured) ? 0x100u : 0u));
   // ONE launch in every configuration (round 5: the kernels without a row jump table used to be followed by k_search_rows and
   // k_search_defer); the 8-byte form, where asked for, is written by the kernel itself
-  k_search4<WIDE, LAYOUT, KT, JT, RW, R3T><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
+  k_search4<WIDE, LAYOUT, KT, JT, RW, R3T, G2><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
                                                                        (R3T || RW) ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters, pk_cap, 0u);
   return hipGetLastError();
 }
@@ -1042,9 +1144,25 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
   if (jt) {      // and the three-step table beside it, for the steps no aligned jump covers
     const unsigned long long *r3 = nullptr;
     if (rows != 0 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
-    if (h->jump_pairs)      // (pairs are built from the three-step table: it is there)
+    if (h->jump_pairs) {    // (pairs are built from the three-step table: it is there)
+      // large batches on the one-hot layout: a PAIR of lanes per pattern, 32 patterns per wave (k_search4<.., G2>) -- half the
+      // lockstep batches per wave; a batch that does not give every wave of that grid a few batches keeps the quads
+      // (FMX_SEARCH_G2=0 / 1: never / whenever the instantiation exists)
+      if constexpr (LAYOUT == kLayoutOneHot) {
+        const char *g2e = getenv("FMX_SEARCH_G2");      // (looked at per launch: the tests switch it inside one process)
+        const int g2 = g2e ? atoi(g2e) : -1;
+        if (r3 && g2 != 0) {
+          if (cal) {                  // fmx_prepare calibrates both instantiations: which one a search takes depends on its size
+            const hipError_t ec = launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, true);
+            if (ec != hipSuccess) return ec;
+          } else if (g2 == 1 || (uint64_t)k >= (uint64_t)h->cu_count * 6 * 128 * 3) {
+            return launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, false);
+          }
+        }
+      }
       return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, cal)
                 : launch_v4kj<WIDE, LAYOUT, KT, 2u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, cal);
+    }
     return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, cal)
               : launch_v4kj<WIDE, LAYOUT, KT, 1u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, cal);
   }

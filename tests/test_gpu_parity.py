@@ -2267,7 +2267,9 @@ def test_search_grid_follows_the_residency_census(layout):
         # a second handle of the same shape finds the instantiation calibrated: prepare has nothing to launch
         hip2 = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
         hip2.prepare(ktab=True, jump=True)
-        assert hip2.stats()["search_residency"] == r0
+        assert hip2.stats()["search_residency"] & 0x100          # (of the instantiation calibrated last: a handle may select two, by batch size)
+        sp2, ep2 = hip2.search_batch(pats.reshape(-1), off)
+        assert hip2.stats()["search_residency"] == r0 and np.array_equal(sp2, first[0]) and np.array_equal(ep2, first[1])
         hip2.close()
         orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
         wsp, wep, _ = orc.search_batch(pats[:5000].reshape(-1), off[:5001])
@@ -2339,6 +2341,43 @@ def test_search_inside_a_captured_graph_leaves_the_census_alone(layout):
     assert any("census" in ln for ln in lines), "FMX_TRACE shows no census launch at all:\n" + r.stderr
     first_search = [i for i, ln in enumerate(lines) if "FIRST-SEARCH" in ln][0]
     assert not any("census" in ln for ln in lines[first_search:]), "a census was read after the first search:\n" + "\n".join(lines)
+
+
+@pytest.mark.parametrize("which", ["modes", "repeats", "spans", "walks", "ragged"])
+def test_pairs_of_lanes_search_kernel(which, monkeypatch):
+    """k_search4<.., G2> (round 5): a pattern served by a PAIR of lanes, 32 patterns per wave, the dictionary's blocks
+    fetched as two 32-byte halves, pattern spans of up to 2 KiB staged -- by default only for batches that give every wave
+    several batches (the C3 tests at full size run it), forced here on the small ones (FMX_SEARCH_G2=1, with the pair table
+    it needs: FMX_JUMP_PAIRS=1): the row-table tests in every mode and entry width, the repetitive texts (intervals of two
+    rows: lane t looks up row sp + t), the staged spans' edges, the parked walks, and ragged lengths 0 .. 70 around the
+    2 KiB span limit -- all against the oracle, executed steps included."""
+    monkeypatch.setenv("FMX_JUMP_PAIRS", "1")
+    monkeypatch.setenv("FMX_SEARCH_G2", "1")
+    if which == "modes":
+        test_row_jump_table_on_and_off_agree("onehot")
+    elif which == "repeats":
+        test_row_tables_on_repetitive_texts("onehot")
+    elif which == "spans":
+        test_staged_pattern_spans_edges("onehot")
+    elif which == "walks":
+        test_parked_walks_flush_inside_the_kernel()
+    else:
+        bwt, eof, counts = synth_bwt(500_000, 1, 12, 77)
+        hip, orc = pair_from_mem(bwt, eof, counts)
+        hip.prepare(ktab=True, jump=True)
+        rng = np.random.default_rng(4)
+        pats = []
+        for m in list(range(0, 71)) * 12:                       # batches of 32 whose spans run from nothing to 2.2 KiB
+            pats += lf_walk_patterns(orc, rng, 1, m, 0.25, alphabet=list(range(1, 13))) if m else [b""]
+        rng.shuffle(pats)
+        pats += lf_walk_patterns(orc, rng, 64, 63, 0.1, alphabet=list(range(1, 13)))      # 32 x 63 + alignment: on the limit
+        pats += lf_walk_patterns(orc, rng, 64, 64, 0.1, alphabet=list(range(1, 13)))      # 32 x 64 = 2 KiB exactly: staged or not by the buffer's alignment
+        pats += lf_walk_patterns(orc, rng, 64, 65, 0.1, alphabet=list(range(1, 13)))      # over it: read from global memory
+        hip.stats_reset()
+        check_search(hip, orc, pats)
+        st = hip.stats()
+        assert st["jump_lookups"] > 0 and st["jump_bytes"] == 32 * orc.n
+        hip.close()
 
 
 def test_result_groups_of_every_size_are_ordered():

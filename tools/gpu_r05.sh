@@ -75,6 +75,15 @@ alloc)
   hipcc -O2 --offload-arch=gfx950 -o tools/ubench/alloc tools/ubench/alloc.hip -lpthread > $O/alloc_build.log 2>&1 || { echo "alloc build failed"; tail -3 $O/alloc_build.log; }
   timeout -k 10 500 tools/ubench/alloc > $O/alloc.txt 2>&1; echo "alloc rc=$?"; cat $O/alloc.txt
   ;;
+sqpmc:*)
+  # the SQ counters of tools/c3_cold.py's launches under an environment setting:  sqpmc:<VAR=val|->   (one rocprofv3 --pmc pass)
+  setting=${PART#sqpmc:}; tag=${setting//[^A-Za-z0-9]/_}
+  mkdir -p $O/sq_$tag
+  ( [ "$setting" != "-" ] && export $setting; cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $REPO/$O/sq_$tag/pass1 -- python3 $REPO/tools/c3_cold.py > $REPO/$O/sq_$tag/pass1.log 2>&1 ) || echo "sq pass failed"
+  ( [ "$setting" != "-" ] && export $setting; cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $REPO/$O/sq_$tag/pass2 -- python3 $REPO/tools/c3_cold.py > $REPO/$O/sq_$tag/pass2.log 2>&1 ) || echo "sq pass 2 failed"
+  python tools/c3_cold_pmc.py $O/sq_$tag $O/sq_${tag}_counters.csv > $O/sq_${tag}_counters.txt 2>&1; grep "^ring\|^s_ring\|^replay " $O/sq_${tag}_counters.txt
+  rm -rf $O/sq_$tag/pass*/
+  ;;
 writevalue)
   hipcc -O2 --offload-arch=gfx950 -o tools/ubench/writevalue tools/ubench/writevalue.hip > $O/wv_build.log 2>&1
   timeout -k 10 120 tools/ubench/writevalue > $O/writevalue.txt 2>&1; echo "writevalue rc=$?"; cat $O/writevalue.txt

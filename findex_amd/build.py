@@ -14,6 +14,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libfmx.so")
+# the same library with fmx_comm.cpp's fault-injection switch compiled in (-DFMX_FAULT_INJECTION): loaded by one test only
+OUT_FAULTS = os.path.join(OUT_DIR, "libfmx_faults.so")
 SOURCES = ["fmx_api.cpp", "fmx_hostpar.cpp", "fmx_comm.cpp", "fmx_hostrank.cpp", "fmx_regex.cpp", "fmx_build.hip", "fmx_kernels.hip", "fmx_search.hip", "fmx_ktab.hip", "fmx_jump.hip", "fmx_select.hip", "fmx_frontier.hip", "fmx_refmatch.hip"]
 HEADERS = ["fmx_device.h", "fmx_host.h", "fmx_hostpar.h", "fmx_nfa.h", "fmx_regex.h"]
 ARCH = "gfx950"
@@ -47,7 +49,7 @@ STAMP = OUT + ".stamp"
 
 
 def _stale():
-    if not os.path.exists(OUT) or not os.path.exists(STAMP):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP) or not os.path.exists(OUT_FAULTS):
         return True
     with open(STAMP) as f:
         return f.read().strip() != _source_stamp()
@@ -106,6 +108,13 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(tmp, OUT)
+    # ... and the tests' twin: fmx_comm.cpp once more with the fault-injection switch, everything else as it is
+    fobj = os.path.join(OUT_DIR, "fmx_comm.cpp.faults.o")
+    subprocess.check_call([_hipcc()] + flags + ["-DFMX_FAULT_INJECTION", "-x", "hip", "-c", os.path.join(CSRC, "fmx_comm.cpp"), "-o", fobj])
+    ftmp = OUT_FAULTS + ".%d.tmp" % os.getpid()
+    subprocess.check_call([_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", ftmp] +
+                          [fobj if o.endswith("fmx_comm.cpp.o") else o for o in objs] + ["-ldl"])
+    os.replace(ftmp, OUT_FAULTS)
     with open(STAMP, "w") as f:
         f.write(stamp + "\n")
     return OUT

@@ -114,11 +114,17 @@ int add_streams(CommSet *c) {
   return FMX_OK;
 }
 
-// FMX_COMM_FAIL_INIT=1: the RCCL initialisation call is reported as failed without being made -- the error path of
-// fmx_comm_create_* (a communicator destroyed before its streams exist) under test without a broken fabric.
+// The error path of fmx_comm_create_* (a communicator destroyed before its streams exist) under test without a broken
+// fabric: in a library compiled with -DFMX_FAULT_INJECTION (findex_amd/lib/libfmx_faults.so, which only the tests load)
+// FMX_COMM_FAIL_INIT=1 reports the RCCL initialisation call as failed without making it.  The product library has no
+// such switch.
 bool fail_init_injected() {
+#ifdef FMX_FAULT_INJECTION
   const char *e = getenv("FMX_COMM_FAIL_INIT");
   return e && e[0] == '1';
+#else
+  return false;
+#endif
 }
 
 // The collective's stream of local rank i waits for the work the caller has enqueued on producer[i] so far (the

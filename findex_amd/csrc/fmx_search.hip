@@ -969,6 +969,9 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
     if (npark > kParkCap - 64u) walk_parked(std::false_type{});
     rows_phase(true);
   }
+#ifdef FMX_SEARCHLOG
+  const unsigned long long sl_tw = __builtin_amdgcn_s_memrealtime();      // the last walk begins
+#endif
   if (kFold) walk_parked(std::true_type{});
 #ifdef FMX_SEARCHLOG
   const unsigned long long sl_t2 = __builtin_amdgcn_s_memrealtime();
@@ -981,7 +984,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
 #ifdef FMX_SEARCHLOG
   if ((threadIdx.x & 63u) == 0 && wave < (1u << 15)) {
     unsigned long long *e = g_searchlog[wave];
-    e[0] = sl_t0; e[1] = sl_t1; e[2] = sl_t2; e[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)sl_batches << 48);
+    e[0] = sl_t0; e[1] = ((sl_t1 - sl_t0) & 0xFFFFFFFFull) | ((sl_tw - sl_t0) << 32); e[2] = sl_t2; e[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)sl_batches << 48);
   }
 #endif
   if (threadIdx.x == 0 && blockIdx.x < kCensusBlocks)       // ... and when its first wave ended

@@ -150,6 +150,16 @@ def test_header_is_plain_c_and_links(tmp_path):
                                   str(ctypes.sizeof(_lib.fmx_result))]
 
 
+def test_product_library_has_no_fault_injection_switch():
+    """fmx_comm.cpp's FMX_COMM_FAIL_INIT switch exists in the tests' twin of the library only."""
+    from findex_amd import build
+    assert b"FMX_COMM_FAIL_INIT" not in open(_lib.LIB_PATH, "rb").read()
+    assert b"FMX_COMM_FAIL_INIT" in open(build.OUT_FAULTS, "rb").read()
+    twin = ctypes.CDLL(build.OUT_FAULTS)
+    for name in declared_functions():
+        assert hasattr(twin, name), name
+
+
 def test_build_lists_cover_the_sources():
     """Every source and header under findex_amd/csrc is named in findex_amd/build.py (the staleness check and
     the compile list are driven by those lists)."""

@@ -1373,7 +1373,7 @@ def test_match_batch_sharded_device_exchange():
     assert got.tobytes() == want.tobytes() and want.size > 100
 
 
-def test_allgather_dev_rccl_in_the_library(monkeypatch):
+def test_allgather_dev_rccl_in_the_library():
     """fmx_comm_* / fmx_allgather_dev / fmx_gather_dev: the exchange as an RCCL call inside libfmx.so (what a JVM caller
     uses).  One GPU here, so the communicators have one rank -- created both ways (ncclCommInitAll over the handles of one
     process; unique id + ncclCommInitRank as one process per GPU does) -- and the gather of the intervals of a real
@@ -1458,15 +1458,33 @@ def test_allgather_dev_rccl_in_the_library(monkeypatch):
     # refused: two handles on one device (RCCL has one rank per GPU)
     twice = (ctypes.c_void_p * 2)(hips[0].handle, hips[0].handle)
     assert L.fmx_comm_create_all(twice, 2, ctypes.byref(comm)) == 3
-    # a failed initialisation (injected) returns FMX_ERR_HIP with a message and leaves nothing behind
-    monkeypatch.setenv("FMX_COMM_FAIL_INIT", "1")
-    comm = ctypes.c_void_p()
-    assert L.fmx_comm_create_rank(hips[0].handle, 1, 0, uid, ctypes.byref(comm)) == 5 and not comm.value
-    assert b"ncclCommInitRank" in L.fmx_last_error()
-    assert L.fmx_comm_create_all(idxs, ndev, ctypes.byref(comm)) == 5 and not comm.value
-    monkeypatch.delenv("FMX_COMM_FAIL_INIT")
-    _lib.check(L.fmx_comm_create_all(idxs, ndev, ctypes.byref(comm)))     # and the library still makes communicators
-    _lib.check(L.fmx_comm_free(comm))
+    # a failed initialisation returns FMX_ERR_HIP with a message and leaves nothing behind: injected, in a process of its own,
+    # through the tests' twin of the library -- the product library has no such switch (findex_amd/build.py, fmx_comm.cpp)
+    from findex_amd import build as fbuild
+    assert b"FMX_COMM_FAIL_INIT" not in open(_lib.LIB_PATH, "rb").read()
+    code = (
+        "import ctypes, os, torch\n"
+        "import findex_amd\n"
+        "from findex_amd import _lib\n"
+        "L = _lib.load()\n"
+        "hip = findex_amd.HipFMSearcher(%r)\n"
+        "uid = ctypes.create_string_buffer(128)\n"
+        "_lib.check(L.fmx_comm_unique_id(uid))\n"
+        "comm = ctypes.c_void_p()\n"
+        "os.environ['FMX_COMM_FAIL_INIT'] = '1'\n"
+        "assert L.fmx_comm_create_rank(hip.handle, 1, 0, uid, ctypes.byref(comm)) == 5 and not comm.value\n"
+        "assert b'ncclCommInitRank' in L.fmx_last_error()\n"
+        "idxs = (ctypes.c_void_p * 1)(hip.handle)\n"
+        "assert L.fmx_comm_create_all(idxs, 1, ctypes.byref(comm)) == 5 and not comm.value\n"
+        "del os.environ['FMX_COMM_FAIL_INIT']\n"
+        "_lib.check(L.fmx_comm_create_all(idxs, 1, ctypes.byref(comm)))     # and the library still makes communicators\n"
+        "_lib.check(L.fmx_comm_free(comm))\n"
+        "print('injected ok')\n" % os.path.join(fbuild.ROOT, "tests", "golden", "testdata", "words.bwt"))
+    import subprocess
+    import sys
+    env = dict(os.environ, FMX_LIB=fbuild.OUT_FAULTS, PYTHONPATH=fbuild.ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "injected ok" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
 
 
 def _nccl_rank(rank, world, port, q):

@@ -34,7 +34,11 @@ print("device ms of the logged call (all its kernels): %.4f" % hip.last_kernel_m
 t3 = log[:, 3] & np.uint64((1 << 48) - 1)
 nb = (log[:, 3] >> np.uint64(48)).astype(np.int64)
 live = log[:, 0] != 0
-t0, t1, t2, t3, nb = log[live, 0].astype(np.int64), log[live, 1].astype(np.int64), log[live, 2].astype(np.int64), t3[live].astype(np.int64), nb[live]
+live &= log[:, 0] + np.uint64(100000) > log[live, 0].max()      # the log is never cleared: entries of earlier, larger launches (within 1 ms of the newest: this launch)
+t0 = log[live, 0].astype(np.int64)
+t1 = t0 + (log[live, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)      # (entry 1: the batch loop's begin and the last walk's, both from t0)
+tw = t0 + (log[live, 1] >> np.uint64(32)).astype(np.int64)
+t2, t3, nb = log[live, 2].astype(np.int64), t3[live].astype(np.int64), nb[live]
 T = 0.01      # us per tick
 z = t0.min()
 span = (t3.max() - z) * T
@@ -44,11 +48,16 @@ def pct(name, v):
     print("%-34s min %7.1f  p10 %7.1f  p50 %7.1f  p90 %7.1f  p99 %7.1f  max %7.1f us" % ((name,) + tuple(q)))
 pct("wave begins at", (t0 - z) * T)
 pct("enters its batch loop at", (t1 - z) * T)
-pct("leaves it at", (t2 - z) * T)
+pct("begins its last walk at", (tw - z) * T)
+pct("last walk takes", (t2 - tw) * T)
+pct("has walked at", (t2 - z) * T)
 pct("ends at", (t3 - z) * T)
 pct("alive for", (t3 - t0) * T)
 pct("set-up (tables into LDS)", (t1 - t0) * T)
-pct("per batch", (t2 - t1) * T / np.maximum(nb, 1))
+pct("per batch", (tw - t1) * T / np.maximum(nb, 1))
+for b in sorted(set(nb.tolist())):
+    sel = nb == b
+    print("waves with %d batches: %5d; batch loop ends p50 %6.1f p99 %6.1f, wave ends p50 %6.1f p99 %6.1f max %6.1f us" % (b, sel.sum(), np.percentile((tw[sel] - z) * T, 50), np.percentile((tw[sel] - z) * T, 99), np.percentile((t3[sel] - z) * T, 50), np.percentile((t3[sel] - z) * T, 99), ((t3[sel] - z) * T).max()))
 print("batches per wave: min %d max %d" % (nb.min(), nb.max()))
 for f in range(0, 11):
     at = z + int(f / 10 * (t3.max() - z))

@@ -283,8 +283,8 @@ int build_index(Index *h, hipStream_t st, const int64_t *given_counts) {
     }
     FMX_TRY(hipMalloc(&h->d_cf, sizeof h->cf), "hipMalloc(cf)");
     FMX_TRY(hipMalloc(&h->d_slot, sizeof h->slot), "hipMalloc(slot)");
-    FMX_TRY(hipMalloc((void **)&h->d_counters, kCounterBytes + kCensusBytes + kCalibScratchBytes), "hipMalloc(counters)");
-    FMX_TRY(hipMemsetAsync(h->d_counters, 0, kCounterBytes + kCensusBytes + kCalibScratchBytes, st), "memset(counters)");
+    FMX_TRY(hipMalloc((void **)&h->d_counters, kCounterBytes + kCensusBytes + kCalibScratchBytes + kTixBytes), "hipMalloc(counters)");
+    FMX_TRY(hipMemsetAsync(h->d_counters, 0, kCounterBytes + kCensusBytes + kCalibScratchBytes + kTixBytes, st), "memset(counters)");
     FMX_TRY(hipMemcpyAsync(h->d_cf, h->cf, sizeof h->cf, hipMemcpyHostToDevice, st), "copy cf");
     FMX_TRY(hipMemcpyAsync(h->d_slot, h->slot, sizeof h->slot, hipMemcpyHostToDevice, st), "copy slot");
     FMX_TRY(hipMemcpyAsync(d_sym, sym_of, sizeof sym_of, hipMemcpyHostToDevice, st), "copy sym");

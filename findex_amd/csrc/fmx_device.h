@@ -431,6 +431,13 @@ constexpr size_t kCounterBytes = (size_t)kCounterSlots * kCounterStride * 8;
 // the first one ended and sizes later grids by that (fmx_search.hip, Residency).
 constexpr uint32_t kCensusBlocks = 4096;
 constexpr size_t kCensusBytes = (size_t)kCensusBlocks * 16 + 16;      // + one word behind the entries: the grid of the launch that wrote them
+// ... and behind that the TICKET areas of the literal search kernel (fmx_search.hip, "the last rounds are drawn"): kTixShards
+// counters per area, each on a 128-byte line of its own (all waves of a launch drawing from ONE counter are ~12 000 returning
+// atomics on one address, 8 ns each: 0.1 ms, measured); area a belongs to one stream at a time (host bookkeeping)
+constexpr uint32_t kTixAreas = 16;
+constexpr uint32_t kTixShards = 64;
+constexpr size_t kTixStride = 16;                                      // words between two counters
+constexpr size_t kTixBytes = (size_t)kTixAreas * kTixShards * kTixStride * 8;
 constexpr size_t kCalibScratchBytes = 64;                             // behind the census: the calibration launch's empty pattern (two zero offsets) and its output words
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {

@@ -130,6 +130,12 @@ struct Index {
   mutable uint64_t row3_bytes = 0;
   mutable double tables_ms = 0.0;             // host time spent building the k-mer table and the select directory (under their mutexes)
   // when the derived tables are built (fmx_jump.hip, tables_due): patterns searched so far, fmx_prepare seen
+  // ticket areas of the literal search kernel (fmx_device.h, kTixAreas): which stream owns which.  A launch draws its last
+  // batches from the area of the stream it is enqueued on; launches on ONE stream follow each other, so an area serves one
+  // launch at a time.  Streams beyond the areas (and streams being captured) get none: their launches stride statically.
+  mutable std::mutex tix_mu;
+  mutable void *tix_owner[16] = {};
+  mutable bool tix_used[16] = {};
   mutable std::atomic<uint64_t> patterns_seen{0};
   mutable std::atomic<uint32_t> search_residency{0};     // fmx_stats.search_residency
   // fmx_prepare has been asked for the k-mer table / the row tables: searches use them (and build what a drop took away)

@@ -134,11 +134,11 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
     counters[(size_t)kCounterSlots * kCounterStride + 2u * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     if (blockIdx.x == 0) counters[(size_t)kCounterSlots * kCounterStride + 2u * kCensusBlocks] = gridDim.x;      // whose entries these are
   }
-  if (spin) {
+  if (spin & 0xFFFFu) {
     // a CALIBRATION launch (search_calibrate, from fmx_prepare): every workgroup stays resident for `spin` ticks of the
     // 100 MHz clock whatever its batch holds, so that "began before the first one ended" means "was resident beside it"
     const unsigned long long c0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - c0 < spin) __builtin_amdgcn_s_sleep(32);
+    while (__builtin_amdgcn_s_memrealtime() - c0 < (spin & 0xFFFFu)) __builtin_amdgcn_s_sleep(32);
   }
   // per symbol: {C[c], x} with x = byte address of the symbol's bit-vector (one-hot layout) or its
   // slot + 2 (bytes layout); x = 0 absent symbol, x = 1 the EOF symbol
@@ -190,6 +190,24 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
   const uint32_t nwaves = gridDim.x * (kSThreads / 64);
   const uint32_t grp = (threadIdx.x & 63) / G;
   const uint32_t nbatch = (k + P - 1) / P;
+  // The last rounds are DRAWN (round 5).  The batches are strided statically over the waves, every wave's pipeline knowing
+  // two batches ahead which ones are its own -- and the launch ends with its slowest wave: the timelines
+  // (profiles/r05_c3_wave_timeline.txt, r05_c5_c2_wave_timeline.txt) have the waves leave their batch loops 20-50 us apart
+  // (C2 83-110 us, C5 244-294 us p10-p99).  So when the host hands the launch a ticket area (bits 16-23 of `spin`; fmx_device.h,
+  // kTixAreas) and there are four rounds or more, all rounds but the last two full ones are strided as before and the rest --
+  // two to three rounds' worth -- is a pool: a wave that has done its share draws batch after batch from it (one returning
+  // atomic each, issued a batch ahead) until it is empty.  A drawn batch starts cold (its offsets, then its bytes: two
+  // round trips the strided ones have behind them), which is why only the end is drawn; the strided part keeps its code
+  // and its registers (tools/r05_tickets.patch drew every batch: +2.5-4 % for the drawing, -6-7 % for its state in the loop).
+  // (not in the quads' kernels with a row jump table: the second copy of the batch body costs them 4 vector and 9 scalar
+  // registers spilled at six waves per SIMD -- C3 by quads 0.137-0.140 -> 0.143 ms; their large batches go to the pairs)
+  constexpr bool kPool = G2 || RW != 0u;
+  const uint32_t tix_area = kPool ? (spin >> 16) & 0xFFu : 0u;
+  uint32_t nstatic = nbatch;
+  if (tix_area) {
+    const uint32_t rounds = nbatch / nwaves, held = spin >> 24;      // held: full rounds that go to the pool with the partial one
+    if (rounds >= held + 2u) nstatic = (rounds - held) * nwaves;
+  }
   // Pattern pipeline.  A wave's 16 (8) patterns lie one behind the other in the pattern buffer, so their bytes are ONE
   // contiguous span: it is fetched with one coalesced wave-level load (16 bytes per lane, up to 1 KiB) while the batch
   // before it is searched, parked in the wave's own LDS area, and every chunk of pattern bytes the search consumes is an
@@ -483,17 +501,17 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
 #ifdef FMX_SEARCHLOG
   sl_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (uint32_t batch = wave; batch < nbatch; batch += nwaves) {
-#ifdef FMX_SEARCHLOG
-    sl_batches++;
-#endif
-    Stage nxt_stage;
+  uint32_t batch = wave;
+  Stage nxt_stage;
+  {
     // One batch, written once and compiled twice: STAGED = its bytes are in LDS; else (a span longer than the LDS area)
     // they are read chunk by chunk from global memory.  Two copies of the code, so that no value of the staged path is
     // ever a merge with the result of a global load -- the compiler waits for ALL outstanding loads (`vmcnt(0)`) where it
     // meets such a value, and the next batch's loads issued below would be among them.
-    auto search_one_batch = [&](auto staged_tag) {
+    // AHEAD: a strided batch, which requests the next one's bytes and the offsets of the one after it; a drawn one does not
+    auto search_one_batch = [&](auto staged_tag, auto ahead_tag) {
     constexpr bool STAGED = decltype(staged_tag)::value;
+    constexpr bool AHEAD = decltype(ahead_tag)::value;
     const uint32_t pid = batch * P + grp;
     const bool act = pid < k;
     const uint64_t *own = po.at(act ? pid : 0u);      // any valid address (pat_chunk)
@@ -545,14 +563,16 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
     uint32_t nx = chunk(KT ? KT / 4 + 1 : 1);                 // the chunk after the current one
     // the next batch's bytes and the offsets of the one after it: requested behind this batch's first lookup (below)
     auto issue_ahead = [&]() {
-      nxt_stage = stage_issue(end1, len1);
-      if constexpr (!kStage) {
+      if constexpr (AHEAD) {
+        nxt_stage = stage_issue(end1, len1);
+        if constexpr (!kStage) {
 #pragma unroll
-        for (uint32_t i = 0; i < NT; i++) tail_ahead.c[i] = len1 > 4u * i ? fetch4(pat, end1 - 4ull * i) : 0u;
+          for (uint32_t i = 0; i < NT; i++) tail_ahead.c[i] = len1 > 4u * i ? fetch4(pat, end1 - 4ull * i) : 0u;
+        }
+        load_off_raw((uint64_t)batch + 2ull * nwaves, raw2a, raw2b);
       }
-      load_off_raw((uint64_t)batch + 2ull * nwaves, raw2a, raw2b);
     };
-    if (KT == 0) { issue_ahead(); stage_park(nxt_stage, par ^ 1u); }
+    if (KT == 0) { issue_ahead(); if constexpr (AHEAD) stage_park(nxt_stage, par ^ 1u); }
     uint64_t sp = 0, ep = ix.n;
     // symbols without a vector: absent (x = 0) or the EOF symbol (x = 1)
     auto special = [&](uint64_t cfc, uint64_t vb, uint64_t x) { return cfc + ((vb == 1 && x > ix.eof) ? 1u : 0u); };
@@ -594,7 +614,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
         steps += ent.y >> 24;           // the reference's loop ran this many steps on these characters
       }
       ktl += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(elig && t == 0));
-      stage_park(nxt_stage, par ^ 1u);      // it was requested beside the entry and has arrived with it
+      if constexpr (AHEAD) stage_park(nxt_stage, par ^ 1u);      // it was requested beside the entry and has arrived with it
       if (__builtin_amdgcn_ballot_w64(act && !elig)) {
         for (uint32_t j = 0; j < KT; j++) {
           const bool stepping = act && !elig && j < len && sp < ep;
@@ -946,29 +966,86 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
     }
     if (act && t == 0 && !deferred) emit(pid, sp, ep);
     };      // search_one_batch
-    if constexpr (kStage) {
-      if (cur.ok) search_one_batch(std::true_type{});
-      else search_one_batch(std::false_type{});
-    } else {
-      search_one_batch(std::false_type{});
-    }
-    if constexpr (RW != 0u) {
-      if (nrows >= 64u) {
-        if (npark > kParkCap - 64u) walk_parked(std::false_type{});         // room for all a rows phase may hand over
-        rows_phase(false);
+    auto one_batch = [&](auto ahead_tag) {
+      if constexpr (kStage) {
+        if (cur.ok) search_one_batch(std::true_type{}, ahead_tag);
+        else search_one_batch(std::false_type{}, ahead_tag);
+      } else {
+        search_one_batch(std::false_type{}, ahead_tag);
       }
-    } else {
-      if (kFold && npark > kParkCap - P) walk_parked(std::false_type{});    // room for a whole batch's groups
+      if constexpr (RW != 0u) {
+        if (nrows >= 64u) {
+          if (npark > kParkCap - 64u) walk_parked(std::false_type{});         // room for all a rows phase may hand over
+          rows_phase(false);
+        }
+      } else {
+        if (kFold && npark > kParkCap - P) walk_parked(std::false_type{});    // room for a whole batch's groups
+      }
+    };
+    // ---- the strided rounds
+    for (; batch < nstatic; batch += nwaves) {
+#ifdef FMX_SEARCHLOG
+      sl_batches++;
+#endif
+      one_batch(std::true_type{});
+      cur = nxt_stage;
+      par ^= 1u;
+      end0 = end1; len0 = len1;
+      fix_off((uint64_t)batch + 2ull * nwaves, raw2a, raw2b, end1, len1);
     }
-    cur = nxt_stage;
-    par ^= 1u;
-    end0 = end1; len0 = len1;
-    fix_off((uint64_t)batch + 2ull * nwaves, raw2a, raw2b, end1, len1);
+    // ---- the pool: batches nstatic .. nbatch - 1 by ticket, from kTixShards counters: the waves of eight consecutive workgroups
+    // (one per XCD) share a counter, wave w draws from counter (w / 32) mod 64, and ticket j of counter c is pool batch c + 64 j
+    // (fewer counters when the grid has fewer than 64 such groups).
+    // Every wave draws until its ticket is past its counter's share -- one failing draw each -- so a counter ends at its share
+    // + its waves, and the wave that drew the last of those sets it back to zero for the stream's next launch (every other
+    // draw from it has returned by then: the counter serialises them).
+    if constexpr (kPool) {
+    if (nstatic != nbatch) {
+      const uint32_t groups = (nwaves + 31u) >> 5;                                                      // of 32 waves (the last may be short)
+      const uint32_t nshards = groups < kTixShards ? groups : kTixShards;
+      const uint32_t shard = (wave >> 5) % nshards;
+      unsigned long long *tix = counters + (kCounterBytes + kCensusBytes + kCalibScratchBytes) / 8 +
+                                ((size_t)(tix_area - 1u) * kTixShards + shard) * kTixStride;
+      const uint32_t npool = nbatch - nstatic;
+      const uint32_t pool = npool > shard ? (npool - shard + nshards - 1u) / nshards : 0u;               // this counter's batches
+      const uint32_t mine = groups > shard ? (groups - shard + nshards - 1u) / nshards : 0u;             // ... its groups of waves
+      const uint32_t drawers = mine * 32u - ((groups - 1u) % nshards == shard ? groups * 32u - nwaves : 0u);
+      uint32_t drawn = 0;
+      if (lane64 == 0) drawn = (uint32_t)atomicAdd(tix, 1ull);
+      for (;;) {
+        const uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+        if (tk >= pool) {
+          if (tk == pool + drawers - 1u && lane64 == 0) atomicExch(tix, 0ull);
+          break;
+        }
+        if (lane64 == 0) drawn = (uint32_t)atomicAdd(tix, 1ull);      // the next one, looked at when this batch is done
+        batch = nstatic + shard + nshards * tk;
+#ifdef FMX_SEARCHLOG
+        sl_batches++;
+#endif
+        {
+          uint64_t a0, a1;
+          load_off_raw(batch, a0, a1);
+          fix_off(batch, a0, a1, end0, len0);
+        }
+        cur = stage_issue(end0, len0);
+        stage_park(cur, par);
+#pragma unroll
+        for (uint32_t i = 0; i < NT; i++) tail_ahead.c[i] = (!kStage && len0 > 4u * i) ? fetch4(pat, end0 - 4ull * i) : 0u;
+        one_batch(std::false_type{});
+      }
+    }
+    }
   }
   if constexpr (RW != 0u) {
     if (npark > kParkCap - 64u) walk_parked(std::false_type{});
     rows_phase(true);
   }
+  // Round 5 also tried the LAST walk of a bytes-layout wave by pairs of lanes (64 of the block's 128 bytes per lane, 32 patterns
+  // per round): a C5 wave's ~20 parked patterns are three rounds of dependent steps by its octets -- 17.7 us at the median, at the
+  // very end of the launch (profiles/r05_c5_c2_wave_timeline.txt) -- and would be one.  It compiles to 73 vector registers where
+  // the octets' walk has 71, i.e. six waves per SIMD instead of seven; held to seven by the occupancy attribute the compiler
+  // also cuts the scalar budget to 94 (21 spills): 0.328-0.332 ms against 0.321 on one box.  Taken out.
 #ifdef FMX_SEARCHLOG
   const unsigned long long sl_tw = __builtin_amdgcn_s_memrealtime();      // the last walk begins
 #endif
@@ -1065,6 +1142,32 @@ static int census_read(const Index *h, int grid, int api, hipStream_t st) {
   return (got >= api - 2 && got >= 1) ? std::min(api, got) : 0;      // fewer: the device was not this launch's alone
 }
 
+// The ticket area (1 .. kTixAreas; 0: none) of the stream a search is enqueued on: k_search4, "The last rounds are DRAWN".
+// FMX_SEARCH_TICKETS=0: none for anybody (every batch strided, as until round 5).
+static uint32_t ticket_area(const Index *h, hipStream_t st) {
+  static const bool off = getenv("FMX_SEARCH_TICKETS") && atoi(getenv("FMX_SEARCH_TICKETS")) == 0;
+  if (off) return 0u;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0u; }
+  if (cs != hipStreamCaptureStatusNone) return 0u;      // a graph may be replayed on any stream, beside anything
+  static_assert(sizeof(h->tix_owner) / sizeof(h->tix_owner[0]) == kTixAreas, "one owner per ticket area");
+  std::lock_guard<std::mutex> lk(h->tix_mu);
+  uint32_t free_at = 0;
+  for (uint32_t i = 0; i < kTixAreas; i++) {
+    if (h->tix_used[i] && h->tix_owner[i] == (void *)st) return i + 1u;
+    if (!h->tix_used[i] && !free_at) free_at = i + 1u;
+  }
+  if (free_at) { h->tix_used[free_at - 1u] = true; h->tix_owner[free_at - 1u] = (void *)st; }
+  return free_at;
+}
+
+// full rounds of batches that are drawn with the partial last one (FMX_SEARCH_POOL_ROUNDS: 1 .. 15; 2 by measurement -- C5 0.318-0.320 /
+// 0.314-0.316 / 0.315-0.316 ms, C3text 0.425 / 0.423 / 0.435 ms with 1 / 2 / 4: every drawn batch starts cold)
+static uint32_t pool_rounds() {
+  static const uint32_t v = [] { const char *e = getenv("FMX_SEARCH_POOL_ROUNDS"); const int x = e ? atoi(e) : 2; return (uint32_t)std::max(1, std::min(x, 15)); }();
+  return v;
+}
+
 // cal: this is search_calibrate's call -- nothing is searched, the instantiation is calibrated
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T = false, bool G2 = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
@@ -1111,8 +1214,20 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
   h->search_residency.store((uint32_t)per_cu | ((forced || measured) ? 0x100u : 0u));
   // ONE launch in every configuration (round 5: the kernels without a row jump table used to be followed by k_search_rows and
   // k_search_defer); the 8-byte form, where asked for, is written by the kernel itself
+  const uint32_t area = ticket_area(h, st);
+  {
+    static const bool trace = getenv("FMX_TRACE") != nullptr;
+    if (trace) {      // (what the kernel will make of it: k_search4, "The last rounds are DRAWN")
+      constexpr uint32_t Pw = 64u / (G2 ? 2u : (uint32_t)Lay<LAYOUT>::G);
+      const uint64_t nbatch = ((uint64_t)k + Pw - 1) / Pw, nw = (uint64_t)grid * (kSThreads / 64), rounds = nbatch / nw;
+      const bool pooled = (G2 || RW != 0u) && area && rounds >= pool_rounds() + 2u;
+      fprintf(stderr, "[fmx] k_search4<%d,%u,%u,%d,%u,%d,%d>: %llu batches over %llu waves, the last %llu drawn from ticket area %u\n", (int)WIDE, LAYOUT, KT,
+              (int)JT, RW, (int)R3T, (int)G2, (unsigned long long)nbatch, (unsigned long long)nw,
+              (unsigned long long)(pooled ? nbatch - (rounds - pool_rounds()) * nw : 0), pooled ? area : 0u);
+    }
+  }
   k_search4<WIDE, LAYOUT, KT, JT, RW, R3T, G2><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
-                                                                       (R3T || RW) ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters, pk_cap, 0u);
+                                                                       (R3T || RW) ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters, pk_cap, (area << 16) | (pool_rounds() << 24));
   return hipGetLastError();
 }
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>

@@ -2361,6 +2361,86 @@ def test_search_inside_a_captured_graph_leaves_the_census_alone(layout):
     assert not any("census" in ln for ln in lines[first_search:]), "a census was read after the first search:\n" + "\n".join(lines)
 
 
+_TICKET_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, findex_amd, oracle
+from helpers import synth_bwt
+layout, mode = sys.argv[2], sys.argv[3]
+findex_amd.set_layout(layout)
+bwt, eof, counts = synth_bwt(3_000_000, 97, 120, 23)
+hip = findex_amd.HipFMSearcher.from_mem(bwt, eof, counts)
+if mode == "pairs":
+    hip.config_set("jump_pairs", "on")
+else:
+    hip.config_set("jump", "rows3")
+hip.prepare(ktab=True, jump=True)
+rng = np.random.default_rng(7)
+k, m = 600_000, 28
+walk, _ = hip.lf_walk_batch(rng.integers(0, bwt.size, size=k), m)
+full = np.ascontiguousarray(walk[:, ::-1])
+lens = rng.integers(6, m + 1, size=k)                      # ragged: the last `len` characters of each walk
+miss = rng.random(k) < 0.1                                  # ... a tenth of them with one character changed
+col = m - 1 - (rng.random(k) * lens).astype(np.int64)      # anywhere in the pattern
+full[miss, col[miss]] = (full[miss, col[miss]] + 1) % 120 + 1
+off = np.zeros(k + 1, dtype=np.int64); off[1:] = np.cumsum(lens)
+pats = np.concatenate([full[i, m - lens[i]:] for i in range(k)]) if k <= 1000 else None
+if pats is None:
+    idx = np.repeat(np.arange(k), lens) * m + (m - np.repeat(lens, lens)) + (np.arange(off[-1]) - np.repeat(off[:-1], lens))
+    pats = full.reshape(-1)[idx]
+dev = torch.device("cuda", 0)
+d_pat = torch.from_numpy(pats).to(dev); d_off = torch.from_numpy(off).to(dev)
+streams = [torch.cuda.Stream() for _ in range(20)]          # more streams than the handle has ticket areas: the last ones stride
+outs = []
+torch.cuda.synchronize()
+for rep in range(3):                                        # one launch after the other on every stream: the counters set themselves back
+    for s in streams[: (20 if rep == 0 else 3)]:
+        sp = torch.full((k,), -1, dtype=torch.int64, device=dev); ep = torch.full((k,), -1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        hip.search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), sp.data_ptr(), ep.data_ptr(), k, s.cuda_stream)
+        outs.append((sp, ep))
+torch.cuda.synchronize()
+for sp, ep in outs[1:]:
+    assert torch.equal(sp, outs[0][0]) and torch.equal(ep, outs[0][1])
+# two streams at once on one handle: each draws from its own area
+a = [torch.full((k,), -1, dtype=torch.int64, device=dev) for _ in range(4)]
+torch.cuda.synchronize()
+for rep in range(2):
+    hip.search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), a[0].data_ptr(), a[1].data_ptr(), k, streams[0].cuda_stream)
+    hip.search_batch_dev(d_pat.data_ptr(), d_off.data_ptr(), a[2].data_ptr(), a[3].data_ptr(), k, streams[1].cuda_stream)
+torch.cuda.synchronize()
+assert torch.equal(a[0], outs[0][0]) and torch.equal(a[2], outs[0][0]) and torch.equal(a[1], outs[0][1]) and torch.equal(a[3], outs[0][1])
+sp, ep = outs[0][0].cpu().numpy().view(np.uint64), outs[0][1].cpu().numpy().view(np.uint64)
+orc = oracle.NaiveFMSearcher.from_mem(bwt, eof, counts)
+for lo, hi in ((0, 4000), (k - 60_000, k)):                 # the pool is the END of the batch list
+    wsp, wep, _ = orc.search_batch(pats[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
+    assert np.array_equal(sp[lo:hi], wsp) and np.array_equal(ep[lo:hi], wep), (lo, hi)
+assert 0.85 < float((sp < ep).mean()) < 0.95
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("layout,mode", [("onehot", "rows3"), ("bytes", "rows3"), ("onehot", "pairs")])
+def test_last_rounds_drawn_by_ticket(layout, mode):
+    """k_search4's pool (fmx_search.hip, "The last rounds are DRAWN"): with a small grid (FMX_SEARCH_WGS=1: 1024 waves) 600 000
+    ragged patterns are dozens of rounds, the last two-to-three of them drawn by ticket.  Launch after launch on one stream
+    (the counters set themselves back), on twenty streams (the handle has sixteen areas: the others stride), two streams at
+    once; all results equal, the first 4000 and the LAST 60 000 patterns -- the pool -- equal to the oracle's.  FMX_TRACE must
+    show launches with a pool and, past the sixteenth stream, launches without."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FMX_TRACE="1", FMX_SEARCH_WGS="1", FMX_SEARCH_G2="1" if mode == "pairs" else "0")
+    env.pop("FMX_SEARCH_TICKETS", None)
+    r = subprocess.run([sys.executable, "-c", _TICKET_SCRIPT, root, layout, mode], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    import re
+    drawn = [(int(m.group(1)), int(m.group(2))) for m in re.finditer(r"the last (\d+) drawn from ticket area (\d+)", r.stderr)]
+    assert len(drawn) >= 30, r.stderr[-2000:]
+    assert sum(1 for d, a in drawn if d > 0 and a > 0) >= 22 and any(d == 0 for d, a in drawn), drawn[:40]
+    assert {a for d, a in drawn if d > 0} == set(range(1, 17)), sorted({a for d, a in drawn})
+
+
 @pytest.mark.parametrize("which", ["modes", "repeats", "spans", "walks", "ragged"])
 def test_pairs_of_lanes_search_kernel(which, monkeypatch):
     """k_search4<.., G2> (round 5): a pattern served by a PAIR of lanes, 32 patterns per wave, the dictionary's blocks

@@ -901,7 +901,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         log(rank, "host path: pageable %.3f ms, page-locked %.3f ms, lean (no offsets, 8-byte intervals) %.3f ms per call"
             % (out["host_path"]["pageable"]["ms_per_call"], out["host_path"]["page_locked"]["ms_per_call"],
                out["host_path"]["lean_pageable"]["ms_per_call"]))
-    if rank == 0 and not args.no_rank_only:
+    if world == 1 and rank == 0 and not args.no_rank_only:      # (like the CPU leg: at N = 1 only -- the other ranks would have left)
         # (after everything else that uses this handle's tables, before the CPU leg, which does not use the handle)
         out["rank_only"] = measure_rank_only(args, torch, hip, batches, k, stream, device, onehot, rank)
     if want_cpu:

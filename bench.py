@@ -758,6 +758,36 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         return e0.elapsed_time(e1) / reps
     replayed_ms = replay(max(args.steps, 5))
 
+    # ---- the same ring asked with FMX_SEARCH_MISS_NONE (fmx.h): a pattern that does not occur may come back as (0, 0) -- None in
+    # the reference either way (findex.scala:30) -- which spares the kernel the walk to the loop's values at the failing step.
+    # What the JVM adapter's search() runs; never the headline (the headline step returns those values).
+    def miss_none(reps):
+        a, b = torch.empty(k, dtype=torch.int64, device=device), torch.empty(k, dtype=torch.int64, device=device)
+        hip.stats_reset()
+        hip.search_batch_ex_dev(pats.data_ptr(), off.data_ptr(), a.data_ptr(), b.data_ptr(), k, stream, miss_none=True)
+        torch.cuda.synchronize()
+        sj = hip.stats()
+        hit = sp0 < ep0                  # (sp0 / ep0: batch 0's intervals from the plain call)
+        assert torch.equal(a[hit], sp0[hit]) and torch.equal(b[hit], ep0[hit]) and bool((a[~hit] >= b[~hit]).all()), "MISS_NONE changed a result"
+        assert int(sj["rank_queries"]) == per_batch[0]["rank_queries"], "MISS_NONE changed the count of the reference's steps"
+        reqs = int(sj["search_requests"] + sj["ktab_lookups"] + sj["jump_lookups"] + sj["row_lookups"])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(3):
+            bp, bo = batches[i % ring]
+            hip.search_batch_ex_dev(bp.data_ptr(), bo.data_ptr(), a.data_ptr(), b.data_ptr(), k, stream, miss_none=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(reps):
+            bp, bo = batches[i % ring]
+            hip.search_batch_ex_dev(bp.data_ptr(), bo.data_ptr(), a.data_ptr(), b.data_ptr(), k, stream, miss_none=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        return {"ms_per_step": ms, "patterns_per_sec": k / (ms * 1e-3), "requests_per_launch": reqs, "requests_G_per_s": reqs / ms / 1e6,
+                "what": "the ring's steps through fmx_search_batch_ex_dev with FMX_SEARCH_MISS_NONE: hits bit-equal to the plain call's, "
+                        "every miss sp >= ep, the reference-equivalent step count unchanged; %d back-to-back steps" % reps}
+    miss_none_rec = miss_none(max(args.steps, 10)) if not (use_dist or os.environ.get("FMX_BENCH_NO_MISS_NONE")) else None      # (the variable: A/B runs against older libraries)
+
     exchange = measure_exchange(args, torch, dist, hip, gather, k, device, stream, use_dist)
     tot = torch.tensor([dt, float(ranks_per_step), float(hits), kernel_ms], dtype=torch.float64, device=device)
     if use_dist:
@@ -854,6 +884,7 @@ def run_literal(args, torch, dist, findex_amd, rank, world, local, device, use_d
         "ms_per_step_is": "steps rotate through %d distinct pattern batches (seeds differ): no step sees a batch the device has just "
                           "searched; the same step on ONE replayed batch: replayed_batch_ms" % ring,
         "replayed_batch_ms": replayed_ms,
+        "miss_none": miss_none_rec,
         # co-headline: what the memory system is asked per second; `value` counts the reference's occ evaluations,
         # which the tables of rounds 2-4 serve with fewer and fewer requests -- compare rounds by patterns_per_sec / this
         "requests_G_per_s": world * all_requests * args.steps / dt / 1e9,

@@ -118,8 +118,11 @@ JNIEXPORT void JNICALL FN(searchBatch0)(JNIEnv *e, jobject self, jlong h, jbyteA
   jbyte *p = in_bytes(e, pat, (*e)->GetArrayLength(e, pat));
   jlong *o = in_longs(e, off, k + 1);
   jlong *r = malloc(sizeof(jlong) * (size_t)(k > 0 ? 2 * k : 1));
-  int rc = (p && o && r) ? fmx_search_batch(H(h), (const uint8_t *)p, (const uint64_t *)o, (uint64_t *)r,
-                                            (uint64_t *)r + k, (size_t)k)
+  /* (what becomes of these pairs is SuffixAlgo.search's Option: a miss is None whatever its values -- FMX_SEARCH_MISS_NONE
+   * spares the device the walk to the reference loop's values at the failing step) */
+  fmx_search_opts opts = {0, FMX_SEARCH_MISS_NONE, 0};
+  int rc = (p && o && r) ? fmx_search_batch_ex(H(h), (const uint8_t *)p, (const uint64_t *)o, (uint64_t *)r,
+                                               (uint64_t *)r + k, (size_t)k, &opts)
                          : FMX_ERR_NOMEM;
   if (rc == FMX_OK && k > 0) (*e)->SetLongArrayRegion(e, out, 0, 2 * k, r);
   free(r);
@@ -151,7 +154,7 @@ JNIEXPORT void JNICALL FN(searchBatchFixed0)(JNIEnv *e, jobject self, jlong h, j
   jlong *r = malloc(sizeof(jlong) * (size_t)(k > 0 ? 2 * k : 1));
   if (!r) { rethrow(e, FMX_ERR_NOMEM); return; }      /* before the pattern bytes are copied out of the JVM */
   jbyte *p = in_bytes(e, pat, nb);
-  fmx_search_opts opts = {(uint32_t)len, 0, 0};
+  fmx_search_opts opts = {(uint32_t)len, FMX_SEARCH_MISS_NONE, 0};
   int rc = (p && r) ? fmx_search_batch_ex(H(h), (const uint8_t *)p, 0, (uint64_t *)r, (uint64_t *)r + k, (size_t)k, &opts) : FMX_ERR_NOMEM;
   if (rc == FMX_OK && k > 0) (*e)->SetLongArrayRegion(e, out, 0, 2 * k, r);
   free(r);

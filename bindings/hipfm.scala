@@ -100,6 +100,8 @@ trait HipSuffixAlgo extends SuffixAlgo {
   def searchBatch(pats: Array[Array[Byte]]): Array[Option[(Int, Int)]] =
     searchBatchLong(pats).map { case (sp, ep) => if (sp < ep) Some((sp.toInt, ep.toInt)) else None }
 
+  // (sp, ep) per pattern; a pattern that does not occur has sp >= ep and nothing else is promised of its pair (the library is
+  // asked with FMX_SEARCH_MISS_NONE: SuffixAlgo.search maps it to None either way, findex.scala:30)
   def searchBatchLong(pats: Array[Array[Byte]]): Array[(Long, Long)] = {
     val k = pats.length
     val off = new Array[Long](k + 1)

@@ -715,8 +715,10 @@ int fmx_search_batch_ex_dev(const fmx_index *idx, const void *d_pat, const void 
     if (!ok) return arg_fail("pattern offsets must be non-decreasing");
   }
   // packed: by the search kernel itself where it finishes every pattern, else in place behind it (d_sp's first k words)
+  if (opts && (opts->packed & ~(FMX_SEARCH_PACKED | FMX_SEARCH_MISS_NONE))) return arg_fail("fmx_search_opts.packed: unknown bits");
   HIP_TRY(launch_search(H(idx), d_pat, fixed ? nullptr : d_off, d_sp, d_ep, k, (hipStream_t)stream, fixed,
-                        (opts && opts->packed) ? (uint64_t)opts->escape_cap : ~0ull), "k_search");
+                        (opts && (opts->packed & FMX_SEARCH_PACKED)) ? (uint64_t)opts->escape_cap : ~0ull,
+                        (opts && (opts->packed & FMX_SEARCH_MISS_NONE)) ? kSearchMissNone : 0u), "k_search");
   return FMX_OK;
 }
 
@@ -822,14 +824,16 @@ int fmx_search_batch(const fmx_index *idx, const uint8_t *pat, const uint64_t *o
 int fmx_search_batch_ex(const fmx_index *idx, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,
                         size_t k, const fmx_search_opts *opts) {
   const uint32_t fixed = opts ? opts->fixed_len : 0u;
-  const bool packed = opts && opts->packed;
+  if (opts && (opts->packed & ~(FMX_SEARCH_PACKED | FMX_SEARCH_MISS_NONE))) return arg_fail("fmx_search_opts.packed: unknown bits");
+  const bool packed = opts && (opts->packed & FMX_SEARCH_PACKED);
+  const uint32_t sflags = (opts && (opts->packed & FMX_SEARCH_MISS_NONE)) ? kSearchMissNone : 0u;
   const size_t esc = packed ? (size_t)opts->escape_cap : 0;
   if (!idx || (k && ((!off && !fixed) || !sp || (!ep && !packed)))) return arg_fail("null argument");
   const Index *h = H(idx);
   int rc = use_device(h);
   if (rc) return rc;
   if (!k) { if (packed && sp) sp[0] = 0; return FMX_OK; }
-  if (fixed || packed) {
+  if (fixed || packed || sflags) {
     // ---- the lean forms of a host batch (round 4): equal-length patterns travel without offsets (8 B per pattern less
     // up the link) and the intervals come back in the 8-byte form (8 B per pattern less down): 56 -> 40 B per
     // 32-character pattern.  Whole arrays up, one chain of kernels, one array down, like the default path below.
@@ -847,7 +851,7 @@ int fmx_search_batch_ex(const fmx_index *idx, const uint8_t *pat, const uint64_t
       HostIn ins[2] = {{total ? pat : nullptr, (size_t)total}, {off, fixed ? 0 : (k + 1) * 8}};
       HostOut outs[2] = {{sp, out_words * 8}, {packed ? nullptr : ep, k * 8}};
       return run_io(h, ins, 2, outs, 2, [&](hipStream_t st, const void *const *di, void *const *dout) {
-        return launch_search(h, di[0], fixed ? nullptr : di[1], dout[0], dout[1], k, st, fixed, packed ? (uint64_t)esc : ~0ull);
+        return launch_search(h, di[0], fixed ? nullptr : di[1], dout[0], dout[1], k, st, fixed, packed ? (uint64_t)esc : ~0ull, sflags);
       });
     }
     Call c0(h);
@@ -869,7 +873,7 @@ int fmx_search_batch_ex(const fmx_index *idx, const uint8_t *pat, const uint64_t
     }
     rc = c0.timed([&](hipStream_t st, EventPair &ev) {
       HIP_TRY(hipEventRecord(ev.a, st), "hipEventRecord");
-      HIP_TRY(launch_search(h, d_pat.p, fixed ? nullptr : d_off.p, d_sp.p, d_ep.p, k, st, fixed, packed ? (uint64_t)esc : ~0ull), "k_search");
+      HIP_TRY(launch_search(h, d_pat.p, fixed ? nullptr : d_off.p, d_sp.p, d_ep.p, k, st, fixed, packed ? (uint64_t)esc : ~0ull, sflags), "k_search");
       HIP_TRY(hipEventRecord(ev.b, st), "hipEventRecord");
       return (int)FMX_OK;
     });

@@ -207,7 +207,9 @@ hipError_t launch_prev_range(const Index *h, const void *d_sp, const void *d_ep,
                              void *d_ep1, uint64_t k, hipStream_t st);
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
                          hipStream_t st, uint32_t fixed_len = 0,       // d_off == nullptr: k patterns of fixed_len bytes each
-                         uint64_t pack_cap = ~0ull);                   // != ~0: the 8-byte form into d_sp (escape list of pack_cap), d_ep scratch
+                         uint64_t pack_cap = ~0ull,                    // != ~0: the 8-byte form into d_sp (escape list of pack_cap), d_ep scratch
+                         uint32_t flags = 0);                          // kSearchMissNone: fmx.h, FMX_SEARCH_MISS_NONE
+constexpr uint32_t kSearchMissNone = 1u;
 // the 8-byte form of a batch's intervals (fmx.h: fmx_pack_intervals_dev); in place when d_packed == d_sp
 hipError_t launch_pack_intervals(const Index *h, const void *d_sp, const void *d_ep, uint64_t k, uint64_t escape_cap,
                                  void *d_packed, hipStream_t st);

@@ -203,9 +203,15 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
   // registers spilled at six waves per SIMD -- C3 by quads 0.137-0.140 -> 0.143 ms; their large batches go to the pairs)
   constexpr bool kPool = G2 || RW != 0u;
   const uint32_t tix_area = kPool ? (spin >> 16) & 0xFFu : 0u;
+  // fmx.h, FMX_SEARCH_MISS_NONE (bit 31 of `spin`): a pattern that a row-table lookup finds to MISS -- its one row's text differs
+  // from it -- is reported as (0, 0), None in the reference (findex.scala:30), instead of being parked and walked to the reference
+  // loop's values at its failing step; the steps the reference's loop made on it are known from where the texts differ.
+  // (Kernels with a row jump table only: in the rows kernels -- C5, C2 -- the walks are 2 % of a launch, and one more scalar
+  // that lives through their loops cost C2 3 %.)
+  const bool miss_none = JT != 0u && (spin >> 31) != 0u;
   uint32_t nstatic = nbatch;
   if (tix_area) {
-    const uint32_t rounds = nbatch / nwaves, held = spin >> 24;      // held: full rounds that go to the pool with the partial one
+    const uint32_t rounds = nbatch / nwaves, held = (spin >> 24) & 0xFu;      // held: full rounds that go to the pool with the partial one
     if (rounds >= held + 2u) nstatic = (rounds - held) * nwaves;
   }
   // Pattern pipeline.  A wave's 16 (8) patterns lie one behind the other in the pattern buffer, so their bytes are ONE
@@ -351,6 +357,8 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
       uint32_t wit = actw ? s_park_it[wave_in_wg][slot] : 0u;
       uint64_t wsp = actw ? s_park_row[wave_in_wg][slot] : 0ull;
       uint32_t wj = (uint32_t)(wsp >> 56);                       // steps that are known to succeed (the lookup that parked it saw them)
+      const bool wnone = wj == 0xFFu;                            // FMX_SEARCH_MISS_NONE: parked as None -- nothing to walk, (0, 0) to write
+      wj = wnone ? 0u : wj;
       wsp &= (1ull << 56) - 1;
       if constexpr (R3T && kLast) {
         // ... three of them at a time by the three-step row table: one 8-byte load where the step loop below spends three
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
           r3l += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(go && t == 0));
         }
       }
-      uint64_t wep = wsp + (actw ? 1u : 0u);
+      uint64_t wep = wsp + ((actw && !wnone) ? 1u : 0u);
       uint64_t wbegin = 0, wend = 0;
       if (actw) po.get(wpid, wbegin, wend);
       const uint32_t wlen = (uint32_t)(wend - wbegin);
@@ -865,10 +873,14 @@ __global__ __launch_bounds__(kSThreads) __attribute__((amdgpu_waves_per_eu(G2 ? 
       if (JT && __builtin_amdgcn_ballot_w64(park_now)) {
         // (sp is still the row the lookup was made with: a parked group's sp is not touched again)
         if constexpr (kFold) {      // (park_now is only ever set by a table lookup: JT)
+          // (miss_none: the entry is parked as "None" -- no row, 0xFF known-good steps -- and the steps the reference made on the
+          // pattern are counted here: the missj that agree with the row's text and the one that does not; the walk then only
+          // writes (0, 0) for it.  Writing it here costs the step loop 5-17 spilled vector registers.)
+          if (miss_none && park_now) steps += missj + 1u;
           const unsigned long long pm = __builtin_amdgcn_ballot_w64(park_now && t == 0);
           const uint32_t lane64p = threadIdx.x & 63u;
           const uint32_t slot = npark + (uint32_t)__builtin_popcountll(pm & ((1ull << lane64p) - 1ull));
-          if (park_now && t == 0) { s_park_row[wave_in_wg][slot] = sp | ((uint64_t)missj << 56); s_park_pid[wave_in_wg][slot] = pid; s_park_it[wave_in_wg][slot] = it + park_ahead; }
+          if (park_now && t == 0) { s_park_row[wave_in_wg][slot] = miss_none ? (0xFFull << 56) : (sp | ((uint64_t)missj << 56)); s_park_pid[wave_in_wg][slot] = pid; s_park_it[wave_in_wg][slot] = it + park_ahead; }
           npark += (uint32_t)__builtin_popcountll(pm);
         }
       }
@@ -1171,7 +1183,7 @@ static uint32_t pool_rounds() {
 // cal: this is search_calibrate's call -- nothing is searched, the instantiation is calibrated
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT, uint32_t JT, uint32_t RW, bool R3T = false, bool G2 = false>
 static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, const unsigned long long *r1, const uint8_t *pat,
-                              const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st, uint64_t pk_cap, bool cal) {
+                              const PatOff off, uint64_t *sp, uint64_t *ep, uint32_t k, hipStream_t st, uint64_t pk_cap, uint32_t flags, bool cal) {
   static const int api = blocks_per_cu(k_search4<WIDE, LAYOUT, KT, JT, RW, R3T, G2>);
   // FMX_SEARCH_WGS: fewer resident workgroups per CU (an experiment on how throughput follows the chains in flight)
   static const int forced = getenv("FMX_SEARCH_WGS") ? std::max(1, std::min(atoi(getenv("FMX_SEARCH_WGS")), api)) : 0;
@@ -1227,12 +1239,12 @@ static hipError_t launch_v4kj(const Index *h, const KTab &kt, const uint4 *jt, c
     }
   }
   k_search4<WIDE, LAYOUT, KT, JT, RW, R3T, G2><<<grid, kSThreads, 0, st>>>(h->dev, KT ? kt.level[KT - 1] : nullptr, kt.dense, kt.sigma, jt, h->jump_chars,
-                                                                       (R3T || RW) ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters, pk_cap, (area << 16) | (pool_rounds() << 24));
+                                                                       (R3T || RW) ? r1 : nullptr, pat, off, sp, ep, k, h->d_counters, pk_cap, (area << 16) | (pool_rounds() << 24) | ((flags & kSearchMissNone) ? 0x80000000u : 0u));
   return hipGetLastError();
 }
 template <bool WIDE, uint32_t LAYOUT, uint32_t KT>
 static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
-                             uint32_t k, hipStream_t st, uint64_t pk_cap, bool cal) {
+                             uint32_t k, hipStream_t st, uint64_t pk_cap, uint32_t flags, bool cal) {
   // the row tables are built by fmx_prepare or by the search that brings the handle's patterns to the threshold
   // (fmx_jump.hip, tables_due); until then -- a per-call adapter's single queries -- every step is walked on the dictionary
   // (the search that finds them due builds them -- it allocates and synchronises, fmx.h says so -- and calibrates the
@@ -1257,7 +1269,7 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
   if (rows == 1) {
     const unsigned long long *r1 = nullptr;
     if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
-    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, h->jump_pairs ? nullptr : jt, r1, pat, off, sp, ep, k, st, pk_cap, cal);
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, h->jump_pairs ? nullptr : jt, r1, pat, off, sp, ep, k, st, pk_cap, flags, cal);
   }
   if (jt) {      // and the three-step table beside it, for the steps no aligned jump covers
     const unsigned long long *r3 = nullptr;
@@ -1271,42 +1283,42 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
         const int g2 = g2e ? atoi(g2e) : -1;
         if (r3 && g2 != 0) {
           if (cal) {                  // fmx_prepare calibrates both instantiations: which one a search takes depends on its size
-            const hipError_t ec = launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, true);
+            const hipError_t ec = launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, true);
             if (ec != hipSuccess) return ec;
           } else if (g2 == 1 || (uint64_t)k >= (uint64_t)h->cu_count * 6 * 128 * 3) {
-            return launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, false);
+            return launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, false);
           }
         }
       }
-      return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, cal)
-                : launch_v4kj<WIDE, LAYOUT, KT, 2u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, cal);
+      return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, cal)
+                : launch_v4kj<WIDE, LAYOUT, KT, 2u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, flags, cal);
     }
-    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, cal)
-              : launch_v4kj<WIDE, LAYOUT, KT, 1u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, cal);
+    return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, cal)
+              : launch_v4kj<WIDE, LAYOUT, KT, 1u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, flags, cal);
   }
   if (rows != 0) {
     const unsigned long long *r3 = nullptr, *r1 = nullptr;
     bool have1;
     { std::lock_guard<std::mutex> lk(h->r1_mu); have1 = h->d_row1 != nullptr; }
     if (!have1 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
-    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st, pk_cap, cal);
+    if (r3) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 3>(h, kt, nullptr, r3, pat, off, sp, ep, k, st, pk_cap, flags, cal);
     if ((e = row1_get(h, st, &r1, due)) != hipSuccess) return e;
-    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st, pk_cap, cal);
+    if (r1) return launch_v4kj<WIDE, LAYOUT, KT, 0u, 1>(h, kt, nullptr, r1, pat, off, sp, ep, k, st, pk_cap, flags, cal);
   }
-  return launch_v4kj<WIDE, LAYOUT, KT, 0u, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st, pk_cap, cal);
+  return launch_v4kj<WIDE, LAYOUT, KT, 0u, 0>(h, kt, nullptr, nullptr, pat, off, sp, ep, k, st, pk_cap, flags, cal);
 }
 
 template <bool WIDE, uint32_t LAYOUT>
 static hipError_t launch_v4(const Index *h, const uint8_t *pat, const PatOff off, uint64_t *sp, uint64_t *ep,
-                            uint32_t k, hipStream_t st, uint64_t pk_cap, bool cal = false) {
+                            uint32_t k, hipStream_t st, uint64_t pk_cap, uint32_t flags = 0u, bool cal = false) {
   KTab kt;
   const hipError_t e = ktab_get(h, st, &kt, !cal && tables_due(h, k, true));
   if (e != hipSuccess) return e;
   // the search uses the table's levels in steps of four characters (all levels are kept: fmx_ktab.hip)
-  if (kt.k >= 12) return launch_v4k<WIDE, LAYOUT, 12>(h, kt, pat, off, sp, ep, k, st, pk_cap, cal);
-  if (kt.k >= 8) return launch_v4k<WIDE, LAYOUT, 8>(h, kt, pat, off, sp, ep, k, st, pk_cap, cal);
-  if (kt.k >= 4) return launch_v4k<WIDE, LAYOUT, 4>(h, kt, pat, off, sp, ep, k, st, pk_cap, cal);
-  return launch_v4k<WIDE, LAYOUT, 0>(h, kt, pat, off, sp, ep, k, st, pk_cap, cal);
+  if (kt.k >= 12) return launch_v4k<WIDE, LAYOUT, 12>(h, kt, pat, off, sp, ep, k, st, pk_cap, flags, cal);
+  if (kt.k >= 8) return launch_v4k<WIDE, LAYOUT, 8>(h, kt, pat, off, sp, ep, k, st, pk_cap, flags, cal);
+  if (kt.k >= 4) return launch_v4k<WIDE, LAYOUT, 4>(h, kt, pat, off, sp, ep, k, st, pk_cap, flags, cal);
+  return launch_v4k<WIDE, LAYOUT, 0>(h, kt, pat, off, sp, ep, k, st, pk_cap, flags, cal);
 }
 
 // One launch per call: no scratch, nothing to own per stream, so concurrent calls on one handle need no lock.
@@ -1315,7 +1327,7 @@ static hipError_t launch_v4(const Index *h, const uint8_t *pat, const PatOff off
 // packed words (its first k words double as the kernels' sp array where a set of kernels cannot pack by itself), d_ep is
 // scratch.
 hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, void *d_sp, void *d_ep, uint64_t k,
-                         hipStream_t st, uint32_t fixed_len, uint64_t pack_cap) {
+                         hipStream_t st, uint32_t fixed_len, uint64_t pack_cap, uint32_t flags) {
   if (pack_cap != ~0ull) {       // the count of wide intervals (word k): zero before anything appends to the list
     const hipError_t e0 = hipMemsetAsync(static_cast<unsigned long long *>(d_sp) + k, 0, 8, st);
     if (e0 != hipSuccess) return e0;
@@ -1328,7 +1340,7 @@ hipError_t launch_search(const Index *h, const void *d_pat, const void *d_off, v
     return e1;
   }
   hipError_t e = hipSuccess;
-#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, po, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st, pack_cap)
+#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)d_pat, po, (uint64_t *)d_sp, (uint64_t *)d_ep, (uint32_t)k, st, pack_cap, flags)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
   return e;
@@ -1339,7 +1351,7 @@ hipError_t search_calibrate(const Index *h, hipStream_t st) {
   if (search_variant() == 1) return hipSuccess;
   hipError_t e = hipSuccess;
   const PatOff po{(const uint64_t *)h->d_cf, 0ull};
-#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)h->d_bwt, po, nullptr, nullptr, 1u, st, ~0ull, true)
+#define CALL(W, L) e = launch_v4<W, L>(h, (const uint8_t *)h->d_bwt, po, nullptr, nullptr, 1u, st, ~0ull, 0u, true)
   FMX_LAYOUT_DISPATCH(h, CALL);
 #undef CALL
   return e;

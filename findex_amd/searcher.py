@@ -243,7 +243,7 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_search_batch(self._h, _ptr(pat), _ptr(off), _ptr(sp), _ptr(ep), k))
         return sp, ep
 
-    def search_batch_ex(self, pat, off=None, fixed_len=0, packed=False, escape_cap=0):
+    def search_batch_ex(self, pat, off=None, fixed_len=0, packed=False, escape_cap=0, miss_none=False):
         """fmx_search_batch_ex: the lean forms of search_batch -- `fixed_len` > 0: k = len(pat) // fixed_len patterns of
         that length, no offsets travel; `packed`: the intervals come back in the 8-byte form (one uint64 array of
         fmx_packed_words(k, escape_cap) words: unpack_intervals).  Returns (sp, ep) or the packed array."""
@@ -257,7 +257,7 @@ class HipFMSearcher:
             k, offp = off.size - 1, _ptr(off)
             if k and int(off[-1]) > pat.size:
                 raise ValueError("offsets run past the pattern buffer")
-        opts = _lib.fmx_search_opts(int(fixed_len), 1 if packed else 0, int(escape_cap))
+        opts = _lib.fmx_search_opts(int(fixed_len), (1 if packed else 0) | (2 if miss_none else 0), int(escape_cap))
         if packed:
             out = np.zeros(int(self._L.fmx_packed_words(k, int(escape_cap))), dtype=np.uint64)
             _lib.check(self._L.fmx_search_batch_ex(self._h, _ptr(pat), offp, _ptr(out), None, k, ctypes.byref(opts)))
@@ -306,10 +306,10 @@ class HipFMSearcher:
         _lib.check(self._L.fmx_search_batch_dev(self._h, _dp(d_pat), _dp(d_off), _dp(d_sp), _dp(d_ep), int(k),
                                                 _dp(stream)))
 
-    def search_batch_ex_dev(self, d_pat, d_off, d_sp, d_ep, k, stream=0, fixed_len=0, packed=False, escape_cap=0):
+    def search_batch_ex_dev(self, d_pat, d_off, d_sp, d_ep, k, stream=0, fixed_len=0, packed=False, escape_cap=0, miss_none=False):
         """fmx_search_batch_ex_dev: d_off may be 0 with fixed_len; with `packed` d_sp receives the packed words (it needs
         fmx_packed_words(k, escape_cap) of them) and d_ep is k words of scratch."""
-        opts = _lib.fmx_search_opts(int(fixed_len), 1 if packed else 0, int(escape_cap))
+        opts = _lib.fmx_search_opts(int(fixed_len), (1 if packed else 0) | (2 if miss_none else 0), int(escape_cap))
         _lib.check(self._L.fmx_search_batch_ex_dev(self._h, _dp(d_pat), _dp(d_off), _dp(d_sp), _dp(d_ep), int(k),
                                                    ctypes.byref(opts), _dp(stream)))
 

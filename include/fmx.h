@@ -209,7 +209,7 @@ int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_
 /* The lean forms of the same search (round 4; what the host link and the multi-GPU exchange carry):
  *   fixed_len > 0 : every pattern has this many bytes and pattern q is pat[q * fixed_len ..): `off` is not read and may be
  *                   NULL -- 8 bytes per pattern less up the link, and the kernels compute the offsets instead of loading them;
- *   packed != 0   : the intervals come back in the 8-BYTE FORM, into `sp` (fmx_packed_words(k, escape_cap) words; `ep` is
+ *   packed & FMX_SEARCH_PACKED : the intervals come back in the 8-BYTE FORM, into `sp` (fmx_packed_words(k, escape_cap) words; `ep` is
  *                   not written and may be NULL in the host form; in the device form d_ep is k words of scratch and d_sp's
  *                   first k words are overwritten in place).
  * The 8-byte form: word q = sp[q] | w << 40 with w = min(ep[q] - sp[q], 0xFFFFFF) -- rows are < 2^38, and a miss (sp == ep:
@@ -218,10 +218,20 @@ int fmx_search_batch_dev(const fmx_index *idx, const void *d_pat, const void *d_
  * number of such intervals, then pairs (q, ep[q]) in no particular order, room for escape_cap of them.  When more than
  * escape_cap intervals are that wide, word k still counts them all, fmx_unpack_intervals returns FMX_ERR_OVERFLOW and the
  * caller asks for the 16-byte form instead (device side: compare word k with escape_cap).
+ *   packed & FMX_SEARCH_MISS_NONE : a pattern that does not occur MAY come back as (0, 0) instead of the loop's values at its
+ *                   failing step.  SuffixAlgo.search returns None for it either way (findex.scala:30: `if (sp < ep) Some((sp, ep))
+ *                   else None`) -- the values a miss ends with are not observable through the reference's API, and finding them
+ *                   costs a walk of up to five dependent memory round trips per miss where a row-table lookup has already shown
+ *                   that the pattern's text differs from its row's.  Hits are unchanged; fmx_stats' rank_queries counts the
+ *                   reference loop's steps on every pattern as before (they are known from where the texts differ).  Which
+ *                   misses are canonicalised is the kernels' business (those found by a table lookup; a miss found by a rank
+ *                   query keeps its values): test sp < ep, nothing else.  The JVM adapter, which returns Option, always asks.
  * opts == NULL is fmx_search_batch[_dev] exactly. */
+#define FMX_SEARCH_PACKED 1u
+#define FMX_SEARCH_MISS_NONE 2u
 typedef struct fmx_search_opts {
   uint32_t fixed_len;
-  uint32_t packed;
+  uint32_t packed;       /* bit set: FMX_SEARCH_PACKED | FMX_SEARCH_MISS_NONE (1 = the packed form, as until ABI 5) */
   uint64_t escape_cap;
 } fmx_search_opts;
 int fmx_search_batch_ex(const fmx_index *idx, const uint8_t *pat, const uint64_t *off, uint64_t *sp, uint64_t *ep,

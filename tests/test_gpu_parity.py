@@ -2478,6 +2478,59 @@ def test_pairs_of_lanes_search_kernel(which, monkeypatch):
         hip.close()
 
 
+@pytest.mark.parametrize("kernel", ["quads", "pairs"])
+def test_misses_as_none(kernel, monkeypatch):
+    """FMX_SEARCH_MISS_NONE (fmx.h): a pattern that does not occur may come back as (0, 0) -- SuffixAlgo.search returns None for
+    it either way (findex.scala:30) -- so the kernels with a row jump table park nothing to walk for it.  Hits bit-equal to the
+    oracle's, every miss sp >= ep, and the count of the reference loop's steps (rank_queries) what the oracle counts, misses
+    included; through the host form, the device form and the 8-byte form, with ragged lengths and a third of the patterns
+    mutated anywhere; by quads and by pairs of lanes.  At least some misses must really have been cut short (0, 0)."""
+    torch = _torch()
+    monkeypatch.setenv("FMX_JUMP_PAIRS", "1")
+    monkeypatch.setenv("FMX_SEARCH_G2", "1" if kernel == "pairs" else "0")
+    bwt, eof, counts = synth_bwt(600_000, 97, 120, 31)
+    hip, orc = pair_from_mem(bwt, eof, counts)
+    hip.prepare(ktab=True, jump=True)
+    rng = np.random.default_rng(12)
+    pats = []
+    for m in (3, 9, 17, 24, 32, 41):
+        pats += lf_walk_patterns(orc, rng, 700, m, 0.35)
+    rng.shuffle(pats)
+    buf, off = pack_patterns(pats)
+    k = len(pats)
+    wsp, wep, wsteps = orc.search_batch(buf, off)
+    hit = wsp < wep
+    assert 0.5 < hit.mean() < 0.8
+    hip.stats_reset()
+    gsp, gep = hip.search_batch_ex(buf, off, miss_none=True)
+    st = hip.stats()
+    assert np.array_equal(gsp[hit], wsp[hit]) and np.array_equal(gep[hit], wep[hit]) and bool((gsp[~hit] >= gep[~hit]).all())
+    assert st["backward_steps"] == int(wsteps.sum()) and st["rank_queries"] == 2 * int(wsteps.sum())
+    cut = int(((gsp == 0) & (gep == 0) & ~hit).sum())
+    assert cut > 100 and st["jump_lookups"] > 0, (cut, st["jump_lookups"])
+    # the device form, and the 8-byte form: a miss is a word of width 0
+    dev = torch.device("cuda", 0)
+    d_pat, d_off = torch.from_numpy(buf).to(dev), torch.from_numpy(off.view(np.int64)).to(dev)
+    d_sp, d_ep = torch.full((k,), -1, dtype=torch.int64, device=dev), torch.full((k,), -1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    hip.search_batch_ex_dev(d_pat.data_ptr(), d_off.data_ptr(), d_sp.data_ptr(), d_ep.data_ptr(), k, stream, miss_none=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_sp.cpu().numpy().view(np.uint64), gsp) and np.array_equal(d_ep.cpu().numpy().view(np.uint64), gep)
+    esc = 64
+    d_pk = torch.zeros(hip.packed_words(k, esc), dtype=torch.int64, device=dev)
+    hip.search_batch_ex_dev(d_pat.data_ptr(), d_off.data_ptr(), d_pk.data_ptr(), d_ep.data_ptr(), k, stream, packed=True, escape_cap=esc, miss_none=True)
+    torch.cuda.synchronize()
+    usp, uep = hip.unpack_intervals(d_pk.cpu().numpy().view(np.uint64), k, esc)
+    assert np.array_equal(usp[hit], wsp[hit]) and np.array_equal(uep[hit], wep[hit]) and bool((usp[~hit] >= uep[~hit]).all())
+    # unknown bits of fmx_search_opts.packed are refused
+    import ctypes
+    from findex_amd import _lib
+    bad = _lib.fmx_search_opts(0, 4, 0)
+    assert _lib.load().fmx_search_batch_ex_dev(hip.handle, ctypes.c_void_p(d_pat.data_ptr()), ctypes.c_void_p(d_off.data_ptr()), ctypes.c_void_p(d_sp.data_ptr()),
+                                               ctypes.c_void_p(d_ep.data_ptr()), k, ctypes.byref(bad), ctypes.c_void_p(stream)) == 3
+    hip.close()
+
+
 def test_result_groups_of_every_size_are_ordered():
     """k_res_sort's paths side by side in one batch of 400 regexes (shuffled, so that every workgroup of 256 regexes
     holds a mix): groups of one result, of 2 .. 12, of 13 .. 64 (every result finds its own place), of 65 .. 1024 (bitonic

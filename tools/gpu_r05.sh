@@ -95,7 +95,7 @@ abenv:*)
     tag=${it%%+*}; envs=""; [ "$it" != "$tag" ] && envs=${it#*+} && envs=${envs//+/ }
     lib=""; [ "$tag" != "-" ] && lib="FMX_LIB=$PWD/findex_amd/lib/variants/libfmx_$tag.so"
     echo -n "$wl [$it]: "
-    env $lib $envs timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-path --no-rank-only --steps 40 --warmup 5 2>$O/abenv.err | python -c "import json,sys; d=json.load(sys.stdin); print('ms/step %.4f kernel %.4f replayed %.4f req/s %s'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['replayed_batch_ms'], d.get('requests_G_per_s', d['roofline'].get('device_rank_queries_G_per_s'))))" || tail -3 $O/abenv.err
+    env $lib $envs timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline --no-host-path --no-rank-only --steps 40 --warmup 5 2>$O/abenv.err | python -c "import json,sys; d=json.load(sys.stdin); print('ms/step %.4f kernel %.4f replayed %.4f req/s %s miss_none %s'%(d['ms_per_step'], d['roofline']['kernel_ms'], d['replayed_batch_ms'], d.get('requests_G_per_s', d['roofline'].get('device_rank_queries_G_per_s')), (d.get('miss_none') or {}).get('ms_per_step')))" || tail -3 $O/abenv.err
   done; done
   ;;
 *) bash tools/gpu_r04.sh $TAG $PART ;;

@@ -1276,7 +1276,9 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
     if (rows != 0 && (e = row3_get(h, st, &r3, due)) != hipSuccess) return e;
     if (h->jump_pairs) {    // (pairs are built from the three-step table: it is there)
       // large batches on the one-hot layout: a PAIR of lanes per pattern, 32 patterns per wave (k_search4<.., G2>) -- half the
-      // lockstep batches per wave; a batch that does not give every wave of that grid a few batches keeps the quads
+      // lockstep batches per wave; a batch that does not give every CU four workgroups of pairs keeps the quads, which spread
+      // it over twice the workgroups (C3 by batch size, pairs / quads: 125 k 0.0296 / 0.0335 ms, 250 k 0.0484 / 0.0493,
+      // 500 k 0.0751 / 0.0744, 1 M 0.127 / 0.133, 4 M 0.482 / 0.499)
       // (FMX_SEARCH_G2=0 / 1: never / whenever the instantiation exists)
       if constexpr (LAYOUT == kLayoutOneHot) {
         const char *g2e = getenv("FMX_SEARCH_G2");      // (looked at per launch: the tests switch it inside one process)
@@ -1285,7 +1287,7 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
           if (cal) {                  // fmx_prepare calibrates both instantiations: which one a search takes depends on its size
             const hipError_t ec = launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, true);
             if (ec != hipSuccess) return ec;
-          } else if (g2 == 1 || (uint64_t)k >= (uint64_t)h->cu_count * 6 * 128 * 3) {
+          } else if (g2 == 1 || (uint64_t)k >= (uint64_t)h->cu_count * 512) {
             return launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, false);
           }
         }

@@ -1295,6 +1295,19 @@ static hipError_t launch_v4k(const Index *h, const KTab &kt, const uint8_t *pat,
       return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 2u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, cal)
                 : launch_v4kj<WIDE, LAYOUT, KT, 2u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, flags, cal);
     }
+    // single entries (an index under 2^30 rows, or one whose budget has no room for pairs): the pairs of LANES serve it just the same
+    if constexpr (LAYOUT == kLayoutOneHot) {
+      const char *g2e = getenv("FMX_SEARCH_G2");
+      const int g2 = g2e ? atoi(g2e) : -1;
+      if (r3 && g2 != 0) {
+        if (cal) {
+          const hipError_t ec = launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, true);
+          if (ec != hipSuccess) return ec;
+        } else if (g2 == 1 || (uint64_t)k >= (uint64_t)h->cu_count * 512) {
+          return launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, false);
+        }
+      }
+    }
     return r3 ? launch_v4kj<WIDE, LAYOUT, KT, 1u, 0, true>(h, kt, jt, r3, pat, off, sp, ep, k, st, pk_cap, flags, cal)
               : launch_v4kj<WIDE, LAYOUT, KT, 1u, 0>(h, kt, jt, nullptr, pat, off, sp, ep, k, st, pk_cap, flags, cal);
   }

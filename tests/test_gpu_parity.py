@@ -2329,13 +2329,15 @@ torch.cuda.synchronize()
 search(0)                                   # the plain call
 torch.cuda.synchronize()
 assert torch.equal(sp[1], sp[0]) and torch.equal(ep[1], ep[0]) and int((sp[0] < ep[0]).sum()) == k
+r1 = hip.stats()["search_residency"]        # (of the instantiation a batch of this size takes: fmx_prepare calibrated it beside the quads')
+assert r1 & 0x100, hex(r1)
 for _ in range(6):
     search(2)
 torch.cuda.synchronize()
 assert torch.equal(sp[2], sp[0]) and torch.equal(ep[2], ep[0])
 st = hip.stats()
 r = st["search_residency"]
-assert r == r0, (hex(r), hex(r0))
+assert r == r1, (hex(r), hex(r1))
 assert st["tables_build_ms"] == built, "a table was built after fmx_prepare"
 print("ok", hex(r))
 """
@@ -2439,6 +2441,20 @@ def test_last_rounds_drawn_by_ticket(layout, mode):
     assert len(drawn) >= 30, r.stderr[-2000:]
     assert sum(1 for d, a in drawn if d > 0 and a > 0) >= 22 and any(d == 0 for d, a in drawn), drawn[:40]
     assert {a for d, a in drawn if d > 0} == set(range(1, 17)), sorted({a for d, a in drawn})
+
+
+@pytest.mark.parametrize("which", ["modes", "repeats", "walks"])
+def test_pairs_of_lanes_with_single_entries(which, monkeypatch):
+    """The pair-of-lanes kernel over a row jump table of SINGLE entries (k_search4<.., JT = 1, .., G2>: an index under 2^30 rows,
+    or one whose budget has no room for pairs of entries): forced onto the small shapes of the row-table tests."""
+    monkeypatch.delenv("FMX_JUMP_PAIRS", raising=False)
+    monkeypatch.setenv("FMX_SEARCH_G2", "1")
+    if which == "modes":
+        test_row_jump_table_on_and_off_agree("onehot")
+    elif which == "repeats":
+        test_row_tables_on_repetitive_texts("onehot")
+    else:
+        test_parked_walks_flush_inside_the_kernel()
 
 
 @pytest.mark.parametrize("which", ["modes", "repeats", "spans", "walks", "ragged"])

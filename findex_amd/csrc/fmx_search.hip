@@ -1159,6 +1159,7 @@ static int census_read(const Index *h, int grid, int api, hipStream_t st) {
 static uint32_t ticket_area(const Index *h, hipStream_t st) {
   static const bool off = getenv("FMX_SEARCH_TICKETS") && atoi(getenv("FMX_SEARCH_TICKETS")) == 0;
   if (off) return 0u;
+  if (st == hipStreamPerThread) return 0u;      // ONE handle value, a stream per host thread: launches "on it" may run side by side
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return 0u; }
   if (cs != hipStreamCaptureStatusNone) return 0u;      // a graph may be replayed on any stream, beside anything
